@@ -1,0 +1,6 @@
+"""Import alias for the package directory ``contrastive-masked-unet_amd/`` (a hyphen is not importable)."""
+import os as _os
+
+__path__ = [_os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "contrastive-masked-unet_amd")]
+with open(_os.path.join(__path__[0], "__init__.py")) as _f:
+    exec(compile(_f.read(), _os.path.join(__path__[0], "__init__.py"), "exec"))

@@ -1,0 +1,118 @@
+"""ctypes binding of libcmunet_hip.so (the C-ABI declared in include/cmunet_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing (or a call fails) this module
+raises.  ``build()`` compiles it in-tree with hipcc for gfx950 (works without a GPU).
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libcmunet_hip.so")
+
+F32, F16, BF16 = 0, 1, 2
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_L = ctypes.c_int64
+_F = ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/cmunet_hip.h one to one.
+_SIGS = {
+    "cmu_last_error": (ctypes.c_char_p, []),
+    "cmu_version": (_I, []),
+    "cmu_dtype_size": (_I, [_I]),
+    "cmu_pack_conv3x3_elems": (_L, [_I, _I, _I, _I]),
+    "cmu_pack_conv3x3": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "cmu_pack_convT2x2_elems": (_L, [_I, _I, _I, _I]),
+    "cmu_pack_convT2x2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "cmu_conv3x3_c1_fwd": (_I, [_P, _P, _I, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P]),
+    "cmu_conv3x3_fwd": (_I, [_P, _L, _P, _P, _I, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "cmu_conv_ntiles": (_I, [_I, _I, _I]),
+    "cmu_bn_finalize_ws_bytes": (_L, [_I]),
+    "cmu_bn_finalize": (_I, [_P, _I, _L, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _I, _P, _P]),
+    "cmu_bnrelu_maxpool_fwd": (_I, [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "cmu_convT2x2_fwd": (_I, [_P, _L, _P, _P, _I, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
+    "cmu_conv1x1_head_fwd": (_I, [_P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "cmu_apply_to_nchw": (_I, [_P, _L, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "cmu_nchw_to_nhwc": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "cmu_nhwc_to_nchw": (_I, [_P, _L, _P, _I, _I, _I, _I, _I, _P]),
+    "cmu_bn_bwd_ws_bytes": (_L, [_I]),
+    "cmu_bn_bwd_reduce": (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "cmu_bn_bwd_apply": (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "cmu_conv3x3_wgrad_ws_bytes": (_L, [_I, _I, _I, _I, _I, _I]),
+    "cmu_conv3x3_wgrad": (_I, [_P, _L, _P, _P, _I, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "cmu_conv3x3_c1_wgrad_ws_bytes": (_L, [_I, _I, _I, _I]),
+    "cmu_conv3x3_c1_wgrad": (_I, [_P, _P, _I, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "cmu_maxpool_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "cmu_convT2x2_dgrad": (_I, [_P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
+    "cmu_convT2x2_wgrad_ws_bytes": (_L, [_I, _I, _I, _I, _I, _I]),
+    "cmu_convT2x2_wgrad": (_I, [_P, _L, _P, _P, _I, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "cmu_conv1x1_head_bwd_ws_bytes": (_L, [_I, _I, _I, _I, _I]),
+    "cmu_conv1x1_head_bwd": (_I, [_P, _P, _L, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "cmu_masked_mse_ws_bytes": (_L, [_I, _I]),
+    "cmu_masked_mse_fwd_bwd": (_I, [_P, _I, _I, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P]),
+    "cmu_softmax_ce_dice_ws_bytes": (_L, [_I, _I, _I]),
+    "cmu_softmax_ce_dice_fwd_bwd": (_I, [_P, _P, _P, _P, _F, _I, _I, _I, _P, _P]),
+    "cmu_infonce_inbatch_fwd_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
+    "cmu_moco_ws_bytes": (_L, [_I, _I]),
+    "cmu_moco_infonce_enqueue": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P]),
+    "cmu_l2_normalize_rows": (_I, [_P, _P, _I, _I, _P]),
+    "cmu_ema_update": (_I, [_P, _P, _L, _F, _P]),
+    "cmu_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _L, _F, _P]),
+}
+
+EXPORTS = tuple(_SIGS.keys())
+
+
+class CmuError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile csrc/*.hip into libcmunet_hip.so with hipcc --offload-arch=gfx950 (in-tree)."""
+    jobs = str(min(8, os.cpu_count() or 1))
+    res = subprocess.run(["make", "-C", CSRC, "-j", jobs], capture_output=not verbose, text=True)
+    if res.returncode != 0:
+        raise CmuError("building libcmunet_hip.so failed:\n" + (res.stdout or "") + (res.stderr or ""))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library (raises if it has not been built: there is no CPU fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CmuError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950). The HIP path has no CPU fallback.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name, None)
+            if fn is None:      # reported by missing_symbols(); calling it raises below
+                continue
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def missing_symbols():
+    """Entry points declared in include/cmunet_hip.h that the built library does not export."""
+    l = lib()
+    return [n for n in _SIGS if getattr(l, n, None) is None]
+
+
+def call(name, *args):
+    """Call an int-returning entry point; raise CmuError with cmu_last_error() on failure."""
+    l = lib()
+    fn = getattr(l, name, None)
+    if fn is None:
+        raise CmuError(f"{name} is not exported by {LIB_PATH}")
+    rc = fn(*args)
+    if rc != 0:
+        raise CmuError(f"{name} failed ({rc}): {l.cmu_last_error().decode()}")
+    return rc

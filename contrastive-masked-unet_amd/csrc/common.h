@@ -1,0 +1,157 @@
+// common.h -- shared host/device helpers for libcmunet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/cmunet_hip.h"
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+void cmu_set_error(const char* fmt, ...);
+
+#define CMU_CHECK_ARG(cond, ...)                 \
+    do {                                         \
+        if (!(cond)) {                           \
+            cmu_set_error(__VA_ARGS__);          \
+            return CMU_ERR_ARG;                  \
+        }                                        \
+    } while (0)
+
+#define CMU_CHECK_LAUNCH(name)                                                        \
+    do {                                                                              \
+        hipError_t e__ = hipGetLastError();                                           \
+        if (e__ != hipSuccess) {                                                      \
+            cmu_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));     \
+            return CMU_ERR_LAUNCH;                                                    \
+        }                                                                             \
+    } while (0)
+
+static inline bool cmu_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---------------------------------------------------------------------------------------------
+// vector types
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// ---------------------------------------------------------------------------------------------
+// dtype traits: T is the storage type of activations / packed weights.
+//   EPC  = elements per 16-byte chunk
+//   unpack(chunk, float[EPC]) / pack(float[EPC]) -> chunk
+//   mma16(a_chunk, b_chunk, acc): acc(32x32 f32) += A(32 x Kc) * B(Kc x 32), Kc = 2*EPC channels split
+//          over the two lane halves (lane half h holds channels [h*EPC, h*EPC+EPC) of the 32-byte k-step)
+// ---------------------------------------------------------------------------------------------
+struct F32Traits {
+    typedef float elem_t;
+    static constexpr int EPC = 4;
+    static constexpr int DT = CMU_F32;
+    __device__ static inline void unpack(const u32x4& c, float* f) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(c[i]);
+    }
+    __device__ static inline u32x4 pack(const float* f) {
+        u32x4 c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c[i] = __float_as_uint(f[i]);
+        return c;
+    }
+    __device__ static inline void mma16(const u32x4& a, const u32x4& b, f32x16& acc) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[i]), __uint_as_float(b[i]), acc, 0, 0, 0);
+    }
+    __device__ static inline float to_float(float v) { return v; }
+    __device__ static inline float from_float(float v) { return v; }
+};
+
+struct F16Traits {
+    typedef _Float16 elem_t;
+    static constexpr int EPC = 8;
+    static constexpr int DT = CMU_F16;
+    __device__ static inline void unpack(const u32x4& c, float* f) {
+        f16x8 h = __builtin_bit_cast(f16x8, c);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = (float)h[i];
+    }
+    __device__ static inline u32x4 pack(const float* f) {
+        f16x8 h;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = (_Float16)f[i];
+        return __builtin_bit_cast(u32x4, h);
+    }
+    __device__ static inline void mma16(const u32x4& a, const u32x4& b, f32x16& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+    }
+    __device__ static inline float to_float(_Float16 v) { return (float)v; }
+    __device__ static inline _Float16 from_float(float v) { return (_Float16)v; }
+};
+
+struct BF16Traits {
+    typedef __bf16 elem_t;
+    static constexpr int EPC = 8;
+    static constexpr int DT = CMU_BF16;
+    __device__ static inline void unpack(const u32x4& c, float* f) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __uint_as_float(c[i] << 16);
+            f[2 * i + 1] = __uint_as_float(c[i] & 0xffff0000u);
+        }
+    }
+    __device__ static inline u32x4 pack(const float* f) {
+        bf16x8 h;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = (__bf16)f[i];
+        return __builtin_bit_cast(u32x4, h);
+    }
+    __device__ static inline void mma16(const u32x4& a, const u32x4& b, f32x16& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+    __device__ static inline float to_float(__bf16 v) { return (float)v; }
+    __device__ static inline __bf16 from_float(float v) { return (__bf16)v; }
+};
+
+// dispatch a templated launcher on the runtime dtype
+#define CMU_DISPATCH_DT(dt, FN, ...)                                        \
+    do {                                                                    \
+        switch (dt) {                                                       \
+            case CMU_F32: return FN<F32Traits>(__VA_ARGS__);                \
+            case CMU_F16: return FN<F16Traits>(__VA_ARGS__);                \
+            case CMU_BF16: return FN<BF16Traits>(__VA_ARGS__);              \
+            default: cmu_set_error("unknown dtype %d", (int)(dt)); return CMU_ERR_ARG; \
+        }                                                                   \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ static inline u32x4 ld_global16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ static inline void st_global16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+__device__ static inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ static inline double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ static inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// spatial tile of the implicit-GEMM kernels
+constexpr int CMU_TH = 16;
+constexpr int CMU_TW = 16;
+static inline int cmu_div_up(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cmu_div_up64(int64_t a, int64_t b) { return (a + b - 1) / b; }

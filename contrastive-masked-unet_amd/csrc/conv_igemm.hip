@@ -1,0 +1,459 @@
+// conv_igemm.hip -- implicit-GEMM convolution on MFMA for gfx950 (CDNA4).
+//
+// One kernel template serves three GEMM-shaped ops of the UNet hot path:
+//   MODE_CONV3       Conv2d 3x3 p1 forward (Finetuning/model.py:17,20) and, with flipped/transposed
+//                    packed weights, its data gradient.
+//   MODE_CONVT_FWD   ConvTranspose2d 2x2 s2 forward (model.py:60,78): GEMM M=pixels, N=4*Cout, K=Cin,
+//                    pixel-shuffle store + bias.
+//   MODE_CONVT_DGRAD ConvTranspose2d data gradient: M=low-res pixels, N=Cin, K=4*Cout gathered stride-2.
+//
+// Design (MI355X-first, not a translation of a cuDNN/CUTLASS tiling):
+//   * workgroup = 256 threads = 4 wave64; output tile = 16x16 pixels (M=256) x 64 channels (N=64);
+//     wave w owns tile rows 4w..4w+3 (M=64) x N=64 as 2x2 MFMA 32x32 accumulators (64 VGPRs).
+//   * K is consumed in 64-BYTE channel slices per pixel (32 x f16/bf16 or 16 x f32).  For the 3x3 conv
+//     one stage = one slice of the 18x18 input halo (staged ONCE in LDS and re-read at 9 shifted
+//     addresses: no im2col buffer, no 9x re-read of the input) + the 9 tap slices of the weights.
+//   * global -> registers -> LDS staging (not LDS-DMA) because the producer's BatchNorm+ReLU is applied
+//     on the way (x*scale[c]+shift[c], max 0) and conv zero-padding must stay zero AFTER that transform;
+//     the loads for stage s+1 are issued before the MFMAs of stage s (register prefetch) and two
+//     workgroups per CU overlap one's staging with the other's MFMAs.
+//   * LDS rows are padded to 80 B (64+16): 16-byte fragment reads (ds_read_b128) of consecutive
+//     pixels / output channels then spread over all 16 slots of the 256-B bank row.
+//   * every MFMA operand fragment is one 16-byte LDS read per lane: 8 x 16-bit -> one
+//     v_mfma_f32_32x32x16_{f16,bf16}; 4 x f32 -> four v_mfma_f32_32x32x2_f32 (exact fp32 chain),
+//     so the three dtypes share one kernel body (traits in common.h).
+//   * epilogue: per-channel sum / sum-of-squares of the raw output (BatchNorm batch statistics) from the
+//     accumulators (in-lane over pixels, one cross-half shuffle, 4-wave LDS combine) into a per-tile slab
+//     (deterministic, no atomics); the tile is transposed through LDS and written as whole 16-byte
+//     channel chunks per pixel (coalesced NHWC rows).
+#include "common.h"
+
+enum { MODE_CONV3 = 0, MODE_CONVT_FWD = 1, MODE_CONVT_DGRAD = 2 };
+
+struct IGParams {
+    const void* x;
+    int64_t ldx;
+    const float* in_scale;
+    const float* in_shift;
+    int relu_from;
+    const void* w;
+    int npad;  // padded rows per (slice, tap) in the packed weights
+    void* y;
+    int64_t ldy;
+    float* stats;
+    const float* bias;
+    int B, H, W;  // pixels of the GEMM's M dimension
+    int K;        // contraction channels per tap (CONV3: Cin; CONVT_FWD: Cin; CONVT_DGRAD: Cout of the convT)
+    int N;        // GEMM N (CONV3: Cout; CONVT_FWD: 4*Cout; CONVT_DGRAD: Cin)
+    int Cq;       // CONVT_FWD: Cout (n -> (ij, co))
+    int nslices;  // total number of 64-byte K slices
+    int tilesX, tilesY, nblk;
+    int64_t total_blocks;
+};
+
+template <class TR, int MODE>
+struct IGCfg {
+    typedef typename TR::elem_t elem_t;
+    static constexpr bool C3 = (MODE == MODE_CONV3);
+    static constexpr int TAPS = C3 ? 9 : 2;  // K slices consumed per stage
+    static constexpr int HALO = C3 ? 1 : 0;
+    static constexpr int LW = CMU_TW + 2 * HALO;
+    static constexpr int LH = CMU_TH + 2 * HALO;
+    static constexpr int NPIX = LW * LH;
+    static constexpr int SLICES_A = C3 ? 1 : TAPS;  // slices stored per LDS pixel
+    static constexpr int PS_A = SLICES_A * 64 + 16;
+    static constexpr int A_BYTES = NPIX * PS_A;
+    static constexpr int PS_W = 80;
+    static constexpr int BN = 64;
+    static constexpr int W_BYTES = TAPS * BN * PS_W;
+    static constexpr int KC = 64 / (int)sizeof(elem_t);
+    static constexpr int EPC = TR::EPC;
+    static constexpr int EPI_ROW = BN * (int)sizeof(elem_t) + 16;
+    static constexpr int EPI_STAGE = 4 * 64 * EPI_ROW;
+    static constexpr int EPI_BYTES = EPI_STAGE + 4 * BN * 2 * 4;
+    static constexpr int MAIN_BYTES = A_BYTES + W_BYTES;
+    static constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
+    static constexpr int A_CHUNKS = NPIX * SLICES_A * 4;
+    static constexpr int A_ITERS = (A_CHUNKS + 255) / 256;
+    static constexpr int W_CHUNKS = TAPS * BN * 4;
+    static constexpr int W_ITERS = (W_CHUNKS + 255) / 256;
+};
+
+template <class TR, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IGParams p) {
+    typedef IGCfg<TR, MODE> C;
+    typedef typename TR::elem_t elem_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r = lane & 31;
+    const int h = lane >> 5;
+
+    // ---- block -> (spatial tile, n-block); XCD-aware: blocks b and b+8 share an XCD (speed only) ----
+    int64_t bid = blockIdx.x;
+    {
+        const int64_t nb = p.total_blocks;
+        const int64_t q = nb >> 3, rem = nb & 7;
+        const int64_t xcd = bid & 7, local = bid >> 3;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+    }
+    const int nbk = (int)(bid % p.nblk);
+    const int64_t tile = bid / p.nblk;
+    const int tx = (int)(tile % p.tilesX);
+    const int ty = (int)((tile / p.tilesX) % p.tilesY);
+    const int b = (int)(tile / ((int64_t)p.tilesX * p.tilesY));
+    const int ty0 = ty * CMU_TH, tx0 = tx * CMU_TW;
+    const int n0 = nbk * C::BN;
+
+    const int Hin = (MODE == MODE_CONVT_DGRAD) ? 2 * p.H : p.H;
+    const int Win = (MODE == MODE_CONVT_DGRAD) ? 2 * p.W : p.W;
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.x);
+    const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w);
+    const int cpi = (MODE == MODE_CONVT_DGRAD) ? (p.K + C::KC - 1) / C::KC : 1;  // slices per (i,j)
+
+    // ---- per-thread staging roles ---------------------------------------------------------------
+    const int cg = tid & 3;                                   // 16-byte chunk within the 64-byte slice
+    const int aslice = C::C3 ? 0 : ((tid >> 2) & (C::SLICES_A - 1));
+    // A chunk it: LDS pixel index and global pixel offset (in elements) / validity, stage independent
+    int a_lds[C::A_ITERS];
+    int64_t a_goff[C::A_ITERS];
+    unsigned a_inb = 0;  // bit it: pixel inside the image (and chunk index in range)
+#pragma unroll
+    for (int it = 0; it < C::A_ITERS; ++it) {
+        const int idx = it * 256 + tid;
+        const int rest = idx >> 2;
+        const int pix = C::C3 ? rest : rest / C::SLICES_A;
+        const int py = pix / C::LW, px = pix % C::LW;
+        int gy = ty0 - C::HALO + py, gx = tx0 - C::HALO + px;
+        bool ok = (idx < C::A_CHUNKS) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        a_lds[it] = pix * C::PS_A + aslice * 64 + cg * 16;
+        if (MODE == MODE_CONVT_DGRAD) { gy *= 2; gx *= 2; }
+        a_goff[it] = ok ? (((int64_t)b * Hin + gy) * Win + gx) * p.ldx : 0;
+        a_inb |= (ok ? 1u : 0u) << it;
+    }
+    int w_lds[C::W_ITERS];
+    int w_n[C::W_ITERS];  // output-channel row of the packed weights
+    int w_t[C::W_ITERS];  // tap / slice within the stage
+#pragma unroll
+    for (int it = 0; it < C::W_ITERS; ++it) {
+        const int idx = it * 256 + tid;
+        const int row = idx >> 2;
+        const int t = row / C::BN, n = row % C::BN;
+        w_lds[it] = C::A_BYTES + row * C::PS_W + cg * 16;
+        w_n[it] = n0 + n;
+        w_t[it] = t;
+    }
+
+    // ---- prefetch registers -----------------------------------------------------------------------
+    u32x4 areg[C::A_ITERS];
+    u32x4 wreg[C::W_ITERS];
+    float sc[C::EPC], sh[C::EPC];
+    bool relu = false, chan_ok = false;
+    const bool has_tf = (p.in_scale != nullptr);
+
+    auto load_stage = [&](int s) {
+        // channel slice handled by this thread in stage s
+        const int kslice = C::C3 ? s : s * C::TAPS + aslice;
+        int c0;         // first channel of this thread's chunk (within the input tensor)
+        int64_t extra;  // extra element offset (CONVT_DGRAD: (i,j) sub-pixel)
+        if (MODE == MODE_CONVT_DGRAD) {
+            const int ij = kslice / cpi, cc = kslice % cpi;
+            c0 = cc * C::KC + cg * C::EPC;
+            chan_ok = (kslice < p.nslices) && (c0 < p.K);
+            extra = ((int64_t)(ij >> 1) * Win + (ij & 1)) * p.ldx;
+        } else {
+            c0 = kslice * C::KC + cg * C::EPC;
+            chan_ok = (kslice < p.nslices) && (c0 < p.K);
+            extra = 0;
+        }
+#pragma unroll
+        for (int it = 0; it < C::A_ITERS; ++it) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (((a_inb >> it) & 1u) && chan_ok)
+                v = ld_global16(xb + (a_goff[it] + extra + c0) * (int64_t)sizeof(elem_t));
+            areg[it] = v;
+        }
+        if (has_tf && chan_ok) {
+#pragma unroll
+            for (int e = 0; e < C::EPC; ++e) {
+                sc[e] = p.in_scale[c0 + e];
+                sh[e] = p.in_shift[c0 + e];
+            }
+            relu = (c0 >= p.relu_from);
+        }
+#pragma unroll
+        for (int it = 0; it < C::W_ITERS; ++it) {
+            const int ws = C::C3 ? s : s * C::TAPS + w_t[it];
+            u32x4 v = {0u, 0u, 0u, 0u};
+            const bool ok = (it * 256 + tid < C::W_CHUNKS) && (ws < p.nslices);
+            if (ok) {
+                const int64_t rowg = ((int64_t)(C::C3 ? s * 9 + w_t[it] : ws)) * p.npad + w_n[it];
+                v = ld_global16(wb + rowg * 64 + cg * 16);
+            }
+            wreg[it] = v;
+        }
+    };
+
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int it = 0; it < C::A_ITERS; ++it) {
+            if (it * 256 + tid < C::A_CHUNKS) {
+                u32x4 v = areg[it];
+                if (has_tf && chan_ok && ((a_inb >> it) & 1u)) {
+                    float f[C::EPC];
+                    TR::unpack(v, f);
+#pragma unroll
+                    for (int e = 0; e < C::EPC; ++e) {
+                        float t = fmaf(f[e], sc[e], sh[e]);
+                        f[e] = relu ? fmaxf(t, 0.f) : t;
+                    }
+                    v = TR::pack(f);
+                }
+                *reinterpret_cast<u32x4*>(smem + a_lds[it]) = v;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < C::W_ITERS; ++it) {
+            if (it * 256 + tid < C::W_CHUNKS) *reinterpret_cast<u32x4*>(smem + w_lds[it]) = wreg[it];
+        }
+    };
+
+    // ---- accumulators and fragment base addresses -------------------------------------------------
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    int a_base[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a_base[i] = ((4 * wave + 2 * i + (r >> 4)) * C::LW + (r & 15)) * C::PS_A + h * 16;
+    const int w_base = C::A_BYTES + r * C::PS_W + h * 16;
+
+    const int nstages = C::C3 ? p.nslices : (p.nslices + C::TAPS - 1) / C::TAPS;
+
+    load_stage(0);
+    for (int s = 0; s < nstages; ++s) {
+        __syncthreads();  // previous stage's fragment reads are done
+        store_stage();
+        __syncthreads();
+        if (s + 1 < nstages) load_stage(s + 1);  // in flight during the MFMAs below
+#pragma unroll
+        for (int t = 0; t < C::TAPS; ++t) {
+            const int aoff = C::C3 ? ((t / 3) * C::LW + (t % 3)) * C::PS_A : t * 64;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const u32x4 a0 = *reinterpret_cast<const u32x4*>(smem + a_base[0] + aoff + ks * 32);
+                const u32x4 a1 = *reinterpret_cast<const u32x4*>(smem + a_base[1] + aoff + ks * 32);
+                const u32x4 b0 = *reinterpret_cast<const u32x4*>(smem + w_base + (t * C::BN) * C::PS_W + ks * 32);
+                const u32x4 b1 = *reinterpret_cast<const u32x4*>(smem + w_base + (t * C::BN + 32) * C::PS_W + ks * 32);
+                TR::mma16(a0, b0, acc[0][0]);
+                TR::mma16(a0, b1, acc[0][1]);
+                TR::mma16(a1, b0, acc[1][0]);
+                TR::mma16(a1, b1, acc[1][1]);
+            }
+        }
+    }
+    __syncthreads();  // all waves done with the A/W images: LDS is reused by the epilogue
+
+    // ---- epilogue -----------------------------------------------------------------------------------
+    // accumulator element e of tile (i,j): pixel m32 = (e&3) + 8*(e>>2) + 4*h of M-block i, channel 32*j + r
+    float* stat_lds = reinterpret_cast<float*>(smem + C::EPI_STAGE);
+    if (MODE == MODE_CONV3 && p.stats != nullptr) {
+        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m32 = (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int row = 4 * wave + 2 * i + (m32 >> 4), col = m32 & 15;
+                const bool ok = (ty0 + row < p.H) && (tx0 + col < p.W);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float v = ok ? acc[i][j][e] : 0.f;
+                    s1[j] += v;
+                    s2[j] = fmaf(v, v, s2[j]);
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            s1[j] += __shfl_xor(s1[j], 32, 64);
+            s2[j] += __shfl_xor(s2[j], 32, 64);
+            if (h == 0) {
+                stat_lds[(wave * C::BN + 32 * j + r) * 2 + 0] = s1[j];
+                stat_lds[(wave * C::BN + 32 * j + r) * 2 + 1] = s2[j];
+            }
+        }
+    }
+    // stage this wave's 64x64 sub-tile as [pixel m][channel n]
+    unsigned char* my = smem + wave * (64 * C::EPI_ROW);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float badd = 0.f;
+            if (MODE == MODE_CONVT_FWD) {
+                const int n = n0 + 32 * j + r;
+                if (n < p.N) badd = p.bias[n % p.Cq];
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                *reinterpret_cast<elem_t*>(my + m * C::EPI_ROW + (32 * j + r) * (int)sizeof(elem_t)) =
+                    TR::from_float(acc[i][j][e] + badd);
+            }
+        }
+    __syncthreads();
+    if (MODE == MODE_CONV3 && p.stats != nullptr && tid < C::BN) {
+        const int n = n0 + tid;
+        if (n < p.N) {
+            float a = 0.f, q = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) {
+                a += stat_lds[(w4 * C::BN + tid) * 2 + 0];
+                q += stat_lds[(w4 * C::BN + tid) * 2 + 1];
+            }
+            p.stats[(tile * 2 + 0) * p.N + n] = a;
+            p.stats[(tile * 2 + 1) * p.N + n] = q;
+        }
+    }
+    // coalesced write-out: each lane moves 16-byte channel chunks of one pixel
+    constexpr int CPR = C::BN / C::EPC;  // chunks per pixel row
+    unsigned char* yb = reinterpret_cast<unsigned char*>(p.y);
+#pragma unroll
+    for (int it = 0; it < (64 * CPR) / 64; ++it) {
+        const int idx = it * 64 + lane;
+        const int m = idx / CPR, q = idx % CPR;
+        const int row = 4 * wave + (m >> 4), col = m & 15;
+        const int gy = ty0 + row, gx = tx0 + col;
+        const int n = n0 + q * C::EPC;
+        if (gy < p.H && gx < p.W && n < p.N) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(my + m * C::EPI_ROW + q * 16);
+            int64_t off;
+            if (MODE == MODE_CONVT_FWD) {
+                const int ij = n / p.Cq, co = n % p.Cq;
+                off = (((int64_t)b * (2 * p.H) + 2 * gy + (ij >> 1)) * (2 * p.W) + 2 * gx + (ij & 1)) * p.ldy + co;
+            } else {
+                off = (((int64_t)b * p.H + gy) * p.W + gx) * p.ldy + n;
+            }
+            st_global16(yb + off * (int64_t)sizeof(elem_t), v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------------
+template <class TR, int MODE>
+static int launch_igemm(const IGParams& p, hipStream_t st, const char* name) {
+    typedef IGCfg<TR, MODE> C;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<TR, MODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) {
+            cmu_set_error("%s: hipFuncSetAttribute(%d B LDS): %s", name, C::LDS_BYTES, hipGetErrorString(e));
+            return CMU_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_igemm_kernel<TR, MODE>), dim3((unsigned)p.total_blocks), dim3(256), C::LDS_BYTES, st, p);
+    CMU_CHECK_LAUNCH(name);
+    return CMU_OK;
+}
+
+static int check_act(const char* name, const void* ptr, int64_t ld, int C, int dt) {
+    const int epc = 16 / cmu_dtype_size(dt);
+    CMU_CHECK_ARG(ptr != nullptr, "%s: null tensor", name);
+    CMU_CHECK_ARG(cmu_aligned16(ptr), "%s: tensor not 16-byte aligned", name);
+    CMU_CHECK_ARG(ld >= C && ld % epc == 0, "%s: pixel stride %lld must be >= C=%d and a multiple of %d", name, (long long)ld, C, epc);
+    CMU_CHECK_ARG(C % epc == 0, "%s: channels %d must be a multiple of %d", name, C, epc);
+    return CMU_OK;
+}
+
+template <class TR>
+static int conv3x3_fwd_t(IGParams p, hipStream_t st) {
+    typedef IGCfg<TR, MODE_CONV3> C;
+    p.nslices = cmu_div_up(p.K, C::KC);
+    return launch_igemm<TR, MODE_CONV3>(p, st, "cmu_conv3x3_fwd");
+}
+template <class TR>
+static int convT_fwd_t(IGParams p, hipStream_t st) {
+    typedef IGCfg<TR, MODE_CONVT_FWD> C;
+    p.nslices = cmu_div_up(p.K, C::KC);
+    return launch_igemm<TR, MODE_CONVT_FWD>(p, st, "cmu_convT2x2_fwd");
+}
+template <class TR>
+static int convT_dgrad_t(IGParams p, hipStream_t st) {
+    typedef IGCfg<TR, MODE_CONVT_DGRAD> C;
+    p.nslices = 4 * cmu_div_up(p.K, C::KC);
+    return launch_igemm<TR, MODE_CONVT_DGRAD>(p, st, "cmu_convT2x2_dgrad");
+}
+
+static void fill_tiles(IGParams& p) {
+    p.tilesX = cmu_div_up(p.W, CMU_TW);
+    p.tilesY = cmu_div_up(p.H, CMU_TH);
+    p.nblk = cmu_div_up(p.N, 64);
+    p.npad = p.nblk * 64;
+    p.total_blocks = (int64_t)p.B * p.tilesX * p.tilesY * p.nblk;
+}
+
+extern "C" int cmu_conv_ntiles(int B, int H, int W) { return B * cmu_div_up(H, CMU_TH) * cmu_div_up(W, CMU_TW); }
+
+extern "C" int cmu_conv3x3_fwd(const void* x, int64_t ldx, const float* in_scale, const float* in_shift, int relu_from,
+                               const void* wpacked, void* y, int64_t ldy, float* stats, int B, int H, int W, int Cin,
+                               int Cout, int dt, void* stream) {
+    CMU_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "cmu_conv3x3_fwd: bad dims");
+    CMU_CHECK_ARG(cmu_dtype_size(dt) > 0, "cmu_conv3x3_fwd: bad dtype %d", dt);
+    int rc;
+    if ((rc = check_act("cmu_conv3x3_fwd(x)", x, ldx, Cin, dt))) return rc;
+    if ((rc = check_act("cmu_conv3x3_fwd(y)", y, ldy, Cout, dt))) return rc;
+    CMU_CHECK_ARG(wpacked && cmu_aligned16(wpacked), "cmu_conv3x3_fwd: packed weights null/unaligned");
+    CMU_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "cmu_conv3x3_fwd: scale/shift must both be set");
+    CMU_CHECK_ARG((int64_t)B * cmu_div_up(H, CMU_TH) * cmu_div_up(W, CMU_TW) * cmu_div_up(Cout, 64) < (1ll << 31),
+                  "cmu_conv3x3_fwd: grid too large");
+    IGParams p = {};
+    p.x = x; p.ldx = ldx; p.in_scale = in_scale; p.in_shift = in_shift; p.relu_from = relu_from;
+    p.w = wpacked; p.y = y; p.ldy = ldy; p.stats = stats; p.bias = nullptr;
+    p.B = B; p.H = H; p.W = W; p.K = Cin; p.N = Cout; p.Cq = Cout;
+    fill_tiles(p);
+    CMU_DISPATCH_DT(dt, conv3x3_fwd_t, p, (hipStream_t)stream);
+}
+
+extern "C" int cmu_convT2x2_fwd(const void* x, int64_t ldx, const float* in_scale, const float* in_shift, int relu_from,
+                                const void* wpacked, const float* bias, void* out, int64_t ldo, int B, int H, int W,
+                                int Cin, int Cout, int dt, void* stream) {
+    CMU_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "cmu_convT2x2_fwd: bad dims");
+    CMU_CHECK_ARG(cmu_dtype_size(dt) > 0, "cmu_convT2x2_fwd: bad dtype %d", dt);
+    int rc;
+    if ((rc = check_act("cmu_convT2x2_fwd(x)", x, ldx, Cin, dt))) return rc;
+    if ((rc = check_act("cmu_convT2x2_fwd(out)", out, ldo, Cout, dt))) return rc;
+    CMU_CHECK_ARG(wpacked && cmu_aligned16(wpacked) && bias, "cmu_convT2x2_fwd: weights/bias null or unaligned");
+    CMU_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "cmu_convT2x2_fwd: scale/shift must both be set");
+    IGParams p = {};
+    p.x = x; p.ldx = ldx; p.in_scale = in_scale; p.in_shift = in_shift; p.relu_from = relu_from;
+    p.w = wpacked; p.y = out; p.ldy = ldo; p.stats = nullptr; p.bias = bias;
+    p.B = B; p.H = H; p.W = W; p.K = Cin; p.N = 4 * Cout; p.Cq = Cout;
+    fill_tiles(p);
+    CMU_DISPATCH_DT(dt, convT_fwd_t, p, (hipStream_t)stream);
+}
+
+extern "C" int cmu_convT2x2_dgrad(const void* dOut, int64_t ldd, const void* wpacked_dgrad, void* dX, int64_t ldx, int B,
+                                  int H, int W, int Cin, int Cout, int dt, void* stream) {
+    CMU_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "cmu_convT2x2_dgrad: bad dims");
+    CMU_CHECK_ARG(cmu_dtype_size(dt) > 0, "cmu_convT2x2_dgrad: bad dtype %d", dt);
+    int rc;
+    if ((rc = check_act("cmu_convT2x2_dgrad(dOut)", dOut, ldd, Cout, dt))) return rc;
+    if ((rc = check_act("cmu_convT2x2_dgrad(dX)", dX, ldx, Cin, dt))) return rc;
+    CMU_CHECK_ARG(wpacked_dgrad && cmu_aligned16(wpacked_dgrad), "cmu_convT2x2_dgrad: packed weights null/unaligned");
+    IGParams p = {};
+    p.x = dOut; p.ldx = ldd; p.in_scale = nullptr; p.in_shift = nullptr; p.relu_from = 0;
+    p.w = wpacked_dgrad; p.y = dX; p.ldy = ldx; p.stats = nullptr; p.bias = nullptr;
+    p.B = B; p.H = H; p.W = W; p.K = Cout; p.N = Cin; p.Cq = Cout;
+    fill_tiles(p);
+    CMU_DISPATCH_DT(dt, convT_dgrad_t, p, (hipStream_t)stream);
+}

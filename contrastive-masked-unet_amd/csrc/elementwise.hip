@@ -1,0 +1,505 @@
+// elementwise.hip -- HBM-bound forward pieces of the UNet hot path and library plumbing (gfx950).
+//   weight packing, BatchNorm statistics finalisation, first-layer (Cin=1) direct conv,
+//   BN+ReLU+MaxPool, 1x1 head, layout converters at the module boundary.
+// All kernels move 16-byte chunks per lane (coalesced NHWC rows) and keep per-channel parameters in
+// registers; reductions use wave64 shuffles + one LDS combine and write per-block partial slabs that a
+// second tiny kernel sums in a fixed order (deterministic, no float atomics).
+#include "common.h"
+#include <string.h>
+
+// ---------------------------------------------------------------------------------------------
+// plumbing
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void cmu_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* cmu_last_error(void) { return g_err; }
+extern "C" int cmu_version(void) { return 100; }
+extern "C" int cmu_dtype_size(int dt) { return dt == CMU_F32 ? 4 : (dt == CMU_F16 || dt == CMU_BF16) ? 2 : 0; }
+
+// ---------------------------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------------------------
+template <class TR>
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, typename TR::elem_t* __restrict__ out, int Cin, int Cout,
+                                    int K, int N, int npad, int64_t total, int tflip) {
+    constexpr int KC = 64 / (int)sizeof(typename TR::elem_t);
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(o % KC);
+        const int n = (int)((o / KC) % npad);
+        const int t = (int)((o / ((int64_t)KC * npad)) % 9);
+        const int s = (int)(o / ((int64_t)KC * npad * 9));
+        const int c = s * KC + k;
+        float v = 0.f;
+        if (n < N && c < K) {
+            const int kh = t / 3, kw = t % 3;
+            if (!tflip) v = w[(((int64_t)n * Cin + c) * 3 + kh) * 3 + kw];               // n = co, c = ci
+            else v = w[(((int64_t)c * Cin + n) * 3 + (2 - kh)) * 3 + (2 - kw)];          // n = ci, c = co
+        }
+        out[o] = TR::from_float(v);
+    }
+}
+
+template <class TR>
+static int pack_conv3x3_t(const float* w, void* out, int Cin, int Cout, int tflip, hipStream_t st) {
+    constexpr int KC = 64 / (int)sizeof(typename TR::elem_t);
+    const int K = tflip ? Cout : Cin, N = tflip ? Cin : Cout;
+    const int npad = cmu_div_up(N, 64) * 64;
+    const int64_t total = (int64_t)cmu_div_up(K, KC) * 9 * npad * KC;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL((pack_conv3x3_kernel<TR>), dim3(grid), dim3(256), 0, st, w, (typename TR::elem_t*)out, Cin, Cout, K, N,
+                       npad, total, tflip);
+    CMU_CHECK_LAUNCH("cmu_pack_conv3x3");
+    return CMU_OK;
+}
+
+extern "C" int64_t cmu_pack_conv3x3_elems(int Cin, int Cout, int dt, int tflip) {
+    const int es = cmu_dtype_size(dt);
+    if (es == 0) return -1;
+    const int KC = 64 / es;
+    const int K = tflip ? Cout : Cin, N = tflip ? Cin : Cout;
+    return (int64_t)cmu_div_up(K, KC) * 9 * (cmu_div_up(N, 64) * 64) * KC;
+}
+extern "C" int cmu_pack_conv3x3(const float* w, void* out, int Cin, int Cout, int dt, int tflip, void* stream) {
+    CMU_CHECK_ARG(w && out && Cin > 0 && Cout > 0, "cmu_pack_conv3x3: bad args");
+    CMU_DISPATCH_DT(dt, pack_conv3x3_t, w, out, Cin, Cout, tflip, (hipStream_t)stream);
+}
+
+template <class TR>
+__global__ void pack_convT_kernel(const float* __restrict__ w, typename TR::elem_t* __restrict__ out, int Cin, int Cout,
+                                  int npad, int cpi, int64_t total, int mode) {
+    constexpr int KC = 64 / (int)sizeof(typename TR::elem_t);
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(o % KC);
+        const int n = (int)((o / KC) % npad);
+        const int s = (int)(o / ((int64_t)KC * npad));
+        float v = 0.f;
+        if (mode == 0) {  // rows n = ij*Cout + co, k -> ci
+            const int ci = s * KC + k;
+            if (n < 4 * Cout && ci < Cin) {
+                const int ij = n / Cout, co = n % Cout;
+                v = w[(((int64_t)ci * Cout + co) * 2 + (ij >> 1)) * 2 + (ij & 1)];
+            }
+        } else {  // slices (ij, cc), rows n = ci, k -> co
+            const int ij = s / cpi, cc = s % cpi;
+            const int co = cc * KC + k;
+            if (n < Cin && co < Cout) v = w[(((int64_t)n * Cout + co) * 2 + (ij >> 1)) * 2 + (ij & 1)];
+        }
+        out[o] = TR::from_float(v);
+    }
+}
+static int64_t convT_pack_elems(int Cin, int Cout, int es, int mode, int* npad_out, int* cpi_out) {
+    const int KC = 64 / es;
+    int64_t slices;
+    int npad, cpi = cmu_div_up(Cout, KC);
+    if (mode == 0) { slices = cmu_div_up(Cin, KC); npad = cmu_div_up(4 * Cout, 64) * 64; }
+    else { slices = 4 * (int64_t)cpi; npad = cmu_div_up(Cin, 64) * 64; }
+    if (npad_out) *npad_out = npad;
+    if (cpi_out) *cpi_out = cpi;
+    return slices * npad * KC;
+}
+template <class TR>
+static int pack_convT_t(const float* w, void* out, int Cin, int Cout, int mode, hipStream_t st) {
+    int npad, cpi;
+    const int64_t total = convT_pack_elems(Cin, Cout, (int)sizeof(typename TR::elem_t), mode, &npad, &cpi);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL((pack_convT_kernel<TR>), dim3(grid), dim3(256), 0, st, w, (typename TR::elem_t*)out, Cin, Cout, npad, cpi,
+                       total, mode);
+    CMU_CHECK_LAUNCH("cmu_pack_convT2x2");
+    return CMU_OK;
+}
+extern "C" int64_t cmu_pack_convT2x2_elems(int Cin, int Cout, int dt, int mode) {
+    const int es = cmu_dtype_size(dt);
+    if (es == 0) return -1;
+    return convT_pack_elems(Cin, Cout, es, mode, nullptr, nullptr);
+}
+extern "C" int cmu_pack_convT2x2(const float* w, void* out, int Cin, int Cout, int dt, int mode, void* stream) {
+    CMU_CHECK_ARG(w && out && Cin > 0 && Cout > 0 && (mode == 0 || mode == 1), "cmu_pack_convT2x2: bad args");
+    CMU_DISPATCH_DT(dt, pack_convT_t, w, out, Cin, Cout, mode, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm statistics: slab [ntiles][2][C] -> mean/var -> pending transform + running stats
+// ---------------------------------------------------------------------------------------------
+constexpr int BN_MAX_SPLITS = 256;
+
+__global__ void bn_reduce_slab_kernel(const float* __restrict__ stats, int ntiles, int C, int nsplit, double* __restrict__ ws) {
+    __shared__ double red[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;
+    const int split = blockIdx.y;
+    const int per = (ntiles + nsplit - 1) / nsplit;
+    const int t0 = split * per, t1 = min(ntiles, t0 + per);
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int t = t0 + part; t < t1; t += 4) {
+            s1 += (double)stats[((int64_t)t * 2 + 0) * C + c];
+            s2 += (double)stats[((int64_t)t * 2 + 1) * C + c];
+        }
+    red[0][part][threadIdx.x & 63] = s1;
+    red[1][part][threadIdx.x & 63] = s2;
+    __syncthreads();
+    if (part == 0 && c < C) {
+        const int l = threadIdx.x;
+        ws[((int64_t)split * 2 + 0) * C + c] = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
+        ws[((int64_t)split * 2 + 1) * C + c] = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
+    }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ ws, int nsplit, double count, const float* __restrict__ conv_bias,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+                                   float* running_var, float momentum, float eps, int training, float* scale, float* shift,
+                                   float* save_mean, float* save_invstd, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float cb = conv_bias ? conv_bias[c] : 0.f;
+    if (training) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int s = 0; s < nsplit; ++s) {
+            s1 += ws[((int64_t)s * 2 + 0) * C + c];
+            s2 += ws[((int64_t)s * 2 + 1) * C + c];
+        }
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double invstd = 1.0 / sqrt(var + (double)eps);
+        const float sc = (float)((double)g * invstd);
+        scale[c] = sc;
+        shift[c] = (float)((double)b - mean * (double)g * invstd);
+        if (save_mean) save_mean[c] = (float)mean;
+        if (save_invstd) save_invstd[c] = (float)invstd;
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)(mean + (double)cb);
+        if (running_var) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        }
+    } else {
+        const float invstd = 1.f / sqrtf(running_var[c] + eps);
+        const float sc = g * invstd;
+        scale[c] = sc;
+        shift[c] = b + (cb - running_mean[c]) * sc;
+        if (save_mean) save_mean[c] = running_mean[c] - cb;
+        if (save_invstd) save_invstd[c] = invstd;
+    }
+}
+
+extern "C" int64_t cmu_bn_finalize_ws_bytes(int C) { return (int64_t)BN_MAX_SPLITS * 2 * C * (int64_t)sizeof(double); }
+
+extern "C" int cmu_bn_finalize(const float* stats, int ntiles, int64_t count, const float* conv_bias, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                               int training, float* scale, float* shift, float* save_mean, float* save_invstd, int C, void* ws,
+                               void* stream) {
+    CMU_CHECK_ARG(C > 0 && scale && shift, "cmu_bn_finalize: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    int nsplit = 1;
+    if (training) {
+        CMU_CHECK_ARG(stats && ws && ntiles > 0 && count > 0, "cmu_bn_finalize: training needs stats/ws");
+        nsplit = ntiles / 16;
+        if (nsplit < 1) nsplit = 1;
+        if (nsplit > BN_MAX_SPLITS) nsplit = BN_MAX_SPLITS;
+        hipLaunchKernelGGL(bn_reduce_slab_kernel, dim3(cmu_div_up(C, 64), nsplit), dim3(256), 0, st, stats, ntiles, C, nsplit,
+                           (double*)ws);
+        CMU_CHECK_LAUNCH("cmu_bn_finalize(reduce)");
+    } else {
+        CMU_CHECK_ARG(running_mean && running_var, "cmu_bn_finalize: eval needs running statistics");
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cmu_div_up(C, 128)), dim3(128), 0, st, (const double*)ws, nsplit, (double)count,
+                       conv_bias, gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift, save_mean,
+                       save_invstd, C);
+    CMU_CHECK_LAUNCH("cmu_bn_finalize");
+    return CMU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// first layer: Conv2d(1, Cout, 3, p=1) direct, optional patch-mask multiply fused into the load
+// ---------------------------------------------------------------------------------------------
+template <class TR>
+__global__ __launch_bounds__(256) void conv3x3_c1_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask,
+                                                            int mask_per_sample, const float* __restrict__ w,
+                                                            typename TR::elem_t* __restrict__ y, int64_t ldy, float* stats, int B,
+                                                            int H, int W, int Cout, int tilesX, int tilesY) {
+    constexpr int EPC = TR::EPC;
+    __shared__ float halo[18 * 18];
+    __shared__ float red[2][256];
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int tx = tile % tilesX, ty = (tile / tilesX) % tilesY, b = tile / (tilesX * tilesY);
+    const int ty0 = ty * 16, tx0 = tx * 16;
+    for (int i = tid; i < 18 * 18; i += 256) {
+        const int gy = ty0 - 1 + i / 18, gx = tx0 - 1 + i % 18;
+        float v = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            v = x[((int64_t)b * H + gy) * W + gx];
+            if (mask) v *= (float)(1 - (int)mask[((int64_t)(mask_per_sample ? b : 0) * H + gy) * W + gx]);
+        }
+        halo[i] = v;
+    }
+    const int nchunk = Cout / EPC;
+    const int ppi = 256 / nchunk;  // pixels per iteration
+    const int chunk = tid % nchunk, prow = tid / nchunk;
+    const bool active = prow < ppi;
+    float wr[EPC][9];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[e][t] = active ? w[(chunk * EPC + e) * 9 + t] : 0.f;
+    __syncthreads();
+    float s1[EPC], s2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
+    if (active)
+        for (int pix = prow; pix < 256; pix += ppi) {
+            const int py = pix >> 4, px = pix & 15;
+            const int gy = ty0 + py, gx = tx0 + px;
+            if (gy >= H || gx >= W) continue;
+            float in[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) in[t] = halo[(py + t / 3) * 18 + px + t % 3];
+            float o[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                float a = 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) a = fmaf(in[t], wr[e][t], a);
+                o[e] = a;
+                s1[e] += a;
+                s2[e] = fmaf(a, a, s2[e]);
+            }
+            st_global16(reinterpret_cast<unsigned char*>(y) + ((((int64_t)b * H + gy) * W + gx) * ldy + chunk * EPC) * sizeof(typename TR::elem_t),
+                        TR::pack(o));
+        }
+    if (stats == nullptr) return;
+    // combine the threads that share a channel chunk (same tid % nchunk): fixed-order tree over prow
+    for (int e = 0; e < EPC; ++e) {
+        __syncthreads();
+        red[0][tid] = s1[e];
+        red[1][tid] = s2[e];
+        __syncthreads();
+        if (tid < nchunk) {
+            float a = 0.f, q = 0.f;
+            for (int k = 0; k < ppi; ++k) {
+                a += red[0][k * nchunk + tid];
+                q += red[1][k * nchunk + tid];
+            }
+            stats[((int64_t)tile * 2 + 0) * Cout + tid * EPC + e] = a;
+            stats[((int64_t)tile * 2 + 1) * Cout + tid * EPC + e] = q;
+        }
+    }
+}
+
+template <class TR>
+static int conv3x3_c1_fwd_t(const float* x, const uint8_t* mask, int mps, const float* w, void* y, int64_t ldy, float* stats,
+                            int B, int H, int W, int Cout, hipStream_t st) {
+    const int tilesX = cmu_div_up(W, 16), tilesY = cmu_div_up(H, 16);
+    hipLaunchKernelGGL((conv3x3_c1_fwd_kernel<TR>), dim3(B * tilesX * tilesY), dim3(256), 0, st, x, mask, mps, w,
+                       (typename TR::elem_t*)y, ldy, stats, B, H, W, Cout, tilesX, tilesY);
+    CMU_CHECK_LAUNCH("cmu_conv3x3_c1_fwd");
+    return CMU_OK;
+}
+
+extern "C" int cmu_conv3x3_c1_fwd(const float* x, const uint8_t* mask, int mask_per_sample, const float* w, void* y, int64_t ldy,
+                                  float* stats, int B, int H, int W, int Cout, int dt, void* stream) {
+    const int es = cmu_dtype_size(dt);
+    CMU_CHECK_ARG(es > 0, "cmu_conv3x3_c1_fwd: bad dtype");
+    const int epc = 16 / es;
+    CMU_CHECK_ARG(x && w && y && B > 0 && H > 0 && W > 0, "cmu_conv3x3_c1_fwd: bad args");
+    CMU_CHECK_ARG(Cout % epc == 0 && Cout / epc <= 256 && Cout > 0, "cmu_conv3x3_c1_fwd: Cout=%d must be a multiple of %d (<= %d)", Cout, epc, 256 * epc);
+    CMU_CHECK_ARG(cmu_aligned16(y) && ldy % epc == 0 && ldy >= Cout, "cmu_conv3x3_c1_fwd: y alignment / stride");
+    CMU_DISPATCH_DT(dt, conv3x3_c1_fwd_t, x, mask, mask_per_sample, w, y, ldy, stats, B, H, W, Cout, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// BN + ReLU + MaxPool2d(2)
+// ---------------------------------------------------------------------------------------------
+template <class TR>
+__global__ void bnrelu_maxpool_kernel(const unsigned char* __restrict__ y, int64_t ldy, const float* __restrict__ scale,
+                                      const float* __restrict__ shift, unsigned char* __restrict__ out, int64_t ldo, int B, int H,
+                                      int W, int C, int64_t total) {
+    constexpr int EPC = TR::EPC;
+    constexpr int ES = (int)sizeof(typename TR::elem_t);
+    const int nchunk = C / EPC;
+    const int Ho = H / 2, Wo = W / 2;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(o % nchunk);
+        const int64_t pix = o / nchunk;
+        const int xo = (int)(pix % Wo), yo = (int)((pix / Wo) % Ho), b = (int)(pix / ((int64_t)Wo * Ho));
+        float sc[EPC], sh[EPC], m[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            sc[e] = scale[ch * EPC + e];
+            sh[e] = shift[ch * EPC + e];
+            m[e] = 0.f;  // ReLU floor
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t src = (((int64_t)b * H + 2 * yo + (q >> 1)) * W + 2 * xo + (q & 1)) * ldy + ch * EPC;
+            float f[EPC];
+            TR::unpack(ld_global16(y + src * ES), f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) m[e] = fmaxf(m[e], fmaf(f[e], sc[e], sh[e]));
+        }
+        st_global16(out + ((((int64_t)b * Ho + yo) * Wo + xo) * ldo + ch * EPC) * ES, TR::pack(m));
+    }
+}
+template <class TR>
+static int bnrelu_maxpool_t(const void* y, int64_t ldy, const float* scale, const float* shift, void* out, int64_t ldo, int B, int H,
+                            int W, int C, hipStream_t st) {
+    const int64_t total = (int64_t)B * (H / 2) * (W / 2) * (C / TR::EPC);
+    const int grid = (int)(cmu_div_up64(total, 256) < 8192 ? cmu_div_up64(total, 256) : 8192);
+    hipLaunchKernelGGL((bnrelu_maxpool_kernel<TR>), dim3(grid), dim3(256), 0, st, (const unsigned char*)y, ldy, scale, shift,
+                       (unsigned char*)out, ldo, B, H, W, C, total);
+    CMU_CHECK_LAUNCH("cmu_bnrelu_maxpool_fwd");
+    return CMU_OK;
+}
+extern "C" int cmu_bnrelu_maxpool_fwd(const void* y, int64_t ldy, const float* scale, const float* shift, void* out, int64_t ldo,
+                                      int B, int H, int W, int C, int dt, void* stream) {
+    const int es = cmu_dtype_size(dt);
+    CMU_CHECK_ARG(es > 0 && y && out && scale && shift, "cmu_bnrelu_maxpool_fwd: bad args");
+    const int epc = 16 / es;
+    CMU_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && H > 0 && W > 0 && B > 0, "cmu_bnrelu_maxpool_fwd: H,W must be even (got %d,%d)", H, W);
+    CMU_CHECK_ARG(C % epc == 0 && ldy % epc == 0 && ldo % epc == 0 && ldy >= C && ldo >= C, "cmu_bnrelu_maxpool_fwd: C/ld alignment");
+    CMU_CHECK_ARG(cmu_aligned16(y) && cmu_aligned16(out), "cmu_bnrelu_maxpool_fwd: pointer alignment");
+    CMU_DISPATCH_DT(dt, bnrelu_maxpool_t, y, ldy, scale, shift, out, ldo, B, H, W, C, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1x1 head: logits (B,K,H,W) fp32 NCHW from the raw NHWC tensor + pending transform
+// ---------------------------------------------------------------------------------------------
+constexpr int HEAD_MAX_K = 8;
+template <class TR>
+__global__ void conv1x1_head_fwd_kernel(const unsigned char* __restrict__ x, int64_t ldx, const float* __restrict__ scale,
+                                        const float* __restrict__ shift, const float* __restrict__ w, const float* __restrict__ bias,
+                                        float* __restrict__ logits, int B, int H, int W, int C, int K, int64_t npix) {
+    constexpr int EPC = TR::EPC;
+    constexpr int ES = (int)sizeof(typename TR::elem_t);
+    const int nchunk = C / EPC;  // power of two <= 64 (checked on the host)
+    const int ch = threadIdx.x % nchunk;
+    const int ppb = blockDim.x / nchunk;
+    float sc[EPC], sh[EPC], wk[HEAD_MAX_K][EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        sc[e] = scale ? scale[ch * EPC + e] : 1.f;
+        sh[e] = scale ? shift[ch * EPC + e] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_K; ++k)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) wk[k][e] = (k < K) ? w[k * C + ch * EPC + e] : 0.f;
+    const int64_t HW = (int64_t)H * W;
+    for (int64_t p0 = (int64_t)blockIdx.x * ppb; p0 < npix; p0 += (int64_t)gridDim.x * ppb) {
+        const int64_t pix = p0 + threadIdx.x / nchunk;
+        const bool ok = pix < npix;
+        float f[EPC];
+        if (ok) TR::unpack(ld_global16(x + (pix * ldx + ch * EPC) * ES), f);
+        float acc[HEAD_MAX_K];
+#pragma unroll
+        for (int k = 0; k < HEAD_MAX_K; ++k) acc[k] = 0.f;
+        if (ok) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                float a = fmaf(f[e], sc[e], sh[e]);
+                if (scale) a = fmaxf(a, 0.f);
+#pragma unroll
+                for (int k = 0; k < HEAD_MAX_K; ++k) acc[k] = fmaf(a, wk[k][e], acc[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < HEAD_MAX_K; ++k)
+            if (k < K)
+                for (int o = 1; o < nchunk; o <<= 1) acc[k] += __shfl_xor(acc[k], o, 64);
+        if (ok && ch == 0) {
+            const int64_t b = pix / HW, r = pix % HW;
+            for (int k = 0; k < K; ++k) logits[(b * K + k) * HW + r] = acc[k] + bias[k];
+        }
+    }
+}
+template <class TR>
+static int conv1x1_head_fwd_t(const void* x, int64_t ldx, const float* scale, const float* shift, const float* w, const float* bias,
+                              float* logits, int B, int H, int W, int C, int K, hipStream_t st) {
+    const int nchunk = C / TR::EPC;
+    const int64_t npix = (int64_t)B * H * W;
+    const int ppb = 256 / nchunk;
+    const int64_t nb = cmu_div_up64(npix, ppb);
+    const int grid = (int)(nb < 8192 ? nb : 8192);
+    hipLaunchKernelGGL((conv1x1_head_fwd_kernel<TR>), dim3(grid), dim3(256), 0, st, (const unsigned char*)x, ldx, scale, shift, w, bias,
+                       logits, B, H, W, C, K, npix);
+    CMU_CHECK_LAUNCH("cmu_conv1x1_head_fwd");
+    return CMU_OK;
+}
+static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+extern "C" int cmu_conv1x1_head_fwd(const void* x, int64_t ldx, const float* in_scale, const float* in_shift, const float* w,
+                                    const float* bias, float* logits, int B, int H, int W, int C, int K, int dt, void* stream) {
+    const int es = cmu_dtype_size(dt);
+    CMU_CHECK_ARG(es > 0 && x && w && bias && logits && B > 0 && H > 0 && W > 0, "cmu_conv1x1_head_fwd: bad args");
+    const int epc = 16 / es;
+    CMU_CHECK_ARG(K >= 1 && K <= HEAD_MAX_K, "cmu_conv1x1_head_fwd: K=%d must be in 1..%d", K, HEAD_MAX_K);
+    CMU_CHECK_ARG(C % epc == 0 && is_pow2(C / epc) && C / epc <= 64, "cmu_conv1x1_head_fwd: C=%d: C/%d must be a power of two <= 64", C, epc);
+    CMU_CHECK_ARG(cmu_aligned16(x) && ldx % epc == 0 && ldx >= C, "cmu_conv1x1_head_fwd: x alignment / stride");
+    CMU_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "cmu_conv1x1_head_fwd: scale/shift must both be set");
+    CMU_DISPATCH_DT(dt, conv1x1_head_fwd_t, x, ldx, in_scale, in_shift, w, bias, logits, B, H, W, C, K, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// module-boundary layout converters (not on the fused hot path)
+// ---------------------------------------------------------------------------------------------
+template <class TR>
+__global__ void apply_to_nchw_kernel(const typename TR::elem_t* __restrict__ y, int64_t ldy, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, int relu_from, float* __restrict__ out, int B, int H, int W,
+                                     int C, int64_t total) {
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(o % W), yy = (int)((o / W) % H), c = (int)((o / ((int64_t)W * H)) % C), b = (int)(o / ((int64_t)W * H * C));
+        float v = TR::to_float(y[(((int64_t)b * H + yy) * W + x) * ldy + c]);
+        if (scale) {
+            v = fmaf(v, scale[c], shift[c]);
+            if (c >= relu_from) v = fmaxf(v, 0.f);
+        }
+        out[o] = v;
+    }
+}
+template <class TR>
+static int apply_to_nchw_t(const void* y, int64_t ldy, const float* scale, const float* shift, int relu_from, float* out, int B,
+                           int H, int W, int C, hipStream_t st) {
+    const int64_t total = (int64_t)B * C * H * W;
+    const int grid = (int)(cmu_div_up64(total, 256) < 8192 ? cmu_div_up64(total, 256) : 8192);
+    hipLaunchKernelGGL((apply_to_nchw_kernel<TR>), dim3(grid), dim3(256), 0, st, (const typename TR::elem_t*)y, ldy, scale, shift,
+                       relu_from, out, B, H, W, C, total);
+    CMU_CHECK_LAUNCH("cmu_apply_to_nchw");
+    return CMU_OK;
+}
+extern "C" int cmu_apply_to_nchw(const void* y, int64_t ldy, const float* scale, const float* shift, int relu_from, float* out,
+                                 int B, int H, int W, int C, int dt, void* stream) {
+    CMU_CHECK_ARG(cmu_dtype_size(dt) > 0 && y && out && B > 0 && H > 0 && W > 0 && C > 0 && ldy >= C, "cmu_apply_to_nchw: bad args");
+    CMU_CHECK_ARG((scale == nullptr) == (shift == nullptr), "cmu_apply_to_nchw: scale/shift must both be set");
+    CMU_DISPATCH_DT(dt, apply_to_nchw_t, y, ldy, scale, shift, relu_from, out, B, H, W, C, (hipStream_t)stream);
+}
+extern "C" int cmu_nhwc_to_nchw(const void* x, int64_t ldx, float* out, int B, int H, int W, int C, int dt, void* stream) {
+    return cmu_apply_to_nchw(x, ldx, nullptr, nullptr, 0, out, B, H, W, C, dt, stream);
+}
+
+template <class TR>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, typename TR::elem_t* __restrict__ out, int64_t ldo, int B, int H,
+                                    int W, int C, int64_t total) {
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(o % C);
+        const int64_t pix = o / C;
+        const int xx = (int)(pix % W), yy = (int)((pix / W) % H), b = (int)(pix / ((int64_t)W * H));
+        out[pix * ldo + c] = TR::from_float(x[(((int64_t)b * C + c) * H + yy) * W + xx]);
+    }
+}
+template <class TR>
+static int nchw_to_nhwc_t(const float* x, void* out, int64_t ldo, int B, int H, int W, int C, hipStream_t st) {
+    const int64_t total = (int64_t)B * C * H * W;
+    const int grid = (int)(cmu_div_up64(total, 256) < 8192 ? cmu_div_up64(total, 256) : 8192);
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<TR>), dim3(grid), dim3(256), 0, st, x, (typename TR::elem_t*)out, ldo, B, H, W, C, total);
+    CMU_CHECK_LAUNCH("cmu_nchw_to_nhwc");
+    return CMU_OK;
+}
+extern "C" int cmu_nchw_to_nhwc(const float* x, void* out, int64_t ldo, int B, int H, int W, int C, int dt, void* stream) {
+    CMU_CHECK_ARG(cmu_dtype_size(dt) > 0 && x && out && B > 0 && H > 0 && W > 0 && C > 0 && ldo >= C, "cmu_nchw_to_nhwc: bad args");
+    CMU_DISPATCH_DT(dt, nchw_to_nhwc_t, x, out, ldo, B, H, W, C, (hipStream_t)stream);
+}

@@ -1,0 +1,272 @@
+"""Tensor-level wrappers over the C-ABI (include/cmunet_hip.h).  PyTorch is used only for device
+memory and streams; every op below runs a hand-written HIP kernel and raises if the library or a
+GPU is missing (no CPU / eager fallback).
+
+``Act`` describes an NHWC activation that may be a channel slice of a wider buffer and may carry a
+*pending transform* (a training-mode BatchNorm+ReLU left for the consumer to apply while it stages
+its input tile) -- see the header for the convention.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import F32, F16, BF16, call
+
+TORCH_DT = {F32: torch.float32, F16: torch.float16, BF16: torch.bfloat16}
+DT_OF = {v: k for k, v in TORCH_DT.items()}
+DT_NAME = {F32: "f32", F16: "f16", BF16: "bf16"}
+NAME_DT = {"f32": F32, "fp32": F32, "float32": F32, "f16": F16, "fp16": F16, "float16": F16, "bf16": BF16, "bfloat16": BF16}
+
+
+def dt_code(dt):
+    if isinstance(dt, str):
+        return NAME_DT[dt]
+    if isinstance(dt, torch.dtype):
+        return DT_OF[dt]
+    return int(dt)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "HIP path: tensor must live on the GPU"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _f32c(t):
+    assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+    return t
+
+
+class Act:
+    """NHWC activation view: channels [coff, coff+C) of ``buf`` (B,H,W,ld) + optional pending transform."""
+
+    __slots__ = ("buf", "coff", "C", "scale", "shift", "relu_from")
+
+    def __init__(self, buf, coff=0, C=None, scale=None, shift=None, relu_from=0):
+        assert buf.dim() == 4 and buf.is_contiguous() and buf.is_cuda
+        self.buf, self.coff = buf, coff
+        self.C = buf.shape[3] - coff if C is None else C
+        self.scale, self.shift, self.relu_from = scale, shift, relu_from
+
+    @property
+    def B(self):
+        return self.buf.shape[0]
+
+    @property
+    def H(self):
+        return self.buf.shape[1]
+
+    @property
+    def W(self):
+        return self.buf.shape[2]
+
+    @property
+    def ld(self):
+        return self.buf.shape[3]
+
+    @property
+    def dt(self):
+        return DT_OF[self.buf.dtype]
+
+    def ptr(self):
+        return ctypes.c_void_p(self.buf.data_ptr() + self.coff * self.buf.element_size())
+
+    def with_transform(self, scale, shift, relu_from=0):
+        return Act(self.buf, self.coff, self.C, scale, shift, relu_from)
+
+    def plain(self):
+        return Act(self.buf, self.coff, self.C)
+
+
+def new_act(B, H, W, C, dt, device):
+    return Act(torch.empty((B, H, W, C), dtype=TORCH_DT[dt_code(dt)], device=device))
+
+
+# ------------------------------------------------------------------------------------------------
+# packing
+# ------------------------------------------------------------------------------------------------
+def pack_conv3x3(w, dt, transpose_flip=False):
+    dt = dt_code(dt)
+    Cout, Cin = w.shape[0], w.shape[1]
+    n = _lib.lib().cmu_pack_conv3x3_elems(Cin, Cout, dt, int(transpose_flip))
+    out = torch.empty(n, dtype=TORCH_DT[dt], device=w.device)
+    call("cmu_pack_conv3x3", _p(_f32c(w)), _p(out), Cin, Cout, dt, int(transpose_flip), _stream())
+    return out
+
+
+def pack_convT2x2(w, dt, mode):
+    dt = dt_code(dt)
+    Cin, Cout = w.shape[0], w.shape[1]
+    n = _lib.lib().cmu_pack_convT2x2_elems(Cin, Cout, dt, mode)
+    out = torch.empty(n, dtype=TORCH_DT[dt], device=w.device)
+    call("cmu_pack_convT2x2", _p(_f32c(w)), _p(out), Cin, Cout, dt, mode, _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# forward
+# ------------------------------------------------------------------------------------------------
+def ntiles(B, H, W):
+    return _lib.lib().cmu_conv_ntiles(B, H, W)
+
+
+def new_stats(B, H, W, C, device):
+    return torch.empty((ntiles(B, H, W), 2, C), dtype=torch.float32, device=device)
+
+
+def conv3x3_c1_fwd(x_bhw, w, out, stats=None, mask=None, mask_per_sample=False):
+    B, H, W = x_bhw.shape
+    Cout = w.shape[0]
+    assert out.C == Cout and (out.B, out.H, out.W) == (B, H, W)
+    if mask is not None:
+        assert mask.dtype == torch.uint8 and mask.is_contiguous()
+    call("cmu_conv3x3_c1_fwd", _p(_f32c(x_bhw)), _p(mask), int(mask_per_sample), _p(_f32c(w)), out.ptr(), out.ld,
+         _p(stats), B, H, W, Cout, out.dt, _stream())
+
+
+def conv3x3_fwd(x, wpacked, out, stats=None):
+    assert x.dt == out.dt and (x.B, x.H, x.W) == (out.B, out.H, out.W)
+    call("cmu_conv3x3_fwd", x.ptr(), x.ld, _p(x.scale), _p(x.shift), x.relu_from, _p(wpacked), out.ptr(), out.ld,
+         _p(stats), x.B, x.H, x.W, x.C, out.C, x.dt, _stream())
+
+
+def bn_finalize(stats, count, conv_bias, gamma, beta, running_mean, running_var, momentum, eps, training,
+                scale, shift, save_mean, save_invstd, ws):
+    C = scale.numel()
+    nt = 0 if stats is None else stats.shape[0]
+    need = _lib.lib().cmu_bn_finalize_ws_bytes(C)
+    assert ws is None or ws.numel() * ws.element_size() >= need
+    call("cmu_bn_finalize", _p(stats), nt, int(count), _p(conv_bias), _p(gamma), _p(beta), _p(running_mean),
+         _p(running_var), float(momentum), float(eps), int(training), _p(scale), _p(shift), _p(save_mean),
+         _p(save_invstd), C, _p(ws), _stream())
+
+
+def bnrelu_maxpool_fwd(y, out):
+    assert y.scale is not None
+    call("cmu_bnrelu_maxpool_fwd", y.ptr(), y.ld, _p(y.scale), _p(y.shift), out.ptr(), out.ld, y.B, y.H, y.W, y.C,
+         y.dt, _stream())
+
+
+def convT2x2_fwd(x, wpacked, bias, out):
+    Cout = out.C
+    assert (out.H, out.W) == (2 * x.H, 2 * x.W)
+    call("cmu_convT2x2_fwd", x.ptr(), x.ld, _p(x.scale), _p(x.shift), x.relu_from, _p(wpacked), _p(_f32c(bias)),
+         out.ptr(), out.ld, x.B, x.H, x.W, x.C, Cout, x.dt, _stream())
+
+
+def conv1x1_head_fwd(x, w, bias, logits):
+    K = w.shape[0]
+    call("cmu_conv1x1_head_fwd", x.ptr(), x.ld, _p(x.scale), _p(x.shift), _p(_f32c(w)), _p(_f32c(bias)),
+         _p(_f32c(logits)), x.B, x.H, x.W, x.C, K, x.dt, _stream())
+
+
+def apply_to_nchw(y, out=None):
+    if out is None:
+        out = torch.empty((y.B, y.C, y.H, y.W), dtype=torch.float32, device=y.buf.device)
+    call("cmu_apply_to_nchw", y.ptr(), y.ld, _p(y.scale), _p(y.shift), y.relu_from, _p(out), y.B, y.H, y.W, y.C,
+         y.dt, _stream())
+    return out
+
+
+def nchw_to_nhwc(x_nchw, out):
+    B, C, H, W = x_nchw.shape
+    call("cmu_nchw_to_nhwc", _p(_f32c(x_nchw)), out.ptr(), out.ld, B, H, W, C, out.dt, _stream())
+
+
+# ------------------------------------------------------------------------------------------------
+# backward
+# ------------------------------------------------------------------------------------------------
+def bn_bwd_reduce(dA, y, save_mean, save_invstd, dgamma, dbeta, coef, ws):
+    call("cmu_bn_bwd_reduce", dA.ptr(), dA.ld, y.ptr(), y.ld, _p(y.scale), _p(y.shift), _p(save_mean), _p(save_invstd),
+         _p(dgamma), _p(dbeta), _p(coef), y.B, y.H, y.W, y.C, y.dt, _p(ws), _stream())
+
+
+def bn_bwd_apply(dA, y, save_mean, save_invstd, coef, dY):
+    call("cmu_bn_bwd_apply", dA.ptr(), dA.ld, y.ptr(), y.ld, _p(y.scale), _p(y.shift), _p(save_mean), _p(save_invstd),
+         _p(coef), dY.ptr(), dY.ld, y.B, y.H, y.W, y.C, y.dt, _stream())
+
+
+def conv3x3_wgrad(x, dY, dW, ws):
+    Cout, Cin = dW.shape[0], dW.shape[1]
+    assert x.C == Cin and dY.C == Cout
+    call("cmu_conv3x3_wgrad", x.ptr(), x.ld, _p(x.scale), _p(x.shift), x.relu_from, dY.ptr(), dY.ld, _p(_f32c(dW)),
+         x.B, x.H, x.W, Cin, Cout, x.dt, _p(ws), _stream())
+
+
+def conv3x3_c1_wgrad(x_bhw, dY, dW, ws, mask=None, mask_per_sample=False):
+    B, H, W = x_bhw.shape
+    call("cmu_conv3x3_c1_wgrad", _p(_f32c(x_bhw)), _p(mask), int(mask_per_sample), dY.ptr(), dY.ld, _p(_f32c(dW)),
+         B, H, W, dW.shape[0], dY.dt, _p(ws), _stream())
+
+
+def maxpool_bwd(dP, dSkip, y, dA):
+    call("cmu_maxpool_bwd", dP.ptr(), dP.ld, None if dSkip is None else dSkip.ptr(), 0 if dSkip is None else dSkip.ld,
+         y.ptr(), y.ld, _p(y.scale), _p(y.shift), dA.ptr(), dA.ld, y.B, y.H, y.W, y.C, y.dt, _stream())
+
+
+def convT2x2_dgrad(dOut, wpacked_dgrad, dX):
+    call("cmu_convT2x2_dgrad", dOut.ptr(), dOut.ld, _p(wpacked_dgrad), dX.ptr(), dX.ld, dX.B, dX.H, dX.W, dX.C, dOut.C,
+         dX.dt, _stream())
+
+
+def convT2x2_wgrad(x, dOut, dW, dbias, ws):
+    Cin, Cout = dW.shape[0], dW.shape[1]
+    call("cmu_convT2x2_wgrad", x.ptr(), x.ld, _p(x.scale), _p(x.shift), x.relu_from, dOut.ptr(), dOut.ld, _p(_f32c(dW)),
+         _p(_f32c(dbias)), x.B, x.H, x.W, Cin, Cout, x.dt, _p(ws), _stream())
+
+
+def conv1x1_head_bwd(dlogits, x, w, dX, dW, dbias, ws):
+    K = w.shape[0]
+    call("cmu_conv1x1_head_bwd", _p(_f32c(dlogits)), x.ptr(), x.ld, _p(x.scale), _p(x.shift), _p(_f32c(w)), dX.ptr(), dX.ld,
+         _p(_f32c(dW)), _p(_f32c(dbias)), x.B, x.H, x.W, x.C, K, x.dt, _p(ws), _stream())
+
+
+# ------------------------------------------------------------------------------------------------
+# losses / heads / optimiser
+# ------------------------------------------------------------------------------------------------
+def masked_mse_fwd_bwd(logits, channel, img, mask, loss, dlogits, loss_scale, ws):
+    B, K, H, W = logits.shape
+    call("cmu_masked_mse_fwd_bwd", _p(_f32c(logits)), K, channel, _p(_f32c(img)), _p(mask), _p(loss), _p(dlogits),
+         float(loss_scale), B, H, W, _p(ws), _stream())
+
+
+def softmax_ce_dice_fwd_bwd(logits, y1h, out, dlogits, loss_scale, ws):
+    B, K, H, W = logits.shape
+    assert K == 2 and y1h.dtype == torch.float64 and y1h.is_contiguous()
+    call("cmu_softmax_ce_dice_fwd_bwd", _p(_f32c(logits)), _p(y1h), _p(out), _p(dlogits), float(loss_scale), B, H, W,
+         _p(ws), _stream())
+
+
+def infonce_inbatch_fwd_bwd(pred, keys, loss, dpred, rank, temperature, ct_weight):
+    B, D = pred.shape
+    call("cmu_infonce_inbatch_fwd_bwd", _p(_f32c(pred)), _p(_f32c(keys)), _p(loss), _p(dpred), B, keys.shape[0], D,
+         rank, float(temperature), float(ct_weight), _stream())
+
+
+def moco_infonce_enqueue(q_raw, k_raw, keys_all, queue, queue_ptr, loss, dq, k_norm_out, temperature, ws):
+    B, D = q_raw.shape
+    K = queue.shape[1]
+    Nk = B if keys_all is None else keys_all.shape[0]
+    call("cmu_moco_infonce_enqueue", _p(_f32c(q_raw)), _p(_f32c(k_raw)), _p(keys_all), Nk, _p(_f32c(queue)),
+         _p(queue_ptr), _p(loss), _p(dq), _p(k_norm_out), B, D, K, float(temperature), _p(ws), _stream())
+
+
+def l2_normalize_rows(x, out):
+    call("cmu_l2_normalize_rows", _p(_f32c(x)), _p(out), x.shape[0], x.shape[1], _stream())
+
+
+def ema_update(target, online, momentum):
+    assert target.numel() == online.numel()
+    call("cmu_ema_update", _p(_f32c(target)), _p(_f32c(online)), target.numel(), float(momentum), _stream())
+
+
+def adam_step(p, g, m, v, wd_mask, lr, beta1, beta2, eps, weight_decay, decoupled, step, grad_scale=1.0):
+    call("cmu_adam_step", _p(_f32c(p)), _p(_f32c(g)), _p(_f32c(m)), _p(_f32c(v)), _p(wd_mask), p.numel(), float(lr),
+         float(beta1), float(beta2), float(eps), float(weight_decay), int(decoupled), int(step), float(grad_scale),
+         _stream())

@@ -1,0 +1,210 @@
+/*
+ * cmunet_hip.h -- C-ABI of the MI355X (gfx950) CM-UNet hot-path library (libcmunet_hip.so).
+ *
+ * The reference (CamilleChallier/Contrastive-Masked-UNet) is 100 % Python: the arithmetic of its hot
+ * path is dispatched by torch.nn modules into ATen/cuDNN.  There is no FFI in the reference; the
+ * entry points below are what a binding for this path replaces, and each one cites the reference
+ * call site whose ATen dispatch it stands for (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - plain C: device pointers, sizes, a dtype enum and a hipStream_t (passed as void*); no torch types.
+ *   - every function returns 0 on success or a negative CMU_ERR_* code; cmu_last_error() returns a
+ *     thread-local message.  Nothing is allocated or freed inside the library; workspaces are passed in
+ *     and sized with the cmu_*_ws_bytes() queries.  No global mutable state; re-entrant.
+ *   - activations are NHWC with an explicit pixel stride `ld` (elements), so a tensor may be a channel
+ *     slice of a wider buffer (the concat-free decoder: UpBlock's torch.cat, Finetuning/model.py:80,
+ *     never materialises).  dtype of activations/packed weights = `dt`; parameters, statistics,
+ *     gradients of parameters and logits are fp32.
+ *   - a "pending transform" (in_scale, in_shift, relu_from) is a training-mode BatchNorm+ReLU that the
+ *     producer left un-applied: the consumer applies  v = x*scale[c]+shift[c]; if (c>=relu_from) v=max(v,0)
+ *     while staging its input tile (BatchNorm2d + ReLU of Finetuning/model.py:18-19,21-22 fused into the
+ *     next conv / pool / convT load).  in_scale == NULL means identity.
+ */
+#ifndef CMUNET_HIP_H
+#define CMUNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { CMU_F32 = 0, CMU_F16 = 1, CMU_BF16 = 2 } cmu_dtype;
+
+#define CMU_OK 0
+#define CMU_ERR_ARG (-1)      /* bad shape / alignment / null pointer */
+#define CMU_ERR_UNSUPPORTED (-2)
+#define CMU_ERR_WORKSPACE (-3)
+#define CMU_ERR_LAUNCH (-4)   /* hipGetLastError() != hipSuccess after a launch */
+
+const char* cmu_last_error(void);
+int cmu_version(void);
+/* element size in bytes of a cmu_dtype */
+int cmu_dtype_size(int dt);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight packing (parameters stay in the reference's layouts; packed copies are per-step scratch)
+ * ------------------------------------------------------------------------------------------- */
+/* nn.Conv2d weight (Cout,Cin,3,3) fp32 -> [chunk][tap][CoutPad][KC] dt for cmu_conv3x3_fwd
+ * (Finetuning/model.py:17,20).  transpose_flip=1 packs the data-gradient form
+ * w'[tap'][c][n] = w[n][c][2-kh][2-kw] so that cmu_conv3x3_fwd computes dX from dY.            */
+int64_t cmu_pack_conv3x3_elems(int Cin, int Cout, int dt, int transpose_flip);
+int cmu_pack_conv3x3(const float* w, void* out, int Cin, int Cout, int dt, int transpose_flip, void* stream);
+/* nn.ConvTranspose2d weight (Cin,Cout,2,2) fp32 (Finetuning/model.py:60).
+ * mode 0: forward form  [chunk(Cin)][1][(ij*Cout+co)Pad][KC]
+ * mode 1: data-grad form [chunk(4*Cout: ij*Cout+co)][1][CinPad][KC]                              */
+int64_t cmu_pack_convT2x2_elems(int Cin, int Cout, int dt, int mode);
+int cmu_pack_convT2x2(const float* w, void* out, int Cin, int Cout, int dt, int mode, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Forward
+ * ------------------------------------------------------------------------------------------- */
+/* (B,H,W) fp32 image -> NHWC 1-channel is the same memory; this entry is the first conv of the
+ * network (Cin == 1): Conv2d(1,C,3,p=1) of model.py:96 (down_conv1) computed directly, with the
+ * optional patch-mask multiply x*(1-mask) of UNet_encoder.py:156 / spark.py:93-94 fused into the load.
+ * mask: uint8 (mask_per_sample ? B : 1, H, W) or NULL.  No bias (BatchNorm follows; see cmu_bn_finalize).
+ * stats: [cmu_conv_ntiles][2][Cout] fp32 partial sums (sum, sum of squares) or NULL.               */
+int cmu_conv3x3_c1_fwd(const float* x, const uint8_t* mask, int mask_per_sample, const float* w /*(Cout,1,3,3)*/,
+                       void* y, int64_t ldy, float* stats, int B, int H, int W, int Cout, int dt, void* stream);
+
+/* Conv2d(Cin,Cout,3,padding=1) as implicit GEMM on MFMA (model.py:17,20), bias-free, with the producer's
+ * pending BN+ReLU applied on load and per-tile channel statistics of the raw output in the epilogue. */
+int cmu_conv3x3_fwd(const void* x, int64_t ldx, const float* in_scale, const float* in_shift, int relu_from,
+                    const void* wpacked, void* y, int64_t ldy, float* stats,
+                    int B, int H, int W, int Cin, int Cout, int dt, void* stream);
+/* number of spatial tiles (rows of the stats slab) for a (B,H,W) problem */
+int cmu_conv_ntiles(int B, int H, int W);
+
+/* BatchNorm2d training statistics (model.py:18,21; eps 1e-5, momentum 0.1): reduces the slab written by
+ * a conv into batch mean / biased var, produces the pending transform scale=gamma*invstd,
+ * shift=beta-mean*scale, saves mean/invstd for backward and updates running_mean (with the conv bias
+ * added back) / running_var (unbiased).  training=0: scale/shift from the running statistics.
+ * ws: cmu_bn_finalize_ws_bytes(C) bytes.                                                          */
+int64_t cmu_bn_finalize_ws_bytes(int C);
+int cmu_bn_finalize(const float* stats, int ntiles, int64_t count, const float* conv_bias, const float* gamma,
+                    const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                    int training, float* scale, float* shift, float* save_mean, float* save_invstd,
+                    int C, void* ws, void* stream);
+
+/* BN+ReLU apply + MaxPool2d(2) (model.py:40,44): raw conv output -> activated pooled tensor. */
+int cmu_bnrelu_maxpool_fwd(const void* y, int64_t ldy, const float* scale, const float* shift,
+                           void* out, int64_t ldo, int B, int H, int W, int C, int dt, void* stream);
+
+/* ConvTranspose2d(Cin,Cout,2,stride=2) (model.py:60,78) as GEMM M=B*H*W, N=4*Cout, K=Cin with the
+ * pending transform on load, bias added, and a pixel-shuffle store into out (B,2H,2W,ldo) -- normally the
+ * left half of the decoder's concat buffer.                                                        */
+int cmu_convT2x2_fwd(const void* x, int64_t ldx, const float* in_scale, const float* in_shift, int relu_from,
+                     const void* wpacked, const float* bias, void* out, int64_t ldo,
+                     int B, int H, int W, int Cin, int Cout, int dt, void* stream);
+
+/* Conv2d(C,K,1) head (model.py:108,130) with pending transform on load: logits (B,K,H,W) fp32 NCHW. */
+int cmu_conv1x1_head_fwd(const void* x, int64_t ldx, const float* in_scale, const float* in_shift,
+                         const float* w /*(K,C)*/, const float* bias, float* logits,
+                         int B, int H, int W, int C, int K, int dt, void* stream);
+
+/* pending transform applied, NHWC dt -> NCHW fp32 (module boundary of DoubleConv/DownBlock/UpBlock). */
+int cmu_apply_to_nchw(const void* y, int64_t ldy, const float* scale, const float* shift, int relu_from,
+                      float* out, int B, int H, int W, int C, int dt, void* stream);
+/* NCHW fp32 -> NHWC dt (module boundary, inputs with C > 1) and back for gradients. */
+int cmu_nchw_to_nhwc(const float* x, void* out, int64_t ldo, int B, int H, int W, int C, int dt, void* stream);
+int cmu_nhwc_to_nchw(const void* x, int64_t ldx, float* out, int B, int H, int W, int C, int dt, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Backward
+ * ------------------------------------------------------------------------------------------- */
+/* BatchNorm2d+ReLU backward, phase 1: per-channel sums of dz = dA*[y*scale+shift>0] and dz*xhat.
+ * Produces dgamma, dbeta (fp32, overwritten) and coef[2][C] = (sum dz / N, sum dz*xhat / N).      */
+int64_t cmu_bn_bwd_ws_bytes(int C);
+int cmu_bn_bwd_reduce(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift,
+                      const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* coef,
+                      int B, int H, int W, int C, int dt, void* ws, void* stream);
+/* phase 2: dY = scale * (dz - coef0 - xhat*coef1), written to dY (may alias dA). */
+int cmu_bn_bwd_apply(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift,
+                     const float* save_mean, const float* save_invstd, const float* coef, void* dY, int64_t ldo,
+                     int B, int H, int W, int C, int dt, void* stream);
+
+/* weight gradient of Conv2d 3x3 (autograd of model.py:17,20): dW (Cout,Cin,3,3) fp32, overwritten.
+ * x is the layer's input with its pending transform (applied on load).  ws: cmu_conv3x3_wgrad_ws_bytes. */
+int64_t cmu_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int dt);
+int cmu_conv3x3_wgrad(const void* x, int64_t ldx, const float* in_scale, const float* in_shift, int relu_from,
+                      const void* dY, int64_t ldd, float* dW, int B, int H, int W, int Cin, int Cout, int dt,
+                      void* ws, void* stream);
+/* first layer (Cin == 1): dW (Cout,1,3,3) from the fp32 image (+ optional mask) and dY. */
+int64_t cmu_conv3x3_c1_wgrad_ws_bytes(int B, int H, int W, int Cout);
+int cmu_conv3x3_c1_wgrad(const float* x, const uint8_t* mask, int mask_per_sample, const void* dY, int64_t ldd,
+                         float* dW, int B, int H, int W, int Cout, int dt, void* ws, void* stream);
+
+/* MaxPool2d(2) backward fused with the skip-branch add: dA = unpool(dP) + dSkip (dSkip may be NULL).
+ * The arg-max is recomputed from the raw output + transform (first max in row-major 2x2 order, as ATen). */
+int cmu_maxpool_bwd(const void* dP, int64_t ldp, const void* dSkip, int64_t lds, const void* y, int64_t ldy,
+                    const float* scale, const float* shift, void* dA, int64_t lda,
+                    int B, int H, int W, int C, int dt, void* stream);
+
+/* ConvTranspose2d 2x2 s2 backward.  data: dX (B,H,W,Cin) from dOut (B,2H,2W,ldd) (GEMM K = 4*Cout).
+ * weight: dW (Cin,Cout,2,2) and dbias (Cout) fp32, overwritten.                                    */
+int cmu_convT2x2_dgrad(const void* dOut, int64_t ldd, const void* wpacked_dgrad, void* dX, int64_t ldx,
+                       int B, int H, int W, int Cin, int Cout, int dt, void* stream);
+int64_t cmu_convT2x2_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int dt);
+int cmu_convT2x2_wgrad(const void* x, int64_t ldx, const float* in_scale, const float* in_shift, int relu_from,
+                       const void* dOut, int64_t ldd, float* dW, float* dbias,
+                       int B, int H, int W, int Cin, int Cout, int dt, void* ws, void* stream);
+
+/* 1x1 head backward: dX (NHWC dt) = dLogits^T W ; dW (K,C), dbias (K) fp32 overwritten. */
+int64_t cmu_conv1x1_head_bwd_ws_bytes(int B, int H, int W, int C, int K);
+int cmu_conv1x1_head_bwd(const float* dlogits, const void* x, int64_t ldx, const float* in_scale, const float* in_shift,
+                         const float* w, void* dX, int64_t ldo, float* dW, float* dbias,
+                         int B, int H, int W, int C, int K, int dt, void* ws, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Losses / pretraining heads
+ * ------------------------------------------------------------------------------------------- */
+/* CM-UNet masked reconstruction (cmunet_head.py:62-70): target = per-row normalised image (unbiased var,
+ * eps 1e-6), loss = sum((pred-target)^2*mask)/sum(mask), pred = logits[:,channel].  Writes loss (1 fp32)
+ * and, if dlogits != NULL, d loss*loss_scale / d logits (B,K,H,W) (zero on the other channels).
+ * mask uint8 (B,H,W).  ws: cmu_masked_mse_ws_bytes(B,H).                                            */
+int64_t cmu_masked_mse_ws_bytes(int B, int H);
+int cmu_masked_mse_fwd_bwd(const float* logits, int K, int channel, const float* img, const uint8_t* mask,
+                           float* loss, float* dlogits, float loss_scale, int B, int H, int W, void* ws, void* stream);
+
+/* Finetune criterion (train.py:455; metrics.py:135-180,503): softmax over 2 classes, CE with one-hot
+ * (probability) targets averaged over B*H*W, Dice/IoU counters on softmax[:,1] > 0.5 (no gradient: A-4).
+ * out[0]=ce, out[1]=dice_loss, out[2]=iou_loss, out[3..5]=tp, sum_pr, sum_gt.  y1h fp64 (B,2,H,W).
+ * dlogits (nullable) = d ce / d logits * loss_scale.                                               */
+int64_t cmu_softmax_ce_dice_ws_bytes(int B, int H, int W);
+int cmu_softmax_ce_dice_fwd_bwd(const float* logits, const double* y1h, float* out, float* dlogits, float loss_scale,
+                                int B, int H, int W, void* ws, void* stream);
+
+/* CM-UNet in-batch InfoNCE (cmunet_head.py:72-88): pred (B,D) raw predictor output (L2-normalised inside),
+ * keys (N,D) gathered, already normalised target projections; label i + B*rank; loss = ct_w*2*t*CE.
+ * dpred (nullable) = d loss / d pred (B,D).                                                        */
+int cmu_infonce_inbatch_fwd_bwd(const float* pred, const float* keys, float* loss, float* dpred,
+                                int B, int N, int D, int rank, float temperature, float ct_weight, void* stream);
+
+/* MoCo-v2 InfoNCE + momentum-queue update in ONE launch (moco2_module.py:256-285, 160-175):
+ * q_raw,k_raw (B,D) encoder outputs (normalised inside); queue (D,K) fp32; logits = [q.k, q@queue]/t,
+ * CE with label 0 on the PRE-enqueue queue; then queue[:, ptr:ptr+Nk] = keys_all^T (keys_all (Nk,D),
+ * the all-gathered normalised keys; may be NULL on one rank = normalised k_raw) and *ptr=(ptr+Nk)%K.
+ * dq (nullable) = d loss / d q_raw.  k_norm_out (nullable, (B,D)) receives normalised keys.
+ * ws: cmu_moco_ws_bytes(B,K).                                                                     */
+int64_t cmu_moco_ws_bytes(int B, int K);
+int cmu_moco_infonce_enqueue(const float* q_raw, const float* k_raw, const float* keys_all, int Nk,
+                             float* queue, int64_t* queue_ptr, float* loss, float* dq, float* k_norm_out,
+                             int B, int D, int K, float temperature, void* ws, void* stream);
+/* L2-normalise rows (F.normalize(dim=1), eps 1e-12) -- used before the key all-gather. */
+int cmu_l2_normalize_rows(const float* x, float* out, int B, int D, void* stream);
+
+/* EMA p_t = m*p_t + (1-m)*p_o over a flat fp32 arena (cmunet.py:78-92, moco2_module.py:153-158). */
+int cmu_ema_update(float* target, const float* online, int64_t n, float momentum, void* stream);
+
+/* Fused Adam/AdamW step over a flat fp32 arena (torch.optim.Adam, train.py:341; AdamW cmunet_config.py:79-83).
+ * decoupled != 0: AdamW (p *= 1 - lr*wd) else L2 (g += wd*p).  wd_mask (nullable, uint8 per element):
+ * weight decay applies where mask != 0 (bias / norm parameters are excluded, cmunet_config.py:84-91).
+ * grad_scale multiplies the gradient first (loss-scale removal / DP mean).                          */
+int cmu_adam_step(float* p, const float* g, float* m, float* v, const uint8_t* wd_mask, int64_t n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled,
+                  int64_t step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMUNET_HIP_H */

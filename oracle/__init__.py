@@ -1,0 +1,23 @@
+"""CPU oracle for the CM-UNet hot path -- TEST INFRASTRUCTURE ONLY.
+
+Nothing under ``oracle/`` is part of the product.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import it, and only as the checker.  The product path
+(``contrastive-masked-unet_amd``) never imports this package and fails loudly
+when its HIP library is missing.
+
+The reference's arithmetic for this path is floating point and lives in
+PyTorch ATen ops, so the restatement is written with
+plain ``torch`` CPU functional ops in fp32/fp64 -- no ``nn.Module`` from the
+reference, no code copied from it.  Each function cites the reference
+file:line it follows.
+
+Pinning (see DESIGN.md "Oracle"):
+  * dense UNet blocks and tensor losses are pinned against the reference
+    itself, imported in the build container by ``oracle/gen_golden.py``
+    (the reference has no tests / golden vectors of its own: SURVEY F2);
+  * the CM-UNet / MoCo parts of the reference cannot be imported
+    (mmengine / lightning absent, hard-coded CUDA): their restatement is
+    pinned only through the shared blocks and closed forms
+    -> "parity unpinned by the reference" for those rows.
+"""

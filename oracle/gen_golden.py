@@ -1,0 +1,272 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE ITSELF (build container only).
+
+TEST INFRASTRUCTURE ONLY.  Imports /root/reference/Finetuning/model.py (unmodified) and
+Finetuning/metrics.py (behind a 3-file scikit-image stub created in a temp dir: SURVEY Appendix C-2),
+feeds them seeded inputs/weights and stores inputs + expected outputs/gradients as small fixtures.
+The reference never travels: only the vectors written here do.  Every fixture is also checked
+against the oracle restatement (oracle/unet.py, oracle/losses.py) before it is written, so a
+fixture that exists implies "oracle == reference" on that case.
+
+Usage (from the repo root, CPU):  python -m oracle.gen_golden
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+sys.dont_write_bytecode = True
+
+
+def import_reference():
+    sys.path.insert(0, os.path.join(REF, "Finetuning"))
+    import model as ref_model  # noqa
+    stub = tempfile.mkdtemp(prefix="skimage_stub_")
+    os.makedirs(os.path.join(stub, "skimage"))
+    with open(os.path.join(stub, "skimage", "__init__.py"), "w") as f:
+        f.write("from . import morphology, measure\n")
+    with open(os.path.join(stub, "skimage", "morphology.py"), "w") as f:
+        f.write("def skeletonize(*a, **k):\n    raise NotImplementedError\n"
+                "def skeletonize_3d(*a, **k):\n    raise NotImplementedError\n")
+    with open(os.path.join(stub, "skimage", "measure.py"), "w") as f:
+        f.write("def find_contours(*a, **k):\n    raise NotImplementedError\n")
+    sys.path.insert(0, stub)
+    import metrics as ref_metrics  # noqa
+    return ref_model, ref_metrics
+
+
+def t2n(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **t2n(arrays))
+    print(f"  wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def close(a, b, tol=2e-5, what=""):
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item() + 1e-12
+    assert err <= tol * max(1.0, ref), f"oracle != reference on {what}: {err} (ref max {ref})"
+
+
+def grads_of(mod):
+    return {k: p.grad.detach().clone() for k, p in mod.named_parameters()}
+
+
+def main():
+    from oracle import unet as OU, losses as OL
+    ref, M = import_reference()
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+
+    def load(mod, sd):
+        missing = mod.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+        return missing
+
+    # ---- 1. DoubleConv ------------------------------------------------------------------
+    for tag, cin, cout, shape in (("a", 1, 16, (2, 20, 24)), ("b", 16, 32, (3, 16, 16)), ("c", 8, 8, (2, 7, 9))):
+        g = torch.Generator().manual_seed(100 + cin)
+        full = OU.make_state_dict(base_ch=cout, depth=1, in_ch=cin, seed=11 + cin, decoder=False)
+        sd = {k[len("double_conv."):]: v for k, v in full.items()}        # keys 'double_conv.0.weight' ...
+        m = ref.DoubleConv(cin, cout)
+        load(m, sd)
+        m.train()
+        x = torch.randn(shape[0], cin, shape[1], shape[2], generator=g, requires_grad=True)
+        go = torch.randn(shape[0], cout, shape[1], shape[2], generator=g)
+        y = m(x)
+        (y * go).sum().backward()
+        osd = OU.clone_sd(sd, requires_grad=True)
+        xo = x.detach().clone().requires_grad_(True)
+        yo = OU.double_conv(xo, osd, "double_conv.", True)
+        (yo * go).sum().backward()
+        close(yo, y, what=f"double_conv_{tag} y")
+        close(xo.grad, x.grad, what=f"double_conv_{tag} dx")
+        for k, p in m.named_parameters():
+            close(osd[k].grad, p.grad, tol=1e-4, what=f"double_conv_{tag} d{k}")
+        close(osd["double_conv.1.running_var"], m.double_conv[1].running_var, what="running_var")
+        out = {"x": x, "go": go, "y": y, "dx": x.grad}
+        out.update({"sd." + k: v for k, v in sd.items()})
+        out.update({"grad." + k: v for k, v in grads_of(m).items()})
+        out.update({"after." + k: v for k, v in m.state_dict().items() if "running" in k or "num_batches" in k})
+        save(f"double_conv_{tag}", **out)
+
+    # ---- 2. DownBlock -------------------------------------------------------------------
+    g = torch.Generator().manual_seed(200)
+    full = OU.make_state_dict(base_ch=32, depth=1, in_ch=16, seed=21, decoder=False)
+    sd = dict(full)                                                       # 'double_conv.double_conv.0.weight'
+    m = ref.DownBlock(16, 32)
+    load(m, sd)
+    m.train()
+    x = torch.randn(2, 16, 16, 16, generator=g, requires_grad=True)
+    gd = torch.randn(2, 32, 8, 8, generator=g)
+    gs = torch.randn(2, 32, 16, 16, generator=g)
+    down, skip = m(x)
+    ((down * gd).sum() + (skip * gs).sum()).backward()
+    osd = OU.clone_sd(sd, requires_grad=True)
+    xo = x.detach().clone().requires_grad_(True)
+    d2, s2 = OU.down_block(xo, osd, "", True)
+    ((d2 * gd).sum() + (s2 * gs).sum()).backward()
+    close(d2, down, what="down_block down"); close(s2, skip, what="down_block skip"); close(xo.grad, x.grad, what="down_block dx")
+    out = {"x": x, "gd": gd, "gs": gs, "down": down, "skip": skip, "dx": x.grad}
+    out.update({"sd." + k: v for k, v in sd.items()})
+    out.update({"grad." + k: v for k, v in grads_of(m).items()})
+    save("down_block", **out)
+
+    # ---- 3. UpBlock (conv_transpose) ----------------------------------------------------
+    g = torch.Generator().manual_seed(300)
+    full = OU.make_state_dict(base_ch=16, depth=2, in_ch=1, seed=31, encoder=False)
+    sd = {k[len("up_conv1."):]: v for k, v in full.items() if k.startswith("up_conv1.")}
+    m = ref.UpBlock(32, 16, "conv_transpose")
+    load(m, sd)
+    m.train()
+    xd = torch.randn(2, 32, 8, 8, generator=g, requires_grad=True)
+    xs = torch.randn(2, 16, 16, 16, generator=g, requires_grad=True)
+    go = torch.randn(2, 16, 16, 16, generator=g)
+    y = m(xd, xs)
+    (y * go).sum().backward()
+    osd = OU.clone_sd(sd, requires_grad=True)
+    xdo, xso = xd.detach().clone().requires_grad_(True), xs.detach().clone().requires_grad_(True)
+    yo = OU.up_block(xdo, xso, osd, "", "conv_transpose", True)
+    (yo * go).sum().backward()
+    close(yo, y, what="up_block y"); close(xdo.grad, xd.grad, what="up_block dxd"); close(xso.grad, xs.grad, what="up_block dxs")
+    out = {"xd": xd, "xs": xs, "go": go, "y": y, "dxd": xd.grad, "dxs": xs.grad}
+    out.update({"sd." + k: v for k, v in sd.items()})
+    out.update({"grad." + k: v for k, v in grads_of(m).items()})
+    save("up_block", **out)
+
+    # bad up_sample_mode -> ValueError (model.py:64)
+    try:
+        ref.UpBlock(4, 2, "nearest")
+        raise AssertionError("reference accepted a bad up_sample_mode")
+    except ValueError as e:
+        bad_mode_msg = str(e)
+
+    # ---- 4. UNet-small: the reference's own blocks composed in the reference's order -----
+    class SmallUNet(torch.nn.Module):          # base 16, depth 3 (BASELINE config 1)
+        def __init__(self):
+            super().__init__()
+            self.down_conv1 = ref.DownBlock(1, 16)
+            self.down_conv2 = ref.DownBlock(16, 32)
+            self.double_conv = ref.DoubleConv(32, 64)
+            self.up_conv2 = ref.UpBlock(64, 32, "conv_transpose")
+            self.up_conv1 = ref.UpBlock(32, 16, "conv_transpose")
+            self.conv_last = torch.nn.Conv2d(16, 2, kernel_size=1)
+
+        def forward(self, x):
+            x = x.unsqueeze(1)
+            x, s1 = self.down_conv1(x)
+            x, s2 = self.down_conv2(x)
+            x = self.double_conv(x)
+            x = self.up_conv2(x, s2)
+            x = self.up_conv1(x, s1)
+            return self.conv_last(x)
+
+    g = torch.Generator().manual_seed(400)
+    sd = OU.make_state_dict(base_ch=16, depth=3, seed=41)
+    m = SmallUNet()
+    load(m, sd)
+    m.train()
+    x = torch.randn(2, 32, 48, generator=g)
+    fg = (torch.rand(2, 32, 48, generator=g) > 0.8)
+    y1h = torch.stack([~fg, fg], 1).to(torch.float64)                      # dataset.py:48 one-hot float64
+    crit = M.DiceLoss(activation="softmax", threshold=0.5, ignore_channels=[0]) + M.CrossEntropyLoss()
+    logits = m(x)
+    loss = crit(logits, y1h)
+    loss.backward()
+    osd = OU.clone_sd(sd, requires_grad=True)
+    lo = OU.unet_forward(x, osd, training=True)
+    losso = OL.dice_ce_loss(lo, y1h)
+    losso.backward()
+    close(lo, logits, what="unet_small logits")
+    close(losso.float(), loss.float(), what="unet_small loss")
+    for k, p in m.named_parameters():
+        close(osd[k].grad, p.grad, tol=2e-4, what=f"unet_small d{k}")
+    out = {"x": x, "y1h": y1h, "logits": logits, "loss": loss.detach(), "crit_name": np.array(crit.__name__)}
+    out.update({"sd." + k: v for k, v in sd.items()})
+    out.update({"grad." + k: v for k, v in grads_of(m).items()})
+    out.update({"after." + k: v for k, v in m.state_dict().items() if "running" in k or "num_batches" in k})
+    m.eval()
+    with torch.no_grad():
+        out["logits_eval"] = m(x)
+    osd_e = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    close(OU.unet_forward(x, osd_e, training=False), out["logits_eval"], what="unet_small eval logits")
+    save("unet_small", **out)
+
+    # ---- 4b. two-step Adam trace on UNet-small (restated batch_update, train.py:163-169) ---
+    m = SmallUNet()
+    load(m, sd)
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    losses = []
+    for step in range(2):
+        opt.zero_grad()
+        pred = m(x)
+        l = crit(pred, y1h)
+        l.backward()
+        opt.step()
+        losses.append(l.detach().clone())
+    save("unet_small_adam_trace", x=x, y1h=y1h, losses=torch.stack(losses),
+         conv_last_weight=m.conv_last.weight.detach(), first_conv_weight=m.down_conv1.double_conv.double_conv[0].weight.detach(),
+         bott_bn_running_var=m.double_conv.double_conv[4].running_var)
+
+    # ---- 5. full reference UNet(), weights by seed (regenerated on the test side) ----------
+    g = torch.Generator().manual_seed(500)
+    sd = OU.make_state_dict(base_ch=64, depth=5, seed=51)
+    m = ref.UNet()
+    assert sum(p.numel() for p in m.parameters()) == 31042434
+    assert set(m.state_dict().keys()) == set(sd.keys()), "state_dict names differ from the reference"
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape) and v.dtype == sd[k].dtype, k
+    load(m, sd)
+    m.train()
+    x = torch.randn(2, 32, 32, generator=g)
+    go = torch.randn(2, 2, 32, 32, generator=g)
+    logits = m(x)
+    (logits * go).sum().backward()
+    osd = OU.clone_sd(sd, requires_grad=True)
+    lo = OU.unet_forward(x, osd, training=True)
+    (lo * go).sum().backward()
+    close(lo, logits, what="unet_full logits")
+    gn = {}
+    for k, p in m.named_parameters():
+        close(osd[k].grad, p.grad, tol=5e-4, what=f"unet_full d{k}")
+        gn[k] = p.grad.norm()
+    keys = sorted(gn.keys())
+    save("unet_full", x=x, go=go, logits=logits, seed=np.array(51), grad_norm_keys=np.array(keys),
+         grad_norms=torch.stack([gn[k] for k in keys]),
+         **{"grad." + k: m.get_parameter(k).grad for k in
+            ("conv_last.weight", "conv_last.bias", "down_conv1.double_conv.double_conv.0.weight",
+             "down_conv1.double_conv.double_conv.1.weight", "up_conv1.up_sample.bias")},
+         state_keys=np.array(list(m.state_dict().keys())),
+         state_shapes=np.array([str(tuple(v.shape)) for v in m.state_dict().values()]))
+
+    # ---- 6. losses -------------------------------------------------------------------------
+    g = torch.Generator().manual_seed(600)
+    logits = torch.randn(2, 2, 40, 40, generator=g, requires_grad=True)
+    fg = torch.rand(2, 40, 40, generator=g) > 0.9
+    y1h = torch.stack([~fg, fg], 1).to(torch.float64)
+    dice = M.DiceLoss(activation="softmax", threshold=0.5, ignore_channels=[0])(logits, y1h)
+    ce = M.CrossEntropyLoss()(logits, y1h)
+    iou = M.IoU(threshold=0.5, activation="softmax", ignore_channels=[0])(logits, y1h)
+    tot = (M.DiceLoss(activation="softmax", threshold=0.5, ignore_channels=[0]) + M.CrossEntropyLoss())(logits, y1h)
+    tot.backward()
+    lo = logits.detach().clone().requires_grad_(True)
+    close(OL.dice_loss(lo, y1h).float(), dice.float(), what="dice")
+    close(OL.cross_entropy_prob(lo, y1h).float(), ce.float(), what="ce")
+    close(OL.iou_loss(lo, y1h).float(), iou.float(), what="iou")
+    OL.dice_ce_loss(lo, y1h).backward()
+    close(lo.grad, logits.grad, what="dlogits")
+    save("losses", logits=logits, y1h=y1h, dice=dice.detach(), ce=ce.detach(), iou=iou.detach(), total=tot.detach(),
+         dlogits=logits.grad, bad_mode_msg=np.array(bad_mode_msg))
+    print("all fixtures written; oracle == reference on every case")
+
+
+if __name__ == "__main__":
+    main()

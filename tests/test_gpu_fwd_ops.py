@@ -1,0 +1,247 @@
+"""GPU parity of each forward C-ABI entry point against the CPU oracle's arithmetic (torch fp64 on the
+same, dtype-quantised inputs).  Tolerances (stated per dtype below) cover accumulation order and the
+final rounding to the storage dtype only, because the oracle is fed the already-quantised operands."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# relative-to-max tolerance per storage dtype: f32 exact-fp32 MFMA chain; f16 11-bit; bf16 8-bit mantissa
+TOL = {"f32": 2e-5, "f16": 2e-3, "bf16": 1.6e-2}
+DTS = ["f32", "f16", "bf16"]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cmunet_amd import ops as o
+    return o
+
+
+def q(t, dt, ops):
+    """quantise an fp32 CPU tensor to the storage dtype and back (so the oracle sees what the GPU sees)."""
+    return t.to(ops.TORCH_DT[ops.dt_code(dt)]).to(torch.float32)
+
+
+def to_act(x_nchw, dt, ops, ld=None, coff=0):
+    B, C, H, W = x_nchw.shape
+    ld = C if ld is None else ld
+    buf = torch.full((B, H, W, ld), 7.0, dtype=ops.TORCH_DT[ops.dt_code(dt)], device="cuda")
+    buf[..., coff:coff + C] = x_nchw.permute(0, 2, 3, 1).to(buf.dtype).cuda()
+    return ops.Act(buf, coff, C)
+
+
+def from_act(a):
+    return a.buf[..., a.coff:a.coff + a.C].float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def check(got, ref, tol, what):
+    err = (got.double() - ref.double()).abs().max().item()
+    scale = max(ref.abs().max().item(), 1e-6)
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (tol {tol})"
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, ldx_extra, ldy_extra, transform
+    (2, 20, 24, 32, 64, 0, 0, False),
+    (1, 16, 16, 16, 16, 0, 0, True),
+    (2, 7, 9, 8, 8, 8, 16, True),
+    (1, 33, 17, 64, 72, 0, 0, True),
+    (1, 16, 32, 128, 64, 64, 0, False),
+]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3x3_fwd(ops, dt, case):
+    B, H, W, Cin, Cout, ex, ey, tf = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = q(torch.randn(B, Cin, H, W, generator=g), dt, ops)
+    w = q(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5, dt, ops)
+    xa = to_act(x, dt, ops, ld=Cin + ex, coff=ex)
+    ref_in = x.double()
+    if tf:
+        sc = torch.rand(Cin, generator=g) + 0.5
+        sh = torch.randn(Cin, generator=g) * 0.3
+        rf = Cin // 2 if Cin >= 16 else 0
+        xa = xa.with_transform(sc.cuda(), sh.cuda(), rf)
+        t = x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+        t[:, rf:] = t[:, rf:].clamp_min(0)
+        # the kernel rounds the transformed value to the storage dtype before the MFMA
+        ref_in = q(t.float(), dt, ops).double()
+    wp = ops.pack_conv3x3(w.cuda(), dt)
+    ybuf = torch.full((B, H, W, Cout + ey), -3.0, dtype=ops.TORCH_DT[ops.dt_code(dt)], device="cuda")
+    ya = ops.Act(ybuf, ey, Cout)
+    stats = ops.new_stats(B, H, W, Cout, "cuda")
+    ops.conv3x3_fwd(xa, wp, ya, stats)
+    torch.cuda.synchronize()
+    ref = F.conv2d(ref_in, w.double(), padding=1)
+    # a transformed 16-bit input is rounded once more inside the kernel: allow for it
+    tol = TOL[dt] * (2.0 if tf else 1.0)
+    check(from_act(ya), ref, tol, "conv3x3 y")
+    if ey:
+        assert (ybuf[..., :ey] == -3.0).all(), "conv wrote outside its channel slice"
+    s = stats.double().sum(0).cpu()
+    check(s[0], ref.sum((0, 2, 3)), 1e-3 if dt != "f32" else 1e-4, "stats sum")
+    check(s[1], (ref * ref).sum((0, 2, 3)), 1e-3 if dt != "f32" else 1e-4, "stats sumsq")
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_conv3x3_dgrad_via_flipped_pack(ops, dt):
+    B, H, W, Cin, Cout = 2, 18, 21, 24, 40
+    g = torch.Generator().manual_seed(5)
+    dy = q(torch.randn(B, Cout, H, W, generator=g), dt, ops)
+    w = q(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cout * 9) ** 0.5, dt, ops)
+    wp = ops.pack_conv3x3(w.cuda(), dt, transpose_flip=True)
+    dx = ops.new_act(B, H, W, Cin, dt, "cuda")
+    ops.conv3x3_fwd(to_act(dy, dt, ops), wp, dx, None)
+    ref = torch.nn.grad.conv2d_input((B, Cin, H, W), w.double(), dy.double(), padding=1)
+    check(from_act(dx), ref, TOL[dt], "dgrad dx")
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape", [(2, 20, 24, 16), (1, 16, 16, 64), (2, 5, 37, 32)])
+@pytest.mark.parametrize("masked", [0, 1, 2])
+def test_conv3x3_c1_fwd(ops, dt, shape, masked):
+    B, H, W, Cout = shape
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, H, W, generator=g)
+    w = torch.randn(Cout, 1, 3, 3, generator=g) / 3
+    mask = None
+    xin = x
+    if masked:
+        m = (torch.rand(B, H, W, generator=g) > 0.5).to(torch.uint8)
+        if masked == 1:   # reference behaviour: mask of sample 0 for the whole batch
+            mask = m[:1].contiguous()
+            xin = x * (1 - mask[0]).float()
+        else:
+            mask = m
+            xin = x * (1 - m).float()
+    ya = ops.new_act(B, H, W, Cout, dt, "cuda")
+    stats = ops.new_stats(B, H, W, Cout, "cuda")
+    ops.conv3x3_c1_fwd(x.cuda(), w.cuda(), ya, stats, None if mask is None else mask.cuda(), masked == 2)
+    ref = F.conv2d(xin.double().unsqueeze(1), w.double(), padding=1)
+    check(from_act(ya), ref, TOL[dt], "c1 conv")
+    s = stats.double().sum(0).cpu()
+    check(s[0], ref.sum((0, 2, 3)), 1e-4, "c1 stats sum")
+    check(s[1], (ref * ref).sum((0, 2, 3)), 1e-4, "c1 stats sumsq")
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_finalize(ops, training):
+    B, H, W, C = 3, 20, 24, 48
+    g = torch.Generator().manual_seed(9)
+    y = torch.randn(B, C, H, W, generator=g) * 2 + 0.5      # bias-free conv output
+    bias = torch.randn(C, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    # slab as the conv epilogue would write it: per-(image,row-block) partial sums
+    parts = y.view(B, C, 4, H // 4, W).permute(0, 2, 1, 3, 4).reshape(B * 4, C, -1)
+    stats = torch.stack([parts.sum(-1), (parts * parts).sum(-1)], 1).contiguous().cuda()
+    rm_d, rv_d = rm.clone().cuda(), rv.clone().cuda()
+    scale, shift = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    smean, sinv = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    from cmunet_amd import _lib
+    ws = torch.empty(_lib.lib().cmu_bn_finalize_ws_bytes(C), dtype=torch.uint8, device="cuda")
+    ops.bn_finalize(stats, B * H * W, bias.cuda(), gamma.cuda(), beta.cuda(), rm_d, rv_d, 0.1, 1e-5, training, scale,
+                    shift, smean, sinv, ws)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    ref = F.batch_norm(y + bias.view(1, -1, 1, 1), rm_ref, rv_ref, gamma, beta, training, 0.1, 1e-5)
+    got = y * scale.cpu().view(1, -1, 1, 1) + shift.cpu().view(1, -1, 1, 1)
+    check(got, ref, 2e-5, "bn apply via scale/shift")
+    check(rm_d.cpu(), rm_ref, 1e-5, "running_mean")
+    check(rv_d.cpu(), rv_ref, 1e-5, "running_var")
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_bnrelu_maxpool(ops, dt):
+    B, H, W, C = 2, 12, 20, 32
+    g = torch.Generator().manual_seed(11)
+    y = q(torch.randn(B, C, H, W, generator=g), dt, ops)
+    sc, sh = torch.randn(C, generator=g), torch.randn(C, generator=g) * 0.2   # negative scales too
+    ya = to_act(y, dt, ops, ld=C + 8, coff=8).with_transform(sc.cuda(), sh.cuda(), 0)
+    out = ops.new_act(B, H // 2, W // 2, C, dt, "cuda")
+    ops.bnrelu_maxpool_fwd(ya, out)
+    ref = F.max_pool2d(F.relu(y.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)), 2)
+    check(from_act(out), ref, TOL[dt], "pool")
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", [(2, 8, 8, 32, 16, True), (1, 5, 9, 64, 32, False), (2, 16, 16, 16, 8, True)])
+def test_convT2x2_fwd(ops, dt, case):
+    B, H, W, Cin, Cout, tf = case
+    if dt != "f32" and Cout % 8:
+        pytest.skip("16-bit needs Cout % 8 == 0")
+    g = torch.Generator().manual_seed(13)
+    x = q(torch.randn(B, Cin, H, W, generator=g), dt, ops)
+    w = q(torch.randn(Cin, Cout, 2, 2, generator=g) / (Cin) ** 0.5, dt, ops)
+    bias = torch.randn(Cout, generator=g)
+    xa = to_act(x, dt, ops)
+    ref_in = x.double()
+    if tf:
+        sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+        xa = xa.with_transform(sc.cuda(), sh.cuda(), 0)
+        ref_in = q(F.relu(x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).float(), dt, ops).double()
+    wp = ops.pack_convT2x2(w.cuda(), dt, 0)
+    obuf = torch.full((B, 2 * H, 2 * W, 2 * Cout), 5.0, dtype=ops.TORCH_DT[ops.dt_code(dt)], device="cuda")
+    oa = ops.Act(obuf, 0, Cout)        # left half of a concat buffer
+    ops.convT2x2_fwd(xa, wp, bias.cuda(), oa)
+    ref = F.conv_transpose2d(ref_in, w.double(), bias.double(), stride=2)
+    check(from_act(oa), ref, TOL[dt] * (2.0 if tf else 1.0), "convT fwd")
+    assert (obuf[..., Cout:] == 5.0).all()
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_convT2x2_dgrad(ops, dt):
+    B, H, W, Cin, Cout = 2, 9, 6, 48, 24
+    g = torch.Generator().manual_seed(15)
+    dout = q(torch.randn(B, Cout, 2 * H, 2 * W, generator=g), dt, ops)
+    w = q(torch.randn(Cin, Cout, 2, 2, generator=g) / (Cout * 4) ** 0.5, dt, ops)
+    wp = ops.pack_convT2x2(w.cuda(), dt, 1)
+    da = to_act(dout, dt, ops, ld=2 * Cout, coff=0)
+    dx = ops.new_act(B, H, W, Cin, dt, "cuda")
+    ops.convT2x2_dgrad(da, wp, dx)
+    ref = F.conv2d(dout.double(), w.double(), stride=2)     # adjoint of conv_transpose2d(stride 2, k 2)
+    check(from_act(dx), ref, TOL[dt], "convT dgrad")
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("C", [16, 64])
+def test_conv1x1_head(ops, dt, C):
+    B, H, W, K = 2, 10, 13, 2
+    g = torch.Generator().manual_seed(17)
+    x = q(torch.randn(B, C, H, W, generator=g), dt, ops)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    w, b = torch.randn(K, C, generator=g) / C ** 0.5, torch.randn(K, generator=g)
+    xa = to_act(x, dt, ops).with_transform(sc.cuda(), sh.cuda(), 0)
+    logits = torch.empty(B, K, H, W, device="cuda")
+    ops.conv1x1_head_fwd(xa, w.cuda(), b.cuda(), logits)
+    a = F.relu(x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+    ref = F.conv2d(a, w.double().view(K, C, 1, 1), b.double())
+    check(logits.cpu(), ref, 2e-5, "head logits")
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_layout_roundtrip(ops, dt):
+    B, C, H, W = 2, 24, 6, 10
+    g = torch.Generator().manual_seed(19)
+    x = q(torch.randn(B, C, H, W, generator=g), dt, ops)
+    a = ops.new_act(B, H, W, C, dt, "cuda")
+    ops.nchw_to_nhwc(x.cuda(), a)
+    assert torch.equal(from_act(a), x)
+    sc, sh = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    out = ops.apply_to_nchw(a.with_transform(sc.cuda(), sh.cuda(), 8))
+    t = x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    t[:, 8:] = t[:, 8:].clamp_min(0)
+    check(out.cpu(), t, 1e-6, "apply_to_nchw")
+
+
+def test_bad_args_fail_loudly(ops):
+    from cmunet_amd._lib import CmuError
+    a = ops.new_act(1, 16, 16, 12, "bf16", "cuda")     # 12 channels: not a multiple of 8
+    o = ops.new_act(1, 16, 16, 16, "bf16", "cuda")
+    w = torch.zeros(16 * 9 * 64, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(CmuError):
+        ops.conv3x3_fwd(a, w, o, None)
