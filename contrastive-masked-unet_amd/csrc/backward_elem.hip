@@ -1,0 +1,458 @@
+// backward_elem.hip -- HBM-bound backward pieces of the UNet hot path (gfx950):
+//   BatchNorm+ReLU backward (reduce + apply), MaxPool backward fused with the skip add,
+//   1x1 head backward, first-layer (Cin=1) weight gradient.
+// Pattern: each lane owns one 16-byte channel chunk (fixed per thread, so per-channel parameters and
+// partial sums live in registers), pixels are walked grid-stride; per-block partial sums go to a slab
+// that a second tiny kernel adds in a fixed order (bitwise reproducible, no float atomics).
+#include "common.h"
+
+constexpr int RED_MAX_BLOCKS = 512;
+
+// block-level sum of `v` over the threads that share `key = tid % cpb` (prow = tid / cpb < ppb).
+// red: LDS float[256].  Result valid for tid < cpb.  All 256 threads must call.
+__device__ static inline float sum_over_rows(float v, float* red, int tid, int cpb, int ppb) {
+    __syncthreads();
+    red[tid] = v;
+    __syncthreads();
+    float a = 0.f;
+    if (tid < cpb)
+        for (int k = 0; k < ppb; ++k) a += red[k * cpb + tid];
+    return a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm2d + ReLU backward (autograd of model.py:18-19, 21-22)
+// ---------------------------------------------------------------------------------------------
+template <class TR>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const unsigned char* __restrict__ dA, int64_t ldd,
+                                                           const unsigned char* __restrict__ y, int64_t ldy,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           float* __restrict__ ws, int64_t npix, int C, int cpb, int ppb) {
+    constexpr int EPC = TR::EPC;
+    constexpr int ES = (int)sizeof(typename TR::elem_t);
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const int nchunk = C / EPC;
+    const int ch = blockIdx.y * cpb + tid % cpb;
+    const int prow = tid / cpb;
+    const bool active = prow < ppb && ch < nchunk;
+    float sc[EPC], sh[EPC], mu[EPC], is[EPC], s1[EPC], s2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const int c = active ? ch * EPC + e : 0;
+        sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; is[e] = invstd[c];
+        s1[e] = s2[e] = 0.f;
+    }
+    if (active)
+        for (int64_t p = (int64_t)blockIdx.x * ppb + prow; p < npix; p += (int64_t)gridDim.x * ppb) {
+            float g[EPC], v[EPC];
+            TR::unpack(ld_global16(dA + (p * ldd + ch * EPC) * ES), g);
+            TR::unpack(ld_global16(y + (p * ldy + ch * EPC) * ES), v);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float dz = fmaf(v[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
+                s1[e] += dz;
+                s2[e] = fmaf(dz, (v[e] - mu[e]) * is[e], s2[e]);
+            }
+        }
+    for (int e = 0; e < EPC; ++e) {
+        const float a = sum_over_rows(s1[e], red, tid, cpb, ppb);
+        const float b = sum_over_rows(s2[e], red, tid, cpb, ppb);
+        if (tid < cpb && blockIdx.y * cpb + tid < nchunk) {
+            const int c = (blockIdx.y * cpb + tid) * EPC + e;
+            ws[((int64_t)blockIdx.x * 2 + 0) * C + c] = a;
+            ws[((int64_t)blockIdx.x * 2 + 1) * C + c] = b;
+        }
+    }
+}
+
+__global__ void bn_bwd_final_kernel(const float* __restrict__ ws, int nblocks, double count, float* dgamma, float* dbeta,
+                                    float* coef, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblocks; ++b) {
+        s1 += (double)ws[((int64_t)b * 2 + 0) * C + c];
+        s2 += (double)ws[((int64_t)b * 2 + 1) * C + c];
+    }
+    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma) dgamma[c] = (float)s2;
+    coef[c] = (float)(s1 / count);
+    coef[C + c] = (float)(s2 / count);
+}
+
+static void chunk_geometry(int nchunk, int* cpb, int* ppb, int* gy) {
+    *cpb = nchunk < 256 ? nchunk : 256;
+    *ppb = 256 / *cpb;
+    *gy = cmu_div_up(nchunk, *cpb);
+}
+
+template <class TR>
+static int bn_bwd_reduce_t(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift,
+                           const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef, int B, int H, int W,
+                           int C, void* ws, hipStream_t st) {
+    int cpb, ppb, gy;
+    chunk_geometry(C / TR::EPC, &cpb, &ppb, &gy);
+    const int64_t npix = (int64_t)B * H * W;
+    int gx = (int)(cmu_div_up64(npix, ppb * 4) < RED_MAX_BLOCKS ? cmu_div_up64(npix, ppb * 4) : RED_MAX_BLOCKS);
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<TR>), dim3(gx, gy), dim3(256), 0, st, (const unsigned char*)dA, ldd,
+                       (const unsigned char*)y, ldy, scale, shift, mean, invstd, (float*)ws, npix, C, cpb, ppb);
+    CMU_CHECK_LAUNCH("cmu_bn_bwd_reduce");
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cmu_div_up(C, 128)), dim3(128), 0, st, (const float*)ws, gx, (double)npix, dgamma,
+                       dbeta, coef, C);
+    CMU_CHECK_LAUNCH("cmu_bn_bwd_reduce(final)");
+    return CMU_OK;
+}
+
+static int check_pair(const char* name, const void* a, int64_t lda, const void* b, int64_t ldb, int C, int dt) {
+    const int es = cmu_dtype_size(dt);
+    CMU_CHECK_ARG(es > 0, "%s: bad dtype %d", name, dt);
+    const int epc = 16 / es;
+    CMU_CHECK_ARG(a && b && cmu_aligned16(a) && cmu_aligned16(b), "%s: null / unaligned tensor", name);
+    CMU_CHECK_ARG(C > 0 && C % epc == 0 && lda % epc == 0 && ldb % epc == 0 && lda >= C && ldb >= C, "%s: C=%d / ld alignment (multiple of %d)", name, C, epc);
+    return CMU_OK;
+}
+
+extern "C" int64_t cmu_bn_bwd_ws_bytes(int C) { return (int64_t)RED_MAX_BLOCKS * 2 * C * (int64_t)sizeof(float); }
+
+extern "C" int cmu_bn_bwd_reduce(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift,
+                                 const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* coef, int B,
+                                 int H, int W, int C, int dt, void* ws, void* stream) {
+    int rc;
+    if ((rc = check_pair("cmu_bn_bwd_reduce", dA, ldd, y, ldy, C, dt))) return rc;
+    CMU_CHECK_ARG(scale && shift && save_mean && save_invstd && coef && ws && B > 0 && H > 0 && W > 0, "cmu_bn_bwd_reduce: null argument");
+    CMU_DISPATCH_DT(dt, bn_bwd_reduce_t, dA, ldd, y, ldy, scale, shift, save_mean, save_invstd, dgamma, dbeta, coef, B, H, W, C, ws,
+                    (hipStream_t)stream);
+}
+
+template <class TR>
+__global__ void bn_bwd_apply_kernel(const unsigned char* __restrict__ dA, int64_t ldd, const unsigned char* __restrict__ y,
+                                    int64_t ldy, const float* __restrict__ scale, const float* __restrict__ shift,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ coef,
+                                    unsigned char* __restrict__ dY, int64_t ldo, int64_t npix, int C, int cpb, int ppb) {
+    constexpr int EPC = TR::EPC;
+    constexpr int ES = (int)sizeof(typename TR::elem_t);
+    const int tid = threadIdx.x;
+    const int nchunk = C / EPC;
+    const int ch = blockIdx.y * cpb + tid % cpb;
+    const int prow = tid / cpb;
+    if (!(prow < ppb && ch < nchunk)) return;
+    float sc[EPC], sh[EPC], mu[EPC], is[EPC], c1[EPC], c2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const int c = ch * EPC + e;
+        sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; is[e] = invstd[c];
+        c1[e] = coef[c]; c2[e] = coef[C + c];
+    }
+    for (int64_t p = (int64_t)blockIdx.x * ppb + prow; p < npix; p += (int64_t)gridDim.x * ppb) {
+        float g[EPC], v[EPC], o[EPC];
+        TR::unpack(ld_global16(dA + (p * ldd + ch * EPC) * ES), g);
+        TR::unpack(ld_global16(y + (p * ldy + ch * EPC) * ES), v);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float dz = fmaf(v[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
+            const float xh = (v[e] - mu[e]) * is[e];
+            o[e] = sc[e] * (dz - c1[e] - xh * c2[e]);
+        }
+        st_global16(dY + (p * ldo + ch * EPC) * ES, TR::pack(o));
+    }
+}
+template <class TR>
+static int bn_bwd_apply_t(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift,
+                          const float* mean, const float* invstd, const float* coef, void* dY, int64_t ldo, int B, int H, int W,
+                          int C, hipStream_t st) {
+    int cpb, ppb, gy;
+    chunk_geometry(C / TR::EPC, &cpb, &ppb, &gy);
+    const int64_t npix = (int64_t)B * H * W;
+    int gx = (int)(cmu_div_up64(npix, ppb * 2) < 4096 ? cmu_div_up64(npix, ppb * 2) : 4096);
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<TR>), dim3(gx, gy), dim3(256), 0, st, (const unsigned char*)dA, ldd,
+                       (const unsigned char*)y, ldy, scale, shift, mean, invstd, coef, (unsigned char*)dY, ldo, npix, C, cpb, ppb);
+    CMU_CHECK_LAUNCH("cmu_bn_bwd_apply");
+    return CMU_OK;
+}
+extern "C" int cmu_bn_bwd_apply(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift,
+                                const float* save_mean, const float* save_invstd, const float* coef, void* dY, int64_t ldo, int B,
+                                int H, int W, int C, int dt, void* stream) {
+    int rc;
+    if ((rc = check_pair("cmu_bn_bwd_apply", dA, ldd, y, ldy, C, dt))) return rc;
+    if ((rc = check_pair("cmu_bn_bwd_apply(dY)", dY, ldo, y, ldy, C, dt))) return rc;
+    CMU_CHECK_ARG(scale && shift && save_mean && save_invstd && coef && B > 0 && H > 0 && W > 0, "cmu_bn_bwd_apply: null argument");
+    CMU_DISPATCH_DT(dt, bn_bwd_apply_t, dA, ldd, y, ldy, scale, shift, save_mean, save_invstd, coef, dY, ldo, B, H, W, C,
+                    (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// MaxPool2d(2) backward + skip-gradient add (autograd of model.py:42-45 where both outputs are used)
+// ---------------------------------------------------------------------------------------------
+template <class TR>
+__global__ void maxpool_bwd_kernel(const unsigned char* __restrict__ dP, int64_t ldp, const unsigned char* __restrict__ dS,
+                                   int64_t lds, const unsigned char* __restrict__ y, int64_t ldy, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, unsigned char* __restrict__ dA, int64_t lda, int B, int H, int W,
+                                   int C, int64_t total) {
+    constexpr int EPC = TR::EPC;
+    constexpr int ES = (int)sizeof(typename TR::elem_t);
+    const int nchunk = C / EPC;
+    const int Ho = H / 2, Wo = W / 2;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(o % nchunk);
+        const int64_t pp = o / nchunk;
+        const int xo = (int)(pp % Wo), yo = (int)((pp / Wo) % Ho), b = (int)(pp / ((int64_t)Wo * Ho));
+        float sc[EPC], sh[EPC], best[EPC], g[EPC];
+        int arg[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            sc[e] = scale[ch * EPC + e];
+            sh[e] = shift[ch * EPC + e];
+        }
+        TR::unpack(ld_global16(dP + (pp * ldp + ch * EPC) * ES), g);
+        int64_t src[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            src[q] = ((int64_t)b * H + 2 * yo + (q >> 1)) * W + 2 * xo + (q & 1);
+            float f[EPC];
+            TR::unpack(ld_global16(y + (src[q] * ldy + ch * EPC) * ES), f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float a = fmaxf(fmaf(f[e], sc[e], sh[e]), 0.f);
+                if (q == 0 || a > best[e]) { best[e] = a; arg[e] = q; }   // first maximum wins (ATen max_pool2d)
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float d[EPC];
+            if (dS) TR::unpack(ld_global16(dS + (src[q] * lds + ch * EPC) * ES), d);
+            else {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) d[e] = 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) d[e] += (arg[e] == q) ? g[e] : 0.f;
+            st_global16(dA + (src[q] * lda + ch * EPC) * ES, TR::pack(d));
+        }
+    }
+}
+template <class TR>
+static int maxpool_bwd_t(const void* dP, int64_t ldp, const void* dS, int64_t lds, const void* y, int64_t ldy, const float* scale,
+                         const float* shift, void* dA, int64_t lda, int B, int H, int W, int C, hipStream_t st) {
+    const int64_t total = (int64_t)B * (H / 2) * (W / 2) * (C / TR::EPC);
+    const int grid = (int)(cmu_div_up64(total, 256) < 8192 ? cmu_div_up64(total, 256) : 8192);
+    hipLaunchKernelGGL((maxpool_bwd_kernel<TR>), dim3(grid), dim3(256), 0, st, (const unsigned char*)dP, ldp, (const unsigned char*)dS,
+                       lds, (const unsigned char*)y, ldy, scale, shift, (unsigned char*)dA, lda, B, H, W, C, total);
+    CMU_CHECK_LAUNCH("cmu_maxpool_bwd");
+    return CMU_OK;
+}
+extern "C" int cmu_maxpool_bwd(const void* dP, int64_t ldp, const void* dSkip, int64_t lds, const void* y, int64_t ldy,
+                               const float* scale, const float* shift, void* dA, int64_t lda, int B, int H, int W, int C, int dt,
+                               void* stream) {
+    int rc;
+    if ((rc = check_pair("cmu_maxpool_bwd(dP,y)", dP, ldp, y, ldy, C, dt))) return rc;
+    if ((rc = check_pair("cmu_maxpool_bwd(dA,y)", dA, lda, y, ldy, C, dt))) return rc;
+    if (dSkip && (rc = check_pair("cmu_maxpool_bwd(dSkip,y)", dSkip, lds, y, ldy, C, dt))) return rc;
+    CMU_CHECK_ARG(scale && shift && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "cmu_maxpool_bwd: bad dims (%d,%d)", H, W);
+    CMU_DISPATCH_DT(dt, maxpool_bwd_t, dP, ldp, dSkip, lds, y, ldy, scale, shift, dA, lda, B, H, W, C, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1x1 head backward (autograd of model.py:130)
+// ---------------------------------------------------------------------------------------------
+constexpr int HEAD_MAX_K = 8;
+template <class TR>
+__global__ __launch_bounds__(256) void conv1x1_head_bwd_kernel(const float* __restrict__ dlogits, const unsigned char* __restrict__ x,
+                                                              int64_t ldx, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, const float* __restrict__ w,
+                                                              unsigned char* __restrict__ dX, int64_t ldo, float* __restrict__ ws,
+                                                              int B, int H, int W, int C, int K, int64_t npix) {
+    constexpr int EPC = TR::EPC;
+    constexpr int ES = (int)sizeof(typename TR::elem_t);
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const int nchunk = C / EPC;  // power of two <= 64
+    const int ch = tid % nchunk;
+    const int ppb = 256 / nchunk;
+    const int prow = tid / nchunk;
+    float sc[EPC], sh[EPC], wk[HEAD_MAX_K][EPC], dw[HEAD_MAX_K][EPC], db[HEAD_MAX_K];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        sc[e] = scale ? scale[ch * EPC + e] : 1.f;
+        sh[e] = scale ? shift[ch * EPC + e] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_K; ++k) {
+        db[k] = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            wk[k][e] = (k < K) ? w[k * C + ch * EPC + e] : 0.f;
+            dw[k][e] = 0.f;
+        }
+    }
+    const int64_t HW = (int64_t)H * W;
+    for (int64_t pix = (int64_t)blockIdx.x * ppb + prow; pix < npix; pix += (int64_t)gridDim.x * ppb) {
+        const int64_t b = pix / HW, r = pix % HW;
+        float f[EPC], o[EPC], dl[HEAD_MAX_K];
+        TR::unpack(ld_global16(x + (pix * ldx + ch * EPC) * ES), f);
+#pragma unroll
+        for (int k = 0; k < HEAD_MAX_K; ++k) dl[k] = (k < K) ? dlogits[(b * K + k) * HW + r] : 0.f;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float a = fmaf(f[e], sc[e], sh[e]);
+            if (scale) a = fmaxf(a, 0.f);
+            float d = 0.f;
+#pragma unroll
+            for (int k = 0; k < HEAD_MAX_K; ++k) {
+                d = fmaf(dl[k], wk[k][e], d);
+                dw[k][e] = fmaf(dl[k], a, dw[k][e]);
+            }
+            o[e] = d;
+        }
+        if (ch == 0) {
+#pragma unroll
+            for (int k = 0; k < HEAD_MAX_K; ++k) db[k] += dl[k];
+        }
+        if (dX) st_global16(dX + (pix * ldo + ch * EPC) * ES, TR::pack(o));
+    }
+    float* out = ws + (int64_t)blockIdx.x * (K * C + K);
+    for (int k = 0; k < K; ++k) {
+        for (int e = 0; e < EPC; ++e) {
+            const float a = sum_over_rows(dw[k][e], red, tid, nchunk, ppb);
+            if (tid < nchunk) out[k * C + tid * EPC + e] = a;
+        }
+        // bias: only ch == 0 threads carry data (tid % nchunk == 0)
+        const float bsum = sum_over_rows(db[k], red, tid, nchunk, ppb);
+        if (tid == 0) out[K * C + k] = bsum;
+    }
+}
+__global__ void sum_slab_kernel(const float* __restrict__ ws, int nblocks, int64_t n, float* __restrict__ out0, int64_t n0,
+                                float* __restrict__ out1) {
+    // out0 gets elements [0,n0), out1 the rest; fixed-order sum over the blocks' partials
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += (double)ws[(int64_t)b * n + i];
+    if (i < n0) out0[i] = (float)s;
+    else if (out1) out1[i - n0] = (float)s;
+}
+template <class TR>
+static int conv1x1_head_bwd_t(const float* dlogits, const void* x, int64_t ldx, const float* scale, const float* shift, const float* w,
+                              void* dX, int64_t ldo, float* dW, float* dbias, int B, int H, int W, int C, int K, void* ws,
+                              hipStream_t st) {
+    const int nchunk = C / TR::EPC;
+    const int ppb = 256 / nchunk;
+    const int64_t npix = (int64_t)B * H * W;
+    int gx = (int)(cmu_div_up64(npix, ppb * 4) < RED_MAX_BLOCKS ? cmu_div_up64(npix, ppb * 4) : RED_MAX_BLOCKS);
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL((conv1x1_head_bwd_kernel<TR>), dim3(gx), dim3(256), 0, st, dlogits, (const unsigned char*)x, ldx, scale, shift, w,
+                       (unsigned char*)dX, ldo, (float*)ws, B, H, W, C, K, npix);
+    CMU_CHECK_LAUNCH("cmu_conv1x1_head_bwd");
+    const int64_t n = (int64_t)K * C + K;
+    hipLaunchKernelGGL(sum_slab_kernel, dim3((unsigned)cmu_div_up64(n, 128)), dim3(128), 0, st, (const float*)ws, gx, n, dW, (int64_t)K * C,
+                       dbias);
+    CMU_CHECK_LAUNCH("cmu_conv1x1_head_bwd(sum)");
+    return CMU_OK;
+}
+extern "C" int64_t cmu_conv1x1_head_bwd_ws_bytes(int B, int H, int W, int C, int K) {
+    return (int64_t)RED_MAX_BLOCKS * ((int64_t)K * C + K) * (int64_t)sizeof(float);
+}
+extern "C" int cmu_conv1x1_head_bwd(const float* dlogits, const void* x, int64_t ldx, const float* in_scale, const float* in_shift,
+                                    const float* w, void* dX, int64_t ldo, float* dW, float* dbias, int B, int H, int W, int C, int K,
+                                    int dt, void* ws, void* stream) {
+    const int es = cmu_dtype_size(dt);
+    CMU_CHECK_ARG(es > 0 && dlogits && x && w && dW && dbias && ws && B > 0 && H > 0 && W > 0, "cmu_conv1x1_head_bwd: bad args");
+    const int epc = 16 / es;
+    const int nchunk = C / epc;
+    CMU_CHECK_ARG(K >= 1 && K <= HEAD_MAX_K, "cmu_conv1x1_head_bwd: K=%d must be in 1..%d", K, HEAD_MAX_K);
+    CMU_CHECK_ARG(C % epc == 0 && nchunk > 0 && (nchunk & (nchunk - 1)) == 0 && nchunk <= 64, "cmu_conv1x1_head_bwd: C=%d unsupported", C);
+    CMU_CHECK_ARG(cmu_aligned16(x) && ldx % epc == 0 && ldx >= C, "cmu_conv1x1_head_bwd: x alignment / stride");
+    CMU_CHECK_ARG(!dX || (cmu_aligned16(dX) && ldo % epc == 0 && ldo >= C), "cmu_conv1x1_head_bwd: dX alignment / stride");
+    CMU_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "cmu_conv1x1_head_bwd: scale/shift must both be set");
+    CMU_DISPATCH_DT(dt, conv1x1_head_bwd_t, dlogits, x, ldx, in_scale, in_shift, w, dX, ldo, dW, dbias, B, H, W, C, K, ws,
+                    (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// first layer weight gradient: dW (Cout,1,3,3) = sum_p dY[p][n] * xm[p + tap]
+// ---------------------------------------------------------------------------------------------
+constexpr int C1W_MAX_BLOCKS = 1024;
+template <class TR>
+__global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask,
+                                                              int mask_per_sample, const unsigned char* __restrict__ dY, int64_t ldd,
+                                                              float* __restrict__ ws, int B, int H, int W, int Cout, int tilesX,
+                                                              int tilesY, int ntiles) {
+    constexpr int EPC = TR::EPC;
+    constexpr int ES = (int)sizeof(typename TR::elem_t);
+    __shared__ float halo[18 * 18];
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const int nchunk = Cout / EPC;
+    const int ppi = 256 / nchunk;
+    const int chunk = tid % nchunk, prow = tid / nchunk;
+    const bool active = prow < ppi;
+    float acc[EPC][9];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[e][t] = 0.f;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % tilesX, ty = (tile / tilesX) % tilesY, b = tile / (tilesX * tilesY);
+        const int ty0 = ty * 16, tx0 = tx * 16;
+        __syncthreads();
+        for (int i = tid; i < 18 * 18; i += 256) {
+            const int gy = ty0 - 1 + i / 18, gx = tx0 - 1 + i % 18;
+            float v = 0.f;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                v = x[((int64_t)b * H + gy) * W + gx];
+                if (mask) v *= (float)(1 - (int)mask[((int64_t)(mask_per_sample ? b : 0) * H + gy) * W + gx]);
+            }
+            halo[i] = v;
+        }
+        __syncthreads();
+        if (active)
+            for (int pix = prow; pix < 256; pix += ppi) {
+                const int py = pix >> 4, px = pix & 15;
+                const int gy = ty0 + py, gx = tx0 + px;
+                if (gy >= H || gx >= W) continue;
+                float g[EPC];
+                TR::unpack(ld_global16(dY + ((((int64_t)b * H + gy) * W + gx) * ldd + chunk * EPC) * ES), g);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float xv = halo[(py + t / 3) * 18 + px + t % 3];
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) acc[e][t] = fmaf(g[e], xv, acc[e][t]);
+                }
+            }
+    }
+    float* out = ws + (int64_t)blockIdx.x * Cout * 9;
+    for (int e = 0; e < EPC; ++e)
+        for (int t = 0; t < 9; ++t) {
+            const float a = sum_over_rows(active ? acc[e][t] : 0.f, red, tid, nchunk, ppi);
+            if (tid < nchunk) out[(tid * EPC + e) * 9 + t] = a;
+        }
+}
+template <class TR>
+static int conv3x3_c1_wgrad_t(const float* x, const uint8_t* mask, int mps, const void* dY, int64_t ldd, float* dW, int B, int H, int W,
+                              int Cout, void* ws, hipStream_t st) {
+    const int tilesX = cmu_div_up(W, 16), tilesY = cmu_div_up(H, 16);
+    const int ntiles = B * tilesX * tilesY;
+    const int grid = ntiles < C1W_MAX_BLOCKS ? ntiles : C1W_MAX_BLOCKS;
+    hipLaunchKernelGGL((conv3x3_c1_wgrad_kernel<TR>), dim3(grid), dim3(256), 0, st, x, mask, mps, (const unsigned char*)dY, ldd, (float*)ws,
+                       B, H, W, Cout, tilesX, tilesY, ntiles);
+    CMU_CHECK_LAUNCH("cmu_conv3x3_c1_wgrad");
+    const int64_t n = (int64_t)Cout * 9;
+    hipLaunchKernelGGL(sum_slab_kernel, dim3((unsigned)cmu_div_up64(n, 128)), dim3(128), 0, st, (const float*)ws, grid, n, dW, n, (float*)nullptr);
+    CMU_CHECK_LAUNCH("cmu_conv3x3_c1_wgrad(sum)");
+    return CMU_OK;
+}
+extern "C" int64_t cmu_conv3x3_c1_wgrad_ws_bytes(int B, int H, int W, int Cout) {
+    return (int64_t)C1W_MAX_BLOCKS * Cout * 9 * (int64_t)sizeof(float);
+}
+extern "C" int cmu_conv3x3_c1_wgrad(const float* x, const uint8_t* mask, int mask_per_sample, const void* dY, int64_t ldd, float* dW,
+                                    int B, int H, int W, int Cout, int dt, void* ws, void* stream) {
+    const int es = cmu_dtype_size(dt);
+    CMU_CHECK_ARG(es > 0 && x && dY && dW && ws && B > 0 && H > 0 && W > 0, "cmu_conv3x3_c1_wgrad: bad args");
+    const int epc = 16 / es;
+    CMU_CHECK_ARG(Cout > 0 && Cout % epc == 0 && Cout / epc <= 256, "cmu_conv3x3_c1_wgrad: Cout=%d unsupported", Cout);
+    CMU_CHECK_ARG(cmu_aligned16(dY) && ldd % epc == 0 && ldd >= Cout, "cmu_conv3x3_c1_wgrad: dY alignment / stride");
+    CMU_DISPATCH_DT(dt, conv3x3_c1_wgrad_t, x, mask, mask_per_sample, dY, ldd, dW, B, H, W, Cout, ws, (hipStream_t)stream);
+}

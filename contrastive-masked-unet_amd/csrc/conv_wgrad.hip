@@ -1,0 +1,452 @@
+// conv_wgrad.hip -- weight gradients of Conv2d 3x3 and ConvTranspose2d 2x2 on MFMA (gfx950).
+//
+//   MODE_W3:  dW[n][c][kh][kw] = sum_p dY[p][n] * act(X)[p + (kh-1,kw-1)][c]        (autograd of model.py:17,20)
+//   MODE_WT:  dW[c][n][i][j]   = sum_p dOut[2p+(i,j)][n] * act(X)[p][c]              (autograd of model.py:60)
+//
+// GEMM view: M = output channels n (rows, operand A = dY^T), N = input channels c (cols, operand B = X),
+// K = pixels.  Both operands are pixel-major NHWC in HBM, i.e. K is the SLOW axis of both -- the opposite of
+// what an MFMA fragment wants (8 consecutive k per lane).  CDNA4 answer: keep the natural [pixel][channel]
+// image in LDS and read fragments with ds_read_b64_tr_b16 (hardware 4x16 transpose), two reads per
+// fragment; for fp32 the 32x32x2 MFMA takes one k per lane-half, so plain ds_read_b32 is already right.
+//
+//   * workgroup = 512 threads = 8 wave64, one per CU; block tile = 128-byte channel rows on both sides
+//     (64x64 channels for f16/bf16, 32x32 for f32) x all 9 taps: each wave keeps 9 accumulator tiles
+//     (144 VGPRs) for its (32n x 32c) block and half (1/8 for f32) of the tile's pixel rows; the A
+//     fragment of a pixel row is loaded once and reused by the 9 taps.
+//   * K loop = 16x16 spatial tiles (split-K over workgroups); per tile the dY tile and the 18x18 X halo are
+//     staged ONCE (global -> regs -> LDS, BatchNorm+ReLU of the producer applied to X on the way) and the
+//     9 taps read the halo at shifted pixel addresses.
+//   * LDS image: 128-byte pixel rows, 64-byte halves XOR-swizzled by bit 1 of the pixel index: the four
+//     pixels a transposed read touches land on the four 64-byte quarters of the 256-byte bank row.
+//   * accumulators of the k-parts are combined through LDS, partial slabs [split][tap][n][c] go to a
+//     workspace and a second kernel sums them in split order (deterministic) into the reference layout.
+#include "common.h"
+
+enum { MODE_W3 = 0, MODE_WT = 1 };
+
+struct WGParams {
+    const void* a;  // dY (MODE_W3) / dOut (MODE_WT)
+    int64_t lda;
+    const void* b;  // X
+    int64_t ldb;
+    const float* b_scale;
+    const float* b_shift;
+    int relu_from;
+    float* ws;
+    int B, H, W;  // pixel grid of the contraction (MODE_WT: the low-res grid)
+    int CA, CB;   // channels of A (output channels) and B (input channels)
+    int CApad, CBpad;
+    int nAB, nBB, splitk, ntiles, tilesX, tilesY;
+};
+
+template <class TR, int MODE>
+struct WGCfg {
+    typedef typename TR::elem_t elem_t;
+    static constexpr int ES = (int)sizeof(elem_t);
+    static constexpr int CW = 128 / ES;
+    static constexpr int NB32 = CW / 32;
+    static constexpr int NT = NB32 * NB32;
+    static constexpr int KPARTS = 8 / NT;
+    static constexpr int RPP = 16 / KPARTS;  // pixel rows per k-part
+    static constexpr int TAPS = (MODE == MODE_W3) ? 9 : 1;
+    static constexpr int HALO = (MODE == MODE_W3) ? 1 : 0;
+    static constexpr int LW = 16 + 2 * HALO;
+    static constexpr int NPIXB = LW * LW;
+    static constexpr int A_BYTES = 256 * 128;
+    static constexpr int B_BYTES = NPIXB * 128;
+    static constexpr int A_ITERS = (256 * 8) / 512;
+    static constexpr int B_ITERS = (NPIXB * 8 + 511) / 512;
+    static constexpr int RED_BYTES = NT * TAPS * 4096;
+    static constexpr int MAIN_BYTES = A_BYTES + B_BYTES;
+    static constexpr int LDS_BYTES = MAIN_BYTES > RED_BYTES ? MAIN_BYTES : RED_BYTES;
+};
+
+__device__ static inline int swz(int pix, int cbyte) { return pix * 128 + (cbyte ^ (((pix >> 1) & 1) << 6)); }
+
+__device__ static inline u32x2 lds_tr16(const unsigned char* smem, int off) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + off));
+    return __builtin_bit_cast(u32x2, v);
+}
+
+template <class TR, int MODE>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WGParams p) {
+    typedef WGCfg<TR, MODE> C;
+    typedef typename TR::elem_t elem_t;
+    constexpr int EPC = TR::EPC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* smA = smem;
+    unsigned char* smB = smem + C::A_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r = lane & 31;
+    const int h = lane >> 5;
+
+    int bid = blockIdx.x;
+    const int ab = bid % p.nAB;
+    bid /= p.nAB;
+    const int bb = bid % p.nBB;
+    bid /= p.nBB;
+    int ij = 0;
+    if (MODE == MODE_WT) { ij = bid & 3; bid >>= 2; }
+    const int split = bid;
+
+    const int tile_id = wave % C::NT;
+    const int kpart = wave / C::NT;
+    const int nb32 = tile_id % C::NB32, cb32 = tile_id / C::NB32;
+
+    const int Ha = (MODE == MODE_WT) ? 2 * p.H : p.H;
+    const int Wa = (MODE == MODE_WT) ? 2 * p.W : p.W;
+    const unsigned char* ga = reinterpret_cast<const unsigned char*>(p.a);
+    const unsigned char* gb = reinterpret_cast<const unsigned char*>(p.b);
+
+    // staging role: 16-byte chunk cgi of the 128-byte channel row, constant per thread
+    const int cgi = tid & 7;
+    const int a_c0 = ab * C::CW + cgi * EPC;
+    const int b_c0 = bb * C::CW + cgi * EPC;
+    const bool a_cok = a_c0 < p.CA;
+    const bool b_cok = b_c0 < p.CB;
+    const bool has_tf = (p.b_scale != nullptr);
+    float sc[EPC], sh[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        sc[e] = (has_tf && b_cok) ? p.b_scale[b_c0 + e] : 1.f;
+        sh[e] = (has_tf && b_cok) ? p.b_shift[b_c0 + e] : 0.f;
+    }
+    const bool relu = has_tf && (b_c0 >= p.relu_from);
+
+    f32x16 acc[C::TAPS];
+#pragma unroll
+    for (int t = 0; t < C::TAPS; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    u32x4 areg[C::A_ITERS];
+    u32x4 breg[C::B_ITERS];
+    unsigned b_ok = 0;  // bit it: B chunk is inside the image (so the transform applies)
+
+    auto load_tile = [&](int tile) {
+        const int tx = tile % p.tilesX, ty = (tile / p.tilesX) % p.tilesY, b = tile / (p.tilesX * p.tilesY);
+        const int ty0 = ty * 16, tx0 = tx * 16;
+#pragma unroll
+        for (int it = 0; it < C::A_ITERS; ++it) {
+            const int pix = (it * 512 + tid) >> 3;
+            const int py = pix >> 4, px = pix & 15;
+            int gy = ty0 + py, gx = tx0 + px;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (a_cok && gy < p.H && gx < p.W) {
+                if (MODE == MODE_WT) { gy = 2 * gy + (ij >> 1); gx = 2 * gx + (ij & 1); }
+                v = ld_global16(ga + ((((int64_t)b * Ha + gy) * Wa + gx) * p.lda + a_c0) * C::ES);
+            }
+            areg[it] = v;
+        }
+        b_ok = 0;
+#pragma unroll
+        for (int it = 0; it < C::B_ITERS; ++it) {
+            const int idx = it * 512 + tid;
+            const int pix = idx >> 3;
+            const int py = pix / C::LW, px = pix % C::LW;
+            const int gy = ty0 - C::HALO + py, gx = tx0 - C::HALO + px;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (idx < C::NPIXB * 8 && b_cok && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+                v = ld_global16(gb + ((((int64_t)b * p.H + gy) * p.W + gx) * p.ldb + b_c0) * C::ES);
+                b_ok |= 1u << it;
+            }
+            breg[it] = v;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < C::A_ITERS; ++it) {
+            const int pix = (it * 512 + tid) >> 3;
+            *reinterpret_cast<u32x4*>(smA + swz(pix, cgi * 16)) = areg[it];
+        }
+#pragma unroll
+        for (int it = 0; it < C::B_ITERS; ++it) {
+            const int idx = it * 512 + tid;
+            if (idx < C::NPIXB * 8) {
+                u32x4 v = breg[it];
+                if (has_tf && ((b_ok >> it) & 1u)) {
+                    float f[EPC];
+                    TR::unpack(v, f);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const float t = fmaf(f[e], sc[e], sh[e]);
+                        f[e] = relu ? fmaxf(t, 0.f) : t;
+                    }
+                    v = TR::pack(f);
+                }
+                *reinterpret_cast<u32x4*>(smB + swz(idx >> 3, cgi * 16)) = v;
+            }
+        }
+    };
+
+    // fragment addressing (16-bit path): 16-lane group g = lane>>4 covers channels 16*(g&1).. of the
+    // wave's 32-block and pixels 8*(g>>1) + 4*t + q of the row; lane li = lane&15: q = li>>2, quad = li&3
+    const int li = lane & 15, g = lane >> 4;
+    const int q4 = li >> 2, quad = li & 3;
+    const int a_cbyte16 = (nb32 * 32 + 16 * (g & 1) + 4 * quad) * 2;
+    const int b_cbyte16 = (cb32 * 32 + 16 * (g & 1) + 4 * quad) * 2;
+    const int a_cbyte32 = (nb32 * 32 + r) * 4;
+    const int b_cbyte32 = (cb32 * 32 + r) * 4;
+
+    int tile = split;
+    if (tile < p.ntiles) load_tile(tile);
+    for (; tile < p.ntiles; tile += p.splitk) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (tile + p.splitk < p.ntiles) load_tile(tile + p.splitk);
+#pragma unroll 1
+        for (int rr = 0; rr < C::RPP; ++rr) {
+            const int py = kpart * C::RPP + rr;
+            if constexpr (EPC == 8) {
+                // A fragment: 8 consecutive pixels (k = 8h + j) of row py for channel row r
+                const int pa = py * 16 + 8 * h + q4;
+                const u32x2 a_lo = lds_tr16(smA, swz(pa, a_cbyte16));
+                const u32x2 a_hi = lds_tr16(smA, swz(pa + 4, a_cbyte16));
+                const u32x4 afrag = {a_lo[0], a_lo[1], a_hi[0], a_hi[1]};
+#pragma unroll
+                for (int t = 0; t < C::TAPS; ++t) {
+                    const int pb = (py + (C::TAPS == 9 ? t / 3 : 0)) * C::LW + (C::TAPS == 9 ? t % 3 : 0) + 8 * h + q4;
+                    const u32x2 b_lo = lds_tr16(smB, swz(pb, b_cbyte16));
+                    const u32x2 b_hi = lds_tr16(smB, swz(pb + 4, b_cbyte16));
+                    const u32x4 bfrag = {b_lo[0], b_lo[1], b_hi[0], b_hi[1]};
+                    TR::mma16(afrag, bfrag, acc[t]);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const float av = *reinterpret_cast<const float*>(smA + swz(py * 16 + 2 * s + h, a_cbyte32));
+#pragma unroll
+                    for (int t = 0; t < C::TAPS; ++t) {
+                        const int pb = (py + (C::TAPS == 9 ? t / 3 : 0)) * C::LW + (C::TAPS == 9 ? t % 3 : 0) + 2 * s + h;
+                        const float bv = *reinterpret_cast<const float*>(smB + swz(pb, b_cbyte32));
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // ---- combine the k-parts through LDS (fixed order), then write the partial slab ----------------------
+    float* red = reinterpret_cast<float*>(smem) + (int64_t)tile_id * (C::TAPS * 1024);
+    for (int kp = 1; kp < C::KPARTS; ++kp) {
+        __syncthreads();
+        if (kpart == kp) {
+#pragma unroll
+            for (int t = 0; t < C::TAPS; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) red[(t * 16 + e) * 64 + lane] = acc[t][e];
+        }
+        __syncthreads();
+        if (kpart == 0) {
+#pragma unroll
+            for (int t = 0; t < C::TAPS; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[t][e] += red[(t * 16 + e) * 64 + lane];
+        }
+    }
+    if (kpart == 0) {
+        const int T = (MODE == MODE_W3) ? 9 : 4;
+#pragma unroll
+        for (int t = 0; t < C::TAPS; ++t) {
+            const int tt = (MODE == MODE_W3) ? t : ij;
+            float* base = p.ws + (((int64_t)split * T + tt) * p.CApad + ab * C::CW + nb32 * 32) * p.CBpad + bb * C::CW + cb32 * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = (e & 3) + 8 * (e >> 2) + 4 * h;
+                base[(int64_t)n * p.CBpad] = acc[t][e];
+            }
+        }
+    }
+}
+
+// partial slabs -> parameter-gradient layout, summed in split order
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int splitk, int T, int CApad, int CBpad, int CA, int CB,
+                                    float* __restrict__ dW, int mode) {
+    const int64_t total = (int64_t)T * CA * CB;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(o % CB);
+        const int n = (int)((o / CB) % CA);
+        const int t = (int)(o / ((int64_t)CB * CA));
+        float s = 0.f;
+        for (int k = 0; k < splitk; ++k) s += ws[(((int64_t)k * T + t) * CApad + n) * CBpad + c];
+        if (mode == MODE_W3) dW[((int64_t)n * CB + c) * 9 + t] = s;      // (Cout,Cin,3,3)
+        else dW[((int64_t)c * CA + n) * 4 + t] = s;                      // (Cin,Cout,2,2)
+    }
+}
+
+// per-channel sum over all pixels (ConvTranspose2d bias gradient)
+template <class TR>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const unsigned char* __restrict__ x, int64_t ldx, float* __restrict__ ws,
+                                                         int64_t npix, int C, int cpb, int ppb) {
+    constexpr int EPC = TR::EPC;
+    constexpr int ES = (int)sizeof(typename TR::elem_t);
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const int nchunk = C / EPC;
+    const int ch = blockIdx.y * cpb + tid % cpb;
+    const int prow = tid / cpb;
+    const bool active = prow < ppb && ch < nchunk;
+    float s[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s[e] = 0.f;
+    if (active)
+        for (int64_t pp = (int64_t)blockIdx.x * ppb + prow; pp < npix; pp += (int64_t)gridDim.x * ppb) {
+            float f[EPC];
+            TR::unpack(ld_global16(x + (pp * ldx + ch * EPC) * ES), f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) s[e] += f[e];
+        }
+    for (int e = 0; e < EPC; ++e) {
+        __syncthreads();
+        red[tid] = s[e];
+        __syncthreads();
+        if (tid < cpb && blockIdx.y * cpb + tid < nchunk) {
+            float a = 0.f;
+            for (int k = 0; k < ppb; ++k) a += red[k * cpb + tid];
+            ws[(int64_t)blockIdx.x * C + (blockIdx.y * cpb + tid) * EPC + e] = a;
+        }
+    }
+}
+__global__ void channel_sum_final_kernel(const float* __restrict__ ws, int nblocks, int C, float* out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += (double)ws[(int64_t)b * C + c];
+    out[c] = (float)s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+static int wg_splitk(int nbase, int ntiles, int mult) {
+    // aim at ~512 workgroups (two rounds over 256 CUs); every split gets at least one tile
+    int s = 512 / (nbase * mult);
+    if (s < 1) s = 1;
+    if (s > ntiles) s = ntiles;
+    return s;
+}
+static void wg_geometry(int B, int H, int W, int CA, int CB, int dt, int mult, WGParams& p) {
+    const int CW = 128 / cmu_dtype_size(dt);
+    p.tilesX = cmu_div_up(W, 16);
+    p.tilesY = cmu_div_up(H, 16);
+    p.ntiles = B * p.tilesX * p.tilesY;
+    p.nAB = cmu_div_up(CA, CW);
+    p.nBB = cmu_div_up(CB, CW);
+    p.CApad = p.nAB * CW;
+    p.CBpad = p.nBB * CW;
+    p.splitk = wg_splitk(p.nAB * p.nBB, p.ntiles, mult);
+}
+constexpr int CSUM_BLOCKS = 256;
+
+template <class TR, int MODE>
+static int launch_wgrad(const WGParams& p, hipStream_t st, const char* name) {
+    typedef WGCfg<TR, MODE> C;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<TR, MODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) {
+            cmu_set_error("%s: hipFuncSetAttribute(%d B LDS): %s", name, C::LDS_BYTES, hipGetErrorString(e));
+            return CMU_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    const int grid = p.nAB * p.nBB * p.splitk * (MODE == MODE_WT ? 4 : 1);
+    hipLaunchKernelGGL((conv_wgrad_kernel<TR, MODE>), dim3(grid), dim3(512), C::LDS_BYTES, st, p);
+    CMU_CHECK_LAUNCH(name);
+    return CMU_OK;
+}
+template <class TR>
+static int wgrad3_t(WGParams p, float* dW, hipStream_t st) {
+    int rc = launch_wgrad<TR, MODE_W3>(p, st, "cmu_conv3x3_wgrad");
+    if (rc) return rc;
+    const int64_t total = (int64_t)9 * p.CA * p.CB;
+    const int grid = (int)(cmu_div_up64(total, 256) < 4096 ? cmu_div_up64(total, 256) : 4096);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)p.ws, p.splitk, 9, p.CApad, p.CBpad, p.CA, p.CB, dW,
+                       (int)MODE_W3);
+    CMU_CHECK_LAUNCH("cmu_conv3x3_wgrad(reduce)");
+    return CMU_OK;
+}
+template <class TR>
+static int wgradT_t(WGParams p, float* dW, float* dbias, float* ws_sum, hipStream_t st) {
+    int rc = launch_wgrad<TR, MODE_WT>(p, st, "cmu_convT2x2_wgrad");
+    if (rc) return rc;
+    const int64_t total = (int64_t)4 * p.CA * p.CB;
+    const int grid = (int)(cmu_div_up64(total, 256) < 4096 ? cmu_div_up64(total, 256) : 4096);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)p.ws, p.splitk, 4, p.CApad, p.CBpad, p.CA, p.CB, dW,
+                       (int)MODE_WT);
+    CMU_CHECK_LAUNCH("cmu_convT2x2_wgrad(reduce)");
+    // bias gradient: sum of dOut over all (B,2H,2W) pixels
+    const int nchunk = p.CA / TR::EPC;
+    const int cpb = nchunk < 256 ? nchunk : 256, ppb = 256 / cpb, gy = cmu_div_up(nchunk, cpb);
+    const int64_t npix = (int64_t)p.B * 4 * p.H * p.W;
+    int gx = (int)(cmu_div_up64(npix, ppb * 4) < CSUM_BLOCKS ? cmu_div_up64(npix, ppb * 4) : CSUM_BLOCKS);
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL((channel_sum_kernel<TR>), dim3(gx, gy), dim3(256), 0, st, (const unsigned char*)p.a, p.lda, ws_sum, npix, p.CA, cpb, ppb);
+    CMU_CHECK_LAUNCH("cmu_convT2x2_wgrad(bias)");
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cmu_div_up(p.CA, 128)), dim3(128), 0, st, (const float*)ws_sum, gx, p.CA, dbias);
+    CMU_CHECK_LAUNCH("cmu_convT2x2_wgrad(bias final)");
+    return CMU_OK;
+}
+
+static int wg_check(const char* name, const void* t, int64_t ld, int C, int dt) {
+    const int es = cmu_dtype_size(dt);
+    CMU_CHECK_ARG(es > 0, "%s: bad dtype %d", name, dt);
+    const int epc = 16 / es;
+    CMU_CHECK_ARG(t && cmu_aligned16(t), "%s: null / unaligned tensor", name);
+    CMU_CHECK_ARG(C > 0 && C % epc == 0 && ld % epc == 0 && ld >= C, "%s: C=%d / ld=%lld must be multiples of %d", name, C, (long long)ld, epc);
+    return CMU_OK;
+}
+
+extern "C" int64_t cmu_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int dt) {
+    if (cmu_dtype_size(dt) == 0 || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return -1;
+    WGParams p = {};
+    wg_geometry(B, H, W, Cout, Cin, dt, 1, p);
+    return (int64_t)p.splitk * 9 * p.CApad * p.CBpad * (int64_t)sizeof(float);
+}
+extern "C" int cmu_conv3x3_wgrad(const void* x, int64_t ldx, const float* in_scale, const float* in_shift, int relu_from, const void* dY,
+                                 int64_t ldd, float* dW, int B, int H, int W, int Cin, int Cout, int dt, void* ws, void* stream) {
+    int rc;
+    if ((rc = wg_check("cmu_conv3x3_wgrad(x)", x, ldx, Cin, dt))) return rc;
+    if ((rc = wg_check("cmu_conv3x3_wgrad(dY)", dY, ldd, Cout, dt))) return rc;
+    CMU_CHECK_ARG(dW && ws && B > 0 && H > 0 && W > 0, "cmu_conv3x3_wgrad: null argument / bad dims");
+    CMU_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "cmu_conv3x3_wgrad: scale/shift must both be set");
+    WGParams p = {};
+    p.a = dY; p.lda = ldd; p.b = x; p.ldb = ldx; p.b_scale = in_scale; p.b_shift = in_shift; p.relu_from = relu_from;
+    p.ws = (float*)ws; p.B = B; p.H = H; p.W = W; p.CA = Cout; p.CB = Cin;
+    wg_geometry(B, H, W, Cout, Cin, dt, 1, p);
+    CMU_DISPATCH_DT(dt, wgrad3_t, p, dW, (hipStream_t)stream);
+}
+
+extern "C" int64_t cmu_convT2x2_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int dt) {
+    if (cmu_dtype_size(dt) == 0 || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return -1;
+    WGParams p = {};
+    wg_geometry(B, H, W, Cout, Cin, dt, 4, p);
+    return ((int64_t)p.splitk * 4 * p.CApad * p.CBpad + (int64_t)CSUM_BLOCKS * Cout) * (int64_t)sizeof(float);
+}
+extern "C" int cmu_convT2x2_wgrad(const void* x, int64_t ldx, const float* in_scale, const float* in_shift, int relu_from, const void* dOut,
+                                  int64_t ldd, float* dW, float* dbias, int B, int H, int W, int Cin, int Cout, int dt, void* ws,
+                                  void* stream) {
+    int rc;
+    if ((rc = wg_check("cmu_convT2x2_wgrad(x)", x, ldx, Cin, dt))) return rc;
+    if ((rc = wg_check("cmu_convT2x2_wgrad(dOut)", dOut, ldd, Cout, dt))) return rc;
+    CMU_CHECK_ARG(dW && dbias && ws && B > 0 && H > 0 && W > 0, "cmu_convT2x2_wgrad: null argument / bad dims");
+    CMU_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "cmu_convT2x2_wgrad: scale/shift must both be set");
+    WGParams p = {};
+    p.a = dOut; p.lda = ldd; p.b = x; p.ldb = ldx; p.b_scale = in_scale; p.b_shift = in_shift; p.relu_from = relu_from;
+    p.ws = (float*)ws; p.B = B; p.H = H; p.W = W; p.CA = Cout; p.CB = Cin;
+    wg_geometry(B, H, W, Cout, Cin, dt, 4, p);
+    float* ws_sum = (float*)ws + (int64_t)p.splitk * 4 * p.CApad * p.CBpad;
+    const int dtc = dt;
+    switch (dtc) {
+        case CMU_F32: return wgradT_t<F32Traits>(p, dW, dbias, ws_sum, (hipStream_t)stream);
+        case CMU_F16: return wgradT_t<F16Traits>(p, dW, dbias, ws_sum, (hipStream_t)stream);
+        case CMU_BF16: return wgradT_t<BF16Traits>(p, dW, dbias, ws_sum, (hipStream_t)stream);
+    }
+    cmu_set_error("cmu_convT2x2_wgrad: unknown dtype %d", dt);
+    return CMU_ERR_ARG;
+}

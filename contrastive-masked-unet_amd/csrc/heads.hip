@@ -1,0 +1,475 @@
+// heads.hip -- losses and pretraining heads of the CM-UNet hot path (gfx950), all fp32/fp64 arithmetic:
+//   masked reconstruction loss (cmunet_head.py:62-70), finetune softmax-CE + Dice/IoU counters
+//   (metrics.py:135-180,503), in-batch InfoNCE (cmunet_head.py:72-88), MoCo InfoNCE + queue update in
+//   one launch (moco2_module.py:160-175,256-285), L2 row normalisation, EMA and Adam over flat arenas.
+// These are latency/HBM-bound: one pass per tensor, wave64 shuffle reductions, fixed-order final sums.
+#include "common.h"
+
+__device__ static inline float block_sum(float v, float* red /*[4]*/) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float a = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) a += red[i];
+    return a;
+}
+__device__ static inline double block_sum_d(double v, double* red /*[4]*/) {
+    v = wave_sum_d(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double a = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) a += red[i];
+    return a;
+}
+__device__ static inline float block_max(float v, float* red /*[4]*/) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float a = red[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) a = fmaxf(a, red[i]);
+    return a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// masked MSE: ws = [rows][4] floats (mean, rstd, num, den) + [2] (loss, den_total)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mmse_rows_kernel(const float* __restrict__ logits, int K, int channel,
+                                                       const float* __restrict__ img, const uint8_t* __restrict__ mask,
+                                                       float* __restrict__ ws, int B, int H, int W) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;  // b*H + y
+    const int b = row / H, yy = row % H;
+    const float* im = img + (int64_t)row * W;
+    const float* pr = logits + (((int64_t)b * K + channel) * H + yy) * W;
+    const uint8_t* mk = mask + (int64_t)row * W;
+    float s = 0.f;
+    for (int x = threadIdx.x; x < W; x += 256) s += im[x];
+    const float mean = block_sum(s, red) / (float)W;
+    float v = 0.f;
+    for (int x = threadIdx.x; x < W; x += 256) {
+        const float d = im[x] - mean;
+        v = fmaf(d, d, v);
+    }
+    const float var = block_sum(v, red) / (float)(W > 1 ? W - 1 : 1);  // unbiased (torch.var default)
+    const float rstd = 1.f / sqrtf(var + 1.e-6f);
+    float num = 0.f, den = 0.f;
+    for (int x = threadIdx.x; x < W; x += 256) {
+        const float t = (im[x] - mean) * rstd;
+        const float d = pr[x] - t;
+        const float m = (float)mk[x];
+        num = fmaf(d * d, m, num);
+        den += m;
+    }
+    num = block_sum(num, red);
+    den = block_sum(den, red);
+    if (threadIdx.x == 0) {
+        ws[row * 4 + 0] = mean;
+        ws[row * 4 + 1] = rstd;
+        ws[row * 4 + 2] = num;
+        ws[row * 4 + 3] = den;
+    }
+}
+__global__ __launch_bounds__(256) void mmse_final_kernel(float* __restrict__ ws, int rows, float* loss) {
+    __shared__ double red[4];
+    double num = 0.0, den = 0.0;
+    for (int r = threadIdx.x; r < rows; r += 256) {
+        num += (double)ws[r * 4 + 2];
+        den += (double)ws[r * 4 + 3];
+    }
+    num = block_sum_d(num, red);
+    den = block_sum_d(den, red);
+    if (threadIdx.x == 0) {
+        loss[0] = (float)(num / den);
+        ws[rows * 4 + 0] = (float)(num / den);
+        ws[rows * 4 + 1] = (float)den;
+    }
+}
+__global__ void mmse_grad_kernel(const float* __restrict__ logits, int K, int channel, const float* __restrict__ img,
+                                 const uint8_t* __restrict__ mask, const float* __restrict__ ws, float* __restrict__ dlogits,
+                                 float loss_scale, int B, int H, int W, int64_t total) {
+    const int rows = B * H;
+    const float k = 2.f * loss_scale / ws[rows * 4 + 1];
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(o % W), yy = (int)((o / W) % H), c = (int)((o / ((int64_t)W * H)) % K), b = (int)(o / ((int64_t)W * H * K));
+        float g = 0.f;
+        if (c == channel) {
+            const int row = b * H + yy;
+            const float t = (img[(int64_t)row * W + x] - ws[row * 4 + 0]) * ws[row * 4 + 1];
+            g = k * (logits[o] - t) * (float)mask[(int64_t)row * W + x];
+        }
+        dlogits[o] = g;
+    }
+}
+extern "C" int64_t cmu_masked_mse_ws_bytes(int B, int H) { return ((int64_t)B * H * 4 + 4) * (int64_t)sizeof(float); }
+extern "C" int cmu_masked_mse_fwd_bwd(const float* logits, int K, int channel, const float* img, const uint8_t* mask, float* loss,
+                                      float* dlogits, float loss_scale, int B, int H, int W, void* ws, void* stream) {
+    CMU_CHECK_ARG(logits && img && mask && loss && ws && B > 0 && H > 0 && W > 0 && K > 0 && channel >= 0 && channel < K,
+                  "cmu_masked_mse_fwd_bwd: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(mmse_rows_kernel, dim3(B * H), dim3(256), 0, st, logits, K, channel, img, mask, (float*)ws, B, H, W);
+    CMU_CHECK_LAUNCH("cmu_masked_mse(rows)");
+    hipLaunchKernelGGL(mmse_final_kernel, dim3(1), dim3(256), 0, st, (float*)ws, B * H, loss);
+    CMU_CHECK_LAUNCH("cmu_masked_mse(final)");
+    if (dlogits) {
+        const int64_t total = (int64_t)B * K * H * W;
+        const int grid = (int)(cmu_div_up64(total, 256) < 8192 ? cmu_div_up64(total, 256) : 8192);
+        hipLaunchKernelGGL(mmse_grad_kernel, dim3(grid), dim3(256), 0, st, logits, K, channel, img, mask, (const float*)ws, dlogits,
+                           loss_scale, B, H, W, total);
+        CMU_CHECK_LAUNCH("cmu_masked_mse(grad)");
+    }
+    return CMU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// softmax CE (probability targets) + Dice / IoU counters, 2 classes
+// ws: [blocks][4] doubles (ce, tp, sum_pr, sum_gt)
+// ---------------------------------------------------------------------------------------------
+constexpr int CE_MAX_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void ce_dice_kernel(const float* __restrict__ logits, const double* __restrict__ y1h,
+                                                     double* __restrict__ ws, float* __restrict__ dlogits, float gscale, int64_t HW,
+                                                     int64_t npix) {
+    __shared__ double red[4];
+    double ce = 0.0, tp = 0.0, spr = 0.0, sgt = 0.0;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = p / HW, r = p % HW;
+        const int64_t i0 = (b * 2) * HW + r, i1 = i0 + HW;
+        const float l0 = logits[i0], l1 = logits[i1];
+        const double y0 = y1h[i0], y1 = y1h[i1];
+        const float m = fmaxf(l0, l1);
+        const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+        const float se = e0 + e1;
+        const float lse = m + logf(se);
+        const float p0 = e0 / se, p1 = e1 / se;
+        ce -= y0 * (double)(l0 - lse) + y1 * (double)(l1 - lse);
+        const double pr = p1 > 0.5f ? 1.0 : 0.0;
+        tp += y1 * pr;
+        spr += pr;
+        sgt += y1;
+        if (dlogits) {
+            const float ys = (float)(y0 + y1);
+            dlogits[i0] = gscale * (p0 * ys - (float)y0);
+            dlogits[i1] = gscale * (p1 * ys - (float)y1);
+        }
+    }
+    ce = block_sum_d(ce, red);
+    tp = block_sum_d(tp, red);
+    spr = block_sum_d(spr, red);
+    sgt = block_sum_d(sgt, red);
+    if (threadIdx.x == 0) {
+        ws[blockIdx.x * 4 + 0] = ce;
+        ws[blockIdx.x * 4 + 1] = tp;
+        ws[blockIdx.x * 4 + 2] = spr;
+        ws[blockIdx.x * 4 + 3] = sgt;
+    }
+}
+__global__ void ce_dice_final_kernel(const double* __restrict__ ws, int nblocks, double npix, float* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double ce = 0.0, tp = 0.0, spr = 0.0, sgt = 0.0;
+    for (int b = 0; b < nblocks; ++b) {
+        ce += ws[b * 4 + 0];
+        tp += ws[b * 4 + 1];
+        spr += ws[b * 4 + 2];
+        sgt += ws[b * 4 + 3];
+    }
+    const double fp = spr - tp, fn = sgt - tp;
+    out[0] = (float)(ce / npix);
+    out[1] = (float)(1.0 - (2.0 * tp + 1e-5) / (2.0 * tp + fn + fp + 1e-5));   // metrics.py:135-157, beta=1, eps 1e-5
+    out[2] = (float)(1.0 - (tp + 1e-7) / (sgt + spr - tp + 1e-7));              // metrics.py:182-198, eps 1e-7
+    out[3] = (float)tp;
+    out[4] = (float)spr;
+    out[5] = (float)sgt;
+}
+extern "C" int64_t cmu_softmax_ce_dice_ws_bytes(int B, int H, int W) { return (int64_t)CE_MAX_BLOCKS * 4 * (int64_t)sizeof(double); }
+extern "C" int cmu_softmax_ce_dice_fwd_bwd(const float* logits, const double* y1h, float* out, float* dlogits, float loss_scale, int B,
+                                           int H, int W, void* ws, void* stream) {
+    CMU_CHECK_ARG(logits && y1h && out && ws && B > 0 && H > 0 && W > 0, "cmu_softmax_ce_dice_fwd_bwd: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t npix = (int64_t)B * H * W;
+    const int grid = (int)(cmu_div_up64(npix, 256) < CE_MAX_BLOCKS ? cmu_div_up64(npix, 256) : CE_MAX_BLOCKS);
+    hipLaunchKernelGGL(ce_dice_kernel, dim3(grid), dim3(256), 0, st, logits, y1h, (double*)ws, dlogits, loss_scale / (float)npix,
+                       (int64_t)H * W, npix);
+    CMU_CHECK_LAUNCH("cmu_softmax_ce_dice");
+    hipLaunchKernelGGL(ce_dice_final_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, grid, (double)npix, out);
+    CMU_CHECK_LAUNCH("cmu_softmax_ce_dice(final)");
+    return CMU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// L2 row normalisation (F.normalize(dim=1), eps 1e-12)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ x, float* __restrict__ out, int D) {
+    __shared__ float red[4];
+    const float* r = x + (int64_t)blockIdx.x * D;
+    float s = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) s = fmaf(r[d], r[d], s);
+    const float inv = 1.f / fmaxf(sqrtf(block_sum(s, red)), 1e-12f);
+    for (int d = threadIdx.x; d < D; d += 256) out[(int64_t)blockIdx.x * D + d] = r[d] * inv;
+}
+extern "C" int cmu_l2_normalize_rows(const float* x, float* out, int B, int D, void* stream) {
+    CMU_CHECK_ARG(x && out && B > 0 && D > 0, "cmu_l2_normalize_rows: bad args");
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, out, D);
+    CMU_CHECK_LAUNCH("cmu_l2_normalize_rows");
+    return CMU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// in-batch InfoNCE (CM-UNet): one block per query row; loss[0] = total, loss[1+b] = per-row terms
+// ---------------------------------------------------------------------------------------------
+constexpr int NCE_MAX_N = 8192;
+__global__ __launch_bounds__(256) void infonce_rows_kernel(const float* __restrict__ pred, const float* __restrict__ keys,
+                                                          float* __restrict__ loss, float* __restrict__ dpred, int B, int N, int D,
+                                                          int rank, float temp, float ct_w) {
+    extern __shared__ float sm[];  // [D] normalised query, [N] scores / probabilities
+    __shared__ float red[4];
+    float* qn = sm;
+    float* sc = sm + D;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* p = pred + (int64_t)b * D;
+    float s = 0.f;
+    for (int d = tid; d < D; d += 256) s = fmaf(p[d], p[d], s);
+    const float nrm = fmaxf(sqrtf(block_sum(s, red)), 1e-12f);
+    for (int d = tid; d < D; d += 256) qn[d] = p[d] / nrm;
+    __syncthreads();
+    // scores: one wave per key, lanes over D (coalesced key rows)
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int n = wave; n < N; n += 4) {
+        const float* k = keys + (int64_t)n * D;
+        float a = 0.f;
+        for (int d = lane; d < D; d += 64) a = fmaf(qn[d], k[d], a);
+        a = wave_sum(a);
+        if (lane == 0) sc[n] = a / temp;
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int n = tid; n < N; n += 256) m = fmaxf(m, sc[n]);
+    m = block_max(m, red);
+    float se = 0.f;
+    for (int n = tid; n < N; n += 256) se += expf(sc[n] - m);
+    se = block_sum(se, red);
+    const int label = b + B * rank;
+    const float lse = m + logf(se);
+    const float coef = ct_w * 2.f * temp;
+    if (tid == 0) loss[1 + b] = coef * (lse - sc[label]) / (float)B;
+    if (dpred == nullptr) return;
+    // d loss / d score = coef/B * (softmax - onehot); d score / d qn = key / temp
+    __syncthreads();
+    for (int n = tid; n < N; n += 256) sc[n] = (coef / (float)B) * (expf(sc[n] - m) / se - (n == label ? 1.f : 0.f)) / temp;
+    __syncthreads();
+    // dqn[d] = sum_n g[n] * key[n][d]; then through the normalisation: (dqn - qn*(qn.dqn)) / nrm
+    float dot = 0.f;
+    for (int d = tid; d < D; d += 256) {
+        float a = 0.f;
+        for (int n = 0; n < N; ++n) a = fmaf(sc[n], keys[(int64_t)n * D + d], a);
+        dpred[(int64_t)b * D + d] = a;  // temporarily dqn
+        dot = fmaf(a, qn[d], dot);
+    }
+    dot = block_sum(dot, red);
+    for (int d = tid; d < D; d += 256) dpred[(int64_t)b * D + d] = (dpred[(int64_t)b * D + d] - qn[d] * dot) / nrm;
+}
+__global__ void sum_small_kernel(float* loss, int B) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int b = 0; b < B; ++b) s += (double)loss[1 + b];
+        loss[0] = (float)s;
+    }
+}
+extern "C" int cmu_infonce_inbatch_fwd_bwd(const float* pred, const float* keys, float* loss, float* dpred, int B, int N, int D,
+                                           int rank, float temperature, float ct_weight, void* stream) {
+    CMU_CHECK_ARG(pred && keys && loss && B > 0 && N > 0 && D > 0 && rank >= 0 && temperature > 0.f, "cmu_infonce_inbatch_fwd_bwd: bad args");
+    CMU_CHECK_ARG(N <= NCE_MAX_N && D <= 4096, "cmu_infonce_inbatch_fwd_bwd: N=%d (max %d) / D=%d (max 4096) too large", N, NCE_MAX_N, D);
+    CMU_CHECK_ARG(B * (rank + 1) <= N, "cmu_infonce_inbatch_fwd_bwd: labels i + B*rank exceed N=%d", N);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)(D + N) * sizeof(float);
+    hipLaunchKernelGGL(infonce_rows_kernel, dim3(B), dim3(256), lds, st, pred, keys, loss, dpred, B, N, D, rank, temperature, ct_weight);
+    CMU_CHECK_LAUNCH("cmu_infonce_inbatch");
+    hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(64), 0, st, loss, B);
+    CMU_CHECK_LAUNCH("cmu_infonce_inbatch(sum)");
+    return CMU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MoCo: InfoNCE against the queue + ring-buffer enqueue in ONE launch.
+//   grid = B blocks (one query row each).  Every block streams the (D,K) queue twice (logits, gradient);
+//   the block that draws the last ticket sums the per-row losses in row order, writes the gathered keys
+//   into queue[:, ptr:ptr+Nk] and advances the pointer -- after all readers of the old queue are done.
+// ws: [0] ticket (u32, zeroed by a memset node before the launch), [4..4+B) per-row losses (float).
+// ---------------------------------------------------------------------------------------------
+constexpr int MOCO_MAX_K_LDS = 16384;
+__global__ __launch_bounds__(256) void moco_kernel(const float* __restrict__ q_raw, const float* __restrict__ k_raw,
+                                                  const float* __restrict__ keys_all, int Nk, float* queue, int64_t* queue_ptr,
+                                                  float* loss, float* __restrict__ dq, float* __restrict__ k_norm_out, int B, int D,
+                                                  int K, float temp, unsigned* ticket, float* row_loss) {
+    extern __shared__ float sm[];  // [D] qn, [D] kn, [K] logits (if K fits)
+    __shared__ float red[4];
+    __shared__ unsigned last_flag;
+    float* qn = sm;
+    float* kn = sm + D;
+    float* lg = sm + 2 * D;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* q = q_raw + (int64_t)b * D;
+    const float* kk = k_raw + (int64_t)b * D;
+    float s = 0.f, s2 = 0.f;
+    for (int d = tid; d < D; d += 256) {
+        s = fmaf(q[d], q[d], s);
+        s2 = fmaf(kk[d], kk[d], s2);
+    }
+    const float qnorm = fmaxf(sqrtf(block_sum(s, red)), 1e-12f);
+    const float knorm = fmaxf(sqrtf(block_sum(s2, red)), 1e-12f);
+    float pos = 0.f;
+    for (int d = tid; d < D; d += 256) {
+        qn[d] = q[d] / qnorm;
+        kn[d] = kk[d] / knorm;
+        pos = fmaf(qn[d], kn[d], pos);
+        if (k_norm_out) k_norm_out[(int64_t)b * D + d] = kn[d];
+    }
+    pos = block_sum(pos, red) / temp;  // also the barrier that publishes qn/kn
+    // pass 1: negatives l_j = qn . queue[:, j] / temp ; thread per column (coalesced over j)
+    const int ptr0 = (int)queue_ptr[0];
+    float m = pos;
+    for (int j = tid; j < K; j += 256) {
+        float a = 0.f;
+        for (int d = 0; d < D; ++d) a = fmaf(qn[d], queue[(int64_t)d * K + j], a);
+        a /= temp;
+        lg[j] = a;
+        m = fmaxf(m, a);
+    }
+    m = block_max(m, red);
+    float se = 0.f;
+    for (int j = tid; j < K; j += 256) se += expf(lg[j] - m);
+    se = block_sum(se, red) + expf(pos - m);
+    const float lse = m + logf(se);
+    if (tid == 0) row_loss[b] = (lse - pos) / (float)B;   // CE with label 0, mean over the batch
+    if (dq) {
+        // d loss / d logit_j = (softmax_j - [j==0]) / B ; d logit / d qn = key / temp
+        const float gpos = (expf(pos - m) / se - 1.f) / ((float)B * temp);
+        __syncthreads();
+        for (int j = tid; j < K; j += 256) lg[j] = expf(lg[j] - m) / se / ((float)B * temp);
+        __syncthreads();
+        // pass 2: dqn[d] = gpos*kn[d] + sum_j g_j queue[d][j]; one wave per d (rows of the queue are contiguous)
+        for (int d = wave; d < D; d += 4) {
+            const float* row = queue + (int64_t)d * K;
+            float a = 0.f;
+            for (int j = lane; j < K; j += 64) a = fmaf(lg[j], row[j], a);
+            a = wave_sum(a);
+            if (lane == 0) kn[d] = fmaf(gpos, kn[d], a);   // kn now holds dqn
+        }
+        __syncthreads();
+        float dot = 0.f;
+        for (int d = tid; d < D; d += 256) dot = fmaf(kn[d], qn[d], dot);
+        dot = block_sum(dot, red);
+        for (int d = tid; d < D; d += 256) dq[(int64_t)b * D + d] = (kn[d] - qn[d] * dot) / qnorm;
+    }
+    // ---- ticket: the last block to finish reading the old queue performs the enqueue -----------------
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = (t == (unsigned)(gridDim.x - 1)) ? 1u : 0u;
+        if (last_flag) __threadfence();
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    if (tid == 0) {
+        double tot = 0.0;
+        for (int r = 0; r < B; ++r) tot += (double)__hip_atomic_load(&row_loss[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        loss[0] = (float)tot;
+    }
+    // queue[:, ptr + i] = key_i  (moco2_module.py:172); keys_all == NULL: this rank's normalised keys
+    for (int64_t o = tid; o < (int64_t)Nk * D; o += 256) {
+        const int d = (int)(o / Nk), i = (int)(o % Nk);   // consecutive threads -> consecutive columns (coalesced store)
+        float v;
+        if (keys_all) v = __hip_atomic_load(&keys_all[(int64_t)i * D + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else {
+            // recompute the normalised key of row i (k_norm_out may be NULL)
+            const float* kr = k_raw + (int64_t)i * D;
+            float ss = 0.f;
+            for (int e = 0; e < D; ++e) ss = fmaf(kr[e], kr[e], ss);
+            v = kr[d] / fmaxf(sqrtf(ss), 1e-12f);
+        }
+        queue[(int64_t)d * K + ptr0 + i] = v;
+    }
+    if (tid == 0) queue_ptr[0] = (int64_t)((ptr0 + Nk) % K);
+}
+extern "C" int64_t cmu_moco_ws_bytes(int B, int K) { return 16 + (int64_t)B * (int64_t)sizeof(float); }
+extern "C" int cmu_moco_infonce_enqueue(const float* q_raw, const float* k_raw, const float* keys_all, int Nk, float* queue,
+                                        int64_t* queue_ptr, float* loss, float* dq, float* k_norm_out, int B, int D, int K,
+                                        float temperature, void* ws, void* stream) {
+    CMU_CHECK_ARG(q_raw && k_raw && queue && queue_ptr && loss && ws && B > 0 && D > 0 && K > 0 && temperature > 0.f,
+                  "cmu_moco_infonce_enqueue: bad args");
+    if (!keys_all) Nk = B;
+    CMU_CHECK_ARG(Nk > 0 && K % Nk == 0, "cmu_moco_infonce_enqueue: K=%d must be a multiple of the gathered batch %d (moco2_module.py:169)", K, Nk);
+    CMU_CHECK_ARG(K <= MOCO_MAX_K_LDS && (size_t)(2 * D + K) * 4 <= 160 * 1024 - 64, "cmu_moco_infonce_enqueue: K=%d, D=%d exceed the LDS-resident logits budget", K, D);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(ws, 0, 16, st);
+    if (e != hipSuccess) { cmu_set_error("cmu_moco_infonce_enqueue: memset: %s", hipGetErrorString(e)); return CMU_ERR_LAUNCH; }
+    const size_t lds = (size_t)(2 * D + K) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&moco_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        if (e != hipSuccess) { cmu_set_error("cmu_moco_infonce_enqueue: LDS attribute: %s", hipGetErrorString(e)); return CMU_ERR_LAUNCH; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(moco_kernel, dim3(B), dim3(256), lds, st, q_raw, k_raw, keys_all, Nk, queue, queue_ptr, loss, dq, k_norm_out, B, D, K,
+                       temperature, (unsigned*)ws, (float*)((char*)ws + 16));
+    CMU_CHECK_LAUNCH("cmu_moco_infonce_enqueue");
+    return CMU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// EMA and Adam over flat fp32 arenas (float4 per lane)
+// ---------------------------------------------------------------------------------------------
+__global__ void ema_kernel(float* __restrict__ t, const float* __restrict__ o, int64_t n, float m) {
+    const int64_t n4 = n >> 2;
+    const float om = 1.f - m;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 a = reinterpret_cast<f32x4*>(t)[i];
+        const f32x4 b = reinterpret_cast<const f32x4*>(o)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = a[e] * m + b[e] * om;   // cmunet.py:85-86 order: p_t*m + p_o*(1-m)
+        reinterpret_cast<f32x4*>(t)[i] = a;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        t[i] = t[i] * m + o[i] * om;
+    }
+}
+extern "C" int cmu_ema_update(float* target, const float* online, int64_t n, float momentum, void* stream) {
+    CMU_CHECK_ARG(target && online && n > 0 && cmu_aligned16(target) && cmu_aligned16(online), "cmu_ema_update: bad args / alignment");
+    const int64_t nb = cmu_div_up64(n >> 2, 256);
+    const int grid = (int)(nb < 4096 ? (nb < 1 ? 1 : nb) : 4096);
+    hipLaunchKernelGGL(ema_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, target, online, n, momentum);
+    CMU_CHECK_LAUNCH("cmu_ema_update");
+    return CMU_OK;
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            const uint8_t* __restrict__ wd_mask, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                            int decoupled, float bc1, float bc2_sqrt, float gscale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float pi = p[i], gi = g[i] * gscale;
+        const float w = (wd_mask == nullptr || wd_mask[i]) ? wd : 0.f;
+        if (decoupled) pi *= (1.f - lr * w);
+        else gi = fmaf(w, pi, gi);
+        const float mi = fmaf(b1, m[i], (1.f - b1) * gi);            // exp_avg.lerp_(grad, 1-beta1)
+        const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);       // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+extern "C" int cmu_adam_step(float* p, const float* g, float* m, float* v, const uint8_t* wd_mask, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int decoupled, int64_t step, float grad_scale, void* stream) {
+    CMU_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "cmu_adam_step: bad args");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const int64_t nb = cmu_div_up64(n, 256);
+    const int grid = (int)(nb < 8192 ? nb : 8192);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, wd_mask, n, lr, beta1, beta2, eps,
+                       weight_decay, decoupled, (float)bc1, (float)sqrt(bc2), grad_scale);
+    CMU_CHECK_LAUNCH("cmu_adam_step");
+    return CMU_OK;
+}

@@ -1,0 +1,280 @@
+"""GPU parity of the backward / loss / optimiser C-ABI entry points against the oracle's arithmetic
+(torch CPU fp64 autograd on the same dtype-quantised operands)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_gpu_fwd_ops import DTS, TOL, check, from_act, q, to_act  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cmunet_amd import ops as o
+    return o
+
+
+def ws_bytes(n):
+    return torch.empty(max(int(n), 16), dtype=torch.uint8, device="cuda")
+
+
+def bn_consts(y, gamma, beta, eps=1e-5):
+    mean = y.double().mean((0, 2, 3))
+    var = y.double().var((0, 2, 3), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + eps)
+    scale = gamma.double() * invstd
+    shift = beta.double() - mean * scale
+    return mean.float(), invstd.float(), scale.float(), shift.float()
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape", [(2, 32, 12, 20), (1, 72, 9, 7), (2, 1024 + 64, 4, 4)])
+def test_bn_relu_backward(ops, dt, shape):
+    from cmunet_amd import _lib
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(C)
+    y = q(torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3, dt, ops)
+    dA = q(torch.randn(B, C, H, W, generator=g), dt, ops)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    mean, invstd, scale, shift = bn_consts(y, gamma, beta)
+    # oracle: autograd through batch_norm(train) + relu in fp64
+    yd = y.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    a = F.relu(F.batch_norm(yd, None, None, gd, bd, True, 0.1, 1e-5))
+    (a * dA.double()).sum().backward()
+    ya = to_act(y, dt, ops, ld=C + 8, coff=8).with_transform(scale.cuda(), shift.cuda(), 0)
+    da = to_act(dA, dt, ops)
+    dgamma, dbeta = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    coef = torch.empty(2, C, device="cuda")
+    ws = ws_bytes(_lib.lib().cmu_bn_bwd_ws_bytes(C))
+    ops.bn_bwd_reduce(da, ya, mean.cuda(), invstd.cuda(), dgamma, dbeta, coef, ws)
+    dy = ops.new_act(B, H, W, C, dt, "cuda")
+    ops.bn_bwd_apply(da, ya, mean.cuda(), invstd.cuda(), coef, dy)
+    # the ReLU gate is evaluated on fp32 scale/shift: elements within rounding of 0 may flip -> tolerance on few
+    check(dgamma.cpu(), gd.grad, 2e-3, "dgamma")
+    check(dbeta.cpu(), bd.grad, 2e-3, "dbeta")
+    check(from_act(dy), yd.grad, max(TOL[dt], 2e-3), "dy")
+
+
+WG_CASES = [(2, 20, 24, 32, 64, True), (1, 16, 16, 16, 16, False), (2, 7, 9, 8, 8, True), (1, 33, 17, 72, 40, True),
+            (3, 16, 32, 128, 64, False)]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", WG_CASES)
+def test_conv3x3_wgrad(ops, dt, case):
+    from cmunet_amd import _lib
+    B, H, W, Cin, Cout, tf = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = q(torch.randn(B, Cin, H, W, generator=g), dt, ops)
+    dy = q(torch.randn(B, Cout, H, W, generator=g), dt, ops)
+    xa = to_act(x, dt, ops, ld=Cin + 16, coff=16)
+    ref_in = x.double()
+    if tf:
+        sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+        rf = Cin // 2 if Cin >= 16 else 0
+        xa = xa.with_transform(sc.cuda(), sh.cuda(), rf)
+        t = x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+        t[:, rf:] = t[:, rf:].clamp_min(0)
+        ref_in = q(t.float(), dt, ops).double()
+    dW = torch.full((Cout, Cin, 3, 3), 9.0, device="cuda")
+    ws = ws_bytes(_lib.lib().cmu_conv3x3_wgrad_ws_bytes(B, H, W, Cin, Cout, ops.dt_code(dt)))
+    ops.conv3x3_wgrad(xa, to_act(dy, dt, ops), dW, ws)
+    ref = torch.nn.grad.conv2d_weight(ref_in, (Cout, Cin, 3, 3), dy.double(), padding=1)
+    check(dW.cpu(), ref, 1e-4 if dt == "f32" else 2e-3, "dW 3x3")
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("masked", [0, 1, 2])
+def test_conv3x3_c1_wgrad(ops, dt, masked):
+    from cmunet_amd import _lib
+    B, H, W, Cout = 2, 20, 37, 32
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, H, W, generator=g)
+    dy = q(torch.randn(B, Cout, H, W, generator=g), dt, ops)
+    mask, xin = None, x
+    if masked:
+        m = (torch.rand(B, H, W, generator=g) > 0.5).to(torch.uint8)
+        mask = m[:1].contiguous() if masked == 1 else m
+        xin = x * (1 - (m[0] if masked == 1 else m)).float()
+    dW = torch.empty(Cout, 1, 3, 3, device="cuda")
+    ws = ws_bytes(_lib.lib().cmu_conv3x3_c1_wgrad_ws_bytes(B, H, W, Cout))
+    ops.conv3x3_c1_wgrad(x.cuda(), to_act(dy, dt, ops), dW, ws, None if mask is None else mask.cuda(), masked == 2)
+    ref = torch.nn.grad.conv2d_weight(xin.double().unsqueeze(1), (Cout, 1, 3, 3), dy.double(), padding=1)
+    check(dW.cpu(), ref, 1e-4, "dW c1")
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("with_skip", [True, False])
+def test_maxpool_bwd(ops, dt, with_skip):
+    B, C, H, W = 2, 32, 8, 12
+    g = torch.Generator().manual_seed(5)
+    y = q(torch.randn(B, C, H, W, generator=g), dt, ops)
+    sc, sh = torch.randn(C, generator=g), torch.randn(C, generator=g) * 0.2
+    dP = q(torch.randn(B, C, H // 2, W // 2, generator=g), dt, ops)
+    dS = q(torch.randn(B, C, H, W, generator=g), dt, ops)
+    a = F.relu(y.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).requires_grad_(True)
+    (F.max_pool2d(a, 2) * dP.double()).sum().backward()
+    ref = a.grad + (dS.double() if with_skip else 0)
+    ya = to_act(y, dt, ops).with_transform(sc.cuda(), sh.cuda(), 0)
+    dA = ops.new_act(B, H, W, C, dt, "cuda")
+    sk = to_act(dS, dt, ops, ld=2 * C, coff=C) if with_skip else None
+    ops.maxpool_bwd(to_act(dP, dt, ops), sk, ya, dA)
+    # positions whose activation is 0 (all-negative windows) may differ in which zero got the gradient;
+    # that gradient is killed by the ReLU gate downstream, so compare after gating with a > 0
+    gate = (a.detach() > 0).double()
+    check(from_act(dA).double() * gate, ref * gate, TOL[dt], "maxpool bwd (gated)")
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", [(2, 8, 8, 32, 16, True), (1, 5, 9, 64, 32, False), (2, 16, 16, 128, 64, True)])
+def test_convT2x2_wgrad(ops, dt, case):
+    from cmunet_amd import _lib
+    B, H, W, Cin, Cout, tf = case
+    g = torch.Generator().manual_seed(7)
+    x = q(torch.randn(B, Cin, H, W, generator=g), dt, ops)
+    dout = q(torch.randn(B, Cout, 2 * H, 2 * W, generator=g), dt, ops)
+    xa = to_act(x, dt, ops)
+    ref_in = x.double()
+    if tf:
+        sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+        xa = xa.with_transform(sc.cuda(), sh.cuda(), 0)
+        ref_in = q(F.relu(x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).float(), dt, ops).double()
+    w = torch.zeros(Cin, Cout, 2, 2, dtype=torch.float64, requires_grad=True)
+    bias = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    (F.conv_transpose2d(ref_in, w, bias, stride=2) * dout.double()).sum().backward()
+    dW, db = torch.empty(Cin, Cout, 2, 2, device="cuda"), torch.empty(Cout, device="cuda")
+    ws = ws_bytes(_lib.lib().cmu_convT2x2_wgrad_ws_bytes(B, H, W, Cin, Cout, ops.dt_code(dt)))
+    ops.convT2x2_wgrad(xa, to_act(dout, dt, ops, ld=2 * Cout, coff=0), dW, db, ws)
+    check(dW.cpu(), w.grad, 1e-4 if dt == "f32" else 2e-3, "dW convT")
+    check(db.cpu(), bias.grad, 1e-4, "dbias convT")
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("C", [16, 64])
+def test_conv1x1_head_bwd(ops, dt, C):
+    from cmunet_amd import _lib
+    B, H, W, K = 2, 10, 13, 2
+    g = torch.Generator().manual_seed(9)
+    x = q(torch.randn(B, C, H, W, generator=g), dt, ops)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    w, b = torch.randn(K, C, generator=g) / C ** 0.5, torch.randn(K, generator=g)
+    dl = torch.randn(B, K, H, W, generator=g)
+    a = F.relu(x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).requires_grad_(True)
+    wd, bd = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    (F.conv2d(a, wd.view(K, C, 1, 1), bd) * dl.double()).sum().backward()
+    xa = to_act(x, dt, ops).with_transform(sc.cuda(), sh.cuda(), 0)
+    dX = ops.new_act(B, H, W, C, dt, "cuda")
+    dW, db = torch.empty(K, C, device="cuda"), torch.empty(K, device="cuda")
+    ws = ws_bytes(_lib.lib().cmu_conv1x1_head_bwd_ws_bytes(B, H, W, C, K))
+    ops.conv1x1_head_bwd(dl.cuda(), xa, w.cuda(), dX, dW, db, ws)
+    check(from_act(dX), a.grad, TOL[dt], "head dX")
+    check(dW.cpu(), wd.grad, 1e-4, "head dW")
+    check(db.cpu(), bd.grad, 1e-4, "head dbias")
+
+
+def test_masked_mse(ops):
+    from cmunet_amd import _lib
+    from oracle import cmunet as OC
+    B, K, H, W = 3, 2, 20, 33
+    g = torch.Generator().manual_seed(11)
+    logits = torch.randn(B, K, H, W, generator=g)
+    img = torch.randn(B, H, W, generator=g) * 2 + 1
+    mask = (torch.rand(B, H, W, generator=g) > 0.4).to(torch.uint8)
+    lo = logits.clone().requires_grad_(True)
+    ref = OC.masked_mse(lo[:, 1], img, mask)
+    (ref * 3.0).backward()
+    loss = torch.empty(1, device="cuda")
+    dl = torch.empty(B, K, H, W, device="cuda")
+    ws = ws_bytes(_lib.lib().cmu_masked_mse_ws_bytes(B, H))
+    ops.masked_mse_fwd_bwd(logits.cuda(), 1, img.cuda(), mask.cuda(), loss, dl, 3.0, ws)
+    check(loss.cpu(), ref.detach().view(1), 1e-5, "masked mse loss")
+    check(dl.cpu(), lo.grad, 1e-5, "masked mse grad")
+
+
+def test_softmax_ce_dice(ops, golden_dir):
+    import numpy as np
+    from cmunet_amd import _lib
+    d = np.load(golden_dir + "/losses.npz")
+    logits, y1h = torch.from_numpy(d["logits"]), torch.from_numpy(d["y1h"])
+    B, K, H, W = logits.shape
+    out = torch.empty(6, device="cuda")
+    dl = torch.empty(B, K, H, W, device="cuda")
+    ws = ws_bytes(_lib.lib().cmu_softmax_ce_dice_ws_bytes(B, H, W))
+    ops.softmax_ce_dice_fwd_bwd(logits.cuda(), y1h.cuda(), out, dl, 1.0, ws)
+    o = out.cpu()
+    assert abs(o[0].item() - float(d["ce"])) < 1e-5
+    assert abs(o[1].item() - float(d["dice"])) < 1e-6          # thresholded counters: exact up to fp32 of the ratio
+    assert abs(o[2].item() - float(d["iou"])) < 1e-6
+    check(dl.cpu(), torch.from_numpy(d["dlogits"]), 1e-5, "dlogits (CE only: Dice has no gradient, A-4)")
+
+
+@pytest.mark.parametrize("rank,world", [(0, 1), (1, 4)])
+def test_infonce_inbatch(ops, rank, world):
+    from oracle import cmunet as OC
+    B, D = 8, 256
+    g = torch.Generator().manual_seed(13)
+    pred = torch.randn(B, D, generator=g)
+    keys = F.normalize(torch.randn(B * world, D, generator=g), dim=1)
+    p = pred.clone().requires_grad_(True)
+    ref = OC.infonce_inbatch(p, keys, 0.07, rank, 1.0)
+    ref.backward()
+    loss = torch.empty(1 + B, device="cuda")
+    dp = torch.empty(B, D, device="cuda")
+    ops.infonce_inbatch_fwd_bwd(pred.cuda(), keys.cuda(), loss, dp, rank, 0.07, 1.0)
+    check(loss[:1].cpu(), ref.detach().view(1), 2e-5, "infonce loss")
+    check(dp.cpu(), p.grad, 1e-4, "infonce dpred")
+
+
+@pytest.mark.parametrize("gathered", [False, True])
+def test_moco_infonce_enqueue(ops, gathered):
+    from cmunet_amd import _lib
+    from oracle import moco as OM
+    B, D, K, T = 8, 128, 512, 0.2
+    g = torch.Generator().manual_seed(17)
+    q_raw, k_raw = torch.randn(B, D, generator=g), torch.randn(B, D, generator=g)
+    queue = OM.init_queue(D, K, seed=3)
+    ptr = torch.tensor([K - (16 if gathered else 8)], dtype=torch.long)       # wraps to 0 after the enqueue
+    qr = q_raw.clone().requires_grad_(True)
+    logits, labels, k, _ = OM.logits_from_embeddings(qr, k_raw, queue, T)
+    keys_all = torch.cat([k, F.normalize(torch.randn(B, D, generator=g), dim=1)]) if gathered else k
+    ref_queue, ref_ptr = queue.clone(), ptr.clone()
+    OM.dequeue_and_enqueue(keys_all, ref_queue, ref_ptr, K)
+    ref = F.cross_entropy(logits, labels)
+    ref.backward()
+    qd, pd = queue.clone().cuda(), ptr.clone().cuda()
+    loss, dq, kn = torch.empty(1, device="cuda"), torch.empty(B, D, device="cuda"), torch.empty(B, D, device="cuda")
+    ws = ws_bytes(_lib.lib().cmu_moco_ws_bytes(B, K))
+    ops.moco_infonce_enqueue(q_raw.cuda(), k_raw.cuda(), keys_all.cuda() if gathered else None, qd, pd, loss, dq, kn, T, ws)
+    check(loss.cpu(), ref.detach().view(1), 2e-5, "moco loss")
+    check(dq.cpu(), qr.grad, 1e-4, "moco dq")
+    check(kn.cpu(), k, 1e-6, "normalised keys")
+    check(qd.cpu(), ref_queue, 1e-6, "queue after enqueue")
+    assert int(pd.item()) == int(ref_ptr.item()) == 0
+
+
+def test_l2norm_ema_adam(ops):
+    g = torch.Generator().manual_seed(19)
+    x = torch.randn(5, 300, generator=g)
+    out = torch.empty(5, 300, device="cuda")
+    ops.l2_normalize_rows(x.cuda(), out)
+    check(out.cpu(), F.normalize(x, dim=1), 1e-6, "l2norm")
+    n = 1003
+    t, o = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    td = t.clone().cuda()
+    ops.ema_update(td, o.cuda(), 0.996)
+    check(td.cpu(), t * 0.996 + o * (1 - 0.996), 1e-6, "ema")
+    for decoupled, wd in ((0, 0.0), (1, 0.05), (0, 1e-4)):
+        p0 = torch.randn(n, generator=g)
+        p = torch.nn.Parameter(p0.clone())
+        opt = (torch.optim.AdamW if decoupled else torch.optim.Adam)([p], lr=1e-3, betas=(0.9, 0.95), weight_decay=wd)
+        pd, m, v = p0.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        for step in range(1, 4):
+            gr = torch.randn(n, generator=g)
+            p.grad = gr.clone()
+            opt.step()
+            ops.adam_step(pd, gr.cuda(), m, v, None, 1e-3, 0.9, 0.95, 1e-8, wd, decoupled, step)
+        check(pd.cpu(), p.detach(), 1e-5, f"adam decoupled={decoupled} wd={wd}")
