@@ -414,6 +414,7 @@ extern "C" int cmu_conv3x3_fwd(const void* x, int64_t ldx, const float* in_scale
     if ((rc = check_act("cmu_conv3x3_fwd(y)", y, ldy, Cout, dt))) return rc;
     CMU_CHECK_ARG(wpacked && cmu_aligned16(wpacked), "cmu_conv3x3_fwd: packed weights null/unaligned");
     CMU_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "cmu_conv3x3_fwd: scale/shift must both be set");
+    CMU_CHECK_ARG(relu_from >= 0 && relu_from % (16 / cmu_dtype_size(dt)) == 0, "cmu_conv3x3_fwd: relu_from=%d must be a multiple of the 16-byte chunk", relu_from);
     CMU_CHECK_ARG((int64_t)B * cmu_div_up(H, CMU_TH) * cmu_div_up(W, CMU_TW) * cmu_div_up(Cout, 64) < (1ll << 31),
                   "cmu_conv3x3_fwd: grid too large");
     IGParams p = {};
@@ -434,6 +435,7 @@ extern "C" int cmu_convT2x2_fwd(const void* x, int64_t ldx, const float* in_scal
     if ((rc = check_act("cmu_convT2x2_fwd(out)", out, ldo, Cout, dt))) return rc;
     CMU_CHECK_ARG(wpacked && cmu_aligned16(wpacked) && bias, "cmu_convT2x2_fwd: weights/bias null or unaligned");
     CMU_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "cmu_convT2x2_fwd: scale/shift must both be set");
+    CMU_CHECK_ARG(relu_from >= 0 && relu_from % (16 / cmu_dtype_size(dt)) == 0, "cmu_convT2x2_fwd: relu_from=%d must be a multiple of the 16-byte chunk", relu_from);
     IGParams p = {};
     p.x = x; p.ldx = ldx; p.in_scale = in_scale; p.in_shift = in_shift; p.relu_from = relu_from;
     p.w = wpacked; p.y = out; p.ldy = ldo; p.stats = nullptr; p.bias = bias;

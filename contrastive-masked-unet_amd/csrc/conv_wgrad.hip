@@ -72,7 +72,6 @@ __device__ static inline u32x2 lds_tr16(const unsigned char* smem, int off) {
 template <class TR, int MODE>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WGParams p) {
     typedef WGCfg<TR, MODE> C;
-    typedef typename TR::elem_t elem_t;
     constexpr int EPC = TR::EPC;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* smA = smem;
@@ -415,6 +414,7 @@ extern "C" int cmu_conv3x3_wgrad(const void* x, int64_t ldx, const float* in_sca
     if ((rc = wg_check("cmu_conv3x3_wgrad(dY)", dY, ldd, Cout, dt))) return rc;
     CMU_CHECK_ARG(dW && ws && B > 0 && H > 0 && W > 0, "cmu_conv3x3_wgrad: null argument / bad dims");
     CMU_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "cmu_conv3x3_wgrad: scale/shift must both be set");
+    CMU_CHECK_ARG(relu_from >= 0 && relu_from % (16 / cmu_dtype_size(dt)) == 0, "cmu_conv3x3_wgrad: relu_from=%d must be a multiple of the 16-byte chunk", relu_from);
     WGParams p = {};
     p.a = dY; p.lda = ldd; p.b = x; p.ldb = ldx; p.b_scale = in_scale; p.b_shift = in_shift; p.relu_from = relu_from;
     p.ws = (float*)ws; p.B = B; p.H = H; p.W = W; p.CA = Cout; p.CB = Cin;
@@ -436,6 +436,7 @@ extern "C" int cmu_convT2x2_wgrad(const void* x, int64_t ldx, const float* in_sc
     if ((rc = wg_check("cmu_convT2x2_wgrad(dOut)", dOut, ldd, Cout, dt))) return rc;
     CMU_CHECK_ARG(dW && dbias && ws && B > 0 && H > 0 && W > 0, "cmu_convT2x2_wgrad: null argument / bad dims");
     CMU_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "cmu_convT2x2_wgrad: scale/shift must both be set");
+    CMU_CHECK_ARG(relu_from >= 0 && relu_from % (16 / cmu_dtype_size(dt)) == 0, "cmu_convT2x2_wgrad: relu_from=%d must be a multiple of the 16-byte chunk", relu_from);
     WGParams p = {};
     p.a = dOut; p.lda = ldd; p.b = x; p.ldb = ldx; p.b_scale = in_scale; p.b_shift = in_shift; p.relu_from = relu_from;
     p.ws = (float*)ws; p.B = B; p.H = H; p.W = W; p.CA = Cout; p.CB = Cin;

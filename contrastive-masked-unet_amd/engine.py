@@ -1,0 +1,302 @@
+"""UNet forward/backward engine: sequences the HIP kernels (ops.py) for the reference's UNet topology.
+
+What the reference expresses as ~60 nn.Module calls per forward (Finetuning/model.py:110-131) becomes a
+fixed kernel schedule over NHWC buffers:
+
+  * every Conv3x3 writes its RAW (pre-BatchNorm) output plus per-tile channel statistics; a tiny finalize
+    kernel turns them into a pending transform (scale, shift) that the CONSUMER applies while loading
+    (next conv, max-pool, conv-transpose, 1x1 head) -- BatchNorm+ReLU never make their own pass over HBM;
+  * torch.cat of UpBlock (model.py:80) never happens: the encoder's second conv writes its raw output
+    straight into the right half of the decoder's concat buffer and the ConvTranspose pixel-shuffles into
+    the left half; the concat's pending transform is (1, 0 | scale, shift) with relu_from = C;
+  * backward mirrors it: BN+ReLU backward = one reduce + one apply pass, data gradients reuse the forward
+    implicit-GEMM kernel with flipped packed weights, weight gradients use the transposed-read MFMA kernel.
+
+The engine works on a dict of named tensors with the reference's ``state_dict`` key names, so the same code
+serves ``UNet`` (model.py), ``UNet_encoder`` (UNet_encoder.py:51-84) and ``MUNetPretrainDecoder``
+(munet_neck.py:52-82).  There is no eager/CPU fallback here: every arithmetic step is a C-ABI call.
+"""
+import torch
+
+from . import _lib, ops
+from .ops import Act
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+class _Scratch:
+    """Byte workspaces cached by purpose (grown on demand, reused across steps)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs = {}
+
+    def get(self, key, nbytes):
+        nbytes = max(int(nbytes), 16)
+        b = self.bufs.get(key)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self.bufs[key] = b
+        return b
+
+
+class _PackCache:
+    """Packed (MFMA-layout) copies of conv weights, refreshed when the parameter's version changes."""
+
+    def __init__(self):
+        self.items = {}
+
+    def get(self, key, param, fn):
+        ver = param._version
+        hit = self.items.get(key)
+        if hit is not None and hit[0] == ver and hit[1] == param.data_ptr():
+            return hit[2]
+        packed = fn()
+        self.items[key] = (ver, param.data_ptr(), packed)
+        return packed
+
+
+class UNetEngine:
+    def __init__(self, dt="bf16", device="cuda"):
+        self.dt = ops.dt_code(dt)
+        self.tdt = ops.TORCH_DT[self.dt]
+        self.device = torch.device(device)
+        self.scratch = _Scratch(self.device)
+        self.packs = _PackCache()
+        self.lib = _lib.lib()
+
+    # ------------------------------------------------------------------------------------------
+    # helpers
+    # ------------------------------------------------------------------------------------------
+    def _new(self, B, H, W, C):
+        return Act(torch.empty((B, H, W, C), dtype=self.tdt, device=self.device))
+
+    def _f32(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.device)
+
+    def _wp(self, name, w, flip):
+        return self.packs.get((name, flip), w, lambda: ops.pack_conv3x3(w.detach(), self.dt, flip))
+
+    def _wpT(self, name, w, mode):
+        return self.packs.get((name, "T", mode), w, lambda: ops.pack_convT2x2(w.detach(), self.dt, mode))
+
+    # one Conv3x3 + BatchNorm2d(+ReLU pending): returns the saved state needed by backward
+    def _convbn_fwd(self, sd, pconv, pbn, x, out, training, x_img=None, mask=None, mask_per_sample=False):
+        w = sd[pconv + "weight"]
+        Cout = w.shape[0]
+        B, H, W = out.B, out.H, out.W
+        stats = ops.new_stats(B, H, W, Cout, self.device) if training else None
+        if x_img is not None:
+            ops.conv3x3_c1_fwd(x_img, w.detach(), out, stats, mask, mask_per_sample)
+        else:
+            ops.conv3x3_fwd(x, self._wp(pconv, w, False), out, stats)
+        scale, shift = self._f32(Cout), self._f32(Cout)
+        mean, invstd = self._f32(Cout), self._f32(Cout)
+        ws = self.scratch.get("bnfin", self.lib.cmu_bn_finalize_ws_bytes(Cout))
+        ops.bn_finalize(stats, B * H * W, sd[pconv + "bias"].detach(), sd[pbn + "weight"].detach(),
+                        sd[pbn + "bias"].detach(), sd[pbn + "running_mean"], sd[pbn + "running_var"], BN_MOMENTUM,
+                        BN_EPS, training, scale, shift, mean, invstd, ws)
+        if training and (pbn + "num_batches_tracked") in sd:
+            sd[pbn + "num_batches_tracked"] += 1
+        return {"pconv": pconv, "pbn": pbn, "x": x, "x_img": x_img, "mask": mask, "mps": mask_per_sample,
+                "y": out.with_transform(scale, shift, 0), "mean": mean, "invstd": invstd}
+
+    def _double_conv_fwd(self, sd, prefix, x, out2, training, x_img=None, mask=None, mask_per_sample=False):
+        """DoubleConv (model.py:16-26).  ``out2``: where the second conv writes its raw output."""
+        w1 = sd[prefix + "0.weight"]
+        B, H, W = out2.B, out2.H, out2.W
+        y1 = self._new(B, H, W, w1.shape[0])
+        s1 = self._convbn_fwd(sd, prefix + "0.", prefix + "1.", x, y1, training, x_img, mask, mask_per_sample)
+        s2 = self._convbn_fwd(sd, prefix + "3.", prefix + "4.", s1["y"], out2, training)
+        return s1, s2
+
+    # backward of one Conv3x3+BN+ReLU given dA (gradient w.r.t. the activated output); returns dX act or None
+    def _convbn_bwd(self, sd, s, dA, grads, need_dx, dx_out=None):
+        y = s["y"]
+        B, H, W, C = y.B, y.H, y.W, y.C
+        w = sd[s["pconv"] + "weight"]
+        dgamma, dbeta, coef = self._f32(C), self._f32(C), self._f32(2, C)
+        ws = self.scratch.get("bnbwd", self.lib.cmu_bn_bwd_ws_bytes(C))
+        ops.bn_bwd_reduce(dA, y, s["mean"], s["invstd"], dgamma, dbeta, coef, ws)
+        dY = Act(dA.buf, dA.coff, dA.C)                       # in place over dA
+        ops.bn_bwd_apply(dA, y, s["mean"], s["invstd"], coef, dY)
+        grads[s["pbn"] + "weight"] = dgamma
+        grads[s["pbn"] + "bias"] = dbeta
+        # conv bias: followed by training-mode BN, its gradient is identically zero (sum of dY over pixels)
+        grads[s["pconv"] + "bias"] = torch.zeros(C, dtype=torch.float32, device=self.device)
+        dW = torch.empty_like(w, dtype=torch.float32)
+        if s["x_img"] is not None:
+            wsb = self.scratch.get("wg", self.lib.cmu_conv3x3_c1_wgrad_ws_bytes(B, H, W, C))
+            ops.conv3x3_c1_wgrad(s["x_img"], dY, dW, wsb, s["mask"], s["mps"])
+        else:
+            Cin = w.shape[1]
+            wsb = self.scratch.get("wg", self.lib.cmu_conv3x3_wgrad_ws_bytes(B, H, W, Cin, C, self.dt))
+            ops.conv3x3_wgrad(s["x"], dY, dW, wsb)
+        grads[s["pconv"] + "weight"] = dW
+        if not need_dx or s["x_img"] is not None:
+            return None
+        dX = dx_out if dx_out is not None else self._new(B, H, W, w.shape[1])
+        ops.conv3x3_fwd(dY, self._wp(s["pconv"], w, True), dX, None)
+        return dX
+
+    # ------------------------------------------------------------------------------------------
+    # encoder (model.py:121-125, UNet_encoder.py:79-83)
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def n_down(sd, prefix=""):
+        n = 0
+        while f"{prefix}down_conv{n + 1}.double_conv.double_conv.0.weight" in sd:
+            n += 1
+        return n
+
+    def encoder_forward(self, sd, x_bhw, training, prefix="", mask=None, mask_per_sample=False, skip_out=None):
+        """x (B,H,W) fp32 cuda.  ``skip_out[i]``: optional Act (right half of a concat buffer) where level i's
+        raw skip is written.  Returns ctx with 'latent' (raw Act + pending transform) and 'skips'."""
+        B, H, W = x_bhw.shape
+        nd = self.n_down(sd, prefix)
+        assert H % (1 << nd) == 0 and W % (1 << nd) == 0, f"H,W must be multiples of {1 << nd}"
+        ctx = {"levels": [], "prefix": prefix}
+        x_act, x_img = None, x_bhw.contiguous()
+        h, w_ = H, W
+        for i in range(1, nd + 1):
+            p = f"{prefix}down_conv{i}.double_conv.double_conv."
+            C = sd[p + "0.weight"].shape[0]
+            out2 = skip_out[i - 1] if skip_out is not None else self._new(B, h, w_, C)
+            s1, s2 = self._double_conv_fwd(sd, p, x_act, out2, training, x_img, mask if i == 1 else None, mask_per_sample)
+            pooled = self._new(B, h // 2, w_ // 2, C)
+            ops.bnrelu_maxpool_fwd(s2["y"], pooled)
+            ctx["levels"].append({"s1": s1, "s2": s2, "pooled": pooled})
+            x_act, x_img = pooled, None
+            h, w_ = h // 2, w_ // 2
+        p = f"{prefix}double_conv.double_conv."
+        C = sd[p + "0.weight"].shape[0]
+        s1, s2 = self._double_conv_fwd(sd, p, x_act, self._new(B, h, w_, C), training, x_img, mask if nd == 0 else None, mask_per_sample)
+        ctx["bott"] = {"s1": s1, "s2": s2}
+        ctx["latent"] = s2["y"]
+        ctx["skips"] = [lv["s2"]["y"] for lv in ctx["levels"]]
+        return ctx
+
+    def encoder_backward(self, sd, ctx, d_latent, d_skips, grads):
+        """d_latent: Act (gradient w.r.t. the activated latent); d_skips[i]: Act or None."""
+        b = ctx["bott"]
+        dA = self._convbn_bwd(sd, b["s2"], d_latent, grads, True)
+        dP = self._convbn_bwd(sd, b["s1"], dA, grads, len(ctx["levels"]) > 0)
+        for i in range(len(ctx["levels"]), 0, -1):
+            lv = ctx["levels"][i - 1]
+            y2 = lv["s2"]["y"]
+            dA2 = self._new(y2.B, y2.H, y2.W, y2.C)
+            ops.maxpool_bwd(dP, d_skips[i - 1] if d_skips is not None else None, y2, dA2)
+            dA1 = self._convbn_bwd(sd, lv["s2"], dA2, grads, True)
+            dP = self._convbn_bwd(sd, lv["s1"], dA1, grads, i > 1)
+        return None
+
+    # ------------------------------------------------------------------------------------------
+    # decoder (model.py:126-130, munet_neck.py:75-82)
+    # ------------------------------------------------------------------------------------------
+    def decoder_alloc(self, sd, B, H, W, prefix=""):
+        """Concat buffers + their pending-transform arrays, one per up level (index i-1 for up_conv{i})."""
+        cats = []
+        i = 1
+        h, w_ = H, W
+        while f"{prefix}up_conv{i}.double_conv.double_conv.0.weight" in sd:
+            wt = sd[f"{prefix}up_conv{i}.double_conv.double_conv.0.weight"]
+            Cout, C2 = wt.shape[0], wt.shape[1]
+            Cs = C2 - Cout if f"{prefix}up_conv{i}.up_sample.weight" not in sd else sd[f"{prefix}up_conv{i}.up_sample.weight"].shape[1]
+            buf = torch.empty((B, h, w_, C2), dtype=self.tdt, device=self.device)
+            scale = torch.ones(C2, dtype=torch.float32, device=self.device)
+            shift = torch.zeros(C2, dtype=torch.float32, device=self.device)
+            cats.append({"buf": buf, "scale": scale, "shift": shift, "Cup": Cs, "Cskip": C2 - Cs})
+            i += 1
+            h, w_ = h // 2, w_ // 2
+        return cats
+
+    def decoder_forward(self, sd, latent, skips, training, prefix="", cats=None, head=True):
+        """latent: Act with pending transform; skips[i-1]: Act with pending transform (level i).
+        If ``cats`` is given and a skip already lives in cats[i-1]['buf'] (fused UNet), no copy is made."""
+        B = latent.B
+        nup = len(skips)
+        if cats is None:
+            cats = self.decoder_alloc(sd, B, skips[0].H, skips[0].W, prefix)
+        ctx = {"levels": [None] * nup, "prefix": prefix, "cats": cats}
+        x = latent
+        for i in range(nup, 0, -1):
+            p = f"{prefix}up_conv{i}."
+            cat = cats[i - 1]
+            Cup, Cs = cat["Cup"], cat["Cskip"]
+            sk = skips[i - 1]
+            assert sk.C == Cs
+            right = Act(cat["buf"], Cup, Cs)
+            if not (sk.buf is cat["buf"] and sk.coff == Cup):
+                right.buf[..., Cup:].copy_(sk.buf[..., sk.coff:sk.coff + sk.C])   # split encoder/decoder: one strided copy
+            cat["scale"][Cup:].copy_(sk.scale)
+            cat["shift"][Cup:].copy_(sk.shift)
+            wt = sd[p + "up_sample.weight"]
+            left = Act(cat["buf"], 0, Cup)
+            ops.convT2x2_fwd(x, self._wpT(p + "up_sample.", wt, 0), sd[p + "up_sample.bias"].detach(), left)
+            cat_act = Act(cat["buf"], 0, Cup + Cs, cat["scale"], cat["shift"], Cup)
+            Cout = sd[p + "double_conv.double_conv.0.weight"].shape[0]
+            s1, s2 = self._double_conv_fwd(sd, p + "double_conv.double_conv.", cat_act, self._new(B, sk.H, sk.W, Cout), training)
+            ctx["levels"][i - 1] = {"s1": s1, "s2": s2, "x_up": x, "cat": cat}
+            x = s2["y"]
+        ctx["out"] = x
+        if head:
+            K = sd[prefix + "conv_last.weight"].shape[0]
+            logits = self._f32(B, K, x.H, x.W)
+            ops.conv1x1_head_fwd(x, sd[prefix + "conv_last.weight"].detach().reshape(K, -1), sd[prefix + "conv_last.bias"].detach(), logits)
+            ctx["logits"] = logits
+        return ctx
+
+    def decoder_backward(self, sd, ctx, dlogits, grads, need_input_grads=True):
+        """Returns (d_latent Act, [d_skip Acts]) -- d_skip[i-1] is the right half of level i's concat gradient."""
+        prefix = ctx["prefix"]
+        x = ctx["out"]
+        K = sd[prefix + "conv_last.weight"].shape[0]
+        wl = sd[prefix + "conv_last.weight"]
+        dA = self._new(x.B, x.H, x.W, x.C)
+        dWl, dbl = self._f32(K, x.C), self._f32(K)
+        ws = self.scratch.get("head", self.lib.cmu_conv1x1_head_bwd_ws_bytes(x.B, x.H, x.W, x.C, K))
+        ops.conv1x1_head_bwd(dlogits.contiguous(), x, wl.detach().reshape(K, -1), dA, dWl, dbl, ws)
+        grads[prefix + "conv_last.weight"] = dWl.view_as(wl)
+        grads[prefix + "conv_last.bias"] = dbl
+        nup = len(ctx["levels"])
+        d_skips = [None] * nup
+        for i in range(1, nup + 1):
+            lv = ctx["levels"][i - 1]
+            p = f"{prefix}up_conv{i}."
+            cat = lv["cat"]
+            Cup, Cs = cat["Cup"], cat["Cskip"]
+            dA1 = self._convbn_bwd(sd, lv["s2"], dA, grads, True)
+            dcat = self._convbn_bwd(sd, lv["s1"], dA1, grads, True)
+            d_skips[i - 1] = Act(dcat.buf, Cup, Cs)
+            dleft = Act(dcat.buf, 0, Cup)
+            wt = sd[p + "up_sample.weight"]
+            xu = lv["x_up"]
+            dWt, dbt = torch.empty_like(wt, dtype=torch.float32), self._f32(Cup)
+            wsb = self.scratch.get("wg", self.lib.cmu_convT2x2_wgrad_ws_bytes(xu.B, xu.H, xu.W, xu.C, Cup, self.dt))
+            ops.convT2x2_wgrad(xu, dleft, dWt, dbt, wsb)
+            grads[p + "up_sample.weight"] = dWt
+            grads[p + "up_sample.bias"] = dbt
+            if i < nup or need_input_grads:
+                dA = self._new(xu.B, xu.H, xu.W, xu.C)
+                ops.convT2x2_dgrad(dleft, self._wpT(p + "up_sample.", wt, 1), dA)
+            else:
+                dA = None
+        return dA, d_skips
+
+    # ------------------------------------------------------------------------------------------
+    # full UNet (model.py:110-131): encoder writes its skips straight into the decoder's concat buffers
+    # ------------------------------------------------------------------------------------------
+    def unet_forward(self, sd, x_bhw, training, mask=None, mask_per_sample=False):
+        B, H, W = x_bhw.shape
+        cats = self.decoder_alloc(sd, B, H, W, "")
+        skip_out = [Act(c["buf"], c["Cup"], c["Cskip"]) for c in cats]
+        ectx = self.encoder_forward(sd, x_bhw, training, "", mask, mask_per_sample, skip_out)
+        dctx = self.decoder_forward(sd, ectx["latent"], ectx["skips"], training, "", cats, True)
+        return dctx["logits"], {"enc": ectx, "dec": dctx}
+
+    def unet_backward(self, sd, ctx, dlogits):
+        grads = {}
+        d_latent, d_skips = self.decoder_backward(sd, ctx["dec"], dlogits, grads, True)
+        self.encoder_backward(sd, ctx["enc"], d_latent, d_skips, grads)
+        return grads

@@ -1,0 +1,204 @@
+"""GPU parity of the drop-in modules (cmunet_amd.model) against the golden fixtures produced by the
+reference itself (tests/golden/*.npz, oracle/gen_golden.py) and against the CPU oracle on fresh inputs.
+
+Tolerances (relative to the reference tensor's max |value|):
+  f32  : 1e-3  -- exact-fp32 MFMA chains, different summation order than ATen's CPU kernels, amplified by
+                  BatchNorm's 1/std and the depth of the network;
+  f16  : 2e-2, bf16: 6e-2 -- storage rounding of every activation / gradient (2^-11 / 2^-8 per tensor).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOLS = {"f32": 1e-3, "f16": 2e-2, "bf16": 6e-2}
+DTS = ["f32", "f16", "bf16"]
+
+
+@pytest.fixture(scope="module")
+def M():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cmunet_amd import model
+    return model
+
+
+def load_fx(golden_dir, name):
+    d = np.load(f"{golden_dir}/{name}.npz", allow_pickle=False)
+    return {k: torch.from_numpy(d[k]) if d[k].dtype.kind in "fiu" and d[k].ndim > 0 else d[k] for k in d.files}
+
+
+def load_sd(module, fx, prefix="sd."):
+    sd = {k[len(prefix):]: v for k, v in fx.items() if k.startswith(prefix)}
+    module.load_state_dict(sd, strict=True)
+
+
+def rel_err(got, ref):
+    return (got.detach().double().cpu() - ref.double()).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+
+
+def assert_close(got, ref, tol, what, report):
+    e = rel_err(got, ref)
+    report.append((what, e))
+    assert e <= tol, f"{what}: rel err {e:.3e} > {tol}"
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("tag,cin,cout", [("a", 1, 16), ("b", 16, 32), ("c", 8, 8)])
+def test_double_conv_fixture(M, golden_dir, dt, tag, cin, cout):
+    fx = load_fx(golden_dir, f"double_conv_{tag}")
+    m = M.DoubleConv(cin, cout, dtype=dt).cuda().train()
+    load_sd(m, fx)
+    x = fx["x"].cuda().requires_grad_(True)
+    y = m(x)
+    (y * fx["go"].cuda()).sum().backward()
+    rep, tol = [], TOLS[dt]
+    assert_close(y, fx["y"], tol, "y", rep)
+    if cin > 1:
+        assert_close(x.grad, fx["dx"], tol, "dx", rep)
+    for k, p in m.named_parameters():
+        ref = fx["grad." + k]
+        if k.endswith("0.bias") or k.endswith("3.bias"):        # conv bias before train-mode BN: exactly 0 here,
+            assert p.grad.abs().max().item() == 0.0             # rounding noise (<1e-5 of the weights' grads) in the reference
+            continue
+        assert_close(p.grad, ref, tol * 3, "d" + k, rep)
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            assert_close(v, fx["after." + k], 1e-4 if dt == "f32" else tol, k, rep)
+        if "num_batches" in k:
+            assert int(v) == int(fx["after." + k])
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_down_block_fixture(M, golden_dir, dt):
+    fx = load_fx(golden_dir, "down_block")
+    m = M.DownBlock(16, 32, dtype=dt).cuda().train()
+    load_sd(m, fx)
+    x = fx["x"].cuda().requires_grad_(True)
+    down, skip = m(x)
+    ((down * fx["gd"].cuda()).sum() + (skip * fx["gs"].cuda()).sum()).backward()
+    rep, tol = [], TOLS[dt]
+    assert_close(down, fx["down"], tol, "down", rep)
+    assert_close(skip, fx["skip"], tol, "skip", rep)
+    assert_close(x.grad, fx["dx"], tol * 2, "dx", rep)
+    for k, p in m.named_parameters():
+        if ".0.bias" in k or ".3.bias" in k:
+            continue
+        assert_close(p.grad, fx["grad." + k], tol * 3, "d" + k, rep)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_up_block_fixture(M, golden_dir, dt):
+    fx = load_fx(golden_dir, "up_block")
+    m = M.UpBlock(32, 16, "conv_transpose", dtype=dt).cuda().train()
+    load_sd(m, fx)
+    xd, xs = fx["xd"].cuda().requires_grad_(True), fx["xs"].cuda().requires_grad_(True)
+    y = m(xd, xs)
+    (y * fx["go"].cuda()).sum().backward()
+    rep, tol = [], TOLS[dt]
+    assert_close(y, fx["y"], tol, "y", rep)
+    assert_close(xd.grad, fx["dxd"], tol * 2, "dxd", rep)
+    assert_close(xs.grad, fx["dxs"], tol * 2, "dxs", rep)
+    for k, p in m.named_parameters():
+        if ".0.bias" in k or ".3.bias" in k:
+            continue
+        assert_close(p.grad, fx["grad." + k], tol * 3, "d" + k, rep)
+
+
+def test_bad_up_sample_mode(M, golden_dir):
+    fx = load_fx(golden_dir, "losses")
+    with pytest.raises(ValueError) as e:
+        M.UpBlock(4, 2, "nearest")
+    assert str(e.value) == str(fx["bad_mode_msg"])
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_unet_small_fixture(M, golden_dir, dt):
+    """BASELINE config 1 shape family: base 16, depth 3, Dice+CE criterion (train.py:455)."""
+    from oracle import losses as OL
+    fx = load_fx(golden_dir, "unet_small")
+    m = M.UNet(base_ch=16, depth=3, dtype=dt).cuda().train()
+    load_sd(m, fx)
+    x, y1h = fx["x"].cuda(), fx["y1h"].cuda()
+    logits = m(x)
+    loss = F.cross_entropy(logits, y1h)          # Dice term has no gradient (A-4); its value is checked below
+    loss.backward()
+    rep, tol = [], TOLS[dt]
+    assert_close(logits, fx["logits"], tol, "logits", rep)
+    total = OL.dice_ce_loss(logits.detach().cpu(), fx["y1h"])
+    assert abs(float(total) - float(fx["loss"])) <= tol * max(1.0, abs(float(fx["loss"]))), (float(total), float(fx["loss"]))
+    worst = 0.0
+    for k, p in m.named_parameters():
+        if ".0.bias" in k or ".3.bias" in k:
+            continue
+        e = rel_err(p.grad, fx["grad." + k])
+        worst = max(worst, e)
+        assert e <= tol * 5, f"d{k}: {e:.3e}"
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            assert_close(v, fx["after." + k], tol, k, rep)
+    # argmax agreement (segmentation mask): exact wherever the reference's logit margin exceeds the tolerance
+    ref = fx["logits"]
+    margin = (ref[:, 1] - ref[:, 0]).abs()
+    sure = margin > 2 * tol * ref.abs().max()
+    got_mask = logits.detach().cpu().argmax(1)
+    assert torch.equal(got_mask[sure], ref.argmax(1)[sure])
+    if dt == "f32":
+        assert (got_mask != ref.argmax(1)).float().mean().item() < 1e-3
+    m.eval()
+    with torch.no_grad():
+        le = m(x)
+    assert_close(le, fx["logits_eval"], tol * 2, "eval logits", rep)
+    print(f"[unet_small {dt}] logits err {rep[0][1]:.2e}, worst param-grad err {worst:.2e}")
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_unet_full_fixture(M, golden_dir, dt):
+    """The reference UNet() itself (31 042 434 parameters), weights regenerated from the fixture's seed."""
+    from oracle import unet as OU
+    fx = load_fx(golden_dir, "unet_full")
+    m = M.UNet(dtype=dt)
+    assert sum(p.numel() for p in m.parameters()) == 31042434
+    keys = [str(k) for k in fx["state_keys"]]
+    assert list(m.state_dict().keys()) == keys
+    assert [str(tuple(v.shape)) for v in m.state_dict().values()] == [str(s) for s in fx["state_shapes"]]
+    m.load_state_dict(OU.make_state_dict(base_ch=64, depth=5, seed=int(fx["seed"])))
+    m = m.cuda().train()
+    logits = m(fx["x"].cuda())
+    (logits * fx["go"].cuda()).sum().backward()
+    tol = TOLS[dt]
+    e = rel_err(logits, fx["logits"])
+    assert e <= tol * 2, f"logits {e:.3e}"
+    # the bottleneck of a 32x32 input is 2x2x2 = 8 values per channel: BatchNorm there is ill-conditioned, so
+    # gradients are compared by norm for all parameters and element-wise for a few named ones
+    gn = {str(k): float(v) for k, v in zip(fx["grad_norm_keys"], fx["grad_norms"])}
+    worst = 0.0
+    for k, p in m.named_parameters():
+        if ".0.bias" in k or ".3.bias" in k:
+            continue
+        r = abs(p.grad.norm().item() - gn[k]) / max(gn[k], 1e-6)
+        worst = max(worst, r)
+        assert r <= tol * 20, f"|d{k}|: {p.grad.norm().item():.4e} vs {gn[k]:.4e}"
+    for k in ("conv_last.weight", "conv_last.bias", "down_conv1.double_conv.double_conv.0.weight", "up_conv1.up_sample.bias"):
+        e2 = rel_err(m.get_parameter(k).grad, fx["grad." + k])
+        assert e2 <= tol * 20, f"d{k}: {e2:.3e}"
+    print(f"[unet_full {dt}] logits err {e:.2e}, worst grad-norm err {worst:.2e}")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_unet_vs_oracle_masked(M, dt):
+    """Fresh seeded input at a non-square size with the fused patch mask (UNet_encoder.py:156) vs the CPU oracle."""
+    from oracle import unet as OU
+    sd = OU.make_state_dict(base_ch=16, depth=4, seed=5)
+    m = M.UNet(base_ch=16, depth=4, dtype=dt)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 48, 80, generator=g)
+    mask = (torch.rand(1, 3, 5, generator=g) > 0.4).to(torch.uint8).repeat_interleave(16, 1).repeat_interleave(16, 2)
+    logits = m(x.cuda(), mask=mask.cuda())
+    osd = OU.clone_sd(sd)
+    ref = OU.unet_forward(x * (1 - mask[0]).float(), osd, training=True)
+    e = rel_err(logits, ref)
+    assert e <= TOLS[dt] * 2, f"{e:.3e}"
