@@ -106,13 +106,43 @@ def missing_symbols():
     return [n for n in _SIGS if getattr(l, n, None) is None]
 
 
-def call(name, *args):
+class EventProfiler:
+    """Optional per-entry-point timing with HIP events on the launch stream (bench.py's roofline leg).
+    ``work`` is the algorithmic FLOP (or byte) count the caller attributes to the launch."""
+
+    def __init__(self):
+        self.records = []      # (name, start_event, end_event, work)
+
+    def summary(self):
+        import torch
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1, work in self.records:
+            d = out.setdefault(name, {"ms": 0.0, "calls": 0, "work": 0.0})
+            d["ms"] += e0.elapsed_time(e1)
+            d["calls"] += 1
+            d["work"] += work
+        return out
+
+
+PROFILER = None
+
+
+def call(name, *args, work=0.0):
     """Call an int-returning entry point; raise CmuError with cmu_last_error() on failure."""
     l = lib()
     fn = getattr(l, name, None)
     if fn is None:
         raise CmuError(f"{name} is not exported by {LIB_PATH}")
-    rc = fn(*args)
+    if PROFILER is not None:
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        PROFILER.records.append((name, e0, e1, work))
+    else:
+        rc = fn(*args)
     if rc != 0:
         raise CmuError(f"{name} failed ({rc}): {l.cmu_last_error().decode()}")
     return rc

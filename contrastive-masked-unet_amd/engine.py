@@ -48,7 +48,7 @@ class _PackCache:
         self.items = {}
 
     def get(self, key, param, fn):
-        ver = param._version
+        ver = (param._version, ops.PARAM_GENERATION)
         hit = self.items.get(key)
         if hit is not None and hit[0] == ver and hit[1] == param.data_ptr():
             return hit[2]
@@ -65,6 +65,16 @@ class UNetEngine:
         self.scratch = _Scratch(self.device)
         self.packs = _PackCache()
         self.lib = _lib.lib()
+        self.grad_target = None      # optional dict name -> preallocated fp32 tensor (FlatParams.grad_views)
+        self.grad_prefix = ""
+
+    def _gbuf(self, name, like):
+        """Where a parameter gradient is written: the caller's arena view if given, else a fresh tensor."""
+        if self.grad_target is not None:
+            t = self.grad_target.get(self.grad_prefix + name)
+            if t is not None:
+                return t
+        return torch.empty(like.shape, dtype=torch.float32, device=self.device)
 
     # ------------------------------------------------------------------------------------------
     # helpers
@@ -116,7 +126,8 @@ class UNetEngine:
         y = s["y"]
         B, H, W, C = y.B, y.H, y.W, y.C
         w = sd[s["pconv"] + "weight"]
-        dgamma, dbeta, coef = self._f32(C), self._f32(C), self._f32(2, C)
+        dgamma, dbeta = self._gbuf(s["pbn"] + "weight", sd[s["pbn"] + "weight"]), self._gbuf(s["pbn"] + "bias", sd[s["pbn"] + "bias"])
+        coef = self._f32(2, C)
         ws = self.scratch.get("bnbwd", self.lib.cmu_bn_bwd_ws_bytes(C))
         ops.bn_bwd_reduce(dA, y, s["mean"], s["invstd"], dgamma, dbeta, coef, ws)
         dY = Act(dA.buf, dA.coff, dA.C)                       # in place over dA
@@ -124,8 +135,10 @@ class UNetEngine:
         grads[s["pbn"] + "weight"] = dgamma
         grads[s["pbn"] + "bias"] = dbeta
         # conv bias: followed by training-mode BN, its gradient is identically zero (sum of dY over pixels)
-        grads[s["pconv"] + "bias"] = torch.zeros(C, dtype=torch.float32, device=self.device)
-        dW = torch.empty_like(w, dtype=torch.float32)
+        gb = self._gbuf(s["pconv"] + "bias", sd[s["pconv"] + "bias"])
+        gb.zero_()
+        grads[s["pconv"] + "bias"] = gb
+        dW = self._gbuf(s["pconv"] + "weight", w)
         if s["x_img"] is not None:
             wsb = self.scratch.get("wg", self.lib.cmu_conv3x3_c1_wgrad_ws_bytes(B, H, W, C))
             ops.conv3x3_c1_wgrad(s["x_img"], dY, dW, wsb, s["mask"], s["mps"])
@@ -254,10 +267,10 @@ class UNetEngine:
         K = sd[prefix + "conv_last.weight"].shape[0]
         wl = sd[prefix + "conv_last.weight"]
         dA = self._new(x.B, x.H, x.W, x.C)
-        dWl, dbl = self._f32(K, x.C), self._f32(K)
+        dWl, dbl = self._gbuf(prefix + "conv_last.weight", wl), self._gbuf(prefix + "conv_last.bias", sd[prefix + "conv_last.bias"])
         ws = self.scratch.get("head", self.lib.cmu_conv1x1_head_bwd_ws_bytes(x.B, x.H, x.W, x.C, K))
-        ops.conv1x1_head_bwd(dlogits.contiguous(), x, wl.detach().reshape(K, -1), dA, dWl, dbl, ws)
-        grads[prefix + "conv_last.weight"] = dWl.view_as(wl)
+        ops.conv1x1_head_bwd(dlogits.contiguous(), x, wl.detach().reshape(K, -1), dA, dWl.view(K, -1), dbl, ws)
+        grads[prefix + "conv_last.weight"] = dWl
         grads[prefix + "conv_last.bias"] = dbl
         nup = len(ctx["levels"])
         d_skips = [None] * nup
@@ -272,7 +285,7 @@ class UNetEngine:
             dleft = Act(dcat.buf, 0, Cup)
             wt = sd[p + "up_sample.weight"]
             xu = lv["x_up"]
-            dWt, dbt = torch.empty_like(wt, dtype=torch.float32), self._f32(Cup)
+            dWt, dbt = self._gbuf(p + "up_sample.weight", wt), self._gbuf(p + "up_sample.bias", sd[p + "up_sample.bias"])
             wsb = self.scratch.get("wg", self.lib.cmu_convT2x2_wgrad_ws_bytes(xu.B, xu.H, xu.W, xu.C, Cup, self.dt))
             ops.convT2x2_wgrad(xu, dleft, dWt, dbt, wsb)
             grads[p + "up_sample.weight"] = dWt

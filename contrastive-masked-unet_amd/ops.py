@@ -133,7 +133,7 @@ def conv3x3_c1_fwd(x_bhw, w, out, stats=None, mask=None, mask_per_sample=False):
 def conv3x3_fwd(x, wpacked, out, stats=None):
     assert x.dt == out.dt and (x.B, x.H, x.W) == (out.B, out.H, out.W)
     call("cmu_conv3x3_fwd", x.ptr(), x.ld, _p(x.scale), _p(x.shift), x.relu_from, _p(wpacked), out.ptr(), out.ld,
-         _p(stats), x.B, x.H, x.W, x.C, out.C, x.dt, _stream())
+         _p(stats), x.B, x.H, x.W, x.C, out.C, x.dt, _stream(), work=2.0 * 9 * x.C * out.C * x.B * x.H * x.W)
 
 
 def bn_finalize(stats, count, conv_bias, gamma, beta, running_mean, running_var, momentum, eps, training,
@@ -157,7 +157,7 @@ def convT2x2_fwd(x, wpacked, bias, out):
     Cout = out.C
     assert (out.H, out.W) == (2 * x.H, 2 * x.W)
     call("cmu_convT2x2_fwd", x.ptr(), x.ld, _p(x.scale), _p(x.shift), x.relu_from, _p(wpacked), _p(_f32c(bias)),
-         out.ptr(), out.ld, x.B, x.H, x.W, x.C, Cout, x.dt, _stream())
+         out.ptr(), out.ld, x.B, x.H, x.W, x.C, Cout, x.dt, _stream(), work=2.0 * 4 * x.C * Cout * x.B * x.H * x.W)
 
 
 def conv1x1_head_fwd(x, w, bias, logits):
@@ -196,7 +196,7 @@ def conv3x3_wgrad(x, dY, dW, ws):
     Cout, Cin = dW.shape[0], dW.shape[1]
     assert x.C == Cin and dY.C == Cout
     call("cmu_conv3x3_wgrad", x.ptr(), x.ld, _p(x.scale), _p(x.shift), x.relu_from, dY.ptr(), dY.ld, _p(_f32c(dW)),
-         x.B, x.H, x.W, Cin, Cout, x.dt, _p(ws), _stream())
+         x.B, x.H, x.W, Cin, Cout, x.dt, _p(ws), _stream(), work=2.0 * 9 * Cin * Cout * x.B * x.H * x.W)
 
 
 def conv3x3_c1_wgrad(x_bhw, dY, dW, ws, mask=None, mask_per_sample=False):
@@ -212,13 +212,13 @@ def maxpool_bwd(dP, dSkip, y, dA):
 
 def convT2x2_dgrad(dOut, wpacked_dgrad, dX):
     call("cmu_convT2x2_dgrad", dOut.ptr(), dOut.ld, _p(wpacked_dgrad), dX.ptr(), dX.ld, dX.B, dX.H, dX.W, dX.C, dOut.C,
-         dX.dt, _stream())
+         dX.dt, _stream(), work=2.0 * 4 * dX.C * dOut.C * dX.B * dX.H * dX.W)
 
 
 def convT2x2_wgrad(x, dOut, dW, dbias, ws):
     Cin, Cout = dW.shape[0], dW.shape[1]
     call("cmu_convT2x2_wgrad", x.ptr(), x.ld, _p(x.scale), _p(x.shift), x.relu_from, dOut.ptr(), dOut.ld, _p(_f32c(dW)),
-         _p(_f32c(dbias)), x.B, x.H, x.W, Cin, Cout, x.dt, _p(ws), _stream())
+         _p(_f32c(dbias)), x.B, x.H, x.W, Cin, Cout, x.dt, _p(ws), _stream(), work=2.0 * 4 * Cin * Cout * x.B * x.H * x.W)
 
 
 def conv1x1_head_bwd(dlogits, x, w, dX, dW, dbias, ws):
@@ -261,12 +261,21 @@ def l2_normalize_rows(x, out):
     call("cmu_l2_normalize_rows", _p(_f32c(x)), _p(out), x.shape[0], x.shape[1], _stream())
 
 
+# bumped whenever a raw kernel rewrites parameters in place (PyTorch's version counters do not see it);
+# the engine's packed-weight caches compare it together with Tensor._version
+PARAM_GENERATION = 0
+
+
 def ema_update(target, online, momentum):
+    global PARAM_GENERATION
+    PARAM_GENERATION += 1
     assert target.numel() == online.numel()
     call("cmu_ema_update", _p(_f32c(target)), _p(_f32c(online)), target.numel(), float(momentum), _stream())
 
 
 def adam_step(p, g, m, v, wd_mask, lr, beta1, beta2, eps, weight_decay, decoupled, step, grad_scale=1.0):
+    global PARAM_GENERATION
+    PARAM_GENERATION += 1
     call("cmu_adam_step", _p(_f32c(p)), _p(_f32c(g)), _p(_f32c(m)), _p(_f32c(v)), _p(wd_mask), p.numel(), float(lr),
          float(beta1), float(beta2), float(eps), float(weight_decay), int(decoupled), int(step), float(grad_scale),
          _stream())

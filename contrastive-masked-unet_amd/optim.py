@@ -1,0 +1,102 @@
+"""Flat parameter / gradient arenas and the fused Adam(W) step.
+
+The reference steps torch.optim.Adam (Finetuning/train.py:341), AdamW with no-decay groups for biases and
+norm parameters (cmunet_config.py:76-91) one tensor at a time.  Here every parameter of a module is
+re-homed into ONE contiguous fp32 arena (and its gradient into a second one): the optimiser is a single
+HIP kernel over the arena, the data-parallel gradient exchange is one RCCL all-reduce over it, and the EMA
+of the momentum encoder is one kernel between two arenas with identical layout.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+class FlatParams:
+    """Re-homes ``module``'s parameters into a flat fp32 arena; ``grad_views[name]`` are views into the
+    gradient arena that the engine's weight-gradient kernels write directly (no per-tensor copies)."""
+
+    def __init__(self, module, names=None):
+        params = [(n, p) for n, p in module.named_parameters() if names is None or names(n)]
+        assert params, "no parameters"
+        dev = params[0][1].device
+        assert dev.type == "cuda", "FlatParams needs the module on the GPU"
+        self.names = [n for n, _ in params]
+        sizes = [((p.numel() + 3) // 4) * 4 for _, p in params]        # keep every tensor 16-byte aligned
+        self.total = sum(sizes)
+        self.arena = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.offsets, self.views, self.grad_views = {}, {}, {}
+        off = 0
+        for (n, p), sz in zip(params, sizes):
+            v = self.arena[off:off + p.numel()].view_as(p)
+            v.copy_(p.data)
+            p.data = v
+            self.offsets[n] = (off, p.numel())
+            self.views[n] = v
+            self.grad_views[n] = self.grad[off:off + p.numel()].view_as(p)
+            off += sz
+        self.params = dict(params)
+
+    def wd_mask(self, decay_filter):
+        """uint8 per element: 1 where weight decay applies (decay_filter(name, param) -> bool)."""
+        m = torch.zeros(self.total, dtype=torch.uint8, device=self.arena.device)
+        for n in self.names:
+            off, cnt = self.offsets[n]
+            if decay_filter(n, self.params[n]):
+                m[off:off + cnt] = 1
+        return m
+
+    def gather_autograd_grads(self):
+        """Copy ``p.grad`` tensors produced by autograd into the gradient arena (drop-in path)."""
+        for n in self.names:
+            g = self.params[n].grad
+            gv = self.grad_views[n]
+            if g is None:
+                gv.zero_()
+            elif g.data_ptr() != gv.data_ptr():
+                gv.copy_(g)
+
+    def all_reduce_mean(self, group=None):
+        """Data-parallel gradient exchange: ONE RCCL all-reduce over the whole arena (C1 in SURVEY 2.5).
+        Returns the scale (1/world) the optimiser kernel folds into its gradient load."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
+            return 1.0 / dist.get_world_size(group)
+        return 1.0
+
+
+def no_decay_bias_norm(name, param):
+    """cmunet_config.py:84-91 ('bias', 'ln', ... decay_mult=0) and the usual 1-D rule for norm weights."""
+    return not (name.endswith(".bias") or param.dim() <= 1)
+
+
+class FusedAdam:
+    """Adam / AdamW over a FlatParams arena in one kernel launch (cmu_adam_step)."""
+
+    def __init__(self, flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=False,
+                 decay_filter=None):
+        self.flat = flat
+        self.lr, self.betas, self.eps, self.weight_decay, self.decoupled = lr, betas, eps, weight_decay, decoupled
+        self.m = torch.zeros_like(flat.arena)
+        self.v = torch.zeros_like(flat.arena)
+        self.wd_mask = flat.wd_mask(decay_filter) if (decay_filter is not None and weight_decay != 0.0) else None
+        self.step_count = 0
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.flat.params.values():
+            p.grad = None
+
+    def step(self, grad_scale=1.0):
+        self.step_count += 1
+        ops.adam_step(self.flat.arena, self.flat.grad, self.m, self.v, self.wd_mask, self.lr, self.betas[0],
+                      self.betas[1], self.eps, self.weight_decay, self.decoupled, self.step_count, grad_scale)
+        # ops.adam_step bumps ops.PARAM_GENERATION: the engine's packed-weight caches see the raw-kernel write
+
+    def state_dict(self):
+        return {"m": self.m, "v": self.v, "step": self.step_count, "lr": self.lr}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+        self.step_count = int(sd["step"])
