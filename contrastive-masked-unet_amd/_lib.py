@@ -89,6 +89,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise CmuError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950). The HIP path has no CPU fallback.")
+        # PyTorch-ROCm bundles its own libamdhip64: import it FIRST so that this library binds to the same
+        # HIP runtime instance as torch's streams/allocator (loading ours first leaves two runtimes in the
+        # process and every launch fails with "no ROCm-capable device is detected").
+        import torch  # noqa: F401
         l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name, None)
