@@ -6,7 +6,7 @@
 // that a second tiny kernel adds in a fixed order (bitwise reproducible, no float atomics).
 #include "common.h"
 
-constexpr int RED_MAX_BLOCKS = 512;
+constexpr int RED_MAX_BLOCKS = 2048;
 
 // block-level sum of `v` over the threads that share `key = tid % cpb` (prow = tid / cpb < ppb).
 // red: LDS float[256].  Result valid for tid < cpb.  All 256 threads must call.
@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const unsigned char*
                 s2[e] = fmaf(dz, (v[e] - mu[e]) * is[e], s2[e]);
             }
         }
+#pragma unroll
     for (int e = 0; e < EPC; ++e) {
         const float a = sum_over_rows(s1[e], red, tid, cpb, ppb);
         const float b = sum_over_rows(s2[e], red, tid, cpb, ppb);
@@ -67,15 +68,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const unsigned char*
     }
 }
 
-__global__ void bn_bwd_final_kernel(const float* __restrict__ ws, int nblocks, double count, float* dgamma, float* dbeta,
-                                    float* coef, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ ws, int nblocks, double count, float* dgamma,
+                                                          float* dbeta, float* coef, int C) {
+    __shared__ double red[2][16][16];
+    const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
-        s1 += (double)ws[((int64_t)b * 2 + 0) * C + c];
-        s2 += (double)ws[((int64_t)b * 2 + 1) * C + c];
-    }
+    if (c < C)
+        for (int b = part; b < nblocks; b += 16) {
+            s1 += (double)ws[((int64_t)b * 2 + 0) * C + c];
+            s2 += (double)ws[((int64_t)b * 2 + 1) * C + c];
+        }
+    red[0][part][cl] = s1;
+    red[1][part][cl] = s2;
+    __syncthreads();
+    if (part != 0 || c >= C) return;
+    s1 = 0.0; s2 = 0.0;
+    for (int q = 0; q < 16; ++q) { s1 += red[0][q][cl]; s2 += red[1][q][cl]; }
     if (dbeta) dbeta[c] = (float)s1;
     if (dgamma) dgamma[c] = (float)s2;
     coef[c] = (float)(s1 / count);
@@ -100,7 +109,7 @@ static int bn_bwd_reduce_t(const void* dA, int64_t ldd, const void* y, int64_t l
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<TR>), dim3(gx, gy), dim3(256), 0, st, (const unsigned char*)dA, ldd,
                        (const unsigned char*)y, ldy, scale, shift, mean, invstd, (float*)ws, npix, C, cpb, ppb);
     CMU_CHECK_LAUNCH("cmu_bn_bwd_reduce");
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cmu_div_up(C, 128)), dim3(128), 0, st, (const float*)ws, gx, (double)npix, dgamma,
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cmu_div_up(C, 16)), dim3(256), 0, st, (const float*)ws, gx, (double)npix, dgamma,
                        dbeta, coef, C);
     CMU_CHECK_LAUNCH("cmu_bn_bwd_reduce(final)");
     return CMU_OK;
@@ -314,7 +323,10 @@ __global__ __launch_bounds__(256) void conv1x1_head_bwd_kernel(const float* __re
         if (dX) st_global16(dX + (pix * ldo + ch * EPC) * ES, TR::pack(o));
     }
     float* out = ws + (int64_t)blockIdx.x * (K * C + K);
-    for (int k = 0; k < K; ++k) {
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_K; ++k) {
+        if (k >= K) break;   // K is uniform; indices stay compile-time constants after unrolling
+#pragma unroll
         for (int e = 0; e < EPC; ++e) {
             const float a = sum_over_rows(dw[k][e], red, tid, nchunk, ppb);
             if (tid < nchunk) out[k * C + tid * EPC + e] = a;
@@ -324,13 +336,20 @@ __global__ __launch_bounds__(256) void conv1x1_head_bwd_kernel(const float* __re
         if (tid == 0) out[K * C + k] = bsum;
     }
 }
-__global__ void sum_slab_kernel(const float* __restrict__ ws, int nblocks, int64_t n, float* __restrict__ out0, int64_t n0,
-                                float* __restrict__ out1) {
-    // out0 gets elements [0,n0), out1 the rest; fixed-order sum over the blocks' partials
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+__global__ __launch_bounds__(256) void sum_slab_kernel(const float* __restrict__ ws, int nblocks, int64_t n, float* __restrict__ out0,
+                                                      int64_t n0, float* __restrict__ out1) {
+    // out0 gets elements [0,n0), out1 the rest; fixed-order sum over the blocks' partials (16 outputs x 16 row-parts)
+    __shared__ double red[16][16];
+    const int il = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int64_t i = (int64_t)blockIdx.x * 16 + il;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += (double)ws[(int64_t)b * n + i];
+    if (i < n)
+        for (int b = part; b < nblocks; b += 16) s += (double)ws[(int64_t)b * n + i];
+    red[part][il] = s;
+    __syncthreads();
+    if (part != 0 || i >= n) return;
+    s = 0.0;
+    for (int q = 0; q < 16; ++q) s += red[q][il];
     if (i < n0) out0[i] = (float)s;
     else if (out1) out1[i - n0] = (float)s;
 }
@@ -347,7 +366,7 @@ static int conv1x1_head_bwd_t(const float* dlogits, const void* x, int64_t ldx, 
                        (unsigned char*)dX, ldo, (float*)ws, B, H, W, C, K, npix);
     CMU_CHECK_LAUNCH("cmu_conv1x1_head_bwd");
     const int64_t n = (int64_t)K * C + K;
-    hipLaunchKernelGGL(sum_slab_kernel, dim3((unsigned)cmu_div_up64(n, 128)), dim3(128), 0, st, (const float*)ws, gx, n, dW, (int64_t)K * C,
+    hipLaunchKernelGGL(sum_slab_kernel, dim3((unsigned)cmu_div_up64(n, 16)), dim3(256), 0, st, (const float*)ws, gx, n, dW, (int64_t)K * C,
                        dbias);
     CMU_CHECK_LAUNCH("cmu_conv1x1_head_bwd(sum)");
     return CMU_OK;
@@ -424,7 +443,9 @@ __global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __re
             }
     }
     float* out = ws + (int64_t)blockIdx.x * Cout * 9;
+#pragma unroll
     for (int e = 0; e < EPC; ++e)
+#pragma unroll
         for (int t = 0; t < 9; ++t) {
             const float a = sum_over_rows(active ? acc[e][t] : 0.f, red, tid, nchunk, ppi);
             if (tid < nchunk) out[(tid * EPC + e) * 9 + t] = a;
@@ -440,7 +461,7 @@ static int conv3x3_c1_wgrad_t(const float* x, const uint8_t* mask, int mps, cons
                        B, H, W, Cout, tilesX, tilesY, ntiles);
     CMU_CHECK_LAUNCH("cmu_conv3x3_c1_wgrad");
     const int64_t n = (int64_t)Cout * 9;
-    hipLaunchKernelGGL(sum_slab_kernel, dim3((unsigned)cmu_div_up64(n, 128)), dim3(128), 0, st, (const float*)ws, grid, n, dW, n, (float*)nullptr);
+    hipLaunchKernelGGL(sum_slab_kernel, dim3((unsigned)cmu_div_up64(n, 16)), dim3(256), 0, st, (const float*)ws, grid, n, dW, n, (float*)nullptr);
     CMU_CHECK_LAUNCH("cmu_conv3x3_c1_wgrad(sum)");
     return CMU_OK;
 }

@@ -263,17 +263,28 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WGParams p) {
 }
 
 // partial slabs -> parameter-gradient layout, summed in split order
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int splitk, int T, int CApad, int CBpad, int CA, int CB,
-                                    float* __restrict__ dW, int mode) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splitk, int T, int CApad, int CBpad, int CA,
+                                                          int CB, float* __restrict__ dW, int mode) {
+    // 64 outputs x 4 split-parts per block; the parts are combined through LDS in a fixed order
+    __shared__ float red[4][64];
     const int64_t total = (int64_t)T * CA * CB;
-    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+    const int ol = threadIdx.x & 63, part = threadIdx.x >> 6;
+    for (int64_t o0 = (int64_t)blockIdx.x * 64; o0 < total; o0 += (int64_t)gridDim.x * 64) {
+        const int64_t o = o0 + ol;
         const int c = (int)(o % CB);
         const int n = (int)((o / CB) % CA);
         const int t = (int)(o / ((int64_t)CB * CA));
         float s = 0.f;
-        for (int k = 0; k < splitk; ++k) s += ws[(((int64_t)k * T + t) * CApad + n) * CBpad + c];
-        if (mode == MODE_W3) dW[((int64_t)n * CB + c) * 9 + t] = s;      // (Cout,Cin,3,3)
-        else dW[((int64_t)c * CA + n) * 4 + t] = s;                      // (Cin,Cout,2,2)
+        if (o < total)
+            for (int k = part; k < splitk; k += 4) s += ws[(((int64_t)k * T + t) * CApad + n) * CBpad + c];
+        __syncthreads();
+        red[part][ol] = s;
+        __syncthreads();
+        if (part == 0 && o < total) {
+            s = (red[0][ol] + red[1][ol]) + (red[2][ol] + red[3][ol]);
+            if (mode == MODE_W3) dW[((int64_t)n * CB + c) * 9 + t] = s;      // (Cout,Cin,3,3)
+            else dW[((int64_t)c * CA + n) * 4 + t] = s;                      // (Cin,Cout,2,2)
+        }
     }
 }
 
@@ -299,6 +310,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const unsigned char* _
 #pragma unroll
             for (int e = 0; e < EPC; ++e) s[e] += f[e];
         }
+#pragma unroll
     for (int e = 0; e < EPC; ++e) {
         __syncthreads();
         red[tid] = s[e];
@@ -364,7 +376,7 @@ static int wgrad3_t(WGParams p, float* dW, hipStream_t st) {
     int rc = launch_wgrad<TR, MODE_W3>(p, st, "cmu_conv3x3_wgrad");
     if (rc) return rc;
     const int64_t total = (int64_t)9 * p.CA * p.CB;
-    const int grid = (int)(cmu_div_up64(total, 256) < 4096 ? cmu_div_up64(total, 256) : 4096);
+    const int grid = (int)(cmu_div_up64(total, 64) < 8192 ? cmu_div_up64(total, 64) : 8192);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)p.ws, p.splitk, 9, p.CApad, p.CBpad, p.CA, p.CB, dW,
                        (int)MODE_W3);
     CMU_CHECK_LAUNCH("cmu_conv3x3_wgrad(reduce)");
@@ -375,7 +387,7 @@ static int wgradT_t(WGParams p, float* dW, float* dbias, float* ws_sum, hipStrea
     int rc = launch_wgrad<TR, MODE_WT>(p, st, "cmu_convT2x2_wgrad");
     if (rc) return rc;
     const int64_t total = (int64_t)4 * p.CA * p.CB;
-    const int grid = (int)(cmu_div_up64(total, 256) < 4096 ? cmu_div_up64(total, 256) : 4096);
+    const int grid = (int)(cmu_div_up64(total, 64) < 8192 ? cmu_div_up64(total, 64) : 8192);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)p.ws, p.splitk, 4, p.CApad, p.CBpad, p.CA, p.CB, dW,
                        (int)MODE_WT);
     CMU_CHECK_LAUNCH("cmu_convT2x2_wgrad(reduce)");

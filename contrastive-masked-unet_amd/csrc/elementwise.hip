@@ -154,16 +154,25 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, int nsplit, do
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
                                    float* running_var, float momentum, float eps, int training, float* scale, float* shift,
                                    float* save_mean, float* save_invstd, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    const float cb = conv_bias ? conv_bias[c] : 0.f;
-    if (training) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int s = 0; s < nsplit; ++s) {
+    // 16 channels x 16 split-parts per 256-thread block; fixed-order combine
+    __shared__ double red[2][16][16];
+    const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (training && c < C)
+        for (int s = part; s < nsplit; s += 16) {
             s1 += ws[((int64_t)s * 2 + 0) * C + c];
             s2 += ws[((int64_t)s * 2 + 1) * C + c];
         }
+    red[0][part][cl] = s1;
+    red[1][part][cl] = s2;
+    __syncthreads();
+    if (part != 0 || c >= C) return;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float cb = conv_bias ? conv_bias[c] : 0.f;
+    if (training) {
+        s1 = 0.0; s2 = 0.0;
+        for (int q = 0; q < 16; ++q) { s1 += red[0][q][cl]; s2 += red[1][q][cl]; }
         const double mean = s1 / count;
         double var = s2 / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -208,7 +217,7 @@ extern "C" int cmu_bn_finalize(const float* stats, int ntiles, int64_t count, co
     } else {
         CMU_CHECK_ARG(running_mean && running_var, "cmu_bn_finalize: eval needs running statistics");
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cmu_div_up(C, 128)), dim3(128), 0, st, (const double*)ws, nsplit, (double)count,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cmu_div_up(C, 16)), dim3(256), 0, st, (const double*)ws, nsplit, (double)count,
                        conv_bias, gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift, save_mean,
                        save_invstd, C);
     CMU_CHECK_LAUNCH("cmu_bn_finalize");
@@ -275,6 +284,7 @@ __global__ __launch_bounds__(256) void conv3x3_c1_fwd_kernel(const float* __rest
         }
     if (stats == nullptr) return;
     // combine the threads that share a channel chunk (same tid % nchunk): fixed-order tree over prow
+#pragma unroll
     for (int e = 0; e < EPC; ++e) {
         __syncthreads();
         red[0][tid] = s1[e];
