@@ -79,6 +79,13 @@ struct IGCfg {
     static constexpr int W_ITERS = (W_CHUNKS + 255) / 256;
 };
 
+// MFMA row index r (0..31) of an M-block -> pixel of its 2x16 pixel strip.  ds_read_b128 services a wave in
+// four 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32); giving each hardware group the 16
+// CONSECUTIVE pixels of one strip row makes the 80-byte-stride A-fragment reads conflict-free (the natural
+// r -> (r>>4, r&15) map mixes the two strip rows inside a group: 2-way conflicts, measured 38 % of LDS cycles).
+__device__ static inline int pm_row(int r) { return __builtin_popcount(r >> 2) & 1; }
+__device__ static inline int pm_col(int r) { return 4 * (r >> 3) + (r & 3); }
+
 template <class TR, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IGParams p) {
     typedef IGCfg<TR, MODE> C;
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IGParams p) {
 
     int a_base[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) a_base[i] = ((4 * wave + 2 * i + (r >> 4)) * C::LW + (r & 15)) * C::PS_A + h * 16;
+    for (int i = 0; i < 2; ++i) a_base[i] = ((4 * wave + 2 * i + pm_row(r)) * C::LW + pm_col(r)) * C::PS_A + h * 16;
     const int w_base = C::A_BYTES + r * C::PS_W + h * 16;
 
     const int nstages = C::C3 ? p.nslices : (p.nslices + C::TAPS - 1) / C::TAPS;
@@ -270,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IGParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m32 = (e & 3) + 8 * (e >> 2) + 4 * h;
-                const int row = 4 * wave + 2 * i + (m32 >> 4), col = m32 & 15;
+                const int row = 4 * wave + 2 * i + pm_row(m32), col = pm_col(m32);
                 const bool ok = (ty0 + row < p.H) && (tx0 + col < p.W);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IGParams p) {
     for (int it = 0; it < (64 * CPR) / 64; ++it) {
         const int idx = it * 64 + lane;
         const int m = idx / CPR, q = idx % CPR;
-        const int row = 4 * wave + (m >> 4), col = m & 15;
+        const int row = 4 * wave + 2 * (m >> 5) + pm_row(m & 31), col = pm_col(m & 31);
         const int gy = ty0 + row, gx = tx0 + col;
         const int n = n0 + q * C::EPC;
         if (gy < p.H && gx < p.W && n < p.N) {

@@ -51,9 +51,11 @@ struct WGCfg {
     static constexpr int TAPS = (MODE == MODE_W3) ? 9 : 1;
     static constexpr int HALO = (MODE == MODE_W3) ? 1 : 0;
     static constexpr int LW = 16 + 2 * HALO;
+    static constexpr int LWP = (MODE == MODE_W3) ? 20 : 16;  // LDS row pitch in pixels: a multiple of 4, so that the
+                                                             // swizzle bit of a fragment read is a per-lane constant
     static constexpr int NPIXB = LW * LW;
     static constexpr int A_BYTES = 256 * 128;
-    static constexpr int B_BYTES = NPIXB * 128;
+    static constexpr int B_BYTES = LW * LWP * 128;
     static constexpr int A_ITERS = (256 * 8) / 512;
     static constexpr int B_ITERS = (NPIXB * 8 + 511) / 512;
     static constexpr int RED_BYTES = NT * TAPS * 4096;
@@ -177,19 +179,29 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WGParams p) {
                     }
                     v = TR::pack(f);
                 }
-                *reinterpret_cast<u32x4*>(smB + swz(idx >> 3, cgi * 16)) = v;
+                const int pix = idx >> 3;
+                *reinterpret_cast<u32x4*>(smB + swz((pix / C::LW) * C::LWP + pix % C::LW, cgi * 16)) = v;
             }
         }
     };
 
-    // fragment addressing (16-bit path): 16-lane group g = lane>>4 covers channels 16*(g&1).. of the
-    // wave's 32-block and pixels 8*(g>>1) + 4*t + q of the row; lane li = lane&15: q = li>>2, quad = li&3
+    // fragment addressing.  16-bit path: 16-lane group g = lane>>4 covers channels 16*(g&1).. of the wave's
+    // 32-block and pixels 8*(g>>1) + 4*t + q of the row; lane li = lane&15: q = li>>2, quad = li&3.
+    // Row pitches (16 / 20 pixels) are multiples of 4, so bit 1 of the pixel index -- the swizzle bit -- depends
+    // only on (kw + q): every read is base(py,kh) + per-lane constant + immediate.
     const int li = lane & 15, g = lane >> 4;
     const int q4 = li >> 2, quad = li & 3;
     const int a_cbyte16 = (nb32 * 32 + 16 * (g & 1) + 4 * quad) * 2;
     const int b_cbyte16 = (cb32 * 32 + 16 * (g & 1) + 4 * quad) * 2;
-    const int a_cbyte32 = (nb32 * 32 + r) * 4;
-    const int b_cbyte32 = (cb32 * 32 + r) * 4;
+    const int a_off16 = (8 * h + q4) * 128 + (a_cbyte16 ^ (((q4 >> 1) & 1) << 6));
+    int b_off16[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) b_off16[kw] = (kw + 8 * h + q4) * 128 + (b_cbyte16 ^ ((((kw + q4) >> 1) & 1) << 6));
+    // f32 path: lane-half h holds pixel 2s+h of the k-pair; swizzle bit = ((kw + h) >> 1 + s) & 1
+    const int a_off32 = h * 128 + (nb32 * 32 + r) * 4;
+    int b_off32[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) b_off32[kw] = (kw + h) * 128 + (((cb32 * 32 + r) * 4) ^ ((((kw + h) >> 1) & 1) << 6));
 
     int tile = split;
     if (tile < p.ntiles) load_tile(tile);
@@ -203,26 +215,28 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WGParams p) {
             const int py = kpart * C::RPP + rr;
             if constexpr (EPC == 8) {
                 // A fragment: 8 consecutive pixels (k = 8h + j) of row py for channel row r
-                const int pa = py * 16 + 8 * h + q4;
-                const u32x2 a_lo = lds_tr16(smA, swz(pa, a_cbyte16));
-                const u32x2 a_hi = lds_tr16(smA, swz(pa + 4, a_cbyte16));
+                const unsigned char* pa = smA + py * (16 * 128) + a_off16;
+                const u32x2 a_lo = lds_tr16(pa, 0);
+                const u32x2 a_hi = lds_tr16(pa, 512);
                 const u32x4 afrag = {a_lo[0], a_lo[1], a_hi[0], a_hi[1]};
+                const unsigned char* pbrow = smB + py * (C::LWP * 128);
 #pragma unroll
                 for (int t = 0; t < C::TAPS; ++t) {
-                    const int pb = (py + (C::TAPS == 9 ? t / 3 : 0)) * C::LW + (C::TAPS == 9 ? t % 3 : 0) + 8 * h + q4;
-                    const u32x2 b_lo = lds_tr16(smB, swz(pb, b_cbyte16));
-                    const u32x2 b_hi = lds_tr16(smB, swz(pb + 4, b_cbyte16));
+                    const int kh = (C::TAPS == 9) ? t / 3 : 0, kw = (C::TAPS == 9) ? t % 3 : 0;
+                    const unsigned char* pb = pbrow + kh * (C::LWP * 128) + b_off16[kw];
+                    const u32x2 b_lo = lds_tr16(pb, 0);
+                    const u32x2 b_hi = lds_tr16(pb, 512);
                     const u32x4 bfrag = {b_lo[0], b_lo[1], b_hi[0], b_hi[1]};
                     TR::mma16(afrag, bfrag, acc[t]);
                 }
             } else {
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
-                    const float av = *reinterpret_cast<const float*>(smA + swz(py * 16 + 2 * s + h, a_cbyte32));
+                    const float av = *reinterpret_cast<const float*>(smA + (py * 16 + 2 * s) * 128 + (a_off32 ^ ((s & 1) << 6)));
 #pragma unroll
                     for (int t = 0; t < C::TAPS; ++t) {
-                        const int pb = (py + (C::TAPS == 9 ? t / 3 : 0)) * C::LW + (C::TAPS == 9 ? t % 3 : 0) + 2 * s + h;
-                        const float bv = *reinterpret_cast<const float*>(smB + swz(pb, b_cbyte32));
+                        const int kh = (C::TAPS == 9) ? t / 3 : 0, kw = (C::TAPS == 9) ? t % 3 : 0;
+                        const float bv = *reinterpret_cast<const float*>(smB + ((py + kh) * C::LWP + 2 * s) * 128 + (b_off32[kw] ^ ((s & 1) << 6)));
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
                     }
                 }
