@@ -149,8 +149,19 @@ def main():
         d = mf[name]
         ach = d["work"] / (d["ms"] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
+        # HBM bytes per launch of that kernel come from a separate rocprofv3 --pmc run of this same command
+        # (tools/profile_round.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes), committed under profiles/
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                tj = json.load(f).get(name)
+            if tj and args.dtype == "bf16" and B == 32 and H == 512:
+                traffic = round(tj["hbm_bytes_per_launch"] / 1e9, 3)
+        except (OSError, ValueError, KeyError):
+            traffic = None
         out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(ach / peak, 4), "traffic": None,
+                           "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "GB/launch (PMC, profiles/traffic.json)",
+                           "algorithmic_gflop_per_launch": round(d["work"] / d["calls"] / 1e9, 1),
                            "launches_per_step": d["calls"] // args.steps,
                            "avg_launch_ms": round(d["ms"] / d["calls"], 4),
                            "share_of_kernel_time": round(d["ms"] / tot_ms, 3)}

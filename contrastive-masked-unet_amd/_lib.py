@@ -59,6 +59,8 @@ _SIGS = {
     "cmu_moco_ws_bytes": (_L, [_I, _I]),
     "cmu_moco_infonce_enqueue": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P]),
     "cmu_l2_normalize_rows": (_I, [_P, _P, _I, _I, _P]),
+    "cmu_gap_fwd": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "cmu_gap_bwd": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "cmu_ema_update": (_I, [_P, _P, _L, _F, _P]),
     "cmu_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _L, _F, _P]),
 }

@@ -473,3 +473,65 @@ extern "C" int cmu_adam_step(float* p, const float* g, float* m, float* v, const
     CMU_CHECK_LAUNCH("cmu_adam_step");
     return CMU_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Global average pool of the activated latent (moco_data_module.py:65: x.mean([2,3])) and its backward
+// ---------------------------------------------------------------------------------------------
+template <class TR>
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const typename TR::elem_t* __restrict__ y, int64_t ldy,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     float* __restrict__ out, int HW, int C) {
+    // grid (ceil(C/64), B); thread = (channel lane, pixel part); fixed-order combine of the 4 parts
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6, b = blockIdx.y;
+    float s = 0.f;
+    if (c < C) {
+        const float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f;
+        for (int p = part; p < HW; p += 4) {
+            float v = fmaf(TR::to_float(y[((int64_t)b * HW + p) * ldy + c]), sc, sh);
+            if (scale) v = fmaxf(v, 0.f);
+            s += v;
+        }
+    }
+    red[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (part == 0 && c < C) {
+        const int l = threadIdx.x;
+        out[(int64_t)b * C + c] = ((red[0][l] + red[1][l]) + (red[2][l] + red[3][l])) / (float)HW;
+    }
+}
+template <class TR>
+__global__ void gap_bwd_kernel(const float* __restrict__ dout, typename TR::elem_t* __restrict__ dA, int64_t ldd, int HW, int C,
+                               int64_t total) {
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(o % C);
+        const int64_t pix = o / C;
+        const int64_t b = pix / HW;
+        dA[pix * ldd + c] = TR::from_float(dout[b * C + c] / (float)HW);
+    }
+}
+template <class TR>
+static int gap_fwd_t(const void* y, int64_t ldy, const float* scale, const float* shift, float* out, int B, int HW, int C, hipStream_t st) {
+    hipLaunchKernelGGL((gap_fwd_kernel<TR>), dim3(cmu_div_up(C, 64), B), dim3(256), 0, st, (const typename TR::elem_t*)y, ldy, scale, shift,
+                       out, HW, C);
+    CMU_CHECK_LAUNCH("cmu_gap_fwd");
+    return CMU_OK;
+}
+template <class TR>
+static int gap_bwd_t(const float* dout, void* dA, int64_t ldd, int B, int HW, int C, hipStream_t st) {
+    const int64_t total = (int64_t)B * HW * C;
+    const int grid = (int)(cmu_div_up64(total, 256) < 4096 ? cmu_div_up64(total, 256) : 4096);
+    hipLaunchKernelGGL((gap_bwd_kernel<TR>), dim3(grid), dim3(256), 0, st, dout, (typename TR::elem_t*)dA, ldd, HW, C, total);
+    CMU_CHECK_LAUNCH("cmu_gap_bwd");
+    return CMU_OK;
+}
+extern "C" int cmu_gap_fwd(const void* y, int64_t ldy, const float* in_scale, const float* in_shift, float* out, int B, int H, int W,
+                           int C, int dt, void* stream) {
+    CMU_CHECK_ARG(cmu_dtype_size(dt) > 0 && y && out && B > 0 && H > 0 && W > 0 && C > 0 && ldy >= C, "cmu_gap_fwd: bad args");
+    CMU_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "cmu_gap_fwd: scale/shift must both be set");
+    CMU_DISPATCH_DT(dt, gap_fwd_t, y, ldy, in_scale, in_shift, out, B, H * W, C, (hipStream_t)stream);
+}
+extern "C" int cmu_gap_bwd(const float* dout, void* dA, int64_t ldd, int B, int H, int W, int C, int dt, void* stream) {
+    CMU_CHECK_ARG(cmu_dtype_size(dt) > 0 && dout && dA && B > 0 && H > 0 && W > 0 && C > 0 && ldd >= C, "cmu_gap_bwd: bad args");
+    CMU_DISPATCH_DT(dt, gap_bwd_t, dout, dA, ldd, B, H * W, C, (hipStream_t)stream);
+}

@@ -261,6 +261,14 @@ def l2_normalize_rows(x, out):
     call("cmu_l2_normalize_rows", _p(_f32c(x)), _p(out), x.shape[0], x.shape[1], _stream())
 
 
+def gap_fwd(y, out):
+    call("cmu_gap_fwd", y.ptr(), y.ld, _p(y.scale), _p(y.shift), _p(_f32c(out)), y.B, y.H, y.W, y.C, y.dt, _stream())
+
+
+def gap_bwd(dout, dA):
+    call("cmu_gap_bwd", _p(_f32c(dout)), dA.ptr(), dA.ld, dA.B, dA.H, dA.W, dA.C, dA.dt, _stream())
+
+
 # bumped whenever a raw kernel rewrites parameters in place (PyTorch's version counters do not see it);
 # the engine's packed-weight caches compare it together with Tensor._version
 PARAM_GENERATION = 0

@@ -176,7 +176,7 @@ int cmu_softmax_ce_dice_fwd_bwd(const float* logits, const double* y1h, float* o
 
 /* CM-UNet in-batch InfoNCE (cmunet_head.py:72-88): pred (B,D) raw predictor output (L2-normalised inside),
  * keys (N,D) gathered, already normalised target projections; label i + B*rank; loss = ct_w*2*t*CE.
- * dpred (nullable) = d loss / d pred (B,D).                                                        */
+ * dpred (nullable) = d loss / d pred (B,D).  loss: 1 + B floats (loss[0] total, loss[1+b] per-row terms).     */
 int cmu_infonce_inbatch_fwd_bwd(const float* pred, const float* keys, float* loss, float* dpred,
                                 int B, int N, int D, int rank, float temperature, float ct_weight, void* stream);
 
@@ -192,6 +192,12 @@ int cmu_moco_infonce_enqueue(const float* q_raw, const float* k_raw, const float
                              int B, int D, int K, float temperature, void* ws, void* stream);
 /* L2-normalise rows (F.normalize(dim=1), eps 1e-12) -- used before the key all-gather. */
 int cmu_l2_normalize_rows(const float* x, float* out, int B, int D, void* stream);
+
+/* Global average pool of the activated latent (moco_data_module.py:65, x.mean([2,3])): out (B,C) fp32 from the
+ * raw NHWC tensor + pending transform; backward broadcasts dout/(H*W) into dA (gradient w.r.t. the activation). */
+int cmu_gap_fwd(const void* y, int64_t ldy, const float* in_scale, const float* in_shift, float* out,
+                int B, int H, int W, int C, int dt, void* stream);
+int cmu_gap_bwd(const float* dout, void* dA, int64_t ldd, int B, int H, int W, int C, int dt, void* stream);
 
 /* EMA p_t = m*p_t + (1-m)*p_o over a flat fp32 arena (cmunet.py:78-92, moco2_module.py:153-158). */
 int cmu_ema_update(float* target, const float* online, int64_t n, float momentum, void* stream);
