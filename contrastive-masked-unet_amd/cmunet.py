@@ -1,0 +1,499 @@
+"""Drop-in for the CM-UNet pretraining model (reference: Pretraining/CM-UNet/cmae/models/...), on the HIP engine.
+
+  UNet_encoder(out_classes, up_sample_mode, patch_size=16, mask_ratio=0.65)   backbones/UNet_encoder.py:51-158
+  MUNetPretrainDecoder(out_classes=2, up_sample_mode='conv_transpose')         necks/munet_neck.py:52-82
+  NonLinearNeck(in_channels, hid_channels, out_channels, num_layers=2, ...)    necks/nonlinear_neck.py:35-102
+  CMUNetPretrainHead(predictor, temperature, ct_weight, rc_weight)             heads/cmunet_head.py:25-91
+  CM_UNet(backbone, neck, head, base_momentum=0.996)                           algorithms/cmunet.py:7-135
+  MomentumUpdateHook.momentum(cur_iter, max_iter)                              core/hooks/momentum_update_hook.py:29-40
+
+The mmengine registry / Runner are not rebuilt (out of scope); the classes take the same config
+dicts (``cmunet_config.py:5-42``) and build their children directly.  Conv blocks, losses, EMA and the
+optimiser run on the HIP kernels; the two MLP necks (fc -> BN1d -> ReLU -> fc, M = batch rows) are plain
+library GEMMs (rocBLAS through torch.nn.functional.linear), which the design rules allow for un-fused GEMMs.
+
+Reference quirks are replicated behind ``ref_compat=True``: the mask of sample 0 masks
+the whole batch (A-1); a fresh randomly initialised Conv2d(1024,256,1) reduces the target latent at every
+call (A-2, weights injectable for tests); per-row target normalisation (A-3).  Hard-coded ``.cuda()`` /
+``"cuda:0"`` strings of the reference become the module's device.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib, ops
+from .model import DoubleConv, DownBlock, UpBlock, _EngineOwner, _named_state, _param_args, _require_cuda
+from .ops import Act
+from .pretrain import create_random_patch_mask, random_patch_mask_device
+
+
+def _init_weights_ref(m):
+    """UNet_encoder.py:90-104 / munet_neck.py:84-116: kaiming-normal(fan_out, relu) convs, BN (1, 0),
+    xavier-normal linears, zero biases."""
+    if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+        nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+        if m.bias is not None:
+            nn.init.zeros_(m.bias)
+    elif isinstance(m, nn.BatchNorm2d):
+        nn.init.constant_(m.weight, 1)
+        nn.init.zeros_(m.bias)
+    elif isinstance(m, nn.Linear):
+        nn.init.xavier_normal_(m.weight)
+        if m.bias is not None:
+            nn.init.zeros_(m.bias)
+
+
+# ---------------------------------------------------------------------------------------------------
+# autograd-wrapped fused losses
+# ---------------------------------------------------------------------------------------------------
+class _MaskedMSEFn(torch.autograd.Function):
+    """cmunet_head.py:62-70 on logits[:, channel] (kernel cmu_masked_mse_fwd_bwd)."""
+
+    @staticmethod
+    def forward(ctx, logits, channel, img, mask):
+        B, K, H, W = logits.shape
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        dl = torch.empty_like(logits)
+        ws = torch.empty(_lib.lib().cmu_masked_mse_ws_bytes(B, H), dtype=torch.uint8, device=logits.device)
+        ops.masked_mse_fwd_bwd(logits.detach().contiguous(), channel, img.contiguous(), mask.contiguous(), loss, dl, 1.0, ws)
+        ctx.save_for_backward(dl)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None, None, None
+
+
+def masked_mse_loss(logits, channel, img, mask):
+    return _MaskedMSEFn.apply(logits, channel, img, mask)
+
+
+class _InfoNCEFn(torch.autograd.Function):
+    """cmunet_head.py:72-88 (kernel cmu_infonce_inbatch_fwd_bwd); keys are detached by construction."""
+
+    @staticmethod
+    def forward(ctx, pred, keys, rank, temperature, ct_weight):
+        B, D = pred.shape
+        loss = torch.empty(1 + B, dtype=torch.float32, device=pred.device)
+        dp = torch.empty_like(pred)
+        ops.infonce_inbatch_fwd_bwd(pred.detach().contiguous(), keys.detach().contiguous(), loss, dp, rank, temperature, ct_weight)
+        ctx.save_for_backward(dp)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dp,) = ctx.saved_tensors
+        return dp * g, None, None, None, None
+
+
+@torch.no_grad()
+def concat_all_gather(tensor):
+    """cmunet_head.py:9-22 (mmengine all_gather -> cat) as one RCCL all-gather into a single tensor."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return tensor
+    out = torch.empty((dist.get_world_size() * tensor.shape[0],) + tuple(tensor.shape[1:]), dtype=tensor.dtype, device=tensor.device)
+    dist.all_gather_into_tensor(out, tensor.contiguous())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# encoder / decoder modules (module-boundary tensors are NCHW fp32 like the reference's)
+# ---------------------------------------------------------------------------------------------------
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, x, mask, mask_per_sample, names, *params):
+        eng = module._engine(x.device)
+        sd = _named_state(module)
+        ectx = eng.encoder_forward(sd, x.detach().float().contiguous(), module.training, "", mask, mask_per_sample)
+        ctx.module, ctx.ectx, ctx.names, ctx.eng = module, ectx, names, eng
+        outs = [ops.apply_to_nchw(ectx["latent"])] + [ops.apply_to_nchw(s) for s in ectx["skips"]]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        eng, ectx = ctx.eng, ctx.ectx
+        sd = _named_state(ctx.module)
+
+        def to_act(g, like):
+            a = eng._new(like.B, like.H, like.W, like.C)
+            ops.nchw_to_nhwc(g.contiguous().float(), a)
+            return a
+        d_latent = to_act(gouts[0], ectx["latent"])
+        d_skips = [to_act(g, s) for g, s in zip(gouts[1:], ectx["skips"])]
+        grads = {}
+        eng.encoder_backward(sd, ectx, d_latent, d_skips, grads)
+        ctx.ectx = None
+        return (None, None, None, None, None, *[grads.get(n) for n in ctx.names])
+
+
+class UNet_encoder(nn.Module, _EngineOwner):
+    """UNet down path + bottleneck with random patch masking (UNet_encoder.py:51-158).
+
+    forward(x (B,H,W)) -> (latent (B,C,H/2^d,W/2^d), mask (B,H,W) uint8 on the device, [skip1..skip4]).
+    """
+
+    def __init__(self, out_classes=2, up_sample_mode='conv_transpose', patch_size=16, mask_ratio=0.65,
+                 base_ch=64, depth=5, dtype="bf16", ref_compat=True):
+        super().__init__()
+        self.up_sample_mode = up_sample_mode
+        self.dtype = dtype
+        self.ref_compat = ref_compat
+        chans = [base_ch * 2 ** i for i in range(depth)]
+        cin = 1
+        for i in range(depth - 1):
+            setattr(self, f"down_conv{i + 1}", DownBlock(cin, chans[i], dtype))
+            cin = chans[i]
+        self.double_conv = DoubleConv(cin, chans[-1], dtype)
+        self.patch_size = patch_size
+        self.mask_ratio = mask_ratio
+
+    def init_weights(self):
+        self.apply(_init_weights_ref)
+
+    def create_random_patch_mask(self, batch_size, img_size=256):
+        """numpy (B,img,img) uint8, the reference's RNG consumption (UNet_encoder.py:106-139)."""
+        return create_random_patch_mask(batch_size, img_size, self.patch_size, self.mask_ratio)
+
+    def make_mask(self, x, generator=None, host_rng=None):
+        B, H, W = x.shape[0], x.shape[-2], x.shape[-1]
+        if host_rng is not None:          # reference-exact host generation
+            return torch.from_numpy(create_random_patch_mask(B, H, self.patch_size, self.mask_ratio, host_rng)).to(x.device)
+        return random_patch_mask_device(B, H, W, self.patch_size, self.mask_ratio, generator, x.device)
+
+    def forward(self, x, mask=None):
+        _require_cuda(x, "UNet_encoder")
+        if mask is None:
+            mask = self.make_mask(x)
+        names, params = _param_args(self)
+        outs = _EncoderFn.apply(self, x, mask, not self.ref_compat, names, *params)
+        return outs[0], mask, list(outs[1:])
+
+
+class _DecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, nskip, names, latent, *rest):
+        skips, params = rest[:nskip], rest[nskip:]
+        eng = module._engine(latent.device)
+        sd = _named_state(module)
+
+        def to_act(t):
+            B, C, H, W = t.shape
+            a = eng._new(B, H, W, C)
+            ops.nchw_to_nhwc(t.detach().float().contiguous(), a)
+            return a
+        dctx = eng.decoder_forward(sd, to_act(latent), [to_act(s) for s in skips], module.training, "", None, True)
+        ctx.module, ctx.dctx, ctx.names, ctx.eng, ctx.nskip = module, dctx, names, eng, nskip
+        return dctx["logits"]
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        sd = _named_state(ctx.module)
+        grads = {}
+        d_latent, d_skips = ctx.eng.decoder_backward(sd, ctx.dctx, dlogits.contiguous().float(), grads, True)
+        gl = ops.apply_to_nchw(d_latent)
+        gs = [ops.apply_to_nchw(d) for d in d_skips]
+        ctx.dctx = None
+        return (None, None, None, gl, *gs, *[grads.get(n) for n in ctx.names])
+
+
+class MUNetPretrainDecoder(nn.Module, _EngineOwner):
+    """UNet up path + 1x1 head (munet_neck.py:52-82). forward(x, skip) with skip = [skip1..skip4]."""
+
+    def __init__(self, out_classes=2, up_sample_mode='conv_transpose', base_ch=64, depth=5, dtype="bf16"):
+        super().__init__()
+        self.up_sample_mode = up_sample_mode
+        self.dtype = dtype
+        chans = [base_ch * 2 ** i for i in range(depth)]
+        for i in range(depth - 1, 0, -1):
+            setattr(self, f"up_conv{i}", UpBlock(chans[i], chans[i - 1], up_sample_mode, dtype))
+        self.conv_last = nn.Conv2d(chans[0], out_classes, kernel_size=1)
+
+    def init_weights(self):
+        self.apply(_init_weights_ref)
+
+    def forward(self, x, skip):
+        _require_cuda(x, "MUNetPretrainDecoder")
+        names, params = _param_args(self)
+        return _DecoderFn.apply(self, len(skip), names, x, *skip, *params)
+
+
+class NonLinearNeck(nn.Module):
+    """fc0 -> BN(eps 1e-6) -> [ReLU -> fc_i (-> BN)]* (nonlinear_neck.py:35-102).  ``norm_cfg`` type 'SyncBN'
+    becomes nn.SyncBatchNorm when a process group with more than one rank exists, else BatchNorm1d."""
+
+    def __init__(self, in_channels, hid_channels, out_channels, num_layers=2, with_bias=False, with_last_bn=True,
+                 with_last_bn_affine=True, with_last_bias=False, with_avg_pool=True, norm_cfg=dict(type='SyncBN', eps=1e-6),
+                 init_cfg=None):
+        super().__init__()
+        self.with_avg_pool = with_avg_pool
+        if with_avg_pool:
+            self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.relu = nn.ReLU(inplace=True)
+        eps = norm_cfg.get("eps", 1e-5)
+        self._sync = norm_cfg.get("type", "BN") == "SyncBN"
+
+        def norm(ch, affine=True):
+            return nn.BatchNorm1d(ch, eps=eps, affine=affine)
+        self.fc0 = nn.Linear(in_channels, hid_channels, bias=with_bias)
+        self.bn0 = norm(hid_channels)
+        self.fc_names, self.bn_names = [], []
+        for i in range(1, num_layers):
+            this = out_channels if i == num_layers - 1 else hid_channels
+            if i != num_layers - 1:
+                self.add_module(f'fc{i}', nn.Linear(hid_channels, this, bias=with_bias))
+                self.add_module(f'bn{i}', norm(this))
+                self.bn_names.append(f'bn{i}')
+            else:
+                self.add_module(f'fc{i}', nn.Linear(hid_channels, this, bias=with_last_bias))
+                if with_last_bn:
+                    self.add_module(f'bn{i}', norm(this, with_last_bn_affine))
+                    self.bn_names.append(f'bn{i}')
+                else:
+                    self.bn_names.append(None)
+            self.fc_names.append(f'fc{i}')
+        for m in self.modules():          # init_cfg: Constant(1) on norm layers (nonlinear_neck.py:47-52)
+            if isinstance(m, nn.BatchNorm1d) and m.affine:
+                nn.init.constant_(m.weight, 1)
+
+    def _bn(self, bn, x):
+        if self._sync and self.training and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # statistics over all ranks (SyncBN, C5 in SURVEY 2.5): one all-reduce of (sum, sumsq)
+            n = torch.tensor([x.shape[0]], dtype=x.dtype, device=x.device)
+            s = torch.cat([x.sum(0), (x * x).sum(0), n])
+            s = _AllReduceSum.apply(s)
+            cnt = s[-1]
+            mean = s[:x.shape[1]] / cnt
+            var = s[x.shape[1]:-1] / cnt - mean * mean
+            with torch.no_grad():
+                bn.running_mean.mul_(1 - bn.momentum).add_(bn.momentum * mean.detach())
+                bn.running_var.mul_(1 - bn.momentum).add_(bn.momentum * var.detach() * cnt / (cnt - 1))
+                bn.num_batches_tracked += 1
+            y = (x - mean) / torch.sqrt(var + bn.eps)
+            return y * bn.weight + bn.bias if bn.affine else y
+        return bn(x)
+
+    def forward(self, x):
+        if self.with_avg_pool:
+            x = self.avgpool(x)
+        else:
+            x = x[:, 0, :]
+        x = x.reshape(x.size(0), -1)
+        x = self.fc0(x)
+        x = self._bn(self.bn0, x)
+        for fc_name, bn_name in zip(self.fc_names, self.bn_names):
+            x = self.relu(x)
+            x = getattr(self, fc_name)(x)
+            if bn_name is not None:
+                x = self._bn(getattr(self, bn_name), x)
+        return x.unsqueeze(dim=1)
+
+
+class _AllReduceSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t):
+        t = t.clone()
+        dist.all_reduce(t)
+        return t
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.clone()
+        dist.all_reduce(g)
+        return g
+
+
+class CMUNetPretrainHead(nn.Module):
+    """Masked-reconstruction + contrastive losses (cmunet_head.py:25-91)."""
+
+    def __init__(self, predictor, temperature=0.07, ct_weight=1.0, rc_weight=1.0):
+        super().__init__()
+        self.predictor = _build(predictor) if isinstance(predictor, dict) else predictor
+        self.t = temperature
+        self.ct_weight = ct_weight
+        self.rc_weight = rc_weight
+
+    def forward(self, x, pred_logits, mask_s, proj_s, proj_t, pred_channel=1):
+        """``pred_logits`` is the pixel decoder's (B,2,H,W) output; the reference passes pred_pixel[:,1]
+        (cmunet.py:133) -- the channel is selected inside the fused loss kernel instead."""
+        loss_rc = masked_mse_loss(pred_logits, pred_channel, x, mask_s)
+        pred_s = self.predictor(proj_s).squeeze(dim=1)
+        pt = proj_t.squeeze(dim=1).detach().contiguous().float()
+        ptn = torch.empty_like(pt)
+        ops.l2_normalize_rows(pt, ptn)                                   # F.normalize(proj_t, dim=1)
+        keys = concat_all_gather(ptn)
+        rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+        loss_ct = _InfoNCEFn.apply(pred_s.float(), keys, rank, self.t, self.ct_weight)    # normalises pred_s inside
+        return {'loss_ct': loss_ct, 'loss_rc': self.rc_weight * loss_rc}
+
+
+_TYPES = {}
+
+
+def _build(cfg):
+    cfg = dict(cfg)
+    return _TYPES[cfg.pop("type")](**cfg)
+
+
+class _CMUNetFn(torch.autograd.Function):
+    """Fused conv part of CM_UNet.forward_train (cmunet.py:121-124): online encoder (masked), target encoder,
+    pixel + feature decoders sharing the skips; boundary tensors are the two 2-channel logit maps and the
+    target latent."""
+
+    @staticmethod
+    def forward(ctx, module, img, img_t, mask, names, *params):
+        eng = module._engine(img.device)
+        sd = _named_state(module)
+        tr = module.training
+        x = img.detach().float().contiguous()
+        ectx = eng.encoder_forward(sd, x, tr, "backbone.", mask, not module.ref_compat)
+        tctx = eng.encoder_forward(sd, img_t.detach().float().contiguous(), tr, "target_backbone.", None)
+        pctx = eng.decoder_forward(sd, ectx["latent"], ectx["skips"], tr, "pixel_decoder.", None, True)
+        fctx = eng.decoder_forward(sd, ectx["latent"], ectx["skips"], tr, "feature_decoder.", None, True)
+        latent_t = ops.apply_to_nchw(tctx["latent"])
+        ctx.module, ctx.names, ctx.eng = module, names, eng
+        ctx.saved = (ectx, pctx, fctx)
+        return pctx["logits"], fctx["logits"], latent_t
+
+    @staticmethod
+    def backward(ctx, d_pix, d_feat, _d_latent_t):
+        eng = ctx.eng
+        sd = _named_state(ctx.module)
+        ectx, pctx, fctx = ctx.saved
+        grads = {}
+        dl_p, ds_p = eng.decoder_backward(sd, pctx, d_pix.contiguous().float(), grads, True)
+        dl_f, ds_f = eng.decoder_backward(sd, fctx, d_feat.contiguous().float(), grads, True)
+        d_latent = Act(dl_p.buf + dl_f.buf)
+
+        def view(a):
+            return a.buf[..., a.coff:a.coff + a.C]
+        d_skips = [Act((view(a) + view(b)).contiguous()) for a, b in zip(ds_p, ds_f)]
+        eng.encoder_backward(sd, ectx, d_latent, d_skips, grads)
+        ctx.saved = None
+        return (None, None, None, None, None, *[grads.get(n) for n in ctx.names])
+
+
+class CM_UNet(nn.Module, _EngineOwner):
+    """Contrastive + masked-reconstruction UNet (cmunet.py:7-135).
+
+    ``backbone`` = dict(online=..., target=...), ``neck`` = dict(pixel=..., feature=..., projector=...),
+    ``head`` = dict(type='CMUNetPretrainHead', ...) exactly as in ``cmunet_config.py:5-42``.
+    forward(img, mode='loss', img_t=...) -> {'loss_ct', 'loss_rc'}.
+    """
+
+    def __init__(self, backbone, neck, head, base_momentum=0.996, init_cfg=None, target_cls=True, dtype="bf16",
+                 ref_compat=True, **kwargs):
+        super().__init__()
+        assert neck is not None and head is not None
+        self.dtype = dtype
+        self.ref_compat = ref_compat
+
+        def with_dt(cfg):
+            cfg = dict(cfg)
+            if cfg.get("type") in ("UNet_encoder", "MUNetPretrainDecoder"):
+                cfg.setdefault("dtype", dtype)
+            return cfg
+        self.backbone = _build(with_dt(backbone['online']))
+        self.target_backbone = _build(with_dt(backbone['target']))
+        self.pixel_decoder = _build(with_dt(neck['pixel']))
+        self.feature_decoder = _build(with_dt(neck['feature']))
+        self.projector = _build(neck['projector'])
+        self.target_projector = _build(neck['projector'])
+        self.target_cls = target_cls
+        self.head = _build(head)
+        self.base_momentum = base_momentum
+        self.momentum = base_momentum
+        for p in self.target_backbone.parameters():
+            p.requires_grad = False
+        for p in self.target_projector.parameters():
+            p.requires_grad = False
+        self._reduce_gen = None
+
+    def init_weights(self):
+        """cmunet.py:61-76: initialise, then copy online -> target for backbone and projector."""
+        self.backbone.init_weights()
+        self.pixel_decoder.init_weights()
+        self.feature_decoder.init_weights()
+        with torch.no_grad():
+            for pb, pm in zip(self.backbone.parameters(), self.target_backbone.parameters()):
+                pm.copy_(pb)
+            for pb, pm in zip(self.projector.parameters(), self.target_projector.parameters()):
+                pm.copy_(pb)
+
+    @torch.no_grad()
+    def momentum_update(self):
+        """cmunet.py:78-92: p_t = p_t*m + p_o*(1-m) over backbone and projector parameters (EMA kernel)."""
+        for src, dst in ((self.backbone, self.target_backbone), (self.projector, self.target_projector)):
+            for pb, pm in zip(src.parameters(), dst.parameters()):
+                ops.ema_update(pm.data.view(-1), pb.data.view(-1), self.momentum)
+
+    def extract_feat(self, img):
+        return self.backbone(img)
+
+    def _reduce_channels(self, latent_t, reduce_w=None, reduce_b=None):
+        """cmunet.py:128-129: nn.Conv2d(C,256,1) constructed (default init) at every call, never trained (A-2)."""
+        C = latent_t.shape[1]
+        if reduce_w is None:
+            # 256 for the reference geometry (1024 channels at /16): whatever makes Cr*(H/2^d)*(W/2^d) == H*W
+            conv = nn.Conv2d(C, self.reduced_channels(), kernel_size=1).to(latent_t.device, latent_t.dtype)
+            reduce_w, reduce_b = conv.weight, conv.bias
+        return F.conv2d(latent_t, reduce_w, reduce_b)
+
+    def reduced_channels(self):
+        n_down = sum(1 for n, _ in self.backbone.named_children() if n.startswith("down_conv"))
+        return 4 ** n_down
+
+    def forward_train(self, img, img_t=None, mask=None, reduce_w=None, reduce_b=None, **kwargs):
+        _require_cuda(img, "CM_UNet")
+        B, H, W = img.shape
+        if mask is None:
+            mask = self.backbone.make_mask(img)
+        names, params = _param_args(self)
+        pred_pixel, pred_feature, latent_t = _CMUNetFn.apply(self, img, img_t, mask, names, *params)
+        proj_s = self.projector(torch.mean(pred_feature, dim=1, keepdim=True))
+        with torch.no_grad():
+            lt = self._reduce_channels(latent_t, reduce_w, reduce_b)
+            lt = lt.reshape(B, -1).reshape(B, 1, H, W)          # 256*(H/16)*(W/16) == H*W (cmunet.py:130)
+            proj_t = self.target_projector(torch.mean(lt, dim=1, keepdim=True))
+        return self.head(img, pred_pixel, mask, proj_s, proj_t)
+
+    def forward(self, img, mode='loss', **kwargs):
+        """base.py:75-113: mode 'tensor' -> features, 'loss' -> dict of losses."""
+        if mode == 'tensor':
+            return self.extract_feat(img)
+        if mode == 'loss':
+            return self.forward_train(img, **kwargs)
+        raise RuntimeError(f'Invalid mode "{mode}".')
+
+
+def momentum_schedule(cur_iter, max_iter, base_momentum=0.996, end_momentum=0.996):
+    """MomentumUpdateHook.before_train_iter (momentum_update_hook.py:29-40)."""
+    return end_momentum - (end_momentum - base_momentum) * (math.cos(math.pi * cur_iter / float(max_iter)) + 1) / 2
+
+
+_TYPES.update({"UNet_encoder": UNet_encoder, "MUNetPretrainDecoder": MUNetPretrainDecoder, "NonLinearNeck": NonLinearNeck,
+               "CMUNetPretrainHead": CMUNetPretrainHead, "CM_UNet": CM_UNet})
+
+
+def cmunet_config(img_size=224, dtype="bf16", temperature=0.07, ct_weight=1.0, rc_weight=1.0, mask_ratio=0.65,
+                  base_ch=64, depth=5):
+    """The ``model`` dict of configs/cmunet_config.py:5-42 with the projector sized for ``img_size``
+    (in_channels = H*W: 50176 at 224, 262144 at 512)."""
+    neck = dict(type='NonLinearNeck', hid_channels=1536, out_channels=256, num_layers=2, with_bias=True, with_last_bn=False,
+                with_avg_pool=False)
+    enc = dict(type='UNet_encoder', patch_size=16, base_ch=base_ch, depth=depth)
+    dec = dict(type='MUNetPretrainDecoder', base_ch=base_ch, depth=depth)
+    return dict(
+        type='CM_UNet', dtype=dtype,
+        backbone=dict(online=dict(enc, mask_ratio=mask_ratio), target=dict(enc, mask_ratio=0.0)),
+        neck=dict(pixel=dict(dec), feature=dict(dec), projector=dict(neck, in_channels=img_size * img_size)),
+        head=dict(type='CMUNetPretrainHead', predictor=dict(neck, in_channels=256), temperature=temperature,
+                  ct_weight=ct_weight, rc_weight=rc_weight))
+
+
+def build_model(cfg):
+    return _build(cfg)

@@ -242,12 +242,18 @@ class UNetEngine:
             right = Act(cat["buf"], Cup, Cs)
             if not (sk.buf is cat["buf"] and sk.coff == Cup):
                 right.buf[..., Cup:].copy_(sk.buf[..., sk.coff:sk.coff + sk.C])   # split encoder/decoder: one strided copy
-            cat["scale"][Cup:].copy_(sk.scale)
-            cat["shift"][Cup:].copy_(sk.shift)
+            if sk.scale is not None:
+                cat["scale"][Cup:].copy_(sk.scale)
+                cat["shift"][Cup:].copy_(sk.shift)
+                relu_from = Cup
+            else:                      # already-activated skip handed over at a module boundary: identity, no ReLU
+                cat["scale"][Cup:].fill_(1.0)
+                cat["shift"][Cup:].zero_()
+                relu_from = Cup + Cs
             wt = sd[p + "up_sample.weight"]
             left = Act(cat["buf"], 0, Cup)
             ops.convT2x2_fwd(x, self._wpT(p + "up_sample.", wt, 0), sd[p + "up_sample.bias"].detach(), left)
-            cat_act = Act(cat["buf"], 0, Cup + Cs, cat["scale"], cat["shift"], Cup)
+            cat_act = Act(cat["buf"], 0, Cup + Cs, cat["scale"], cat["shift"], relu_from)
             Cout = sd[p + "double_conv.double_conv.0.weight"].shape[0]
             s1, s2 = self._double_conv_fwd(sd, p + "double_conv.double_conv.", cat_act, self._new(B, sk.H, sk.W, Cout), training)
             ctx["levels"][i - 1] = {"s1": s1, "s2": s2, "x_up": x, "cat": cat}

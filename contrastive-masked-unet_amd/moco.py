@@ -1,0 +1,149 @@
+"""Drop-in for the MoCo-v2 baseline on the UNet encoder (reference:
+Pretraining/MoCo/pl_bolts/models/self_supervised/moco/moco2_module.py:80-309, moco_data_module.py:47-66).
+
+PyTorch-Lightning's Trainer is not rebuilt; ``Moco_v2`` keeps the reference's constructor
+arguments, buffers (``queue (emb_dim, K)``, ``queue_ptr (1,) int64``) and method names:
+
+  forward(img_q, img_k, queue) -> (logits, labels, k, q)            moco2_module.py:224-270 (API-faithful; the
+                                                                     (N, 1+K) logits are a plain library GEMM)
+  training_step((x_q, x_k))   -> loss                                moco2_module.py:287-309, fused:
+      EMA of the key encoder (cmu_ema_update, BEFORE the forward: A-8), both encoders on the HIP engine with
+      the global average pool fused on the raw latent (cmu_gap_fwd), all-gather of the normalised keys,
+      InfoNCE against the queue + ring-buffer enqueue in ONE kernel (cmu_moco_infonce_enqueue).
+"""
+import copy
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib, ops
+from .cmunet import UNet_encoder as _MaskEncoder, concat_all_gather
+from .model import _EngineOwner, _named_state, _param_args, _require_cuda
+
+
+class _EncoderGapFn(torch.autograd.Function):
+    """UNet down path + bottleneck + mean over (H,W) (moco_data_module.py:59-66) -> (B, C) fp32."""
+
+    @staticmethod
+    def forward(ctx, module, x, names, *params):
+        eng = module._engine(x.device)
+        sd = _named_state(module)
+        B = x.shape[0]
+        ectx = eng.encoder_forward(sd, x.detach().float().contiguous().view(B, x.shape[-2], x.shape[-1]), module.training, "")
+        lat = ectx["latent"]
+        out = torch.empty((B, lat.C), dtype=torch.float32, device=x.device)
+        ops.gap_fwd(lat, out)
+        ctx.module, ctx.ectx, ctx.names, ctx.eng = module, ectx, names, eng
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        eng, ectx = ctx.eng, ctx.ectx
+        sd = _named_state(ctx.module)
+        lat = ectx["latent"]
+        dA = eng._new(lat.B, lat.H, lat.W, lat.C)
+        ops.gap_bwd(dout.contiguous().float(), dA)
+        grads = {}
+        eng.encoder_backward(sd, ectx, dA, None, grads)
+        ctx.ectx = None
+        return (None, None, None, *[grads.get(n) for n in ctx.names])
+
+
+class UNet_encoder(_MaskEncoder):
+    """moco_data_module.py:47-66: the UNet encoder followed by torch.mean(x, dim=[2,3]); input (B,1,H,W)."""
+
+    def __init__(self, out_classes=2, up_sample_mode='conv_transpose', base_ch=64, depth=5, dtype="bf16"):
+        super().__init__(out_classes, up_sample_mode, patch_size=16, mask_ratio=0.0, base_ch=base_ch, depth=depth, dtype=dtype)
+
+    def forward(self, x):
+        _require_cuda(x, "UNet_encoder")
+        names, params = _param_args(self)
+        return _EncoderGapFn.apply(self, x, names, *params)
+
+
+class Moco_v2(nn.Module):
+    def __init__(self, base_encoder=None, emb_dim=1024, num_negatives=65536, encoder_momentum=0.999,
+                 softmax_temperature=0.07, learning_rate=0.03, momentum=0.9, weight_decay=1e-4, batch_size=256,
+                 use_mlp=False, dtype="bf16", base_ch=64, depth=5, **kwargs):
+        super().__init__()
+        self.hparams = dict(emb_dim=emb_dim, num_negatives=num_negatives, encoder_momentum=encoder_momentum,
+                            softmax_temperature=softmax_temperature, learning_rate=learning_rate, momentum=momentum,
+                            weight_decay=weight_decay, batch_size=batch_size, use_mlp=use_mlp)
+        if use_mlp:
+            raise NotImplementedError("use_mlp needs an fc attribute the reference's UNet_encoder does not have "
+                                      "(moco2_module.py:115-118 would fail there too)")
+        base_encoder = base_encoder if isinstance(base_encoder, nn.Module) else UNet_encoder(base_ch=base_ch, depth=depth, dtype=dtype)
+        self.encoder_q, self.encoder_k = self.init_encoders(base_encoder)
+        for pq, pk in zip(self.encoder_q.parameters(), self.encoder_k.parameters()):
+            pk.data.copy_(pq.data)
+            pk.requires_grad = False
+        self.register_buffer("queue", F.normalize(torch.randn(emb_dim, num_negatives), dim=0))
+        self.register_buffer("queue_ptr", torch.zeros(1, dtype=torch.long))
+        self.register_buffer("val_queue", F.normalize(torch.randn(emb_dim, num_negatives), dim=0))
+        self.register_buffer("val_queue_ptr", torch.zeros(1, dtype=torch.long))
+
+    def init_encoders(self, base_encoder):
+        return copy.deepcopy(base_encoder), copy.deepcopy(base_encoder)
+
+    @torch.no_grad()
+    def _momentum_update_key_encoder(self):
+        em = self.hparams["encoder_momentum"]
+        for pq, pk in zip(self.encoder_q.parameters(), self.encoder_k.parameters()):
+            ops.ema_update(pk.data.view(-1), pq.data.view(-1), em)
+
+    @torch.no_grad()
+    def _dequeue_and_enqueue(self, keys, queue_ptr, queue):
+        """moco2_module.py:160-175 (API-faithful torch version; the fused step enqueues inside its kernel)."""
+        keys = concat_all_gather(keys)
+        bs = keys.shape[0]
+        ptr = int(queue_ptr)
+        assert self.hparams["num_negatives"] % bs == 0
+        queue[:, ptr:ptr + bs] = keys.T
+        queue_ptr[0] = (ptr + bs) % self.hparams["num_negatives"]
+
+    def forward(self, img_q, img_k, queue):
+        q = F.normalize(self.encoder_q(img_q), dim=1)
+        with torch.no_grad():
+            k = F.normalize(self.encoder_k(img_k), dim=1)
+        l_pos = torch.einsum("nc,nc->n", [q, k]).unsqueeze(-1)
+        l_neg = torch.einsum("nc,ck->nk", [q, queue.clone().detach()])
+        logits = torch.cat([l_pos, l_neg], dim=1) / self.hparams["softmax_temperature"]
+        labels = torch.zeros(logits.shape[0], dtype=torch.long, device=logits.device)
+        return logits, labels, k, q
+
+    def training_step(self, batch, batch_idx=0):
+        """Fused step; ``batch`` = (img_q, img_k) or ((img_q, img_k), _) like the reference's loader output."""
+        x = batch[0] if isinstance(batch[0], (tuple, list)) else batch
+        img_q, img_k = x[0], x[1]
+        self._momentum_update_key_encoder()
+        q_raw = self.encoder_q(img_q)
+        with torch.no_grad():
+            k_raw = self.encoder_k(img_k)
+        return _MocoLossFn.apply(q_raw, k_raw, self.queue, self.queue_ptr, self.hparams["softmax_temperature"])
+
+
+class _MocoLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q_raw, k_raw, queue, queue_ptr, temperature):
+        B, D = q_raw.shape
+        K = queue.shape[1]
+        dev = q_raw.device
+        keys_all = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            kn = torch.empty_like(k_raw)
+            ops.l2_normalize_rows(k_raw.detach().contiguous(), kn)
+            keys_all = concat_all_gather(kn)                       # moco2_module.py:163-164
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        dq = torch.empty_like(q_raw)
+        ws = torch.empty(_lib.lib().cmu_moco_ws_bytes(B, K), dtype=torch.uint8, device=dev)
+        ops.moco_infonce_enqueue(q_raw.detach().contiguous(), k_raw.detach().contiguous(), keys_all, queue, queue_ptr, loss, dq,
+                                 None, temperature, ws)
+        ctx.save_for_backward(dq)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dq,) = ctx.saved_tensors
+        return dq * g, None, None, None, None

@@ -12,6 +12,15 @@ import torch.distributed as dist
 from . import ops
 
 
+def all_reduce_sum_scale(tensor, group=None):
+    """SUM all-reduce of ``tensor`` in place over the data-parallel group (RCCL on the GPU, gloo in the CPU
+    tests); returns the 1/world factor that turns it into the mean (folded into the optimiser kernel)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
+        return 1.0 / dist.get_world_size(group)
+    return 1.0
+
+
 class FlatParams:
     """Re-homes ``module``'s parameters into a flat fp32 arena; ``grad_views[name]`` are views into the
     gradient arena that the engine's weight-gradient kernels write directly (no per-tensor copies)."""
@@ -60,10 +69,7 @@ class FlatParams:
     def all_reduce_mean(self, group=None):
         """Data-parallel gradient exchange: ONE RCCL all-reduce over the whole arena (C1 in SURVEY 2.5).
         Returns the scale (1/world) the optimiser kernel folds into its gradient load."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
-            return 1.0 / dist.get_world_size(group)
-        return 1.0
+        return all_reduce_sum_scale(self.grad, group)
 
 
 def no_decay_bias_norm(name, param):

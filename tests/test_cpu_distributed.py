@@ -1,0 +1,75 @@
+"""World-size-2 gloo tests (CPU) of the data-parallel logic around the hot path: embedding
+all-gather with rank-offset labels, gathered-key queue update staying replicated, gradient mean via one
+all-reduce with the 1/world scale folded into the optimiser.  The arithmetic checker is the oracle."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cmunet_amd.cmunet import concat_all_gather
+        from cmunet_amd.optim import all_reduce_sum_scale
+        from oracle import cmunet as OC, moco as OM
+        B, D = 4, 16
+        g = torch.Generator().manual_seed(0)                      # same data on every rank, sliced by rank
+        pred_all = torch.randn(world * B, D, generator=g)
+        proj_all = F.normalize(torch.randn(world * B, D, generator=g), dim=1)
+        pred, proj = pred_all[rank * B:(rank + 1) * B], proj_all[rank * B:(rank + 1) * B]
+        keys = concat_all_gather(proj)                             # cmunet_head.py:77
+        assert torch.equal(keys, proj_all)
+        loss_rank = OC.infonce_inbatch(pred, keys, 0.07, rank=rank)            # labels i + B*rank
+        t = loss_rank.detach().clone()
+        dist.all_reduce(t)
+        single = OC.infonce_inbatch(pred_all, proj_all, 0.07, rank=0)          # one process, concatenated batch
+        assert abs(float(t) / world - float(single)) < 1e-5
+        # MoCo: every rank enqueues the SAME gathered keys -> queue and pointer stay replicated
+        queue, ptr = OM.init_queue(D, 32, seed=1), torch.zeros(1, dtype=torch.long)
+        OM.dequeue_and_enqueue(concat_all_gather(proj), queue, ptr, 32)
+        ref = queue.clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(ref, queue) and int(ptr) == world * B
+        # gradient mean: sum-all-reduce + 1/world scale == gradient of the big batch
+        w = torch.randn(D, 3, generator=g, requires_grad=True)
+        x_all, y_all = torch.randn(world * B, D, generator=g), torch.randn(world * B, 3, generator=g)
+        loss = ((x_all[rank * B:(rank + 1) * B] @ w - y_all[rank * B:(rank + 1) * B]) ** 2).mean()
+        loss.backward()
+        grad = w.grad.clone()
+        scale = all_reduce_sum_scale(grad)
+        w2 = w.detach().clone().requires_grad_(True)
+        ((x_all @ w2 - y_all) ** 2).mean().backward()
+        assert torch.allclose(grad * scale, w2.grad, atol=1e-6)
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res

@@ -1,0 +1,162 @@
+"""GPU parity of the pretraining models (CM-UNet joint step, MoCo-v2 step, fused masked-recon trainer)
+against the CPU oracle restatement (oracle/cmunet.py, oracle/moco.py) on small seeded configurations.
+fp32 storage; tolerance 2e-3 relative (max norm) on losses and gradients -- the chain is
+conv blocks -> mean -> Linear(H*W, 1536) -> BN1d over 4 rows -> ... so rounding is amplified."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cuda():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda")
+
+
+def rel(got, ref):
+    return (got.detach().double().cpu() - ref.detach().double()).abs().max().item() / max(ref.detach().abs().max().item(), 1e-9)
+
+
+def test_cmunet_joint_step_vs_oracle(cuda):
+    from cmunet_amd import cmunet as C
+    from cmunet_amd.pretrain import create_random_patch_mask
+    from oracle import cmunet as OC
+    torch.manual_seed(0)
+    B, S = 4, 32
+    model = C.build_model(C.cmunet_config(img_size=S, dtype="f32", base_ch=16, depth=3)).to(cuda).train()
+    with torch.no_grad():                                   # non-trivial BN affine parameters everywhere
+        for n, p in model.named_parameters():
+            if p.dim() == 1 and ("bn" in n or ".1." in n or ".4." in n):
+                p.add_(0.2 * torch.randn_like(p))
+        for pb, pm in zip(model.backbone.parameters(), model.target_backbone.parameters()):
+            pm.copy_(pb * 0.9)
+        for pb, pm in zip(model.projector.parameters(), model.target_projector.parameters()):
+            pm.copy_(pb * 1.1)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(1)
+    img, img_t = torch.randn(B, S, S, generator=g), torch.randn(B, S, S, generator=g)
+    mask = torch.from_numpy(create_random_patch_mask(B, S, 16, 0.65, np.random.RandomState(2)))
+    Cr = model.reduced_channels()
+    rw, rb = torch.randn(Cr, 64, 1, 1, generator=g) * 0.1, torch.randn(Cr, generator=g) * 0.1
+
+    losses = model(img.to(cuda), mode='loss', img_t=img_t.to(cuda), mask=mask.to(cuda), reduce_w=rw.to(cuda), reduce_b=rb.to(cuda))
+    (losses['loss_ct'] + losses['loss_rc']).backward()
+
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and not k.startswith("target_") else v.clone())
+           for k, v in sd.items()}
+    ref = OC.forward_train(img, img_t, mask.numpy(), rw, rb, osd, temperature=0.07, ct_weight=1.0, rc_weight=1.0)
+    (ref['loss_ct'] + ref['loss_rc']).backward()
+
+    assert abs(float(losses['loss_rc']) - float(ref['loss_rc'])) <= 2e-4 * max(1, abs(float(ref['loss_rc'])))
+    assert abs(float(losses['loss_ct']) - float(ref['loss_ct'])) <= 2e-3 * max(1, abs(float(ref['loss_ct'])))
+    params = dict(model.named_parameters())
+    checked = 0
+    for k, v in osd.items():
+        if not (torch.is_tensor(v) and v.requires_grad) or v.grad is None:
+            continue
+        if ".0.bias" in k or ".3.bias" in k:                 # conv bias under train-mode BN: identically zero here
+            continue
+        e = rel(params[k].grad, v.grad)
+        assert e <= 5e-3, f"d{k}: {e:.2e}"
+        checked += 1
+    assert checked > 60
+    for k in sd:                                             # target networks got no gradient, BN buffers advanced
+        if k.startswith("target_") and k in params:
+            assert params[k].grad is None
+    assert int(model.state_dict()["target_backbone.double_conv.double_conv.1.num_batches_tracked"]) == 1
+
+    # EMA (cmunet.py:78-92)
+    before = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    model.momentum = 0.9
+    model.momentum_update()
+    OC.momentum_update(before, 0.9)
+    for k, v in model.state_dict().items():
+        if k.startswith("target_") and v.is_floating_point() and "running" not in k:
+            assert rel(v, before[k]) <= 1e-6, k
+
+
+def test_cmunet_modules_standalone(cuda):
+    """UNet_encoder / MUNetPretrainDecoder used on their own keep the reference's tensor contract."""
+    from cmunet_amd import cmunet as C
+    from oracle import unet as OU, cmunet as OC
+    enc = C.UNet_encoder(base_ch=16, depth=3, dtype="f32", mask_ratio=0.5).to(cuda).train()
+    dec = C.MUNetPretrainDecoder(base_ch=16, depth=3, dtype="f32").to(cuda).train()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 32, 48, generator=g)
+    latent, mask, skips = enc(x.to(cuda))
+    assert latent.shape == (2, 64, 8, 12) and mask.shape == (2, 32, 48) and mask.dtype == torch.uint8
+    assert [tuple(s.shape) for s in skips] == [(2, 16, 32, 48), (2, 32, 16, 24)]
+    assert int(mask[0].sum()) == int(0.5 * 32 * 48) // 256 * 256
+    esd = {k: v.detach().cpu().clone() for k, v in enc.state_dict().items()}
+    lat_ref, _, sk_ref = OC.encoder(x, mask.cpu().numpy(), esd, "", True, True)
+    assert rel(latent, lat_ref) <= 1e-3 and rel(skips[0], sk_ref[0]) <= 1e-3
+    out = dec(latent, skips)
+    dsd = {k: v.detach().cpu().clone() for k, v in dec.state_dict().items()}
+    ref = OC.decoder(lat_ref, sk_ref, dsd, "", True)
+    assert out.shape == (2, 2, 32, 48) and rel(out, ref) <= 2e-3
+    out.sum().backward()
+    assert enc.down_conv1.double_conv.double_conv[0].weight.grad is not None
+
+
+def test_moco_step_vs_oracle(cuda):
+    from cmunet_amd import moco as M
+    from oracle import moco as OM
+    torch.manual_seed(0)
+    B, S, K, T = 4, 32, 64, 0.2
+    m = M.Moco_v2(emb_dim=64, num_negatives=K, softmax_temperature=T, encoder_momentum=0.99, dtype="f32", base_ch=16, depth=3).to(cuda).train()
+    with torch.no_grad():
+        for pk in m.encoder_k.parameters():
+            pk.mul_(0.95)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    xq, xk = torch.randn(B, 1, S, S, generator=g), torch.randn(B, 1, S, S, generator=g)
+    loss = m.training_step(((xq.to(cuda), xk.to(cuda)), 0))
+    loss.backward()
+    osd = {k: (v.clone().requires_grad_(True) if k.startswith("encoder_q.") and v.is_floating_point() and "running" not in k else v.clone())
+           for k, v in sd.items()}
+    queue, ptr = sd["queue"].clone(), sd["queue_ptr"].clone()
+    ref, logits, k = OM.training_step(xq, xk, osd, queue, ptr, T, 0.99)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) <= 1e-3 * max(1.0, abs(float(ref)))
+    assert rel(m.queue, queue) <= 1e-4 and int(m.queue_ptr) == int(ptr) == B
+    pq = dict(m.named_parameters())
+    for kname in ("encoder_q.down_conv1.double_conv.double_conv.0.weight", "encoder_q.double_conv.double_conv.3.weight",
+                  "encoder_q.down_conv2.double_conv.double_conv.4.bias"):
+        assert rel(pq[kname].grad, osd[kname].grad) <= 5e-3, kname
+    # key encoder after the EMA (before the forward, A-8)
+    assert rel(m.encoder_k.double_conv.double_conv[0].weight, osd["encoder_k.double_conv.double_conv.0.weight"]) <= 1e-6
+    # API-faithful forward(): logits (N, 1+K), labels 0
+    lg, lb, kk, qq = m(xq.to(cuda), xk.to(cuda), m.queue)
+    assert lg.shape == (B, 1 + K) and int(lb.sum()) == 0 and kk.shape == (B, 64)
+
+
+def test_masked_recon_trainer_matches_autograd_path(cuda):
+    """The fused trainer (arena gradients, fused AdamW) and the drop-in autograd path agree after 3 steps."""
+    from cmunet_amd import model as M
+    from cmunet_amd.cmunet import masked_mse_loss
+    from cmunet_amd.pretrain import MaskedReconPretrainer, random_patch_mask_device
+    from oracle import unet as OU
+    sd = OU.make_state_dict(base_ch=16, depth=3, seed=9)
+    a, b = M.UNet(base_ch=16, depth=3, dtype="f32"), M.UNet(base_ch=16, depth=3, dtype="f32")
+    a.load_state_dict(sd); b.load_state_dict(sd)
+    a, b = a.to(cuda).train(), b.to(cuda).train()
+    tr = MaskedReconPretrainer(a, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05)
+    decay = [p for n, p in b.named_parameters() if not (n.endswith(".bias") or p.dim() <= 1)]
+    nodecay = [p for n, p in b.named_parameters() if n.endswith(".bias") or p.dim() <= 1]
+    opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.05}, {"params": nodecay, "weight_decay": 0.0}], lr=1e-3, betas=(0.9, 0.95))
+    g = torch.Generator(device=cuda).manual_seed(0)
+    for it in range(3):
+        x = torch.randn(2, 32, 32, generator=g, device=cuda)
+        mask = random_patch_mask_device(2, 32, 32, 16, 0.5, g, cuda)
+        la = tr.step(x, mask)
+        opt.zero_grad()
+        lb = masked_mse_loss(b(x, mask=mask), 1, x, mask)
+        lb.backward()
+        opt.step()
+        assert abs(float(la) - float(lb)) <= 1e-5 * max(1.0, abs(float(lb)))
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert rel(pa, pb.detach().cpu()) <= 1e-4, n
