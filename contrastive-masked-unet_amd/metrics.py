@@ -1,0 +1,158 @@
+"""Drop-in for the tensor losses / metrics of the reference's ``Finetuning/metrics.py`` that sit on the
+training step: the ``Loss`` algebra (``DiceLoss(...) + CrossEntropyLoss()`` with the
+reference's snake-case ``__name__``s, metrics.py:9-82), ``DiceLoss`` (:160-180), ``CrossEntropyLoss`` (:503)
+and ``IoU`` (:200-220), computed by ONE fused kernel per (prediction, target) pair:
+``cmu_softmax_ce_dice_fwd_bwd`` makes a single pass over the logits and yields the CE (with its gradient),
+and the thresholded Dice / IoU counters -- the reference makes 4-5 elementwise passes and a host sync each.
+
+Only the configuration the reference's driver uses is implemented on the HIP path (train.py:455-461:
+2 classes, activation 'softmax', threshold 0.5, ignore_channels [0], eps 1e-5 / 1e-7); other settings raise.
+``hausdorff`` / ``radius_arteries`` (CPU scikit-image / scipy geometry, metrics.py:224-395) are out of scope.
+The Dice term has no gradient, exactly like the reference's thresholded version (SURVEY A-4).
+"""
+import re
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+
+
+class BaseObject(nn.Module):
+    def __init__(self, name=None):
+        super().__init__()
+        self._name = name
+
+    @property
+    def __name__(self):
+        if self._name is None:
+            s1 = re.sub("(.)([A-Z][a-z]+)", r"\1_\2", self.__class__.__name__)
+            return re.sub("([a-z0-9])([A-Z])", r"\1_\2", s1).lower()
+        return self._name
+
+
+class Metric(BaseObject):
+    pass
+
+
+class Loss(BaseObject):
+    def __add__(self, other):
+        if isinstance(other, Loss):
+            return SumOfLosses(self, other)
+        raise ValueError("Loss should be inherited from `Loss` class")
+
+    def __radd__(self, other):
+        return self.__add__(other)
+
+    def __mul__(self, value):
+        if isinstance(value, (int, float)):
+            return MultipliedLoss(self, value)
+        raise ValueError("Loss should be inherited from `BaseLoss` class")
+
+    def __rmul__(self, other):
+        return self.__mul__(other)
+
+
+class SumOfLosses(Loss):
+    def __init__(self, l1, l2):
+        super().__init__(name="{} + {}".format(l1.__name__, l2.__name__))
+        self.l1, self.l2 = l1, l2
+
+    def __call__(self, *inputs):
+        return self.l1.forward(*inputs) + self.l2.forward(*inputs)
+
+
+class MultipliedLoss(Loss):
+    def __init__(self, loss, multiplier):
+        fmt = "{} * ({})" if len(loss.__name__.split("+")) > 1 else "{} * {}"
+        super().__init__(name=fmt.format(multiplier, loss.__name__))
+        self.loss, self.multiplier = loss, multiplier
+
+    def __call__(self, *inputs):
+        return self.multiplier * self.loss.forward(*inputs)
+
+    def forward(self, *inputs):
+        return self.multiplier * self.loss.forward(*inputs)
+
+
+# ---------------------------------------------------------------------------------------------------
+# one fused pass per (logits, target) pair, shared by every loss / metric object evaluated on it
+# ---------------------------------------------------------------------------------------------------
+class _SegStatsFn(torch.autograd.Function):
+    """out[0..2] = (ce, dice_loss, iou_loss); gradient flows through the CE entry only."""
+
+    @staticmethod
+    def forward(ctx, logits, y1h):
+        B, K, H, W = logits.shape
+        out = torch.empty(6, dtype=torch.float32, device=logits.device)
+        dl = torch.empty_like(logits)
+        ws = torch.empty(_lib.lib().cmu_softmax_ce_dice_ws_bytes(B, H, W), dtype=torch.uint8, device=logits.device)
+        ops.softmax_ce_dice_fwd_bwd(logits.detach().contiguous(), y1h.contiguous(), out, dl, 1.0, ws)
+        ctx.save_for_backward(dl)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g[0], None
+
+
+_cache = {"key": None, "out": None}
+
+
+def seg_stats(y_pr, y_gt):
+    if not y_pr.is_cuda:
+        raise RuntimeError("metrics: the HIP path needs CUDA/ROCm tensors (no CPU fallback)")
+    if y_pr.dim() != 4 or y_pr.shape[1] != 2 or y_gt.shape != y_pr.shape:
+        raise NotImplementedError("fused segmentation losses support (B,2,H,W) logits with one-hot targets of the same shape")
+    y = y_gt if y_gt.dtype == torch.float64 else y_gt.double()
+    key = (y_pr.data_ptr(), y_pr._version, y_gt.data_ptr(), y_gt._version, tuple(y_pr.shape), y_pr.requires_grad)
+    if _cache["key"] != key:
+        _cache["key"], _cache["out"] = key, _SegStatsFn.apply(y_pr.float(), y)
+    return _cache["out"]
+
+
+def _check_cfg(activation, threshold, ignore_channels, what):
+    if activation not in ("softmax", "softmax2d") or threshold != 0.5 or list(ignore_channels or []) != [0]:
+        raise NotImplementedError(f"{what}: the HIP path implements the reference driver's configuration only "
+                                  "(activation='softmax', threshold=0.5, ignore_channels=[0]; train.py:455-461)")
+
+
+class DiceLoss(Loss):
+    def __init__(self, eps=1e-5, beta=1.0, activation=None, ignore_channels=None, threshold=None, **kwargs):
+        super().__init__(**kwargs)
+        _check_cfg(activation, threshold, ignore_channels, "DiceLoss")
+        if eps != 1e-5 or beta != 1.0:
+            raise NotImplementedError("DiceLoss: eps=1e-5, beta=1 only")
+        self.eps, self.beta, self.threshold, self.ignore_channels = eps, beta, threshold, ignore_channels
+
+    def forward(self, y_pr, y_gt):
+        return seg_stats(y_pr, y_gt)[1].detach().double()
+
+
+class CrossEntropyLoss(Loss):
+    """nn.CrossEntropyLoss() with probability (one-hot float) targets, mean over B*H*W (metrics.py:503)."""
+
+    def forward(self, y_pr, y_gt):
+        return seg_stats(y_pr, y_gt)[0].double()
+
+
+class IoU(Metric):
+    __name__ = "iou_loss"
+
+    def __init__(self, eps=1e-7, threshold=0.5, activation=None, ignore_channels=None, **kwargs):
+        super().__init__(**kwargs)
+        _check_cfg(activation, threshold, ignore_channels, "IoU")
+        if eps != 1e-7:
+            raise NotImplementedError("IoU: eps=1e-7 only")
+
+    def forward(self, y_pr, y_gt):
+        return seg_stats(y_pr, y_gt)[2].detach().double()
+
+
+class DiceMetric(Metric):
+    """The Dice loss value used as a metric (train.py:456-461 lists DiceLoss among the metrics)."""
+    __name__ = "dice_loss"
+
+    def forward(self, y_pr, y_gt):
+        return seg_stats(y_pr, y_gt)[1].detach().double()

@@ -60,6 +60,9 @@ def test_cmunet_joint_step_vs_oracle(cuda):
             continue
         if ".0.bias" in k or ".3.bias" in k:                 # conv bias under train-mode BN: identically zero here
             continue
+        if v.grad.abs().max() < 1e-6:                         # analytically zero (e.g. a constant shift in front of a
+            assert params[k].grad.abs().max() < 1e-5, k        # batch-normalised Linear): only rounding noise on both sides
+            continue
         e = rel(params[k].grad, v.grad)
         assert e <= 5e-3, f"d{k}: {e:.2e}"
         checked += 1
