@@ -131,7 +131,7 @@ class _EncoderFn(torch.autograd.Function):
         return (None, None, None, None, None, *[grads.get(n) for n in ctx.names])
 
 
-class UNet_encoder(nn.Module, _EngineOwner):
+class UNet_encoder(_EngineOwner, nn.Module):
     """UNet down path + bottleneck with random patch masking (UNet_encoder.py:51-158).
 
     forward(x (B,H,W)) -> (latent (B,C,H/2^d,W/2^d), mask (B,H,W) uint8 on the device, [skip1..skip4]).
@@ -201,7 +201,7 @@ class _DecoderFn(torch.autograd.Function):
         return (None, None, None, gl, *gs, *[grads.get(n) for n in ctx.names])
 
 
-class MUNetPretrainDecoder(nn.Module, _EngineOwner):
+class MUNetPretrainDecoder(_EngineOwner, nn.Module):
     """UNet up path + 1x1 head (munet_neck.py:52-82). forward(x, skip) with skip = [skip1..skip4]."""
 
     def __init__(self, out_classes=2, up_sample_mode='conv_transpose', base_ch=64, depth=5, dtype="bf16"):
@@ -377,7 +377,7 @@ class _CMUNetFn(torch.autograd.Function):
         return (None, None, None, None, None, *[grads.get(n) for n in ctx.names])
 
 
-class CM_UNet(nn.Module, _EngineOwner):
+class CM_UNet(_EngineOwner, nn.Module):
     """Contrastive + masked-reconstruction UNet (cmunet.py:7-135).
 
     ``backbone`` = dict(online=..., target=...), ``neck`` = dict(pixel=..., feature=..., projector=...),

@@ -59,7 +59,8 @@ struct WGCfg {
     static constexpr int A_ITERS = (256 * 8) / 512;
     static constexpr int B_ITERS = (NPIXB * 8 + 511) / 512;
     static constexpr int RED_BYTES = NT * TAPS * 4096;
-    static constexpr int MAIN_BYTES = A_BYTES + B_BYTES;
+    static constexpr int BUF_BYTES = A_BYTES + B_BYTES;   // one stage: dY tile + X halo
+    static constexpr int MAIN_BYTES = 2 * BUF_BYTES;      // double-buffered: stage t+1 is written while t is read
     static constexpr int LDS_BYTES = MAIN_BYTES > RED_BYTES ? MAIN_BYTES : RED_BYTES;
 };
 
@@ -76,8 +77,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WGParams p) {
     typedef WGCfg<TR, MODE> C;
     constexpr int EPC = TR::EPC;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* smA = smem;
+    unsigned char* smA = smem;                 // buffer being read (swapped every tile)
     unsigned char* smB = smem + C::A_BYTES;
+    unsigned char* stA = smem;                 // buffer being written by store_tile
+    unsigned char* stB = smem + C::A_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WGParams p) {
 #pragma unroll
         for (int it = 0; it < C::A_ITERS; ++it) {
             const int pix = (it * 512 + tid) >> 3;
-            *reinterpret_cast<u32x4*>(smA + swz(pix, cgi * 16)) = areg[it];
+            *reinterpret_cast<u32x4*>(stA + swz(pix, cgi * 16)) = areg[it];
         }
 #pragma unroll
         for (int it = 0; it < C::B_ITERS; ++it) {
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WGParams p) {
                     v = TR::pack(f);
                 }
                 const int pix = idx >> 3;
-                *reinterpret_cast<u32x4*>(smB + swz((pix / C::LW) * C::LWP + pix % C::LW, cgi * 16)) = v;
+                *reinterpret_cast<u32x4*>(stB + swz((pix / C::LW) * C::LWP + pix % C::LW, cgi * 16)) = v;
             }
         }
     };
@@ -203,13 +206,19 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WGParams p) {
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) b_off32[kw] = (kw + h) * 128 + (((cb32 * 32 + r) * 4) ^ ((((kw + h) >> 1) & 1) << 6));
 
+    // software pipeline over this split's tiles: LDS holds tile t (being read) and tile t+1 (being written by
+    // store_tile from registers loaded one iteration earlier); registers are then refilled with tile t+2.
+    // One barrier per tile; a wave's LDS writes overlap the other waves' MFMAs.
     int tile = split;
-    if (tile < p.ntiles) load_tile(tile);
-    for (; tile < p.ntiles; tile += p.splitk) {
-        __syncthreads();
+    if (tile < p.ntiles) {
+        load_tile(tile);
         store_tile();
-        __syncthreads();
         if (tile + p.splitk < p.ntiles) load_tile(tile + p.splitk);
+    }
+    __syncthreads();
+    for (; tile < p.ntiles; tile += p.splitk) {
+        stA = (smA == smem) ? smem + C::BUF_BYTES : smem;
+        stB = stA + C::A_BYTES;
 #pragma unroll 1
         for (int rr = 0; rr < C::RPP; ++rr) {
             const int py = kpart * C::RPP + rr;
@@ -242,6 +251,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WGParams p) {
                 }
             }
         }
+        if (tile + p.splitk < p.ntiles) store_tile();                       // tile t+1: registers -> the other buffer
+        __syncthreads();
+        if (tile + 2 * p.splitk < p.ntiles) load_tile(tile + 2 * p.splitk);  // tile t+2: in flight during the next compute
+        smA = stA;
+        smB = stB;
     }
     // ---- combine the k-parts through LDS (fixed order), then write the partial slab ----------------------
     float* red = reinterpret_cast<float*>(smem) + (int64_t)tile_id * (C::TAPS * 1024);

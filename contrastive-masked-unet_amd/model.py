@@ -37,8 +37,8 @@ def _named_state(module):
 class _EngineOwner:
     """Lazily creates one UNetEngine per (module, dtype, device)."""
 
-    def __getstate__(self):          # torch.save(model) (train.py:212) must not pickle device scratch
-        d = self.__dict__.copy()
+    def __getstate__(self):          # torch.save(model) (train.py:212) must not pickle device scratch / the CDLL
+        d = dict(super().__getstate__())     # nn.Module.__getstate__ (this mixin precedes nn.Module in the MRO)
         d.pop("_eng", None)
         return d
 
@@ -82,7 +82,7 @@ def _param_args(module):
     return tuple(names), params
 
 
-class DoubleConv(nn.Module, _EngineOwner):
+class DoubleConv(_EngineOwner, nn.Module):
     """[Conv3x3 -> BatchNorm2d -> ReLU] x 2 (model.py:4-26)."""
 
     def __init__(self, in_channels, out_channels, dtype="bf16"):
@@ -103,7 +103,7 @@ class DoubleConv(nn.Module, _EngineOwner):
         return _BlockFn.apply(self, "double", names, x, None, *params)
 
 
-class DownBlock(nn.Module, _EngineOwner):
+class DownBlock(_EngineOwner, nn.Module):
     """DoubleConv -> MaxPool2d(2); returns (down_out, skip_out) (model.py:29-45)."""
 
     def __init__(self, in_channels, out_channels, dtype="bf16"):
@@ -118,7 +118,7 @@ class DownBlock(nn.Module, _EngineOwner):
         return _BlockFn.apply(self, "down", names, x, None, *params)
 
 
-class UpBlock(nn.Module, _EngineOwner):
+class UpBlock(_EngineOwner, nn.Module):
     """ConvTranspose2d(k2,s2) -> cat([up, skip], 1) -> DoubleConv (model.py:48-81)."""
 
     def __init__(self, in_channels, out_channels, up_sample_mode, dtype="bf16"):
@@ -227,7 +227,7 @@ class _BlockFn(torch.autograd.Function):
         return (None, None, None, gx, gskip, *out)
 
 
-class UNet(nn.Module, _EngineOwner):
+class UNet(_EngineOwner, nn.Module):
     """U-Net: 4 down blocks, 1024-channel bottleneck, 4 up blocks, 1x1 head (model.py:84-131).
 
     forward(x: (B,H,W)) -> logits (B,out_classes,H,W) fp32.  H and W must be multiples of 2**(depth-1).
