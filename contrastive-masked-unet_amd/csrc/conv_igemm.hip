@@ -27,6 +27,7 @@
 //     (deterministic, no atomics); the tile is transposed through LDS and written as whole 16-byte
 //     channel chunks per pixel (coalesced NHWC rows).
 #include "common.h"
+#include <stdlib.h>
 
 enum { MODE_CONV3 = 0, MODE_CONVT_FWD = 1, MODE_CONVT_DGRAD = 2 };
 
@@ -47,6 +48,7 @@ struct IGParams {
     int N;        // GEMM N (CONV3: Cout; CONVT_FWD: 4*Cout; CONVT_DGRAD: Cin)
     int Cq;       // CONVT_FWD: Cout (n -> (ij, co))
     int nslices;  // total number of 64-byte K slices
+    int nslices32;  // CONV3: number of 32-byte slices in the packed weights
     int tilesX, tilesY, nblk;
     int64_t total_blocks;
 };
@@ -194,9 +196,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IGParams p) {
         for (int it = 0; it < C::W_ITERS; ++it) {
             const int ws = C::C3 ? s : s * C::TAPS + w_t[it];
             u32x4 v = {0u, 0u, 0u, 0u};
-            const bool ok = (it * 256 + tid < C::W_CHUNKS) && (ws < p.nslices);
-            if (ok) {
-                const int64_t rowg = ((int64_t)(C::C3 ? s * 9 + w_t[it] : ws)) * p.npad + w_n[it];
+            bool ok = (it * 256 + tid < C::W_CHUNKS) && (ws < p.nslices);
+            if (C::C3) {
+                // packed 3x3 weights use 32-byte K slices [slice32][tap][npad][32 B] (shared with the v2 kernel):
+                // chunk cg of this 64-byte stage row lives in slice 2s + (cg >> 1), half (cg & 1)
+                const int s32 = 2 * s + (cg >> 1);
+                ok = ok && (s32 < p.nslices32);
+                if (ok) v = ld_global16(wb + (((int64_t)s32 * 9 + w_t[it]) * p.npad + w_n[it]) * 32 + (cg & 1) * 16);
+            } else if (ok) {
+                const int64_t rowg = (int64_t)ws * p.npad + w_n[it];
                 v = ld_global16(wb + rowg * 64 + cg * 16);
             }
             wreg[it] = v;
@@ -352,6 +360,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IGParams p) {
     }
 }
 
+// CMU_CONV_V1=1 in the environment forces the first-generation kernel everywhere (A/B measurements, tests)
+static bool cmu_force_v1() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("CMU_CONV_V1");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+
+#include "conv_igemm2.inc"
+
 // ---------------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------------
@@ -385,7 +405,11 @@ static int check_act(const char* name, const void* ptr, int64_t ld, int C, int d
 template <class TR>
 static int conv3x3_fwd_t(IGParams p, hipStream_t st) {
     typedef IGCfg<TR, MODE_CONV3> C;
+    // wide layers: double-buffered one-workgroup-per-CU pipeline (conv_igemm2.inc); narrow ones: first kernel
+    if (p.N >= 128 && p.K >= 128 && p.K <= IG2Cfg<TR>::MAX_K && !cmu_force_v1()) return launch_igemm2<TR>(p, st);
     p.nslices = cmu_div_up(p.K, C::KC);
+    p.nslices32 = cmu_div_up(p.K, C::KC / 2);
+    p.npad = cmu_conv3x3_npad(p.N);
     return launch_igemm<TR, MODE_CONV3>(p, st, "cmu_conv3x3_fwd");
 }
 template <class TR>

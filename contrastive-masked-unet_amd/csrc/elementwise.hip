@@ -27,7 +27,7 @@ extern "C" int cmu_dtype_size(int dt) { return dt == CMU_F32 ? 4 : (dt == CMU_F1
 template <class TR>
 __global__ void pack_conv3x3_kernel(const float* __restrict__ w, typename TR::elem_t* __restrict__ out, int Cin, int Cout,
                                     int K, int N, int npad, int64_t total, int tflip) {
-    constexpr int KC = 64 / (int)sizeof(typename TR::elem_t);
+    constexpr int KC = 32 / (int)sizeof(typename TR::elem_t);   // one 32-byte K slice per row
     for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
         const int k = (int)(o % KC);
         const int n = (int)((o / KC) % npad);
@@ -46,9 +46,9 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, typename TR::el
 
 template <class TR>
 static int pack_conv3x3_t(const float* w, void* out, int Cin, int Cout, int tflip, hipStream_t st) {
-    constexpr int KC = 64 / (int)sizeof(typename TR::elem_t);
+    constexpr int KC = 32 / (int)sizeof(typename TR::elem_t);
     const int K = tflip ? Cout : Cin, N = tflip ? Cin : Cout;
-    const int npad = cmu_div_up(N, 64) * 64;
+    const int npad = cmu_conv3x3_npad(N);
     const int64_t total = (int64_t)cmu_div_up(K, KC) * 9 * npad * KC;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL((pack_conv3x3_kernel<TR>), dim3(grid), dim3(256), 0, st, w, (typename TR::elem_t*)out, Cin, Cout, K, N,
@@ -60,9 +60,9 @@ static int pack_conv3x3_t(const float* w, void* out, int Cin, int Cout, int tfli
 extern "C" int64_t cmu_pack_conv3x3_elems(int Cin, int Cout, int dt, int tflip) {
     const int es = cmu_dtype_size(dt);
     if (es == 0) return -1;
-    const int KC = 64 / es;
+    const int KC = 32 / es;
     const int K = tflip ? Cout : Cin, N = tflip ? Cin : Cout;
-    return (int64_t)cmu_div_up(K, KC) * 9 * (cmu_div_up(N, 64) * 64) * KC;
+    return (int64_t)cmu_div_up(K, KC) * 9 * cmu_conv3x3_npad(N) * KC;
 }
 extern "C" int cmu_pack_conv3x3(const float* w, void* out, int Cin, int Cout, int dt, int tflip, void* stream) {
     CMU_CHECK_ARG(w && out && Cin > 0 && Cout > 0, "cmu_pack_conv3x3: bad args");
