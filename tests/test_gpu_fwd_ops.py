@@ -50,6 +50,12 @@ CONV_CASES = [
     (2, 7, 9, 8, 8, 8, 16, True),
     (1, 33, 17, 64, 72, 0, 0, True),
     (1, 16, 32, 128, 64, 64, 0, False),
+    # wide layers -> second-generation kernel (Cin >= 128 and Cout >= 128): partial tiles, partial n-blocks,
+    # channel-sliced buffers, a last K slice that is only half full
+    (1, 20, 33, 128, 128, 0, 0, True),
+    (2, 16, 16, 256, 192, 0, 64, True),
+    (1, 7, 9, 136, 256, 8, 0, False),
+    (1, 32, 16, 512, 128, 0, 0, True),
 ]
 
 
