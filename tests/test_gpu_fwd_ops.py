@@ -251,3 +251,38 @@ def test_bad_args_fail_loudly(ops):
     w = torch.zeros(16 * 9 * 64, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(CmuError):
         ops.conv3x3_fwd(a, w, o, None)
+
+
+def test_conv3x3_second_generation_kernel_matches_first():
+    """The opt-in double-buffered kernel (CMU_CONV_V2=1, conv_igemm2.inc) computes the same convolution as the
+    default one (different fp32 summation order only): run both in subprocesses and compare."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from cmunet_amd import ops
+g = torch.Generator().manual_seed(0)
+B, H, W, Cin, Cout = 2, 20, 33, 256, 192
+x = torch.randn(B, H, W, Cin, generator=g).to(torch.bfloat16).cuda()
+w = (torch.randn(Cout, Cin, 3, 3, generator=g) / 48).cuda()
+sc, sh = (torch.rand(Cin, generator=g) + 0.5).cuda(), (torch.randn(Cin, generator=g) * 0.3).cuda()
+y = ops.new_act(B, H, W, Cout, "bf16", "cuda")
+st = ops.new_stats(B, H, W, Cout, "cuda")
+ops.conv3x3_fwd(ops.Act(x, 0, Cin, sc, sh, 0), ops.pack_conv3x3(w, "bf16"), y, st)
+torch.save({"y": y.buf.float().cpu(), "s": st.sum(0).cpu()}, sys.argv[1])
+''' % root
+    outs = []
+    for v2 in ("0", "1"):
+        with tempfile.NamedTemporaryFile(suffix=".pt", delete=False) as f:
+            path = f.name
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, CMU_CONV_V2=v2), timeout=300)
+        outs.append(torch.load(path))
+        os.unlink(path)
+    check(outs[1]["y"], outs[0]["y"], 8e-3, "v2 vs v1 y (bf16 rounding of different fp32 sums)")
+    check(outs[1]["s"], outs[0]["s"], 1e-4, "v2 vs v1 stats")
