@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of the 3x3 conv kernels inside one gpurun call (same box, back to back)
-for cfg in "CMU_CONV_V2=0" "CMU_CONV_V2=1 CMU_IG2_VARIANT=0" "CMU_CONV_V2=1 CMU_IG2_VARIANT=1" "CMU_CONV_V2=1 CMU_IG2_VARIANT=2"; do
-  env $cfg python bench.py --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/ab.log 2>&1
+for cfg in "$@"; do
+  env $cfg python bench.py --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/ab.log 2>&1
   python - <<PY
 import json
 d=json.loads(open("gpurun_out/ab.log").read().strip().splitlines()[-1])
