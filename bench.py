@@ -82,11 +82,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs (one-GPU box): CMU_DIST_BACKEND=gloo CMU_SINGLE_DEVICE=1 run all ranks on cuda:0 over gloo
+    backend = os.environ.get("CMU_DIST_BACKEND", "nccl")
+    single_dev = os.environ.get("CMU_SINGLE_DEVICE", "0") == "1"
+    dev_index = 0 if (world == 1 or single_dev) else local_rank
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))   # RCCL over xGMI
+        else:
+            dist.init_process_group(backend=backend)
     assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
     B, H, W = args.batch, args.size, args.size
