@@ -45,12 +45,13 @@ _SIGS = {
     "cmu_conv3x3_wgrad": (_I, [_P, _L, _P, _P, _I, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "cmu_conv3x3_c1_wgrad_ws_bytes": (_L, [_I, _I, _I, _I]),
     "cmu_conv3x3_c1_wgrad": (_I, [_P, _P, _I, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),
-    "cmu_maxpool_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "cmu_maxpool_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "cmu_bn_bwd_finalize": (_I, [_P, _L, _P, _P, _P, _I, _P]),
     "cmu_convT2x2_dgrad": (_I, [_P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
     "cmu_convT2x2_wgrad_ws_bytes": (_L, [_I, _I, _I, _I, _I, _I]),
     "cmu_convT2x2_wgrad": (_I, [_P, _L, _P, _P, _I, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "cmu_conv1x1_head_bwd_ws_bytes": (_L, [_I, _I, _I, _I, _I]),
-    "cmu_conv1x1_head_bwd": (_I, [_P, _P, _L, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "cmu_conv1x1_head_bwd": (_I, [_P, _P, _L, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "cmu_masked_mse_ws_bytes": (_L, [_I, _I]),
     "cmu_masked_mse_fwd_bwd": (_I, [_P, _I, _I, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P]),
     "cmu_softmax_ce_dice_ws_bytes": (_L, [_I, _I, _I]),

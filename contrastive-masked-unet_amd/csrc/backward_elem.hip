@@ -7,6 +7,10 @@
 #include "common.h"
 
 constexpr int RED_MAX_BLOCKS = 2048;
+// BN-backward partial-sum slab ("bn_ws"): int32 header word 0 = number of rows written by the producer kernel
+// (device side, no host sync), then float rows [row][2][C] from byte 16 on.  Producers: cmu_bn_bwd_reduce,
+// cmu_maxpool_bwd, cmu_conv1x1_head_bwd (fused); consumer: bn_bwd_final_kernel.
+constexpr int BNWS_HDR = 16;
 
 // block-level sum of `v` over the threads that share `key = tid % cpb` (prow = tid / cpb < ppb).
 // red: LDS float[256].  Result valid for tid < cpb.  All 256 threads must call.
@@ -33,6 +37,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const unsigned char*
     constexpr int ES = (int)sizeof(typename TR::elem_t);
     __shared__ float red[256];
     const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *reinterpret_cast<int*>(ws) = (int)gridDim.x;
+    ws += BNWS_HDR / 4;
     const int nchunk = C / EPC;
     const int ch = blockIdx.y * cpb + tid % cpb;
     const int prow = tid / cpb;
@@ -68,9 +74,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const unsigned char*
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ ws, int nblocks, double count, float* dgamma,
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ ws, double count, float* dgamma,
                                                           float* dbeta, float* coef, int C) {
     __shared__ double red[2][16][16];
+    const int nblocks = *reinterpret_cast<const int*>(ws);
+    ws += BNWS_HDR / 4;
     const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     double s1 = 0.0, s2 = 0.0;
@@ -109,7 +117,7 @@ static int bn_bwd_reduce_t(const void* dA, int64_t ldd, const void* y, int64_t l
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<TR>), dim3(gx, gy), dim3(256), 0, st, (const unsigned char*)dA, ldd,
                        (const unsigned char*)y, ldy, scale, shift, mean, invstd, (float*)ws, npix, C, cpb, ppb);
     CMU_CHECK_LAUNCH("cmu_bn_bwd_reduce");
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cmu_div_up(C, 16)), dim3(256), 0, st, (const float*)ws, gx, (double)npix, dgamma,
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cmu_div_up(C, 16)), dim3(256), 0, st, (const float*)ws, (double)npix, dgamma,
                        dbeta, coef, C);
     CMU_CHECK_LAUNCH("cmu_bn_bwd_reduce(final)");
     return CMU_OK;
@@ -124,7 +132,15 @@ static int check_pair(const char* name, const void* a, int64_t lda, const void* 
     return CMU_OK;
 }
 
-extern "C" int64_t cmu_bn_bwd_ws_bytes(int C) { return (int64_t)RED_MAX_BLOCKS * 2 * C * (int64_t)sizeof(float); }
+extern "C" int64_t cmu_bn_bwd_ws_bytes(int C) { return BNWS_HDR + (int64_t)RED_MAX_BLOCKS * 2 * C * (int64_t)sizeof(float); }
+
+extern "C" int cmu_bn_bwd_finalize(const void* bn_ws, int64_t count, float* dgamma, float* dbeta, float* coef, int C, void* stream) {
+    CMU_CHECK_ARG(bn_ws && coef && C > 0 && count > 0, "cmu_bn_bwd_finalize: bad args");
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cmu_div_up(C, 16)), dim3(256), 0, (hipStream_t)stream, (const float*)bn_ws, (double)count,
+                       dgamma, dbeta, coef, C);
+    CMU_CHECK_LAUNCH("cmu_bn_bwd_finalize");
+    return CMU_OK;
+}
 
 extern "C" int cmu_bn_bwd_reduce(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift,
                                  const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* coef, int B,
@@ -197,71 +213,114 @@ extern "C" int cmu_bn_bwd_apply(const void* dA, int64_t ldd, const void* y, int6
 // MaxPool2d(2) backward + skip-gradient add (autograd of model.py:42-45 where both outputs are used)
 // ---------------------------------------------------------------------------------------------
 template <class TR>
-__global__ void maxpool_bwd_kernel(const unsigned char* __restrict__ dP, int64_t ldp, const unsigned char* __restrict__ dS,
-                                   int64_t lds, const unsigned char* __restrict__ y, int64_t ldy, const float* __restrict__ scale,
-                                   const float* __restrict__ shift, unsigned char* __restrict__ dA, int64_t lda, int B, int H, int W,
-                                   int C, int64_t total) {
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* __restrict__ dP, int64_t ldp,
+                                                         const unsigned char* __restrict__ dS, int64_t lds,
+                                                         const unsigned char* __restrict__ y, int64_t ldy,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         unsigned char* __restrict__ dA, int64_t lda, int B, int H, int W, int C,
+                                                         int cpb, int ppb, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, float* __restrict__ bn_ws) {
     constexpr int EPC = TR::EPC;
     constexpr int ES = (int)sizeof(typename TR::elem_t);
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
     const int nchunk = C / EPC;
+    const int ch = blockIdx.y * cpb + tid % cpb;
+    const int prow = tid / cpb;
+    const bool active = prow < ppb && ch < nchunk;
     const int Ho = H / 2, Wo = W / 2;
-    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(o % nchunk);
-        const int64_t pp = o / nchunk;
-        const int xo = (int)(pp % Wo), yo = (int)((pp / Wo) % Ho), b = (int)(pp / ((int64_t)Wo * Ho));
-        float sc[EPC], sh[EPC], best[EPC], g[EPC];
-        int arg[EPC];
+    const int64_t npool = (int64_t)B * Ho * Wo;
+    float sc[EPC], sh[EPC], mu[EPC], is[EPC], s1[EPC], s2[EPC];
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            sc[e] = scale[ch * EPC + e];
-            sh[e] = shift[ch * EPC + e];
-        }
-        TR::unpack(ld_global16(dP + (pp * ldp + ch * EPC) * ES), g);
-        int64_t src[4];
+    for (int e = 0; e < EPC; ++e) {
+        const int c = active ? ch * EPC + e : 0;
+        sc[e] = scale[c];
+        sh[e] = shift[c];
+        mu[e] = bn_ws ? mean[c] : 0.f;
+        is[e] = bn_ws ? invstd[c] : 0.f;
+        s1[e] = s2[e] = 0.f;
+    }
+    if (active)
+        for (int64_t pp = (int64_t)blockIdx.x * ppb + prow; pp < npool; pp += (int64_t)gridDim.x * ppb) {
+            const int xo = (int)(pp % Wo), yo = (int)((pp / Wo) % Ho), b = (int)(pp / ((int64_t)Wo * Ho));
+            float best[EPC], g[EPC], f[4][EPC];
+            int arg[EPC];
+            TR::unpack(ld_global16(dP + (pp * ldp + ch * EPC) * ES), g);
+            int64_t src[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            src[q] = ((int64_t)b * H + 2 * yo + (q >> 1)) * W + 2 * xo + (q & 1);
-            float f[EPC];
-            TR::unpack(ld_global16(y + (src[q] * ldy + ch * EPC) * ES), f);
+            for (int q = 0; q < 4; ++q) {
+                src[q] = ((int64_t)b * H + 2 * yo + (q >> 1)) * W + 2 * xo + (q & 1);
+                TR::unpack(ld_global16(y + (src[q] * ldy + ch * EPC) * ES), f[q]);
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                const float a = fmaxf(fmaf(f[e], sc[e], sh[e]), 0.f);
-                if (q == 0 || a > best[e]) { best[e] = a; arg[e] = q; }   // first maximum wins (ATen max_pool2d)
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float d[EPC];
-            if (dS) TR::unpack(ld_global16(dS + (src[q] * lds + ch * EPC) * ES), d);
-            else {
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) d[e] = 0.f;
+                for (int e = 0; e < EPC; ++e) {
+                    const float a = fmaxf(fmaf(f[q][e], sc[e], sh[e]), 0.f);
+                    if (q == 0 || a > best[e]) { best[e] = a; arg[e] = q; }   // first maximum wins (ATen max_pool2d)
+                }
             }
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) d[e] += (arg[e] == q) ? g[e] : 0.f;
-            st_global16(dA + (src[q] * lda + ch * EPC) * ES, TR::pack(d));
+            for (int q = 0; q < 4; ++q) {
+                float d[EPC];
+                if (dS) TR::unpack(ld_global16(dS + (src[q] * lds + ch * EPC) * ES), d);
+                else {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) d[e] = 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) d[e] += (arg[e] == q) ? g[e] : 0.f;
+                const u32x4 packed = TR::pack(d);
+                st_global16(dA + (src[q] * lda + ch * EPC) * ES, packed);
+                if (bn_ws) {   // BatchNorm+ReLU backward statistics of this layer, on the values as stored
+                    float dr[EPC];
+                    TR::unpack(packed, dr);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const float dz = fmaf(f[q][e], sc[e], sh[e]) > 0.f ? dr[e] : 0.f;
+                        s1[e] += dz;
+                        s2[e] = fmaf(dz, (f[q][e] - mu[e]) * is[e], s2[e]);
+                    }
+                }
+            }
+        }
+    if (bn_ws == nullptr) return;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *reinterpret_cast<int*>(bn_ws) = (int)gridDim.x;
+    float* ws = bn_ws + BNWS_HDR / 4;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const float a = sum_over_rows(s1[e], red, tid, cpb, ppb);
+        const float bsum = sum_over_rows(s2[e], red, tid, cpb, ppb);
+        if (tid < cpb && blockIdx.y * cpb + tid < nchunk) {
+            const int c = (blockIdx.y * cpb + tid) * EPC + e;
+            ws[((int64_t)blockIdx.x * 2 + 0) * C + c] = a;
+            ws[((int64_t)blockIdx.x * 2 + 1) * C + c] = bsum;
         }
     }
 }
 template <class TR>
 static int maxpool_bwd_t(const void* dP, int64_t ldp, const void* dS, int64_t lds, const void* y, int64_t ldy, const float* scale,
-                         const float* shift, void* dA, int64_t lda, int B, int H, int W, int C, hipStream_t st) {
-    const int64_t total = (int64_t)B * (H / 2) * (W / 2) * (C / TR::EPC);
-    const int grid = (int)(cmu_div_up64(total, 256) < 8192 ? cmu_div_up64(total, 256) : 8192);
-    hipLaunchKernelGGL((maxpool_bwd_kernel<TR>), dim3(grid), dim3(256), 0, st, (const unsigned char*)dP, ldp, (const unsigned char*)dS,
-                       lds, (const unsigned char*)y, ldy, scale, shift, (unsigned char*)dA, lda, B, H, W, C, total);
+                         const float* shift, void* dA, int64_t lda, int B, int H, int W, int C, const float* mean, const float* invstd,
+                         void* bn_ws, hipStream_t st) {
+    int cpb, ppb, gy;
+    chunk_geometry(C / TR::EPC, &cpb, &ppb, &gy);
+    const int64_t npool = (int64_t)B * (H / 2) * (W / 2);
+    int gx = (int)(cmu_div_up64(npool, ppb * 2) < RED_MAX_BLOCKS ? cmu_div_up64(npool, ppb * 2) : RED_MAX_BLOCKS);
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL((maxpool_bwd_kernel<TR>), dim3(gx, gy), dim3(256), 0, st, (const unsigned char*)dP, ldp, (const unsigned char*)dS,
+                       lds, (const unsigned char*)y, ldy, scale, shift, (unsigned char*)dA, lda, B, H, W, C, cpb, ppb, mean, invstd,
+                       (float*)bn_ws);
     CMU_CHECK_LAUNCH("cmu_maxpool_bwd");
     return CMU_OK;
 }
 extern "C" int cmu_maxpool_bwd(const void* dP, int64_t ldp, const void* dSkip, int64_t lds, const void* y, int64_t ldy,
-                               const float* scale, const float* shift, void* dA, int64_t lda, int B, int H, int W, int C, int dt,
-                               void* stream) {
+                               const float* scale, const float* shift, void* dA, int64_t lda, const float* save_mean,
+                               const float* save_invstd, void* bn_ws, int B, int H, int W, int C, int dt, void* stream) {
+    CMU_CHECK_ARG(bn_ws == nullptr || (save_mean && save_invstd), "cmu_maxpool_bwd: fused BN statistics need save_mean / save_invstd");
     int rc;
     if ((rc = check_pair("cmu_maxpool_bwd(dP,y)", dP, ldp, y, ldy, C, dt))) return rc;
     if ((rc = check_pair("cmu_maxpool_bwd(dA,y)", dA, lda, y, ldy, C, dt))) return rc;
     if (dSkip && (rc = check_pair("cmu_maxpool_bwd(dSkip,y)", dSkip, lds, y, ldy, C, dt))) return rc;
     CMU_CHECK_ARG(scale && shift && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "cmu_maxpool_bwd: bad dims (%d,%d)", H, W);
-    CMU_DISPATCH_DT(dt, maxpool_bwd_t, dP, ldp, dSkip, lds, y, ldy, scale, shift, dA, lda, B, H, W, C, (hipStream_t)stream);
+    CMU_DISPATCH_DT(dt, maxpool_bwd_t, dP, ldp, dSkip, lds, y, ldy, scale, shift, dA, lda, B, H, W, C, save_mean, save_invstd, bn_ws,
+                    (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -273,7 +332,9 @@ __global__ __launch_bounds__(256) void conv1x1_head_bwd_kernel(const float* __re
                                                               int64_t ldx, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, const float* __restrict__ w,
                                                               unsigned char* __restrict__ dX, int64_t ldo, float* __restrict__ ws,
-                                                              int B, int H, int W, int C, int K, int64_t npix) {
+                                                              int B, int H, int W, int C, int K, int64_t npix,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              float* __restrict__ bn_ws) {
     constexpr int EPC = TR::EPC;
     constexpr int ES = (int)sizeof(typename TR::elem_t);
     __shared__ float red[256];
@@ -282,11 +343,14 @@ __global__ __launch_bounds__(256) void conv1x1_head_bwd_kernel(const float* __re
     const int ch = tid % nchunk;
     const int ppb = 256 / nchunk;
     const int prow = tid / nchunk;
-    float sc[EPC], sh[EPC], wk[HEAD_MAX_K][EPC], dw[HEAD_MAX_K][EPC], db[HEAD_MAX_K];
+    float sc[EPC], sh[EPC], wk[HEAD_MAX_K][EPC], dw[HEAD_MAX_K][EPC], db[HEAD_MAX_K], mu[EPC], is[EPC], s1[EPC], s2[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
         sc[e] = scale ? scale[ch * EPC + e] : 1.f;
         sh[e] = scale ? shift[ch * EPC + e] : 0.f;
+        mu[e] = bn_ws ? mean[ch * EPC + e] : 0.f;
+        is[e] = bn_ws ? invstd[ch * EPC + e] : 0.f;
+        s1[e] = s2[e] = 0.f;
     }
 #pragma unroll
     for (int k = 0; k < HEAD_MAX_K; ++k) {
@@ -320,7 +384,31 @@ __global__ __launch_bounds__(256) void conv1x1_head_bwd_kernel(const float* __re
 #pragma unroll
             for (int k = 0; k < HEAD_MAX_K; ++k) db[k] += dl[k];
         }
-        if (dX) st_global16(dX + (pix * ldo + ch * EPC) * ES, TR::pack(o));
+        const u32x4 packed = TR::pack(o);
+        if (dX) st_global16(dX + (pix * ldo + ch * EPC) * ES, packed);
+        if (bn_ws) {   // BN+ReLU backward statistics of the producing layer, on dX as stored
+            float dr[EPC];
+            TR::unpack(packed, dr);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float dz = fmaf(f[e], sc[e], sh[e]) > 0.f ? dr[e] : 0.f;
+                s1[e] += dz;
+                s2[e] = fmaf(dz, (f[e] - mu[e]) * is[e], s2[e]);
+            }
+        }
+    }
+    if (bn_ws) {
+        if (blockIdx.x == 0 && tid == 0) *reinterpret_cast<int*>(bn_ws) = (int)gridDim.x;
+        float* bws = bn_ws + BNWS_HDR / 4;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float a = sum_over_rows(s1[e], red, tid, nchunk, ppb);
+            const float bsum = sum_over_rows(s2[e], red, tid, nchunk, ppb);
+            if (tid < nchunk) {
+                bws[((int64_t)blockIdx.x * 2 + 0) * C + tid * EPC + e] = a;
+                bws[((int64_t)blockIdx.x * 2 + 1) * C + tid * EPC + e] = bsum;
+            }
+        }
     }
     float* out = ws + (int64_t)blockIdx.x * (K * C + K);
 #pragma unroll
@@ -356,14 +444,14 @@ __global__ __launch_bounds__(256) void sum_slab_kernel(const float* __restrict__
 template <class TR>
 static int conv1x1_head_bwd_t(const float* dlogits, const void* x, int64_t ldx, const float* scale, const float* shift, const float* w,
                               void* dX, int64_t ldo, float* dW, float* dbias, int B, int H, int W, int C, int K, void* ws,
-                              hipStream_t st) {
+                              const float* mean, const float* invstd, void* bn_ws, hipStream_t st) {
     const int nchunk = C / TR::EPC;
     const int ppb = 256 / nchunk;
     const int64_t npix = (int64_t)B * H * W;
     int gx = (int)(cmu_div_up64(npix, ppb * 4) < RED_MAX_BLOCKS ? cmu_div_up64(npix, ppb * 4) : RED_MAX_BLOCKS);
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL((conv1x1_head_bwd_kernel<TR>), dim3(gx), dim3(256), 0, st, dlogits, (const unsigned char*)x, ldx, scale, shift, w,
-                       (unsigned char*)dX, ldo, (float*)ws, B, H, W, C, K, npix);
+                       (unsigned char*)dX, ldo, (float*)ws, B, H, W, C, K, npix, mean, invstd, (float*)bn_ws);
     CMU_CHECK_LAUNCH("cmu_conv1x1_head_bwd");
     const int64_t n = (int64_t)K * C + K;
     hipLaunchKernelGGL(sum_slab_kernel, dim3((unsigned)cmu_div_up64(n, 16)), dim3(256), 0, st, (const float*)ws, gx, n, dW, (int64_t)K * C,
@@ -375,8 +463,10 @@ extern "C" int64_t cmu_conv1x1_head_bwd_ws_bytes(int B, int H, int W, int C, int
     return (int64_t)RED_MAX_BLOCKS * ((int64_t)K * C + K) * (int64_t)sizeof(float);
 }
 extern "C" int cmu_conv1x1_head_bwd(const float* dlogits, const void* x, int64_t ldx, const float* in_scale, const float* in_shift,
-                                    const float* w, void* dX, int64_t ldo, float* dW, float* dbias, int B, int H, int W, int C, int K,
-                                    int dt, void* ws, void* stream) {
+                                    const float* w, void* dX, int64_t ldo, float* dW, float* dbias, const float* save_mean,
+                                    const float* save_invstd, void* bn_ws, int B, int H, int W, int C, int K, int dt, void* ws,
+                                    void* stream) {
+    CMU_CHECK_ARG(bn_ws == nullptr || (save_mean && save_invstd && dX && in_scale), "cmu_conv1x1_head_bwd: fused BN statistics need dX, the transform and save_mean / save_invstd");
     const int es = cmu_dtype_size(dt);
     CMU_CHECK_ARG(es > 0 && dlogits && x && w && dW && dbias && ws && B > 0 && H > 0 && W > 0, "cmu_conv1x1_head_bwd: bad args");
     const int epc = 16 / es;
@@ -386,8 +476,8 @@ extern "C" int cmu_conv1x1_head_bwd(const float* dlogits, const void* x, int64_t
     CMU_CHECK_ARG(cmu_aligned16(x) && ldx % epc == 0 && ldx >= C, "cmu_conv1x1_head_bwd: x alignment / stride");
     CMU_CHECK_ARG(!dX || (cmu_aligned16(dX) && ldo % epc == 0 && ldo >= C), "cmu_conv1x1_head_bwd: dX alignment / stride");
     CMU_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "cmu_conv1x1_head_bwd: scale/shift must both be set");
-    CMU_DISPATCH_DT(dt, conv1x1_head_bwd_t, dlogits, x, ldx, in_scale, in_shift, w, dX, ldo, dW, dbias, B, H, W, C, K, ws,
-                    (hipStream_t)stream);
+    CMU_DISPATCH_DT(dt, conv1x1_head_bwd_t, dlogits, x, ldx, in_scale, in_shift, w, dX, ldo, dW, dbias, B, H, W, C, K, ws, save_mean,
+                    save_invstd, bn_ws, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -122,14 +122,22 @@ class UNetEngine:
         return s1, s2
 
     # backward of one Conv3x3+BN+ReLU given dA (gradient w.r.t. the activated output); returns dX act or None
-    def _convbn_bwd(self, sd, s, dA, grads, need_dx, dx_out=None):
+    def _bn_ws(self, C):
+        return self.scratch.get("bnbwd", self.lib.cmu_bn_bwd_ws_bytes(C))
+
+    def _convbn_bwd(self, sd, s, dA, grads, need_dx, dx_out=None, fused_stats=False):
+        """``fused_stats``: the kernel that produced dA already wrote this layer's BN-backward partial sums into
+        the shared slab (max-pool / head backward) -- only the finalisation is left of phase 1."""
         y = s["y"]
         B, H, W, C = y.B, y.H, y.W, y.C
         w = sd[s["pconv"] + "weight"]
         dgamma, dbeta = self._gbuf(s["pbn"] + "weight", sd[s["pbn"] + "weight"]), self._gbuf(s["pbn"] + "bias", sd[s["pbn"] + "bias"])
         coef = self._f32(2, C)
-        ws = self.scratch.get("bnbwd", self.lib.cmu_bn_bwd_ws_bytes(C))
-        ops.bn_bwd_reduce(dA, y, s["mean"], s["invstd"], dgamma, dbeta, coef, ws)
+        ws = self._bn_ws(C)
+        if fused_stats:
+            ops.bn_bwd_finalize(ws, B * H * W, dgamma, dbeta, coef)
+        else:
+            ops.bn_bwd_reduce(dA, y, s["mean"], s["invstd"], dgamma, dbeta, coef, ws)
         dY = Act(dA.buf, dA.coff, dA.C)                       # in place over dA
         ops.bn_bwd_apply(dA, y, s["mean"], s["invstd"], coef, dY)
         grads[s["pbn"] + "weight"] = dgamma
@@ -199,8 +207,9 @@ class UNetEngine:
             lv = ctx["levels"][i - 1]
             y2 = lv["s2"]["y"]
             dA2 = self._new(y2.B, y2.H, y2.W, y2.C)
-            ops.maxpool_bwd(dP, d_skips[i - 1] if d_skips is not None else None, y2, dA2)
-            dA1 = self._convbn_bwd(sd, lv["s2"], dA2, grads, True)
+            ops.maxpool_bwd(dP, d_skips[i - 1] if d_skips is not None else None, y2, dA2, lv["s2"]["mean"], lv["s2"]["invstd"],
+                            self._bn_ws(y2.C))
+            dA1 = self._convbn_bwd(sd, lv["s2"], dA2, grads, True, fused_stats=True)
             dP = self._convbn_bwd(sd, lv["s1"], dA1, grads, i > 1)
         return None
 
@@ -275,7 +284,10 @@ class UNetEngine:
         dA = self._new(x.B, x.H, x.W, x.C)
         dWl, dbl = self._gbuf(prefix + "conv_last.weight", wl), self._gbuf(prefix + "conv_last.bias", sd[prefix + "conv_last.bias"])
         ws = self.scratch.get("head", self.lib.cmu_conv1x1_head_bwd_ws_bytes(x.B, x.H, x.W, x.C, K))
-        ops.conv1x1_head_bwd(dlogits.contiguous(), x, wl.detach().reshape(K, -1), dA, dWl.view(K, -1), dbl, ws)
+        last = ctx["levels"][0]["s2"] if ctx["levels"] else None      # the conv+BN layer that produced ``x``
+        fused = last is not None and last["y"] is x
+        ops.conv1x1_head_bwd(dlogits.contiguous(), x, wl.detach().reshape(K, -1), dA, dWl.view(K, -1), dbl, ws,
+                             last["mean"] if fused else None, last["invstd"] if fused else None, self._bn_ws(x.C) if fused else None)
         grads[prefix + "conv_last.weight"] = dWl
         grads[prefix + "conv_last.bias"] = dbl
         nup = len(ctx["levels"])
@@ -285,7 +297,7 @@ class UNetEngine:
             p = f"{prefix}up_conv{i}."
             cat = lv["cat"]
             Cup, Cs = cat["Cup"], cat["Cskip"]
-            dA1 = self._convbn_bwd(sd, lv["s2"], dA, grads, True)
+            dA1 = self._convbn_bwd(sd, lv["s2"], dA, grads, True, fused_stats=(fused and i == 1))
             dcat = self._convbn_bwd(sd, lv["s1"], dA1, grads, True)
             d_skips[i - 1] = Act(dcat.buf, Cup, Cs)
             dleft = Act(dcat.buf, 0, Cup)

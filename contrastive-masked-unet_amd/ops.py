@@ -205,9 +205,14 @@ def conv3x3_c1_wgrad(x_bhw, dY, dW, ws, mask=None, mask_per_sample=False):
          B, H, W, dW.shape[0], dY.dt, _p(ws), _stream())
 
 
-def maxpool_bwd(dP, dSkip, y, dA):
+def maxpool_bwd(dP, dSkip, y, dA, save_mean=None, save_invstd=None, bn_ws=None):
     call("cmu_maxpool_bwd", dP.ptr(), dP.ld, None if dSkip is None else dSkip.ptr(), 0 if dSkip is None else dSkip.ld,
-         y.ptr(), y.ld, _p(y.scale), _p(y.shift), dA.ptr(), dA.ld, y.B, y.H, y.W, y.C, y.dt, _stream())
+         y.ptr(), y.ld, _p(y.scale), _p(y.shift), dA.ptr(), dA.ld, _p(save_mean), _p(save_invstd), _p(bn_ws),
+         y.B, y.H, y.W, y.C, y.dt, _stream())
+
+
+def bn_bwd_finalize(bn_ws, count, dgamma, dbeta, coef):
+    call("cmu_bn_bwd_finalize", _p(bn_ws), int(count), _p(dgamma), _p(dbeta), _p(coef), coef.shape[1], _stream())
 
 
 def convT2x2_dgrad(dOut, wpacked_dgrad, dX):
@@ -221,10 +226,11 @@ def convT2x2_wgrad(x, dOut, dW, dbias, ws):
          _p(_f32c(dbias)), x.B, x.H, x.W, Cin, Cout, x.dt, _p(ws), _stream(), work=2.0 * 4 * Cin * Cout * x.B * x.H * x.W)
 
 
-def conv1x1_head_bwd(dlogits, x, w, dX, dW, dbias, ws):
+def conv1x1_head_bwd(dlogits, x, w, dX, dW, dbias, ws, save_mean=None, save_invstd=None, bn_ws=None):
     K = w.shape[0]
     call("cmu_conv1x1_head_bwd", _p(_f32c(dlogits)), x.ptr(), x.ld, _p(x.scale), _p(x.shift), _p(_f32c(w)), dX.ptr(), dX.ld,
-         _p(_f32c(dW)), _p(_f32c(dbias)), x.B, x.H, x.W, x.C, K, x.dt, _p(ws), _stream())
+         _p(_f32c(dW)), _p(_f32c(dbias)), _p(save_mean), _p(save_invstd), _p(bn_ws), x.B, x.H, x.W, x.C, K, x.dt, _p(ws),
+         _stream())
 
 
 # ------------------------------------------------------------------------------------------------

@@ -118,6 +118,9 @@ int64_t cmu_bn_bwd_ws_bytes(int C);
 int cmu_bn_bwd_reduce(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift,
                       const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* coef,
                       int B, int H, int W, int C, int dt, void* ws, void* stream);
+/* finalisation of a slab written by a fused producer (cmu_maxpool_bwd / cmu_conv1x1_head_bwd with bn_ws):
+ * dgamma, dbeta (nullable) and coef[2][C], summed in row order (bitwise reproducible).                          */
+int cmu_bn_bwd_finalize(const void* bn_ws, int64_t count, float* dgamma, float* dbeta, float* coef, int C, void* stream);
 /* phase 2: dY = scale * (dz - coef0 - xhat*coef1), written to dY (may alias dA). */
 int cmu_bn_bwd_apply(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift,
                      const float* save_mean, const float* save_invstd, const float* coef, void* dY, int64_t ldo,
@@ -136,8 +139,12 @@ int cmu_conv3x3_c1_wgrad(const float* x, const uint8_t* mask, int mask_per_sampl
 
 /* MaxPool2d(2) backward fused with the skip-branch add: dA = unpool(dP) + dSkip (dSkip may be NULL).
  * The arg-max is recomputed from the raw output + transform (first max in row-major 2x2 order, as ATen). */
+/* bn_ws != NULL additionally fuses phase 1 of this layer's BatchNorm backward: the partial sums of
+ * dz and dz*xhat over the dA values just written go to the slab bn_ws (cmu_bn_bwd_ws_bytes(C) bytes; a device-side
+ * header word holds the row count) -- follow with cmu_bn_bwd_finalize instead of cmu_bn_bwd_reduce.          */
 int cmu_maxpool_bwd(const void* dP, int64_t ldp, const void* dSkip, int64_t lds, const void* y, int64_t ldy,
                     const float* scale, const float* shift, void* dA, int64_t lda,
+                    const float* save_mean, const float* save_invstd, void* bn_ws,
                     int B, int H, int W, int C, int dt, void* stream);
 
 /* ConvTranspose2d 2x2 s2 backward.  data: dX (B,H,W,Cin) from dOut (B,2H,2W,ldd) (GEMM K = 4*Cout).
@@ -153,6 +160,7 @@ int cmu_convT2x2_wgrad(const void* x, int64_t ldx, const float* in_scale, const 
 int64_t cmu_conv1x1_head_bwd_ws_bytes(int B, int H, int W, int C, int K);
 int cmu_conv1x1_head_bwd(const float* dlogits, const void* x, int64_t ldx, const float* in_scale, const float* in_shift,
                          const float* w, void* dX, int64_t ldo, float* dW, float* dbias,
+                         const float* save_mean, const float* save_invstd, void* bn_ws /* optional, as cmu_maxpool_bwd */,
                          int B, int H, int W, int C, int K, int dt, void* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

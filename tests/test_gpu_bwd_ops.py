@@ -122,7 +122,17 @@ def test_maxpool_bwd(ops, dt, with_skip):
     ya = to_act(y, dt, ops).with_transform(sc.cuda(), sh.cuda(), 0)
     dA = ops.new_act(B, H, W, C, dt, "cuda")
     sk = to_act(dS, dt, ops, ld=2 * C, coff=C) if with_skip else None
-    ops.maxpool_bwd(to_act(dP, dt, ops), sk, ya, dA)
+    # fused BatchNorm-backward statistics (phase 1) of the same layer, checked against the separate reduce kernel
+    from cmunet_amd import _lib
+    mean, invstd = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    ws = ws_bytes(_lib.lib().cmu_bn_bwd_ws_bytes(C))
+    ops.maxpool_bwd(to_act(dP, dt, ops), sk, ya, dA, mean.cuda(), invstd.cuda(), ws)
+    coef_f, coef_r = torch.empty(2, C, device="cuda"), torch.empty(2, C, device="cuda")
+    dg_f, db_f, dg_r, db_r = (torch.empty(C, device="cuda") for _ in range(4))
+    ops.bn_bwd_finalize(ws, B * H * W, dg_f, db_f, coef_f)
+    ops.bn_bwd_reduce(dA, ya, mean.cuda(), invstd.cuda(), dg_r, db_r, coef_r, ws_bytes(_lib.lib().cmu_bn_bwd_ws_bytes(C)))
+    check(dg_f.cpu(), dg_r.cpu(), 1e-5, "fused dgamma"); check(db_f.cpu(), db_r.cpu(), 1e-5, "fused dbeta")
+    check(coef_f.cpu(), coef_r.cpu(), 1e-5, "fused coef")
     # positions whose activation is 0 (all-negative windows) may differ in which zero got the gradient;
     # that gradient is killed by the ReLU gate downstream, so compare after gating with a > 0
     gate = (a.detach() > 0).double()
@@ -170,7 +180,14 @@ def test_conv1x1_head_bwd(ops, dt, C):
     dX = ops.new_act(B, H, W, C, dt, "cuda")
     dW, db = torch.empty(K, C, device="cuda"), torch.empty(K, device="cuda")
     ws = ws_bytes(_lib.lib().cmu_conv1x1_head_bwd_ws_bytes(B, H, W, C, K))
-    ops.conv1x1_head_bwd(dl.cuda(), xa, w.cuda(), dX, dW, db, ws)
+    mean, invstd = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    bws = ws_bytes(_lib.lib().cmu_bn_bwd_ws_bytes(C))
+    ops.conv1x1_head_bwd(dl.cuda(), xa, w.cuda(), dX, dW, db, ws, mean.cuda(), invstd.cuda(), bws)
+    coef_f, coef_r = torch.empty(2, C, device="cuda"), torch.empty(2, C, device="cuda")
+    dg_f, db_f, dg_r, db_r = (torch.empty(C, device="cuda") for _ in range(4))
+    ops.bn_bwd_finalize(bws, B * H * W, dg_f, db_f, coef_f)
+    ops.bn_bwd_reduce(dX, xa, mean.cuda(), invstd.cuda(), dg_r, db_r, coef_r, ws_bytes(_lib.lib().cmu_bn_bwd_ws_bytes(C)))
+    check(dg_f.cpu(), dg_r.cpu(), 1e-5, "fused dgamma (head)"); check(coef_f.cpu(), coef_r.cpu(), 1e-5, "fused coef (head)")
     check(from_act(dX), a.grad, TOL[dt], "head dX")
     check(dW.cpu(), wd.grad, 1e-4, "head dW")
     check(db.cpu(), bd.grad, 1e-4, "head dbias")
