@@ -60,6 +60,13 @@ _SIGS = {
     "cmu_moco_ws_bytes": (_L, [_I, _I]),
     "cmu_moco_infonce_enqueue": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P]),
     "cmu_l2_normalize_rows": (_I, [_P, _P, _I, _I, _P]),
+    "cmu_masked_stats_rows": (_I, []),
+    "cmu_masked_channel_stats": (_I, [_P, _L, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "cmu_mask_select": (_I, [_P, _L, _P, _P, _I, _P, _I, _I, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "cmu_bn_bwd_reduce_masked": (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P, _P]),
+    "cmu_bn_bwd_apply_masked": (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "cmu_spark_loss_ws_bytes": (_L, [_I, _I]),
+    "cmu_spark_loss_fwd_bwd": (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P]),
     "cmu_gap_fwd": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cmu_gap_bwd": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "cmu_ema_update": (_I, [_P, _P, _L, _F, _P]),

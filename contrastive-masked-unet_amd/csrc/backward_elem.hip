@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const unsigned char*
                                                            const unsigned char* __restrict__ y, int64_t ldy,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           float* __restrict__ ws, int64_t npix, int C, int cpb, int ppb) {
+                                                           float* __restrict__ ws, int64_t npix, int C, int cpb, int ppb,
+                                                           const uint8_t* __restrict__ amask, int f, int sbits, int H, int W) {
     constexpr int EPC = TR::EPC;
     constexpr int ES = (int)sizeof(typename TR::elem_t);
     __shared__ float red[256];
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const unsigned char*
     }
     if (active)
         for (int64_t p = (int64_t)blockIdx.x * ppb + prow; p < npix; p += (int64_t)gridDim.x * ppb) {
+            if (amask && !sp_active(amask, f, sbits, (int)(p / ((int64_t)W * H)), (int)((p / W) % H), (int)(p % W), 0)) continue;
             float g[EPC], v[EPC];
             TR::unpack(ld_global16(dA + (p * ldd + ch * EPC) * ES), g);
             TR::unpack(ld_global16(y + (p * ldy + ch * EPC) * ES), v);
@@ -108,16 +110,17 @@ static void chunk_geometry(int nchunk, int* cpb, int* ppb, int* gy) {
 template <class TR>
 static int bn_bwd_reduce_t(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift,
                            const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef, int B, int H, int W,
-                           int C, void* ws, hipStream_t st) {
+                           int C, void* ws, const uint8_t* active, int f, int64_t count, hipStream_t st) {
     int cpb, ppb, gy;
     chunk_geometry(C / TR::EPC, &cpb, &ppb, &gy);
     const int64_t npix = (int64_t)B * H * W;
+    const int sbits = active ? sp_shift_bits(H, f) : 0;
     int gx = (int)(cmu_div_up64(npix, ppb * 4) < RED_MAX_BLOCKS ? cmu_div_up64(npix, ppb * 4) : RED_MAX_BLOCKS);
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<TR>), dim3(gx, gy), dim3(256), 0, st, (const unsigned char*)dA, ldd,
-                       (const unsigned char*)y, ldy, scale, shift, mean, invstd, (float*)ws, npix, C, cpb, ppb);
+                       (const unsigned char*)y, ldy, scale, shift, mean, invstd, (float*)ws, npix, C, cpb, ppb, active, f, sbits, H, W);
     CMU_CHECK_LAUNCH("cmu_bn_bwd_reduce");
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cmu_div_up(C, 16)), dim3(256), 0, st, (const float*)ws, (double)npix, dgamma,
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cmu_div_up(C, 16)), dim3(256), 0, st, (const float*)ws, (double)(active ? count : npix), dgamma,
                        dbeta, coef, C);
     CMU_CHECK_LAUNCH("cmu_bn_bwd_reduce(final)");
     return CMU_OK;
@@ -149,14 +152,26 @@ extern "C" int cmu_bn_bwd_reduce(const void* dA, int64_t ldd, const void* y, int
     if ((rc = check_pair("cmu_bn_bwd_reduce", dA, ldd, y, ldy, C, dt))) return rc;
     CMU_CHECK_ARG(scale && shift && save_mean && save_invstd && coef && ws && B > 0 && H > 0 && W > 0, "cmu_bn_bwd_reduce: null argument");
     CMU_DISPATCH_DT(dt, bn_bwd_reduce_t, dA, ldd, y, ldy, scale, shift, save_mean, save_invstd, dgamma, dbeta, coef, B, H, W, C, ws,
-                    (hipStream_t)stream);
+                    (const uint8_t*)nullptr, 0, (int64_t)0, (hipStream_t)stream);
+}
+extern "C" int cmu_bn_bwd_reduce_masked(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift,
+                                        const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* coef,
+                                        const uint8_t* active, int f, int64_t count, int B, int H, int W, int C, int dt, void* ws,
+                                        void* stream) {
+    int rc;
+    if ((rc = check_pair("cmu_bn_bwd_reduce_masked", dA, ldd, y, ldy, C, dt))) return rc;
+    CMU_CHECK_ARG(scale && shift && save_mean && save_invstd && coef && ws && active && count > 0 && B > 0, "cmu_bn_bwd_reduce_masked: null argument");
+    CMU_CHECK_ARG(sp_shift_bits(H, f) >= 0 && (f << sp_shift_bits(H, f)) == W, "cmu_bn_bwd_reduce_masked: H,W must be f times a power of two");
+    CMU_DISPATCH_DT(dt, bn_bwd_reduce_t, dA, ldd, y, ldy, scale, shift, save_mean, save_invstd, dgamma, dbeta, coef, B, H, W, C, ws, active, f,
+                    count, (hipStream_t)stream);
 }
 
 template <class TR>
 __global__ void bn_bwd_apply_kernel(const unsigned char* __restrict__ dA, int64_t ldd, const unsigned char* __restrict__ y,
                                     int64_t ldy, const float* __restrict__ scale, const float* __restrict__ shift,
                                     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ coef,
-                                    unsigned char* __restrict__ dY, int64_t ldo, int64_t npix, int C, int cpb, int ppb) {
+                                    unsigned char* __restrict__ dY, int64_t ldo, int64_t npix, int C, int cpb, int ppb,
+                                    const uint8_t* __restrict__ amask, int f, int sbits, int H, int W) {
     constexpr int EPC = TR::EPC;
     constexpr int ES = (int)sizeof(typename TR::elem_t);
     const int tid = threadIdx.x;
@@ -172,6 +187,10 @@ __global__ void bn_bwd_apply_kernel(const unsigned char* __restrict__ dA, int64_
         c1[e] = coef[c]; c2[e] = coef[C + c];
     }
     for (int64_t p = (int64_t)blockIdx.x * ppb + prow; p < npix; p += (int64_t)gridDim.x * ppb) {
+        if (amask && !sp_active(amask, f, sbits, (int)(p / ((int64_t)W * H)), (int)((p / W) % H), (int)(p % W), 0)) {
+            st_global16(dY + (p * ldo + ch * EPC) * ES, u32x4{0u, 0u, 0u, 0u});   // sparse BN: no gradient at masked positions
+            continue;
+        }
         float g[EPC], v[EPC], o[EPC];
         TR::unpack(ld_global16(dA + (p * ldd + ch * EPC) * ES), g);
         TR::unpack(ld_global16(y + (p * ldy + ch * EPC) * ES), v);
@@ -187,14 +206,16 @@ __global__ void bn_bwd_apply_kernel(const unsigned char* __restrict__ dA, int64_
 template <class TR>
 static int bn_bwd_apply_t(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift,
                           const float* mean, const float* invstd, const float* coef, void* dY, int64_t ldo, int B, int H, int W,
-                          int C, hipStream_t st) {
+                          int C, const uint8_t* active, int f, hipStream_t st) {
     int cpb, ppb, gy;
     chunk_geometry(C / TR::EPC, &cpb, &ppb, &gy);
     const int64_t npix = (int64_t)B * H * W;
+    const int sbits = active ? sp_shift_bits(H, f) : 0;
     int gx = (int)(cmu_div_up64(npix, ppb * 2) < 4096 ? cmu_div_up64(npix, ppb * 2) : 4096);
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL((bn_bwd_apply_kernel<TR>), dim3(gx, gy), dim3(256), 0, st, (const unsigned char*)dA, ldd,
-                       (const unsigned char*)y, ldy, scale, shift, mean, invstd, coef, (unsigned char*)dY, ldo, npix, C, cpb, ppb);
+                       (const unsigned char*)y, ldy, scale, shift, mean, invstd, coef, (unsigned char*)dY, ldo, npix, C, cpb, ppb, active, f,
+                       sbits, H, W);
     CMU_CHECK_LAUNCH("cmu_bn_bwd_apply");
     return CMU_OK;
 }
@@ -206,6 +227,17 @@ extern "C" int cmu_bn_bwd_apply(const void* dA, int64_t ldd, const void* y, int6
     if ((rc = check_pair("cmu_bn_bwd_apply(dY)", dY, ldo, y, ldy, C, dt))) return rc;
     CMU_CHECK_ARG(scale && shift && save_mean && save_invstd && coef && B > 0 && H > 0 && W > 0, "cmu_bn_bwd_apply: null argument");
     CMU_DISPATCH_DT(dt, bn_bwd_apply_t, dA, ldd, y, ldy, scale, shift, save_mean, save_invstd, coef, dY, ldo, B, H, W, C,
+                    (const uint8_t*)nullptr, 0, (hipStream_t)stream);
+}
+extern "C" int cmu_bn_bwd_apply_masked(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift,
+                                       const float* save_mean, const float* save_invstd, const float* coef, void* dY, int64_t ldo,
+                                       const uint8_t* active, int f, int B, int H, int W, int C, int dt, void* stream) {
+    int rc;
+    if ((rc = check_pair("cmu_bn_bwd_apply_masked", dA, ldd, y, ldy, C, dt))) return rc;
+    if ((rc = check_pair("cmu_bn_bwd_apply_masked(dY)", dY, ldo, y, ldy, C, dt))) return rc;
+    CMU_CHECK_ARG(scale && shift && save_mean && save_invstd && coef && active && B > 0, "cmu_bn_bwd_apply_masked: null argument");
+    CMU_CHECK_ARG(sp_shift_bits(H, f) >= 0 && (f << sp_shift_bits(H, f)) == W, "cmu_bn_bwd_apply_masked: H,W must be f times a power of two");
+    CMU_DISPATCH_DT(dt, bn_bwd_apply_t, dA, ldd, y, ldy, scale, shift, save_mean, save_invstd, coef, dY, ldo, B, H, W, C, active, f,
                     (hipStream_t)stream);
 }
 

@@ -150,6 +150,17 @@ __device__ static inline float wave_max(float v) {
     return v;
 }
 
+// SparK patch mask: pixel (y, x) of a level whose side is f << sbits looks up active[b][y >> sbits][x >> sbits]
+__device__ static inline bool sp_active(const uint8_t* __restrict__ active, int f, int sbits, int b, int y, int x, int invert) {
+    const bool a = active[((int64_t)b * f + (y >> sbits)) * f + (x >> sbits)] != 0;
+    return invert ? !a : a;
+}
+static inline int sp_shift_bits(int H, int f) {
+    int s = 0;
+    while ((f << s) < H) ++s;
+    return ((f << s) == H) ? s : -1;
+}
+
 // spatial tile of the implicit-GEMM kernels
 constexpr int CMU_TH = 16;
 constexpr int CMU_TW = 16;

@@ -267,6 +267,41 @@ def l2_normalize_rows(x, out):
     call("cmu_l2_normalize_rows", _p(_f32c(x)), _p(out), x.shape[0], x.shape[1], _stream())
 
 
+# ------------------------------------------------------------------------------------------------
+# SparK sparse ops
+# ------------------------------------------------------------------------------------------------
+def masked_channel_stats(x, active, invert=False):
+    """-> slab [rows][2][C] fp32 (rows = cmu_masked_stats_rows()) of sums over the selected pixels."""
+    rows = _lib.lib().cmu_masked_stats_rows()
+    slab = torch.empty((rows, 2, x.C), dtype=torch.float32, device=x.buf.device)
+    call("cmu_masked_channel_stats", x.ptr(), x.ld, _p(active), active.shape[-1], int(invert), _p(slab), x.B, x.H, x.W, x.C, x.dt,
+         _stream())
+    return slab
+
+
+def mask_select(x, active, out, relu=False, invert=False, fill=None, use_transform=True):
+    sc = x.scale if use_transform else None
+    sh = x.shift if use_transform else None
+    call("cmu_mask_select", x.ptr(), x.ld, _p(sc), _p(sh), int(relu), _p(active), active.shape[-1], int(invert), _p(fill), out.ptr(),
+         out.ld, x.B, x.H, x.W, x.C, x.dt, _stream())
+
+
+def bn_bwd_reduce_masked(dA, y, save_mean, save_invstd, dgamma, dbeta, coef, active, count, ws):
+    call("cmu_bn_bwd_reduce_masked", dA.ptr(), dA.ld, y.ptr(), y.ld, _p(y.scale), _p(y.shift), _p(save_mean), _p(save_invstd),
+         _p(dgamma), _p(dbeta), _p(coef), _p(active), active.shape[-1], int(count), y.B, y.H, y.W, y.C, y.dt, _p(ws), _stream())
+
+
+def bn_bwd_apply_masked(dA, y, save_mean, save_invstd, coef, dY, active):
+    call("cmu_bn_bwd_apply_masked", dA.ptr(), dA.ld, y.ptr(), y.ld, _p(y.scale), _p(y.shift), _p(save_mean), _p(save_invstd),
+         _p(coef), dY.ptr(), dY.ld, _p(active), active.shape[-1], y.B, y.H, y.W, y.C, y.dt, _stream())
+
+
+def spark_loss_fwd_bwd(rec, img, active, loss, drec, loss_scale, p, ws):
+    B, f = active.shape[0], active.shape[-1]
+    call("cmu_spark_loss_fwd_bwd", _p(_f32c(rec)), _p(_f32c(img)), _p(active), _p(loss), _p(drec), float(loss_scale), B, f, p, _p(ws),
+         _stream())
+
+
 def gap_fwd(y, out):
     call("cmu_gap_fwd", y.ptr(), y.ld, _p(y.scale), _p(y.shift), _p(_f32c(out)), y.B, y.H, y.W, y.C, y.dt, _stream())
 

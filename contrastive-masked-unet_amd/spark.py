@@ -1,0 +1,256 @@
+"""Drop-in for the SparK sparse masked-conv pretraining variant on the UNet (reference:
+Pretraining/Spark/{spark.py:20-149, encoder.py:12-56,158-208, decoder.py:39-58, models/custom.py:113-182,
+models/__init__.py:40-49}).
+
+  build_sparse_encoder('unet_sparse', input_size, sbn=False) -> SparseEncoder   (models/__init__.py, encoder.py:158-208)
+  UnetDecoder(width=768, in_chans=1)                                             (decoder.py:39-58)
+  SparK(sparse_encoder, dense_decoder, mask_ratio=0.6, densify_norm='', sbn=False)
+      .mask(B, device, generator)          spark.py:82-86
+      .forward(inp_bchw, active_b1ff=None) spark.py:88-131  -> reconstruction loss on the non-active patches
+      state_dict keys: sparse_encoder.sp_cnn.*, dense_decoder.*, mask_tokens.{i}, densify_projs.{i}.* (built but
+      unused for the full UNet, kept for key parity: SURVEY A-10)
+
+The module-global ``_cur_active`` of the reference (encoder.py:12) is an explicit argument here.  Round-1
+execution model (csrc/sparse.hip): the dense implicit-GEMM kernels compute every conv; sparse-BatchNorm
+statistics over the active positions, the masked BN+ReLU apply, the densify step and the loss are HBM-bound
+kernels with the patch mask looked up per pixel.  SparseSyncBatchNorm (``sbn=True``) is not implemented.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from .engine import BN_EPS, BN_MOMENTUM
+from .model import DoubleConv, DownBlock, UpBlock, _EngineOwner, _named_state, _param_args, _require_cuda
+from .ops import Act
+
+
+class UNET_MAE_SPARSE(nn.Module):
+    """Parameter container with the reference's names (models/custom.py:113-182); executed by SparK."""
+
+    def __init__(self, in_chans=1, base_ch=64, depth=5, dtype="bf16", **kwargs):
+        super().__init__()
+        chans = [base_ch * 2 ** i for i in range(depth)]
+        cin = in_chans
+        for i in range(depth - 1):
+            setattr(self, f"down_conv{i + 1}", DownBlock(cin, chans[i], dtype))
+            cin = chans[i]
+        self.double_conv = DoubleConv(cin, chans[-1], dtype)
+        self._chans = chans
+
+    def get_downsample_ratio(self):
+        return 2 ** (len(self._chans) - 1)
+
+    def get_feature_map_channels(self):
+        return list(self._chans)
+
+
+class SparseEncoder(nn.Module):
+    def __init__(self, cnn, input_size, sbn=False, verbose=False):
+        super().__init__()
+        if sbn:
+            raise NotImplementedError("SparseSyncBatchNorm2d (sbn=True) is not implemented on the HIP path")
+        self.sp_cnn = cnn
+        self.input_size, self.downsample_raito, self.enc_feat_map_chs = input_size, cnn.get_downsample_ratio(), cnn.get_feature_map_channels()
+
+
+def build_sparse_encoder(name, input_size, sbn=False, drop_path_rate=0.0, verbose=False, base_ch=64, depth=5, dtype="bf16"):
+    if name not in ("unet_sparse", "unet"):
+        raise NotImplementedError(f"only the UNet encoders of the reference's hot path are built here (got {name})")
+    return SparseEncoder(UNET_MAE_SPARSE(base_ch=base_ch, depth=depth, dtype=dtype), input_size=input_size, sbn=sbn, verbose=verbose)
+
+
+class UnetDecoder(nn.Module):
+    def __init__(self, width=768, in_chans=1, base_ch=64, depth=5, dtype="bf16"):
+        super().__init__()
+        self.width = width
+        self.up_sample_mode = 'conv_transpose'
+        chans = [base_ch * 2 ** i for i in range(depth)]
+        for i in range(depth - 1, 0, -1):
+            setattr(self, f"up_conv{i}", UpBlock(chans[i], chans[i - 1], self.up_sample_mode, dtype))
+        self.conv_last = nn.Conv2d(chans[0], in_chans, kernel_size=1)
+
+
+class _SparKFn(torch.autograd.Function):
+    """Whole SparK step: the backward pass is run together with the forward (gradients for a unit loss weight are
+    kept and scaled by the incoming gradient), so one Function covers encoder, densify, decoder and loss."""
+
+    @staticmethod
+    def forward(ctx, module, inp, active, names, *params):
+        loss, grads = module._step(inp, active, need_grads=torch.is_grad_enabled() and module.training)
+        ctx.names, ctx.grads = names, grads
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        grads = ctx.grads or {}
+        out = [None if grads.get(n) is None else grads[n] * g for n in ctx.names]
+        ctx.grads = None
+        return (None, None, None, None, *out)
+
+
+class SparK(_EngineOwner, nn.Module):
+    def __init__(self, sparse_encoder, dense_decoder, mask_ratio=0.6, densify_norm='', sbn=False, dtype="bf16"):
+        super().__init__()
+        if densify_norm.lower() not in ("", "identity", "none"):
+            raise NotImplementedError("the UNet configuration of the reference uses densify_norm='' (arg_util.py:124-130)")
+        self.dtype = dtype
+        input_size, r = sparse_encoder.input_size, sparse_encoder.downsample_raito
+        self.downsample_raito = r
+        self.fmap_h = self.fmap_w = input_size // r
+        self.mask_ratio = mask_ratio
+        self.len_keep = round(self.fmap_h * self.fmap_w * (1 - mask_ratio))
+        self.sparse_encoder, self.dense_decoder = sparse_encoder, dense_decoder
+        self.full_unet = isinstance(dense_decoder, UnetDecoder)
+        self.sbn = sbn
+        self.hierarchy = len(sparse_encoder.enc_feat_map_chs)
+        self.densify_norm_str = densify_norm.lower()
+        self.densify_projs = nn.ModuleList()
+        self.mask_tokens = nn.ParameterList()
+        e_widths, d_width = list(sparse_encoder.enc_feat_map_chs), dense_decoder.width
+        for i in range(self.hierarchy):
+            e_width = e_widths.pop()
+            p = nn.Parameter(torch.zeros(1, e_width, 1, 1))
+            nn.init.trunc_normal_(p, mean=0, std=.02, a=-.02, b=.02)
+            self.mask_tokens.append(p)
+            if i == 0 and e_width == d_width:
+                self.densify_projs.append(nn.Identity())
+            else:
+                k = 1 if i <= 0 else 3
+                self.densify_projs.append(nn.Conv2d(e_width, d_width, kernel_size=k, stride=1, padding=k // 2, bias=True))
+            d_width //= 2
+
+    def mask(self, B, device, generator=None):
+        h, w = self.fmap_h, self.fmap_w
+        idx = torch.rand(B, h * w, generator=generator).argsort(dim=1)[:, :self.len_keep].to(device)
+        return torch.zeros(B, h * w, dtype=torch.bool, device=device).scatter_(dim=1, index=idx, value=True).view(B, 1, h, w)
+
+    def forward(self, inp_bchw, active_b1ff=None, vis=False):
+        _require_cuda(inp_bchw, "SparK")
+        if vis:
+            raise NotImplementedError("vis=True (visualisation tensors) is not part of the training hot path")
+        if active_b1ff is None:
+            active_b1ff = self.mask(inp_bchw.shape[0], inp_bchw.device)
+        names, params = _param_args(self)
+        return _SparKFn.apply(self, inp_bchw, active_b1ff, names, *params)
+
+    # ---------------------------------------------------------------------------------------------
+    def _ident(self, eng, C):
+        cache = eng.__dict__.setdefault("_ident", {})
+        if C not in cache:
+            cache[C] = (torch.ones(C, dtype=torch.float32, device=eng.device), torch.zeros(C, dtype=torch.float32, device=eng.device))
+        return cache[C]
+
+    def _sp_convbn_fwd(self, eng, sd, pconv, pbn, x, x_img, inv_pix, active, count, B, H, W, training):
+        w = sd[pconv + "weight"]
+        C = w.shape[0]
+        y = eng._new(B, H, W, C)
+        if x_img is not None:
+            ops.conv3x3_c1_fwd(x_img, w.detach(), y, None, inv_pix, True)
+        else:
+            ops.conv3x3_fwd(x, eng._wp(pconv, w, False), y, None)
+        scale, shift, mean, invstd = eng._f32(C), eng._f32(C), eng._f32(C), eng._f32(C)
+        slab = ops.masked_channel_stats(y, active) if training else None          # statistics over ACTIVE pixels only
+        ws = eng.scratch.get("bnfin", eng.lib.cmu_bn_finalize_ws_bytes(C))
+        ops.bn_finalize(slab, count, sd[pconv + "bias"].detach(), sd[pbn + "weight"].detach(), sd[pbn + "bias"].detach(),
+                        sd[pbn + "running_mean"], sd[pbn + "running_var"], BN_MOMENTUM, BN_EPS, training, scale, shift, mean, invstd, ws)
+        if training:
+            sd[pbn + "num_batches_tracked"] += 1
+        yt = y.with_transform(scale, shift, 0)
+        a = eng._new(B, H, W, C)
+        ops.mask_select(yt, active, a, relu=True)                                  # BN + ReLU, zeros at masked positions
+        return {"pconv": pconv, "pbn": pbn, "x": x, "x_img": x_img, "mask": inv_pix, "mps": True, "y": yt, "a": a,
+                "mean": mean, "invstd": invstd}
+
+    def _sp_convbn_bwd(self, eng, sd, s, dA, active, count, grads, need_dx):
+        y = s["y"]
+        B, H, W, C = y.B, y.H, y.W, y.C
+        w = sd[s["pconv"] + "weight"]
+        dgamma, dbeta, coef = eng._f32(C), eng._f32(C), eng._f32(2, C)
+        ops.bn_bwd_reduce_masked(dA, y, s["mean"], s["invstd"], dgamma, dbeta, coef, active, count, eng._bn_ws(C))
+        dY = Act(dA.buf, dA.coff, dA.C)
+        ops.bn_bwd_apply_masked(dA, y, s["mean"], s["invstd"], coef, dY, active)
+        grads[s["pbn"] + "weight"], grads[s["pbn"] + "bias"] = dgamma, dbeta
+        grads[s["pconv"] + "bias"] = torch.zeros(C, dtype=torch.float32, device=eng.device)
+        dW = torch.empty_like(w, dtype=torch.float32)
+        if s["x_img"] is not None:
+            ops.conv3x3_c1_wgrad(s["x_img"], dY, dW, eng.scratch.get("wg", eng.lib.cmu_conv3x3_c1_wgrad_ws_bytes(B, H, W, C)), s["mask"], True)
+        else:
+            ops.conv3x3_wgrad(s["x"], dY, dW, eng.scratch.get("wg", eng.lib.cmu_conv3x3_wgrad_ws_bytes(B, H, W, w.shape[1], C, eng.dt)))
+        grads[s["pconv"] + "weight"] = dW
+        if not need_dx or s["x_img"] is not None:
+            return None
+        dX = eng._new(B, H, W, w.shape[1])
+        ops.conv3x3_fwd(dY, eng._wp(s["pconv"], w, True), dX, None)
+        return dX
+
+    def _step(self, inp_bchw, active_b1ff, need_grads):
+        eng = self._engine(inp_bchw.device)
+        sd = _named_state(self)
+        training = self.training
+        B, _, H, W = inp_bchw.shape
+        f, r = active_b1ff.shape[-1], self.downsample_raito
+        assert H == f * r and W == f * r, "input size must be fmap * downsample ratio"
+        active = active_b1ff.reshape(B, f, f).to(torch.uint8).contiguous()
+        n_cells = int(active.sum().item())                        # once per step; the random mask keeps len_keep per sample
+        x_img = inp_bchw.detach().float().reshape(B, H, W).contiguous()
+        inv_pix = (1 - active).repeat_interleave(r, 1).repeat_interleave(r, 2).contiguous()
+        ep, dp = "sparse_encoder.sp_cnn.", "dense_decoder."
+        nd = eng.n_down(sd, ep)
+
+        # ---- sparse encoder (custom.py:152-182) ----
+        levels = []
+        x, ximg, h, w_ = None, x_img, H, W
+        for i in range(1, nd + 1):
+            p = f"{ep}down_conv{i}.double_conv.double_conv."
+            cnt = n_cells * (h // f) * (w_ // f)
+            s1 = self._sp_convbn_fwd(eng, sd, p + "0.", p + "1.", x, ximg, inv_pix if ximg is not None else None, active, cnt, B, h, w_, training)
+            s2 = self._sp_convbn_fwd(eng, sd, p + "3.", p + "4.", s1["a"], None, None, active, cnt, B, h, w_, training)
+            C = s2["a"].C
+            one, zero = self._ident(eng, C)
+            pooled = eng._new(B, h // 2, w_ // 2, C)
+            ops.bnrelu_maxpool_fwd(s2["a"].with_transform(one, zero, 0), pooled)   # zeros stay zeros: pool then *= active
+            levels.append({"s1": s1, "s2": s2, "cnt": cnt})
+            x, ximg, h, w_ = pooled, None, h // 2, w_ // 2
+        p = f"{ep}double_conv.double_conv."
+        cnt_b = n_cells * (h // f) * (w_ // f)
+        b1 = self._sp_convbn_fwd(eng, sd, p + "0.", p + "1.", x, ximg, None, active, cnt_b, B, h, w_, training)
+        b2 = self._sp_convbn_fwd(eng, sd, p + "3.", p + "4.", b1["a"], None, None, active, cnt_b, B, h, w_, training)
+
+        # ---- densify (spark.py:98-111): feature maps from the smallest to the largest, mask_tokens[i] likewise ----
+        feats = [b2["a"]] + [lv["s2"]["a"] for lv in reversed(levels)]
+        to_dec = []
+        for i, a in enumerate(feats):
+            tok = self.mask_tokens[i].detach().reshape(-1).contiguous()
+            d = eng._new(a.B, a.H, a.W, a.C)
+            ops.mask_select(a, active, d, relu=False, fill=tok, use_transform=False)
+            to_dec.append(d)
+
+        # ---- dense decoder (decoder.py:49-55) + loss (spark.py:112-123) ----
+        skips = list(reversed(to_dec[1:]))                       # skips[i-1] belongs to up_conv{i}
+        dctx = eng.decoder_forward(sd, to_dec[0], skips, training, dp, None, True)
+        rec = dctx["logits"]                                     # (B,1,H,W)
+        loss = torch.empty(1, dtype=torch.float32, device=eng.device)
+        drec = torch.empty_like(rec) if need_grads else None
+        ws = eng.scratch.get("sploss", eng.lib.cmu_spark_loss_ws_bytes(B, f))
+        ops.spark_loss_fwd_bwd(rec.view(B, H, W), x_img, active, loss, drec, 1.0, r, ws)
+        if not need_grads:
+            return loss[0], None
+
+        # ---- backward ----
+        grads = {}
+        d_lat, d_skips = eng.decoder_backward(sd, dctx, drec, grads, True)
+        d_feats = [d_lat] + list(reversed(d_skips))              # same order as feats / mask_tokens
+        for i, d in enumerate(d_feats):
+            slab = ops.masked_channel_stats(Act(d.buf, d.coff, d.C), active, invert=True)     # sum over NON-active pixels
+            grads[f"mask_tokens.{i}"] = slab[:, 0, :].sum(0).view_as(self.mask_tokens[i])
+        dA = self._sp_convbn_bwd(eng, sd, b2, d_feats[0], active, cnt_b, grads, True)
+        dP = self._sp_convbn_bwd(eng, sd, b1, dA, active, cnt_b, grads, nd > 0)
+        for i in range(nd, 0, -1):
+            lv = levels[i - 1]
+            a2 = lv["s2"]["a"]
+            one, zero = self._ident(eng, a2.C)
+            dA2 = eng._new(a2.B, a2.H, a2.W, a2.C)
+            ops.maxpool_bwd(dP, d_feats[nd - i + 1], a2.with_transform(one, zero, 0), dA2)
+            dA1 = self._sp_convbn_bwd(eng, sd, lv["s2"], dA2, active, lv["cnt"], grads, True)
+            dP = self._sp_convbn_bwd(eng, sd, lv["s1"], dA1, active, lv["cnt"], grads, i > 1)
+        return loss[0], grads

@@ -201,6 +201,38 @@ int cmu_moco_infonce_enqueue(const float* q_raw, const float* k_raw, const float
 /* L2-normalise rows (F.normalize(dim=1), eps 1e-12) -- used before the key all-gather. */
 int cmu_l2_normalize_rows(const float* x, float* out, int B, int D, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * SparK sparse (masked) convolution support (Pretraining/Spark/encoder.py:12-56, spark.py:88-131).
+ * `active` = (B,f,f) uint8 patch map; a (H,W) level with H = f << s looks up active[b][y>>s][x>>s].
+ * ------------------------------------------------------------------------------------------- */
+/* per-channel sum / sum-of-squares over the selected pixels (active, or non-active if invert): the statistics of
+ * sp_bn_forward (encoder.py:26-36) and the mask-token gradient.  slab: [cmu_masked_stats_rows()][2][C] fp32,
+ * fully written; feed it to cmu_bn_finalize with count = number of selected pixels.                       */
+int cmu_masked_stats_rows(void);
+int cmu_masked_channel_stats(const void* x, int64_t ldx, const uint8_t* active, int f, int invert, float* slab,
+                             int B, int H, int W, int C, int dt, void* stream);
+/* out = selected ? (relu ? max(x*scale+shift,0) : x*scale+shift) : fill[c]   (scale/shift/fill nullable = 1/0/0):
+ * sparse BN apply + ReLU with zeros at masked positions, `x *= active` (encoder.py:20-23), densify with mask
+ * tokens torch.where(active, feat, token) (spark.py:103-107), and their gradients.                         */
+int cmu_mask_select(const void* x, int64_t ldx, const float* scale, const float* shift, int relu, const uint8_t* active,
+                    int f, int invert, const float* fill, void* out, int64_t ldo, int B, int H, int W, int C, int dt,
+                    void* stream);
+/* BatchNorm backward restricted to the active positions (autograd of sp_bn_forward): count = number of active
+ * pixels; masked positions contribute nothing and receive dY = 0.                                          */
+int cmu_bn_bwd_reduce_masked(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift,
+                             const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* coef,
+                             const uint8_t* active, int f, int64_t count, int B, int H, int W, int C, int dt, void* ws,
+                             void* stream);
+int cmu_bn_bwd_apply_masked(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift,
+                            const float* save_mean, const float* save_invstd, const float* coef, void* dY, int64_t ldo,
+                            const uint8_t* active, int f, int B, int H, int W, int C, int dt, void* stream);
+/* SparK loss (spark.py:112-123): p x p patches, target patch normalised with its own mean / unbiased variance
+ * (eps 1e-6), l2 = patch mean of (rec-target)^2, loss = sum over NON-active patches / (count + 1e-8).
+ * rec, img (B,f*p,f*p) fp32; drec nullable.  ws: cmu_spark_loss_ws_bytes(B,f).                              */
+int64_t cmu_spark_loss_ws_bytes(int B, int f);
+int cmu_spark_loss_fwd_bwd(const float* rec, const float* img, const uint8_t* active, float* loss, float* drec,
+                           float loss_scale, int B, int f, int p, void* ws, void* stream);
+
 /* Global average pool of the activated latent (moco_data_module.py:65, x.mean([2,3])): out (B,C) fp32 from the
  * raw NHWC tensor + pending transform; backward broadcasts dout/(H*W) into dA (gradient w.r.t. the activation). */
 int cmu_gap_fwd(const void* y, int64_t ldy, const float* in_scale, const float* in_shift, float* out,

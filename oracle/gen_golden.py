@@ -60,6 +60,101 @@ def grads_of(mod):
     return {k: p.grad.detach().clone() for k, p in mod.named_parameters()}
 
 
+def import_spark():
+    """Pretraining/Spark with minimal stand-ins for timm / tensorboard and the stale `UNET` package name."""
+    import importlib.util
+    import types
+    stub = tempfile.mkdtemp(prefix="spark_stub_")
+    os.makedirs(os.path.join(stub, "timm", "models"))
+    os.makedirs(os.path.join(stub, "timm", "loss"))
+    os.makedirs(os.path.join(stub, "UNET"))
+    with open(os.path.join(stub, "timm", "__init__.py"), "w") as f:
+        f.write("_REG = {}\ndef create_model(name, **kw):\n    kw.pop('pretrained', None)\n    return _REG[name](**kw)\n")
+    with open(os.path.join(stub, "timm", "models", "__init__.py"), "w") as f:
+        f.write("from .. import create_model\n")
+    with open(os.path.join(stub, "timm", "models", "layers.py"), "w") as f:
+        f.write("import torch.nn as nn\nfrom types import SimpleNamespace\nfrom torch.nn.init import trunc_normal_\n"
+                "class DropPath(nn.Identity):\n    def __init__(self, *a, **k):\n        super().__init__()\n"
+                "drop = SimpleNamespace(DropPath=DropPath)\n")
+    with open(os.path.join(stub, "timm", "models", "registry.py"), "w") as f:
+        f.write("import timm\ndef register_model(fn):\n    timm._REG[fn.__name__] = fn\n    return fn\n")
+    with open(os.path.join(stub, "timm", "loss", "__init__.py"), "w") as f:
+        f.write("import torch.nn as nn\nclass SoftTargetCrossEntropy(nn.Module):\n    pass\n")
+    with open(os.path.join(stub, "UNET", "__init__.py"), "w") as f:
+        f.write("")
+    with open(os.path.join(stub, "UNET", "model.py"), "w") as f:
+        f.write("import importlib.util\n_s = importlib.util.spec_from_file_location('ref_unet_model', '%s/Finetuning/model.py')\n"
+                "_m = importlib.util.module_from_spec(_s)\n_s.loader.exec_module(_m)\n"
+                "DoubleConv, DownBlock, UpBlock, UNet = _m.DoubleConv, _m.DownBlock, _m.UpBlock, _m.UNet\n" % REF)
+    tb = types.ModuleType("torch.utils.tensorboard")
+    tb.SummaryWriter = object
+    sys.modules["torch.utils.tensorboard"] = tb
+    # Finetuning/utils.py (a plain module) would shadow Spark's namespace package `utils/`: drop it for this import
+    sys.path[:] = [q for q in sys.path if not q.rstrip("/").endswith("Finetuning")]
+    sys.modules.pop("utils", None)
+    sys.path.insert(0, os.path.join(REF, "Pretraining", "Spark"))
+    sys.path.insert(0, stub)
+    import encoder as sp_encoder  # noqa
+    import decoder as sp_decoder  # noqa
+    import spark as sp_spark  # noqa
+    from models import build_sparse_encoder  # noqa
+    return sp_encoder, sp_decoder, sp_spark, build_sparse_encoder
+
+
+def gen_spark(ref):
+    from oracle import unet as OU, spark as OS
+    enc_mod, dec_mod, spark_mod, build_sparse_encoder = import_spark()
+    torch.manual_seed(0)
+    S, B = 64, 2                                  # f = 4 patches per side; the reference model is size-agnostic
+    senc = build_sparse_encoder("unet_sparse", input_size=S, sbn=False)
+    model = spark_mod.SparK(sparse_encoder=senc, dense_decoder=dec_mod.UnetDecoder(), mask_ratio=0.6, densify_norm='', sbn=False)
+    assert model.fmap_h == 4 and model.len_keep == round(16 * 0.4) and model.hierarchy == 5
+    sd = OU.make_state_dict(base_ch=64, depth=5, seed=71)
+    msd = model.state_dict()
+    for k, v in sd.items():
+        if "up_conv" in k or "conv_last" in k:
+            kk = "dense_decoder." + k
+            if kk == "dense_decoder.conv_last.weight":
+                v = v[:1].clone()
+            if kk == "dense_decoder.conv_last.bias":
+                v = v[:1].clone()
+        else:
+            kk = "sparse_encoder.sp_cnn." + k
+        assert kk in msd and tuple(msd[kk].shape) == tuple(v.shape), (kk, tuple(v.shape))
+        msd[kk] = v.clone()
+    g = torch.Generator().manual_seed(72)
+    tokens = [0.3 * torch.randn_like(p, generator=None) for p in model.mask_tokens]
+    for i, t in enumerate(tokens):
+        msd[f"mask_tokens.{i}"] = t
+    model.load_state_dict(msd)
+    model.train()
+    x = torch.randn(B, 1, S, S, generator=g)
+    active = OS.make_active(B, 4, 0.6, g)
+    loss = model(x, active_b1ff=active)
+    loss.backward()
+    # oracle restatement
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in msd.items()
+           if k.startswith("sparse_encoder.sp_cnn.") or k.startswith("dense_decoder.")}
+    otok = [t.clone().requires_grad_(True) for t in tokens]
+    lo, rec = OS.forward(x, active, osd, otok)
+    lo.backward()
+    close(lo.detach(), loss.detach(), what="spark loss")
+    named = dict(model.named_parameters())
+    for k, v in osd.items():
+        if torch.is_tensor(v) and v.requires_grad and named[k].grad is not None:
+            close(v.grad, named[k].grad, tol=5e-4, what=f"spark d{k}")
+    for i, t in enumerate(otok):
+        close(t.grad, model.mask_tokens[i].grad, tol=5e-4, what=f"spark dtoken{i}")
+    gkeys = sorted(k for k in osd if osd[k].is_floating_point() and "running" not in k)
+    save("spark_unet", x=x, active=active.to(torch.uint8), loss=loss.detach(), seed=np.array(71),
+         tokens_flat=torch.cat([t.flatten() for t in tokens]),
+         grad_norm_keys=np.array(gkeys), grad_norms=torch.stack([named[k].grad.norm() for k in gkeys]),
+         token_grads_flat=torch.cat([p.grad.flatten() for p in model.mask_tokens]),
+         **{"grad." + k: named[k].grad for k in ("dense_decoder.conv_last.weight", "sparse_encoder.sp_cnn.down_conv1.double_conv.double_conv.0.weight",
+                                                "sparse_encoder.sp_cnn.down_conv1.double_conv.double_conv.1.bias")},
+         bott_running_var=model.state_dict()["sparse_encoder.sp_cnn.double_conv.double_conv.4.running_var"])
+
+
 def main():
     from oracle import unet as OU, losses as OL
     ref, M = import_reference()
@@ -265,6 +360,8 @@ def main():
     close(lo.grad, logits.grad, what="dlogits")
     save("losses", logits=logits, y1h=y1h, dice=dice.detach(), ce=ce.detach(), iou=iou.detach(), total=tot.detach(),
          dlogits=logits.grad, bad_mode_msg=np.array(bad_mode_msg))
+    # ---- 7. SparK (sparse masked conv) -- reference imported behind the stubs of SURVEY Appendix C-3 ---------
+    gen_spark(ref)
     print("all fixtures written; oracle == reference on every case")
 
 

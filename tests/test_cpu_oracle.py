@@ -157,3 +157,23 @@ def test_oracle_vs_imported_reference():
     x = torch.randn(1, 16, 32, generator=torch.Generator().manual_seed(2))
     with torch.no_grad():
         assert close(OU.unet_forward(x, OU.clone_sd(sd), training=True), m(x), 1e-4)
+
+
+def test_spark_golden(golden_dir):
+    """oracle/spark.py reproduces the loss the reference's SparK produced (fixture written by gen_golden.py)."""
+    from oracle import spark as OS
+    d = np.load(f"{golden_dir}/spark_unet.npz")
+    sd = OU.make_state_dict(base_ch=64, depth=5, seed=int(d["seed"]))
+    osd = {}
+    for k, v in sd.items():
+        if "up_conv" in k or "conv_last" in k:
+            osd["dense_decoder." + k] = v[:1].clone() if "conv_last" in k else v.clone()
+        else:
+            osd["sparse_encoder.sp_cnn." + k] = v.clone()
+    tok, off, toks = torch.from_numpy(d["tokens_flat"]), 0, []
+    for c in (1024, 512, 256, 128, 64):
+        toks.append(tok[off:off + c].view(1, c, 1, 1)); off += c
+    loss, rec = OS.forward(torch.from_numpy(d["x"]), torch.from_numpy(d["active"]).bool(), osd, toks)
+    assert abs(float(loss) - float(d["loss"])) < 1e-5 and rec.shape == (2, 1, 64, 64)
+    a = OS.make_active(3, 16, 0.6, torch.Generator().manual_seed(0))
+    assert a.shape == (3, 1, 16, 16) and a.view(3, -1).sum(1).tolist() == [round(256 * 0.4)] * 3     # spark.py:29,82-86

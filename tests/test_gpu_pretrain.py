@@ -163,3 +163,57 @@ def test_masked_recon_trainer_matches_autograd_path(cuda):
         assert abs(float(la) - float(lb)) <= 1e-5 * max(1.0, abs(float(lb)))
     for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
         assert rel(pa, pb.detach().cpu()) <= 1e-4, n
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_spark_step_vs_reference_fixture(cuda, golden_dir, dt):
+    """SparK sparse masked-conv step against the fixture produced by the reference's own SparK code
+    (oracle/gen_golden.py: Pretraining/Spark imported behind stubs).  f32: max-norm 2e-3; bf16: loss 3e-2 and
+    gradient norms 15 % (storage rounding through 18 sparse BatchNorms with as few as 6 active positions)."""
+    from cmunet_amd import spark as S
+    from oracle import unet as OU
+    d = np.load(f"{golden_dir}/spark_unet.npz")
+    x, active = torch.from_numpy(d["x"]), torch.from_numpy(d["active"]).bool()
+    enc = S.build_sparse_encoder("unet_sparse", input_size=64, dtype=dt)
+    model = S.SparK(enc, S.UnetDecoder(dtype=dt), mask_ratio=0.6, densify_norm='', dtype=dt)
+    assert model.fmap_h == 4 and model.len_keep == 6 and model.hierarchy == 5
+    sd = OU.make_state_dict(base_ch=64, depth=5, seed=int(d["seed"]))
+    msd = model.state_dict()
+    for k, v in sd.items():
+        if "up_conv" in k or "conv_last" in k:
+            kk = "dense_decoder." + k
+            if "conv_last" in k:
+                v = v[:1].clone()
+        else:
+            kk = "sparse_encoder.sp_cnn." + k
+        assert kk in msd and msd[kk].shape == v.shape, kk
+        msd[kk] = v.clone()
+    off = 0
+    tok = torch.from_numpy(d["tokens_flat"])
+    for i, p in enumerate(model.mask_tokens):
+        msd[f"mask_tokens.{i}"] = tok[off:off + p.numel()].view_as(p).clone()
+        off += p.numel()
+    model.load_state_dict(msd)
+    model = model.to(cuda).train()
+    loss = model(x.to(cuda), active_b1ff=active.to(cuda))
+    loss.backward()
+    ltol, gtol = (2e-4, 2e-3) if dt == "f32" else (3e-2, 0.15)
+    assert abs(float(loss) - float(d["loss"])) <= ltol * max(1.0, abs(float(d["loss"]))), (float(loss), float(d["loss"]))
+    named = dict(model.named_parameters())
+    worst = 0.0
+    for k, n in zip(d["grad_norm_keys"], d["grad_norms"]):
+        k = str(k)
+        if ".0.bias" in k or ".3.bias" in k or float(n) < 1e-7:
+            continue
+        e = abs(named[k].grad.norm().item() - float(n)) / float(n)
+        worst = max(worst, e)
+        assert e <= gtol * 5, f"|d{k}| {named[k].grad.norm().item():.4e} vs {float(n):.4e}"
+    tg = torch.cat([p.grad.flatten() for p in model.mask_tokens]).cpu()
+    assert rel(tg, torch.from_numpy(d["token_grads_flat"])) <= (gtol if dt == "f32" else 0.3)
+    if dt == "f32":
+        for k in ("dense_decoder.conv_last.weight", "sparse_encoder.sp_cnn.down_conv1.double_conv.double_conv.0.weight",
+                  "sparse_encoder.sp_cnn.down_conv1.double_conv.double_conv.1.bias"):
+            assert rel(named[k].grad, torch.from_numpy(d["grad." + k])) <= 5e-3, k
+        assert rel(model.state_dict()["sparse_encoder.sp_cnn.double_conv.double_conv.4.running_var"],
+                   torch.from_numpy(d["bott_running_var"])) <= 1e-3
+    print(f"[spark {dt}] loss {float(loss):.5f} vs {float(d['loss']):.5f}, worst grad-norm err {worst:.2e}")
