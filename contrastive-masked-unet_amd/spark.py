@@ -75,8 +75,8 @@ class _SparKFn(torch.autograd.Function):
     kept and scaled by the incoming gradient), so one Function covers encoder, densify, decoder and loss."""
 
     @staticmethod
-    def forward(ctx, module, inp, active, names, *params):
-        loss, grads = module._step(inp, active, need_grads=torch.is_grad_enabled() and module.training)
+    def forward(ctx, module, inp, active, need_grads, names, *params):
+        loss, grads = module._step(inp, active, need_grads=need_grads)     # (grad mode is off inside Function.forward)
         ctx.names, ctx.grads = names, grads
         return loss
 
@@ -85,7 +85,7 @@ class _SparKFn(torch.autograd.Function):
         grads = ctx.grads or {}
         out = [None if grads.get(n) is None else grads[n] * g for n in ctx.names]
         ctx.grads = None
-        return (None, None, None, None, *out)
+        return (None, None, None, None, None, *out)
 
 
 class SparK(_EngineOwner, nn.Module):
@@ -131,7 +131,8 @@ class SparK(_EngineOwner, nn.Module):
         if active_b1ff is None:
             active_b1ff = self.mask(inp_bchw.shape[0], inp_bchw.device)
         names, params = _param_args(self)
-        return _SparKFn.apply(self, inp_bchw, active_b1ff, names, *params)
+        need_grads = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _SparKFn.apply(self, inp_bchw, active_b1ff, need_grads, names, *params)
 
     # ---------------------------------------------------------------------------------------------
     def _ident(self, eng, C):
