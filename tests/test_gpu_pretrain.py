@@ -209,7 +209,8 @@ def test_spark_step_vs_reference_fixture(cuda, golden_dir, dt):
         worst = max(worst, e)
         assert e <= gtol * 5, f"|d{k}| {named[k].grad.norm().item():.4e} vs {float(n):.4e}"
     tg = torch.cat([p.grad.flatten() for p in model.mask_tokens]).cpu()
-    assert rel(tg, torch.from_numpy(d["token_grads_flat"])) <= (gtol if dt == "f32" else 0.3)
+    # token gradients pass through sparse BatchNorms normalising as few as 6 active positions per channel: 1e-2 in f32
+    assert rel(tg, torch.from_numpy(d["token_grads_flat"])) <= (1e-2 if dt == "f32" else 0.3)
     if dt == "f32":
         for k in ("dense_decoder.conv_last.weight", "sparse_encoder.sp_cnn.down_conv1.double_conv.double_conv.0.weight",
                   "sparse_encoder.sp_cnn.down_conv1.double_conv.double_conv.1.bias"):
