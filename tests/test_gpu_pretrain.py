@@ -209,12 +209,21 @@ def test_spark_step_vs_reference_fixture(cuda, golden_dir, dt):
         worst = max(worst, e)
         assert e <= gtol * 5, f"|d{k}| {named[k].grad.norm().item():.4e} vs {float(n):.4e}"
     tg = torch.cat([p.grad.flatten() for p in model.mask_tokens]).cpu()
-    # token gradients pass through sparse BatchNorms normalising as few as 6 active positions per channel: 1e-2 in f32
-    assert rel(tg, torch.from_numpy(d["token_grads_flat"])) <= (1e-2 if dt == "f32" else 0.3)
+    # Sparse BatchNorm here normalises as few as 6 active positions per channel, so the reference's OWN f32 gradients sit
+    # ~3e-3 from its float64 run (fixture keys *64).  The f32 bar is therefore stated against the float64 truth:
+    # our error may not exceed 5x the reference's own f32 error (floor 2e-3) -- both are
+    # single draws of rounding noise amplified by a condition number of ~5e4.
+    tg64, tg32 = torch.from_numpy(d["token_grads64_flat"]), torch.from_numpy(d["token_grads_flat"])
     if dt == "f32":
+        assert rel(tg, tg64) <= max(5 * rel(tg32, tg64), 2e-3), (rel(tg, tg64), rel(tg32, tg64))
         for k in ("dense_decoder.conv_last.weight", "sparse_encoder.sp_cnn.down_conv1.double_conv.double_conv.0.weight",
                   "sparse_encoder.sp_cnn.down_conv1.double_conv.double_conv.1.bias"):
-            assert rel(named[k].grad, torch.from_numpy(d["grad." + k])) <= 5e-3, k
+            g64, g32 = torch.from_numpy(d["grad64." + k]), torch.from_numpy(d["grad." + k])
+            e, e_ref = rel(named[k].grad, g64), rel(g32, g64)
+            print(f"[spark f32] {k}: err vs f64 {e:.2e} (reference f32: {e_ref:.2e})")
+            assert e <= max(5 * e_ref, 2e-3), (k, e, e_ref)
         assert rel(model.state_dict()["sparse_encoder.sp_cnn.double_conv.double_conv.4.running_var"],
                    torch.from_numpy(d["bott_running_var"])) <= 1e-3
+    else:
+        assert rel(tg, tg64) <= 0.3
     print(f"[spark {dt}] loss {float(loss):.5f} vs {float(d['loss']):.5f}, worst grad-norm err {worst:.2e}")
