@@ -88,6 +88,22 @@ struct IGCfg {
 __device__ static inline int pm_row(int r) { return __builtin_popcount(r >> 2) & 1; }
 __device__ static inline int pm_col(int r) { return 4 * (r >> 3) + (r & 3); }
 
+#ifdef CMU_IG_STAMPS
+// diagnostic build only (tools/igemm_stamps.py): wave 0 of every 61st workgroup stamps s_memtime around the phases of
+// its first 16 stages into a buffer nothing else reads
+__device__ unsigned long long g_ig_stamps[64 * 16 * 8];
+extern "C" int cmu_debug_ig_stamps(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ig_stamps), sizeof(g_ig_stamps));
+}
+#define IG_STAMP(k)                                                                          \
+    do {                                                                                      \
+        if (stamp_slot >= 0 && s < 16 && tid == 0)                                            \
+            g_ig_stamps[(stamp_slot * 16 + s) * 8 + (k)] = __builtin_amdgcn_s_memtime();      \
+    } while (0)
+#else
+#define IG_STAMP(k) do {} while (0)
+#endif
+
 template <class TR, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IGParams p) {
     typedef IGCfg<TR, MODE> C;
@@ -251,12 +267,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IGParams p) {
 
     const int nstages = C::C3 ? p.nslices : (p.nslices + C::TAPS - 1) / C::TAPS;
 
+#ifdef CMU_IG_STAMPS
+    const int stamp_slot = (blockIdx.x % 61 == 0 && blockIdx.x / 61 < 64) ? (int)(blockIdx.x / 61) : -1;
+#endif
     load_stage(0);
     for (int s = 0; s < nstages; ++s) {
+        IG_STAMP(0);
         __syncthreads();  // previous stage's fragment reads are done
+        IG_STAMP(1);
         store_stage();
+        IG_STAMP(2);
         __syncthreads();
+        IG_STAMP(3);
         if (s + 1 < nstages) load_stage(s + 1);  // in flight during the MFMAs below
+        IG_STAMP(4);
 #pragma unroll
         for (int t = 0; t < C::TAPS; ++t) {
             const int aoff = C::C3 ? ((t / 3) * C::LW + (t % 3)) * C::PS_A : t * 64;
@@ -272,6 +296,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IGParams p) {
                 TR::mma16(a1, b1, acc[1][1]);
             }
         }
+        IG_STAMP(5);
     }
     __syncthreads();  // all waves done with the A/W images: LDS is reused by the epilogue
 
@@ -360,19 +385,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IGParams p) {
     }
 }
 
-// CMU_CONV_V2=1 in the environment routes the wide layers to the second-generation kernel (conv_igemm2.inc).
-// Measured on MI355X (round 1, bench workload): both kernels sustain the same ~950-1000 TFLOP/s with the MFMA
-// pipe ~44 % busy by cycles at ~1.9 GHz, whatever the pipeline structure -- the first kernel stays the default.
-static bool cmu_force_v1() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("CMU_CONV_V2");
-        v = (e && e[0] == '1') ? 0 : 1;
-    }
-    return v == 1;
-}
-
-#include "conv_igemm2.inc"
+#include "conv_igemm3.inc"
 
 // ---------------------------------------------------------------------------------------------------
 // host launchers
@@ -407,8 +420,8 @@ static int check_act(const char* name, const void* ptr, int64_t ld, int C, int d
 template <class TR>
 static int conv3x3_fwd_t(IGParams p, hipStream_t st) {
     typedef IGCfg<TR, MODE_CONV3> C;
-    // wide layers: double-buffered one-workgroup-per-CU pipeline (conv_igemm2.inc); narrow ones: first kernel
-    if (p.N >= 128 && p.K >= 128 && p.K <= IG2Cfg<TR>::MAX_K && !cmu_force_v1()) return launch_igemm2<TR>(p, st);
+    // channel counts in whole 64-byte slices / 64-channel blocks: wide-tile kernel (conv_igemm3.inc); else the first kernel
+    if (igemm3_eligible<TR>(p)) return launch_igemm3<TR>(p, st);
     p.nslices = cmu_div_up(p.K, C::KC);
     p.nslices32 = cmu_div_up(p.K, C::KC / 2);
     p.npad = cmu_conv3x3_npad(p.N);

@@ -50,12 +50,18 @@ CONV_CASES = [
     (2, 7, 9, 8, 8, 8, 16, True),
     (1, 33, 17, 64, 72, 0, 0, True),
     (1, 16, 32, 128, 64, 64, 0, False),
-    # wide layers -> second-generation kernel (Cin >= 128 and Cout >= 128): partial tiles, partial n-blocks,
-    # channel-sliced buffers, a last K slice that is only half full
+    # whole 64-byte K slices and 64/128-channel blocks -> wide-tile kernel (conv_igemm3.inc): partial tiles in both
+    # directions, a tile whose right 16x16 half is outside the image, several n-blocks, channel-sliced buffers
     (1, 20, 33, 128, 128, 0, 0, True),
+    (2, 16, 16, 256, 256, 0, 64, True),
+    (1, 7, 9, 64, 256, 32, 0, False),
+    (1, 32, 16, 512, 128, 0, 0, True),
+    (2, 35, 70, 64, 64, 0, 0, True),
+    (1, 17, 40, 96, 64, 0, 32, False),
+    (1, 48, 64, 32, 384, 0, 0, True),
+    # not eligible (N = 192 is not a multiple of 128; K = 136 has a ragged slice): first kernel
     (2, 16, 16, 256, 192, 0, 64, True),
     (1, 7, 9, 136, 256, 8, 0, False),
-    (1, 32, 16, 512, 128, 0, 0, True),
 ]
 
 
@@ -95,8 +101,9 @@ def test_conv3x3_fwd(ops, dt, case):
 
 
 @pytest.mark.parametrize("dt", DTS)
-def test_conv3x3_dgrad_via_flipped_pack(ops, dt):
-    B, H, W, Cin, Cout = 2, 18, 21, 24, 40
+@pytest.mark.parametrize("shape", [(2, 18, 21, 24, 40), (1, 18, 37, 128, 64), (2, 16, 32, 64, 128)])
+def test_conv3x3_dgrad_via_flipped_pack(ops, dt, shape):
+    B, H, W, Cin, Cout = shape
     g = torch.Generator().manual_seed(5)
     dy = q(torch.randn(B, Cout, H, W, generator=g), dt, ops)
     w = q(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cout * 9) ** 0.5, dt, ops)
@@ -253,9 +260,9 @@ def test_bad_args_fail_loudly(ops):
         ops.conv3x3_fwd(a, w, o, None)
 
 
-def test_conv3x3_second_generation_kernel_matches_first():
-    """The opt-in double-buffered kernel (CMU_CONV_V2=1, conv_igemm2.inc) computes the same convolution as the
-    default one (different fp32 summation order only): run both in subprocesses and compare."""
+def test_conv3x3_wide_tile_kernel_matches_first():
+    """The wide-tile kernel (conv_igemm3.inc) computes the same convolution as the first one, which CMU_CONV_WIDE=0
+    selects for every layer (different fp32 summation order only): run both in subprocesses and compare."""
     import os
     import subprocess
     import sys
@@ -268,7 +275,7 @@ import sys, torch
 sys.path.insert(0, %r)
 from cmunet_amd import ops
 g = torch.Generator().manual_seed(0)
-B, H, W, Cin, Cout = 2, 20, 33, 256, 192
+B, H, W, Cin, Cout = 2, 20, 33, 256, 256
 x = torch.randn(B, H, W, Cin, generator=g).to(torch.bfloat16).cuda()
 w = (torch.randn(Cout, Cin, 3, 3, generator=g) / 48).cuda()
 sc, sh = (torch.rand(Cin, generator=g) + 0.5).cuda(), (torch.randn(Cin, generator=g) * 0.3).cuda()
@@ -278,11 +285,11 @@ ops.conv3x3_fwd(ops.Act(x, 0, Cin, sc, sh, 0), ops.pack_conv3x3(w, "bf16"), y, s
 torch.save({"y": y.buf.float().cpu(), "s": st.sum(0).cpu()}, sys.argv[1])
 ''' % root
     outs = []
-    for v2 in ("0", "1"):
+    for wide in ("0", "1"):
         with tempfile.NamedTemporaryFile(suffix=".pt", delete=False) as f:
             path = f.name
-        subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, CMU_CONV_V2=v2), timeout=300)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, CMU_CONV_WIDE=wide), timeout=300)
         outs.append(torch.load(path))
         os.unlink(path)
-    check(outs[1]["y"], outs[0]["y"], 8e-3, "v2 vs v1 y (bf16 rounding of different fp32 sums)")
-    check(outs[1]["s"], outs[0]["s"], 1e-4, "v2 vs v1 stats")
+    check(outs[1]["y"], outs[0]["y"], 8e-3, "wide vs first y (bf16 rounding of different fp32 sums)")
+    check(outs[1]["s"], outs[0]["s"], 1e-4, "wide vs first stats")
