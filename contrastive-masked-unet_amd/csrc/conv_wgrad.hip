@@ -21,6 +21,7 @@
 //   * accumulators of the k-parts are combined through LDS, partial slabs [split][tap][n][c] go to a
 //     workspace and a second kernel sums them in split order (deterministic) into the reference layout.
 #include "common.h"
+#include <stdlib.h>
 
 enum { MODE_W3 = 0, MODE_WT = 1 };
 
@@ -72,6 +73,20 @@ __device__ static inline u32x2 lds_tr16(const unsigned char* smem, int off) {
     return __builtin_bit_cast(u32x2, v);
 }
 
+#ifdef CMU_IG_STAMPS
+__device__ unsigned long long g_wg_stamps[64 * 16 * 8];
+extern "C" int cmu_debug_wg_stamps(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wg_stamps), sizeof(g_wg_stamps));
+}
+#define WG_STAMP(k_)                                                                          \
+    do {                                                                                       \
+        if (stamp_slot >= 0 && stamp_i < 16 && tid == 0)                                       \
+            g_wg_stamps[(stamp_slot * 16 + stamp_i) * 8 + (k_)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define WG_STAMP(k_) do {} while (0)
+#endif
+
 template <class TR, int MODE>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WGParams p) {
     typedef WGCfg<TR, MODE> C;
@@ -88,7 +103,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WGParams p) {
     const int r = lane & 31;
     const int h = lane >> 5;
 
-    int bid = blockIdx.x;
+    // XCD-aware (see conv_wgrad2.inc): the workgroups that stream the same pixels share one XCD's L2
+    int bid;
+    {
+        const int nb = (int)gridDim.x, q = nb >> 3, rem = nb & 7;
+        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+    }
     const int ab = bid % p.nAB;
     bid /= p.nAB;
     const int bb = bid % p.nBB;
@@ -216,7 +237,15 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WGParams p) {
         if (tile + p.splitk < p.ntiles) load_tile(tile + p.splitk);
     }
     __syncthreads();
+#ifdef CMU_IG_STAMPS
+    const int stamp_slot = (blockIdx.x % 7 == 0 && blockIdx.x / 7 < 64) ? (int)(blockIdx.x / 7) : -1;
+    int stamp_i = -1;
+#endif
     for (; tile < p.ntiles; tile += p.splitk) {
+#ifdef CMU_IG_STAMPS
+        ++stamp_i;
+#endif
+        WG_STAMP(0);
         stA = (smA == smem) ? smem + C::BUF_BYTES : smem;
         stB = stA + C::A_BYTES;
 #pragma unroll 1
@@ -251,9 +280,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WGParams p) {
                 }
             }
         }
+        WG_STAMP(1);
         if (tile + p.splitk < p.ntiles) store_tile();                       // tile t+1: registers -> the other buffer
+        WG_STAMP(2);
         __syncthreads();
+        WG_STAMP(3);
         if (tile + 2 * p.splitk < p.ntiles) load_tile(tile + 2 * p.splitk);  // tile t+2: in flight during the next compute
+        WG_STAMP(4);
         smA = stA;
         smB = stB;
     }
@@ -289,6 +322,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WGParams p) {
         }
     }
 }
+
+#include "conv_wgrad2.inc"
 
 // partial slabs -> parameter-gradient layout, summed in split order
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splitk, int T, int CApad, int CBpad, int CA,
@@ -381,6 +416,50 @@ static void wg_geometry(int B, int H, int W, int CA, int CB, int dt, int mult, W
 }
 constexpr int CSUM_BLOCKS = 256;
 
+// wide-tile kernel (conv_wgrad2.inc): 16-bit dtypes, Cout in whole 128-blocks, Cin in whole 64-blocks.  CMU_WGRAD_WIDE=0 keeps
+// every layer on the first kernel (A/B switch for the benches).
+static bool wg2_shape_ok(int CA, int CB, int dt) {
+    static const bool on = []() { const char* e = getenv("CMU_WGRAD_WIDE"); return !(e && e[0] == '0'); }();
+    return on && cmu_dtype_size(dt) == 2 && CA % 128 == 0 && CB % 64 == 0;
+}
+static void wg2_geometry(int B, int H, int W, int CA, int CB, WGParams& p) {
+    p.tilesX = cmu_div_up(W, 16);
+    p.tilesY = cmu_div_up(H, 8);
+    p.ntiles = B * p.tilesX * p.tilesY;
+    p.nAB = CA / 128;
+    p.nBB = CB / 64;
+    p.CApad = CA;
+    p.CBpad = CB;
+    p.splitk = wg_splitk(p.nAB * p.nBB, p.ntiles, 1);
+}
+template <class TR>
+static int wgrad3_wide_t(WGParams p, float* dW, hipStream_t st) {
+    typedef WG2Cfg<TR> C;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad2_kernel<TR>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           C::LDS_BYTES);
+        if (e != hipSuccess) {
+            cmu_set_error("cmu_conv3x3_wgrad(wide): hipFuncSetAttribute(%d B LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
+            return CMU_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    WG2Params pp;
+    pp.g = p;
+    pp.dtx = p.splitk % p.tilesX;
+    pp.dty = (p.splitk / p.tilesX) % p.tilesY;
+    pp.dtb = p.splitk / (p.tilesX * p.tilesY);
+    hipLaunchKernelGGL((conv_wgrad2_kernel<TR>), dim3(p.nAB * p.nBB * p.splitk), dim3(512), C::LDS_BYTES, st, pp);
+    CMU_CHECK_LAUNCH("cmu_conv3x3_wgrad(wide)");
+    const int64_t total = (int64_t)9 * p.CA * p.CB;
+    const int grid = (int)(cmu_div_up64(total, 64) < 8192 ? cmu_div_up64(total, 64) : 8192);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)p.ws, p.splitk, 9, p.CApad, p.CBpad, p.CA, p.CB, dW,
+                       (int)MODE_W3);
+    CMU_CHECK_LAUNCH("cmu_conv3x3_wgrad(reduce)");
+    return CMU_OK;
+}
+
 template <class TR, int MODE>
 static int launch_wgrad(const WGParams& p, hipStream_t st, const char* name) {
     typedef WGCfg<TR, MODE> C;
@@ -445,7 +524,14 @@ extern "C" int64_t cmu_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int 
     if (cmu_dtype_size(dt) == 0 || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return -1;
     WGParams p = {};
     wg_geometry(B, H, W, Cout, Cin, dt, 1, p);
-    return (int64_t)p.splitk * 9 * p.CApad * p.CBpad * (int64_t)sizeof(float);
+    int64_t need = (int64_t)p.splitk * 9 * p.CApad * p.CBpad * (int64_t)sizeof(float);
+    if (wg2_shape_ok(Cout, Cin, dt)) {   // either kernel may run (the wide one needs 4 GiB-addressable tensors)
+        WGParams q = {};
+        wg2_geometry(B, H, W, Cout, Cin, q);
+        const int64_t w = (int64_t)q.splitk * 9 * q.CApad * q.CBpad * (int64_t)sizeof(float);
+        if (w > need) need = w;
+    }
+    return need;
 }
 extern "C" int cmu_conv3x3_wgrad(const void* x, int64_t ldx, const float* in_scale, const float* in_shift, int relu_from, const void* dY,
                                  int64_t ldd, float* dW, int B, int H, int W, int Cin, int Cout, int dt, void* ws, void* stream) {
@@ -458,6 +544,13 @@ extern "C" int cmu_conv3x3_wgrad(const void* x, int64_t ldx, const float* in_sca
     WGParams p = {};
     p.a = dY; p.lda = ldd; p.b = x; p.ldb = ldx; p.b_scale = in_scale; p.b_shift = in_shift; p.relu_from = relu_from;
     p.ws = (float*)ws; p.B = B; p.H = H; p.W = W; p.CA = Cout; p.CB = Cin;
+    const int64_t px = (int64_t)B * H * W;
+    if (wg2_shape_ok(Cout, Cin, dt) && (px * ldd + Cout) * 2 < 0x7fff0000ll && ((px + W + 1) * ldx + Cin) * 2 < 0x7fff0000ll &&
+        (in_scale == nullptr || ((reinterpret_cast<uintptr_t>(in_scale) | reinterpret_cast<uintptr_t>(in_shift)) & 3) == 0)) {
+        wg2_geometry(B, H, W, Cout, Cin, p);
+        if (dt == CMU_F16) return wgrad3_wide_t<F16Traits>(p, dW, (hipStream_t)stream);
+        return wgrad3_wide_t<BF16Traits>(p, dW, (hipStream_t)stream);
+    }
     wg_geometry(B, H, W, Cout, Cin, dt, 1, p);
     CMU_DISPATCH_DT(dt, wgrad3_t, p, dW, (hipStream_t)stream);
 }

@@ -60,7 +60,11 @@ def test_bn_relu_backward(ops, dt, shape):
 
 
 WG_CASES = [(2, 20, 24, 32, 64, True), (1, 16, 16, 16, 16, False), (2, 7, 9, 8, 8, True), (1, 33, 17, 72, 40, True),
-            (3, 16, 32, 128, 64, False)]
+            (3, 16, 32, 128, 64, False),
+            # Cout % 128 == 0 and Cin % 64 == 0 -> wide-tile kernel (conv_wgrad2.inc) for the 16-bit dtypes: partial tiles in
+            # both directions, several blocks per operand, a single tile per split, more splits than tiles
+            (2, 20, 24, 64, 128, True), (1, 7, 37, 128, 256, False), (3, 33, 16, 192, 128, True), (1, 8, 16, 64, 128, True),
+            (1, 5, 3, 64, 128, True)]
 
 
 @pytest.mark.parametrize("dt", DTS)

@@ -1,0 +1,56 @@
+"""Diagnostic: per-layer throughput of cmu_conv3x3_wgrad and (with the -DCMU_IG_STAMPS build) its in-kernel timeline."""
+import ctypes
+import sys
+
+import numpy as np
+import torch
+
+LIB = sys.argv[1]
+B = 32
+H = W = int(sys.argv[2]); Cin = int(sys.argv[3]); Cout = int(sys.argv[4])
+dev = torch.device("cuda:0")
+lib = ctypes.CDLL(LIB)
+lib.cmu_conv3x3_wgrad_ws_bytes.restype = ctypes.c_int64
+lib.cmu_last_error.restype = ctypes.c_char_p
+vp, i64 = ctypes.c_void_p, ctypes.c_int64
+torch.manual_seed(0)
+x = torch.randn(B, H, W, Cin, device=dev).to(torch.bfloat16)
+dy = torch.randn(B, H, W, Cout, device=dev).to(torch.bfloat16)
+sc = torch.rand(Cin, device=dev) + 0.5
+sh = torch.randn(Cin, device=dev) * 0.1
+dW = torch.empty(Cout, Cin, 3, 3, device=dev)
+ws = torch.empty(lib.cmu_conv3x3_wgrad_ws_bytes(B, H, W, Cin, Cout, 2), dtype=torch.uint8, device=dev)
+
+
+def run():
+    rc = lib.cmu_conv3x3_wgrad(vp(x.data_ptr()), i64(Cin), vp(sc.data_ptr()), vp(sh.data_ptr()), 0, vp(dy.data_ptr()), i64(Cout),
+                               vp(dW.data_ptr()), B, H, W, Cin, Cout, 2, vp(ws.data_ptr()), vp(0))
+    assert rc == 0, lib.cmu_last_error()
+
+
+for _ in range(10):
+    run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    run()
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 20
+print(f"wgrad {Cin}->{Cout} @ {H}x{W} B={B}: {ms:.3f} ms  {2.0 * B * H * W * Cin * Cout * 9 / ms / 1e9:.0f} TFLOP/s (incl. reduce)")
+if not hasattr(lib, "cmu_debug_wg_stamps"):
+    sys.exit(0)
+buf = np.zeros(64 * 16 * 8, dtype=np.uint64)
+assert lib.cmu_debug_wg_stamps(buf.ctypes.data_as(vp)) == 0
+st = buf.reshape(64, 16, 8).astype(np.int64)
+st = st[st[:, 0, 0] > 0]
+nst = int((st[0, :, 0] > 0).sum()) - 1
+print("blocks", st.shape[0], "tiles/block stamped", nst + 1)
+for k, nm in enumerate((sys.argv[5].split(",") if len(sys.argv) > 5 else ["compute", "store_tile", "barrier", "load_issue"])):
+    d = st[:, 1:nst, k + 1] - st[:, 1:nst, k]
+    print(f"  {nm:11s} avg {d.mean():8.0f} cyc (min {d.min()}, max {d.max()})")
+if (st[:, 1:nst, 5] > 0).all():
+    d = st[:, 1:nst, 5] - st[:, 1:nst, 2]
+    print(f"  (stage: store part avg {d.mean():.0f} cyc, load-issue part avg {(st[:, 1:nst, 3] - st[:, 1:nst, 5]).mean():.0f} cyc)")
+print(f"  per-tile total {(st[:, 2:nst, 0] - st[:, 1:nst - 1, 0]).mean():.0f} cyc")
