@@ -103,13 +103,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WGParams p) {
     const int r = lane & 31;
     const int h = lane >> 5;
 
-    // XCD-aware (see conv_wgrad2.inc): the workgroups that stream the same pixels share one XCD's L2
-    int bid;
-    {
-        const int nb = (int)gridDim.x, q = nb >> 3, rem = nb & 7;
-        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
-    }
+    int bid = blockIdx.x;
     const int ab = bid % p.nAB;
     bid /= p.nAB;
     const int bb = bid % p.nBB;
@@ -334,11 +328,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int ol = threadIdx.x & 63, part = threadIdx.x >> 6;
     for (int64_t o0 = (int64_t)blockIdx.x * 64; o0 < total; o0 += (int64_t)gridDim.x * 64) {
         const int64_t o = o0 + ol;
-        const int c = (int)(o % CB);
-        const int n = (int)((o / CB) % CA);
+        int c = (int)(o % CB);
+        int n = (int)((o / CB) % CA);
         const int t = (int)(o / ((int64_t)CB * CA));
         float s = 0.f;
-        if (o < total)
+        if (mode == 2) {   // wide ConvTranspose kernel: slabs are [split][ij][c][n], n fastest
+            n = (int)(o % CA);
+            c = (int)((o / CA) % CB);
+            if (o < total)
+                for (int k = part; k < splitk; k += 4) s += ws[(((int64_t)k * T + t) * CB + c) * CA + n];
+        } else if (o < total)
             for (int k = part; k < splitk; k += 4) s += ws[(((int64_t)k * T + t) * CApad + n) * CBpad + c];
         __syncthreads();
         red[part][ol] = s;
@@ -431,6 +430,49 @@ static void wg2_geometry(int B, int H, int W, int CA, int CB, WGParams& p) {
     p.CApad = CA;
     p.CBpad = CB;
     p.splitk = wg_splitk(p.nAB * p.nBB, p.ntiles, 1);
+}
+static bool wgT2_shape_ok(int CA, int CB, int dt) {
+    static const bool on = []() { const char* e = getenv("CMU_WGRAD_WIDE"); return !(e && e[0] == '0'); }();
+    return on && cmu_dtype_size(dt) == 2 && CA % 64 == 0 && CB % 128 == 0;
+}
+static void wgT2_geometry(int B, int H, int W, int CA, int CB, WGParams& p) {
+    p.tilesX = cmu_div_up(W, 16);
+    p.tilesY = cmu_div_up(H, 4);
+    p.ntiles = B * p.tilesX * p.tilesY;
+    p.nAB = CA / 64;
+    p.nBB = CB / 128;
+    p.CApad = CA;
+    p.CBpad = CB;
+    p.splitk = wg_splitk(p.nAB * p.nBB, p.ntiles, 1);
+}
+template <class TR>
+static int wgradT_wide_t(WGParams p, float* dW, float* dbias, hipStream_t st) {
+    typedef WGT2Cfg<TR> C;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgradT2_kernel<TR>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           C::LDS_BYTES);
+        if (e != hipSuccess) {
+            cmu_set_error("cmu_convT2x2_wgrad(wide): hipFuncSetAttribute(%d B LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
+            return CMU_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    WG2Params pp;
+    pp.g = p;
+    pp.dtx = p.splitk % p.tilesX;
+    pp.dty = (p.splitk / p.tilesX) % p.tilesY;
+    pp.dtb = p.splitk / (p.tilesX * p.tilesY);
+    hipLaunchKernelGGL((conv_wgradT2_kernel<TR>), dim3(p.nAB * p.nBB * p.splitk), dim3(512), C::LDS_BYTES, st, pp);
+    CMU_CHECK_LAUNCH("cmu_convT2x2_wgrad(wide)");
+    const int64_t total = (int64_t)4 * p.CA * p.CB;
+    const int grid = (int)(cmu_div_up64(total, 64) < 8192 ? cmu_div_up64(total, 64) : 8192);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)p.ws, p.splitk, 4, p.CApad, p.CBpad, p.CA, p.CB, dW, 2);
+    CMU_CHECK_LAUNCH("cmu_convT2x2_wgrad(reduce)");
+    const float* ws_sum = p.ws + (int64_t)p.splitk * 4 * p.CB * p.CA;
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cmu_div_up(p.CA, 128)), dim3(128), 0, st, ws_sum, p.splitk, p.CA, dbias);
+    CMU_CHECK_LAUNCH("cmu_convT2x2_wgrad(bias final)");
+    return CMU_OK;
 }
 template <class TR>
 static int wgrad3_wide_t(WGParams p, float* dW, hipStream_t st) {
@@ -544,7 +586,7 @@ extern "C" int cmu_conv3x3_wgrad(const void* x, int64_t ldx, const float* in_sca
     WGParams p = {};
     p.a = dY; p.lda = ldd; p.b = x; p.ldb = ldx; p.b_scale = in_scale; p.b_shift = in_shift; p.relu_from = relu_from;
     p.ws = (float*)ws; p.B = B; p.H = H; p.W = W; p.CA = Cout; p.CB = Cin;
-    const int64_t px = (int64_t)B * H * W;
+    const int64_t px = (int64_t)H * W;   // per image: the buffer descriptors are per image
     if (wg2_shape_ok(Cout, Cin, dt) && (px * ldd + Cout) * 2 < 0x7fff0000ll && ((px + W + 1) * ldx + Cin) * 2 < 0x7fff0000ll &&
         (in_scale == nullptr || ((reinterpret_cast<uintptr_t>(in_scale) | reinterpret_cast<uintptr_t>(in_shift)) & 3) == 0)) {
         wg2_geometry(B, H, W, Cout, Cin, p);
@@ -559,7 +601,14 @@ extern "C" int64_t cmu_convT2x2_wgrad_ws_bytes(int B, int H, int W, int Cin, int
     if (cmu_dtype_size(dt) == 0 || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return -1;
     WGParams p = {};
     wg_geometry(B, H, W, Cout, Cin, dt, 4, p);
-    return ((int64_t)p.splitk * 4 * p.CApad * p.CBpad + (int64_t)CSUM_BLOCKS * Cout) * (int64_t)sizeof(float);
+    int64_t need = ((int64_t)p.splitk * 4 * p.CApad * p.CBpad + (int64_t)CSUM_BLOCKS * Cout) * (int64_t)sizeof(float);
+    if (wgT2_shape_ok(Cout, Cin, dt)) {
+        WGParams q = {};
+        wgT2_geometry(B, H, W, Cout, Cin, q);
+        const int64_t w = (int64_t)q.splitk * ((int64_t)4 * Cout * Cin + Cout) * (int64_t)sizeof(float);
+        if (w > need) need = w;
+    }
+    return need;
 }
 extern "C" int cmu_convT2x2_wgrad(const void* x, int64_t ldx, const float* in_scale, const float* in_shift, int relu_from, const void* dOut,
                                   int64_t ldd, float* dW, float* dbias, int B, int H, int W, int Cin, int Cout, int dt, void* ws,
@@ -573,6 +622,12 @@ extern "C" int cmu_convT2x2_wgrad(const void* x, int64_t ldx, const float* in_sc
     WGParams p = {};
     p.a = dOut; p.lda = ldd; p.b = x; p.ldb = ldx; p.b_scale = in_scale; p.b_shift = in_shift; p.relu_from = relu_from;
     p.ws = (float*)ws; p.B = B; p.H = H; p.W = W; p.CA = Cout; p.CB = Cin;
+    const int64_t px = (int64_t)H * W;   // per image: the buffer descriptors are per image
+    if (wgT2_shape_ok(Cout, Cin, dt) && (4 * px * ldd + Cout) * 2 < 0x7fff0000ll && (px * ldx + Cin) * 2 < 0x7fff0000ll) {
+        wgT2_geometry(B, H, W, Cout, Cin, p);
+        if (dt == CMU_F16) return wgradT_wide_t<F16Traits>(p, dW, dbias, (hipStream_t)stream);
+        return wgradT_wide_t<BF16Traits>(p, dW, dbias, (hipStream_t)stream);
+    }
     wg_geometry(B, H, W, Cout, Cin, dt, 4, p);
     float* ws_sum = (float*)ws + (int64_t)p.splitk * 4 * p.CApad * p.CBpad;
     const int dtc = dt;

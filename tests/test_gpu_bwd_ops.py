@@ -144,7 +144,10 @@ def test_maxpool_bwd(ops, dt, with_skip):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("case", [(2, 8, 8, 32, 16, True), (1, 5, 9, 64, 32, False), (2, 16, 16, 128, 64, True)])
+@pytest.mark.parametrize("case", [(2, 8, 8, 32, 16, True), (1, 5, 9, 64, 32, False), (2, 16, 16, 128, 64, True),
+                                  # Cin % 128 == 0 and Cout % 64 == 0 -> wide kernel for the 16-bit dtypes (conv_wgrad2.inc)
+                                  (1, 5, 9, 128, 64, True), (2, 7, 33, 256, 128, False), (3, 4, 16, 128, 192, True),
+                                  (1, 1, 2, 256, 64, True)])
 def test_convT2x2_wgrad(ops, dt, case):
     from cmunet_amd import _lib
     B, H, W, Cin, Cout, tf = case
