@@ -48,6 +48,9 @@ _SIGS = {
     "cmu_maxpool_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cmu_bn_bwd_finalize": (_I, [_P, _L, _P, _P, _P, _I, _P]),
     "cmu_convT2x2_dgrad": (_I, [_P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
+    "cmu_convT2x2_dgrad_bn": (_I, [_P, _L, _P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "cmu_conv3x3_dgrad_bn": (_I, [_P, _L, _P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "cmu_bn_bwd_finalize_tiles": (_I, [_P, _I, _L, _P, _P, _P, _I, _P, _P]),
     "cmu_convT2x2_wgrad_ws_bytes": (_L, [_I, _I, _I, _I, _I, _I]),
     "cmu_convT2x2_wgrad": (_I, [_P, _L, _P, _P, _I, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "cmu_conv1x1_head_bwd_ws_bytes": (_L, [_I, _I, _I, _I, _I]),

@@ -51,6 +51,11 @@ struct IGParams {
     int nslices32;  // CONV3: number of 32-byte slices in the packed weights
     int tilesX, tilesY, nblk;
     int64_t total_blocks;
+    // optional BatchNorm+ReLU backward statistics of the layer the output gradient flows into (dgrad entries)
+    const void* bx;       // that layer's raw conv output (same pixel grid / channels as y)
+    int64_t ldbx;
+    const float *b_scale, *b_shift, *b_mean, *b_invstd;
+    float* bstats;        // slab [cmu_conv_ntiles][2][N]
 };
 
 template <class TR, int MODE>
@@ -329,6 +334,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IGParams p) {
             }
         }
     }
+    // (BN-backward statistics) the producer layer's raw-output chunks this lane will need: in flight before the
+    // accumulators go through LDS (see conv_igemm3.inc)
+    constexpr int CPRp = C::BN / C::EPC;
+    u32x4 xr[CPRp];
+    if ((MODE != MODE_CONVT_FWD) && p.bstats != nullptr) {
+#pragma unroll
+        for (int it = 0; it < CPRp; ++it) {
+            const int idx = it * 64 + lane;
+            const int m = idx / CPRp, q = idx % CPRp;
+            const int row = 4 * wave + 2 * (m >> 5) + pm_row(m & 31), col = pm_col(m & 31);
+            const int gy = ty0 + row < p.H ? ty0 + row : p.H - 1, gx = tx0 + col < p.W ? tx0 + col : p.W - 1;  // clamped
+            int n = n0 + q * C::EPC;
+            n = n < p.N ? n : 0;
+            const int64_t xo = (((int64_t)b * p.H + gy) * p.W + gx) * p.ldbx + n;
+            xr[it] = ld_global16(reinterpret_cast<const unsigned char*>(p.bx) + xo * (int64_t)sizeof(elem_t));
+        }
+    }
     // stage this wave's 64x64 sub-tile as [pixel m][channel n]
     unsigned char* my = smem + wave * (64 * C::EPI_ROW);
 #pragma unroll
@@ -364,6 +386,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IGParams p) {
     // coalesced write-out: each lane moves 16-byte channel chunks of one pixel
     constexpr int CPR = C::BN / C::EPC;  // chunks per pixel row
     unsigned char* yb = reinterpret_cast<unsigned char*>(p.y);
+    // optional BatchNorm+ReLU backward statistics of the layer this gradient flows into (see conv_igemm3.inc)
+    const bool bs = (MODE != MODE_CONVT_FWD) && p.bstats != nullptr;
+    constexpr int EPCc = C::EPC;
+    float bsc[EPCc], bsh[EPCc], bmu[EPCc], bis[EPCc], bs1[EPCc], bs2[EPCc];
+    const int nq = n0 + (lane % CPR) * EPCc;
+    if (bs) {
+#pragma unroll
+        for (int e = 0; e < EPCc; ++e) {
+            const int c = nq + e < p.N ? nq + e : 0;
+            bsc[e] = p.b_scale[c]; bsh[e] = p.b_shift[c]; bmu[e] = p.b_mean[c]; bis[e] = p.b_invstd[c];
+            bs1[e] = bs2[e] = 0.f;
+        }
+    }
 #pragma unroll
     for (int it = 0; it < (64 * CPR) / 64; ++it) {
         const int idx = it * 64 + lane;
@@ -381,6 +416,43 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IGParams p) {
                 off = (((int64_t)b * p.H + gy) * p.W + gx) * p.ldy + n;
             }
             st_global16(yb + off * (int64_t)sizeof(elem_t), v);
+            if (bs) {
+                float gv[EPCc], xv[EPCc];
+                TR::unpack(v, gv);
+                TR::unpack(xr[it], xv);
+#pragma unroll
+                for (int e = 0; e < EPCc; ++e) {
+                    const float dz = fmaf(xv[e], bsc[e], bsh[e]) > 0.f ? gv[e] : 0.f;
+                    bs1[e] += dz;
+                    bs2[e] = fmaf(dz, xv[e], bs2[e]);   // sum(dz*x); xhat is applied per channel below
+                }
+            }
+        }
+    }
+    if (bs) {
+#pragma unroll
+        for (int e = 0; e < EPCc; ++e) {
+#pragma unroll
+            for (int o = CPR; o < 64; o <<= 1) {
+                bs1[e] += __shfl_xor(bs1[e], o, 64);
+                bs2[e] += __shfl_xor(bs2[e], o, 64);
+            }
+            bs2[e] = (bs2[e] - bmu[e] * bs1[e]) * bis[e];   // sum(dz*(x-mean)*invstd) over this wave's <= 512 pixels
+            if (lane < CPR) {
+                stat_lds[(wave * C::BN + lane * EPCc + e) * 2 + 0] = bs1[e];
+                stat_lds[(wave * C::BN + lane * EPCc + e) * 2 + 1] = bs2[e];
+            }
+        }
+        __syncthreads();
+        if (tid < C::BN && n0 + tid < p.N) {
+            float a = 0.f, q = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) {
+                a += stat_lds[(w4 * C::BN + tid) * 2 + 0];
+                q += stat_lds[(w4 * C::BN + tid) * 2 + 1];
+            }
+            p.bstats[(tile * 2 + 0) * p.N + n0 + tid] = a;
+            p.bstats[(tile * 2 + 1) * p.N + n0 + tid] = q;
         }
     }
 }
@@ -502,6 +574,55 @@ extern "C" int cmu_convT2x2_dgrad(const void* dOut, int64_t ldd, const void* wpa
     p.x = dOut; p.ldx = ldd; p.in_scale = nullptr; p.in_shift = nullptr; p.relu_from = 0;
     p.w = wpacked_dgrad; p.y = dX; p.ldy = ldx; p.stats = nullptr; p.bias = nullptr;
     p.B = B; p.H = H; p.W = W; p.K = Cout; p.N = Cin; p.Cq = Cout;
+    fill_tiles(p);
+    CMU_DISPATCH_DT(dt, convT_dgrad_t, p, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// data-gradient entries that also produce the BatchNorm+ReLU backward statistics of the layer the gradient flows into
+// ---------------------------------------------------------------------------------------------------
+static int check_bnstats(const char* name, const void* yraw, int64_t ldy, const float* scale, const float* shift, const float* mean,
+                         const float* invstd, const float* bstats, int N, int dt) {
+    int rc;
+    if ((rc = check_act(name, yraw, ldy, N, dt))) return rc;
+    CMU_CHECK_ARG(scale && shift && mean && invstd && bstats, "%s: null BatchNorm argument", name);
+    return CMU_OK;
+}
+
+extern "C" int cmu_conv3x3_dgrad_bn(const void* dY, int64_t ldd, const void* wpacked_flip, void* dX, int64_t ldx, const void* yraw,
+                                    int64_t ldy, const float* scale, const float* shift, const float* save_mean,
+                                    const float* save_invstd, float* bstats, int B, int H, int W, int K, int N, int dt, void* stream) {
+    CMU_CHECK_ARG(B > 0 && H > 0 && W > 0 && K > 0 && N > 0, "cmu_conv3x3_dgrad_bn: bad dims");
+    CMU_CHECK_ARG(cmu_dtype_size(dt) > 0, "cmu_conv3x3_dgrad_bn: bad dtype %d", dt);
+    int rc;
+    if ((rc = check_act("cmu_conv3x3_dgrad_bn(dY)", dY, ldd, K, dt))) return rc;
+    if ((rc = check_act("cmu_conv3x3_dgrad_bn(dX)", dX, ldx, N, dt))) return rc;
+    if ((rc = check_bnstats("cmu_conv3x3_dgrad_bn(yraw)", yraw, ldy, scale, shift, save_mean, save_invstd, bstats, N, dt))) return rc;
+    CMU_CHECK_ARG(wpacked_flip && cmu_aligned16(wpacked_flip), "cmu_conv3x3_dgrad_bn: packed weights null/unaligned");
+    CMU_CHECK_ARG((int64_t)B * cmu_div_up(H, CMU_TH) * cmu_div_up(W, CMU_TW) * cmu_div_up(N, 64) < (1ll << 31), "cmu_conv3x3_dgrad_bn: grid too large");
+    IGParams p = {};
+    p.x = dY; p.ldx = ldd; p.w = wpacked_flip; p.y = dX; p.ldy = ldx;
+    p.B = B; p.H = H; p.W = W; p.K = K; p.N = N; p.Cq = N;
+    p.bx = yraw; p.ldbx = ldy; p.b_scale = scale; p.b_shift = shift; p.b_mean = save_mean; p.b_invstd = save_invstd; p.bstats = bstats;
+    fill_tiles(p);
+    CMU_DISPATCH_DT(dt, conv3x3_fwd_t, p, (hipStream_t)stream);
+}
+
+extern "C" int cmu_convT2x2_dgrad_bn(const void* dOut, int64_t ldd, const void* wpacked_dgrad, void* dX, int64_t ldx, const void* yraw,
+                                     int64_t ldy, const float* scale, const float* shift, const float* save_mean,
+                                     const float* save_invstd, float* bstats, int B, int H, int W, int Cin, int Cout, int dt,
+                                     void* stream) {
+    CMU_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "cmu_convT2x2_dgrad_bn: bad dims");
+    CMU_CHECK_ARG(cmu_dtype_size(dt) > 0, "cmu_convT2x2_dgrad_bn: bad dtype %d", dt);
+    int rc;
+    if ((rc = check_act("cmu_convT2x2_dgrad_bn(dOut)", dOut, ldd, Cout, dt))) return rc;
+    if ((rc = check_act("cmu_convT2x2_dgrad_bn(dX)", dX, ldx, Cin, dt))) return rc;
+    if ((rc = check_bnstats("cmu_convT2x2_dgrad_bn(yraw)", yraw, ldy, scale, shift, save_mean, save_invstd, bstats, Cin, dt))) return rc;
+    CMU_CHECK_ARG(wpacked_dgrad && cmu_aligned16(wpacked_dgrad), "cmu_convT2x2_dgrad_bn: packed weights null/unaligned");
+    IGParams p = {};
+    p.x = dOut; p.ldx = ldd; p.w = wpacked_dgrad; p.y = dX; p.ldy = ldx;
+    p.B = B; p.H = H; p.W = W; p.K = Cout; p.N = Cin; p.Cq = Cout;
+    p.bx = yraw; p.ldbx = ldy; p.b_scale = scale; p.b_shift = shift; p.b_mean = save_mean; p.b_invstd = save_invstd; p.bstats = bstats;
     fill_tiles(p);
     CMU_DISPATCH_DT(dt, convT_dgrad_t, p, (hipStream_t)stream);
 }

@@ -224,6 +224,45 @@ extern "C" int cmu_bn_finalize(const float* stats, int ntiles, int64_t count, co
     return CMU_OK;
 }
 
+// BatchNorm backward phase 1 from a per-tile slab written by the data-gradient kernels (cmu_conv3x3_dgrad_bn,
+// cmu_convT2x2_dgrad_bn): same two-level fixed-order reduction as the forward statistics
+__global__ void bn_bwd_final_tiles_kernel(const double* __restrict__ ws, int nsplit, double count, float* dgamma, float* dbeta,
+                                          float* coef, int C) {
+    __shared__ double red[2][16][16];
+    const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int s = part; s < nsplit; s += 16) {
+            s1 += ws[((int64_t)s * 2 + 0) * C + c];
+            s2 += ws[((int64_t)s * 2 + 1) * C + c];
+        }
+    red[0][part][cl] = s1;
+    red[1][part][cl] = s2;
+    __syncthreads();
+    if (part != 0 || c >= C) return;
+    s1 = 0.0; s2 = 0.0;
+    for (int q = 0; q < 16; ++q) { s1 += red[0][q][cl]; s2 += red[1][q][cl]; }
+    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma) dgamma[c] = (float)s2;
+    coef[c] = (float)(s1 / count);
+    coef[C + c] = (float)(s2 / count);
+}
+extern "C" int cmu_bn_bwd_finalize_tiles(const float* bstats, int ntiles, int64_t count, float* dgamma, float* dbeta, float* coef, int C,
+                                         void* ws, void* stream) {
+    CMU_CHECK_ARG(bstats && coef && ws && C > 0 && ntiles > 0 && count > 0, "cmu_bn_bwd_finalize_tiles: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    int nsplit = ntiles / 16;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > BN_MAX_SPLITS) nsplit = BN_MAX_SPLITS;
+    hipLaunchKernelGGL(bn_reduce_slab_kernel, dim3(cmu_div_up(C, 64), nsplit), dim3(256), 0, st, bstats, ntiles, C, nsplit, (double*)ws);
+    CMU_CHECK_LAUNCH("cmu_bn_bwd_finalize_tiles(reduce)");
+    hipLaunchKernelGGL(bn_bwd_final_tiles_kernel, dim3(cmu_div_up(C, 16)), dim3(256), 0, st, (const double*)ws, nsplit, (double)count,
+                       dgamma, dbeta, coef, C);
+    CMU_CHECK_LAUNCH("cmu_bn_bwd_finalize_tiles");
+    return CMU_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // first layer: Conv2d(1, Cout, 3, p=1) direct, optional patch-mask multiply fused into the load
 // ---------------------------------------------------------------------------------------------

@@ -125,16 +125,28 @@ class UNetEngine:
     def _bn_ws(self, C):
         return self.scratch.get("bnbwd", self.lib.cmu_bn_bwd_ws_bytes(C))
 
-    def _convbn_bwd(self, sd, s, dA, grads, need_dx, dx_out=None, fused_stats=False):
+    def _tile_slab(self, y):
+        """Shared per-tile statistics slab for the data-gradient kernels that fuse the next BN-backward reduction."""
+        n = ops.ntiles(y.B, y.H, y.W)
+        return self.scratch.get("bst", n * 2 * y.C * 4)[:n * 2 * y.C * 4].view(torch.float32).view(n, 2, y.C)
+
+    def _convbn_bwd(self, sd, s, dA, grads, need_dx, dx_out=None, fused_stats=False, next_bn=None):
         """``fused_stats``: the kernel that produced dA already wrote this layer's BN-backward partial sums into
-        the shared slab (max-pool / head backward) -- only the finalisation is left of phase 1."""
+        the shared slab (max-pool / head backward) -- only the finalisation is left of phase 1.  The same holds when the
+        producer was a data-gradient kernel, which leaves a per-tile slab in ``s["bstats"]``.
+        ``next_bn``: saved state of the conv+BN layer whose activated output is this conv's input: its BN-backward
+        partial sums are produced by this layer's data-gradient kernel (consumed by the next ``_convbn_bwd`` call)."""
         y = s["y"]
         B, H, W, C = y.B, y.H, y.W, y.C
         w = sd[s["pconv"] + "weight"]
         dgamma, dbeta = self._gbuf(s["pbn"] + "weight", sd[s["pbn"] + "weight"]), self._gbuf(s["pbn"] + "bias", sd[s["pbn"] + "bias"])
         coef = self._f32(2, C)
         ws = self._bn_ws(C)
-        if fused_stats:
+        bst = s.pop("bstats", None)
+        if bst is not None:
+            ops.bn_bwd_finalize_tiles(bst, B * H * W, dgamma, dbeta, coef,
+                                      self.scratch.get("bnfin", self.lib.cmu_bn_finalize_ws_bytes(C)))
+        elif fused_stats:
             ops.bn_bwd_finalize(ws, B * H * W, dgamma, dbeta, coef)
         else:
             ops.bn_bwd_reduce(dA, y, s["mean"], s["invstd"], dgamma, dbeta, coef, ws)
@@ -158,7 +170,12 @@ class UNetEngine:
         if not need_dx or s["x_img"] is not None:
             return None
         dX = dx_out if dx_out is not None else self._new(B, H, W, w.shape[1])
-        ops.conv3x3_fwd(dY, self._wp(s["pconv"], w, True), dX, None)
+        if next_bn is not None and next_bn["y"].C == dX.C:
+            slab = self._tile_slab(next_bn["y"])
+            ops.conv3x3_dgrad_bn(dY, self._wp(s["pconv"], w, True), dX, next_bn["y"], next_bn["mean"], next_bn["invstd"], slab)
+            next_bn["bstats"] = slab
+        else:
+            ops.conv3x3_fwd(dY, self._wp(s["pconv"], w, True), dX, None)
         return dX
 
     # ------------------------------------------------------------------------------------------
@@ -201,7 +218,7 @@ class UNetEngine:
     def encoder_backward(self, sd, ctx, d_latent, d_skips, grads):
         """d_latent: Act (gradient w.r.t. the activated latent); d_skips[i]: Act or None."""
         b = ctx["bott"]
-        dA = self._convbn_bwd(sd, b["s2"], d_latent, grads, True)
+        dA = self._convbn_bwd(sd, b["s2"], d_latent, grads, True, next_bn=b["s1"])
         dP = self._convbn_bwd(sd, b["s1"], dA, grads, len(ctx["levels"]) > 0)
         for i in range(len(ctx["levels"]), 0, -1):
             lv = ctx["levels"][i - 1]
@@ -209,7 +226,7 @@ class UNetEngine:
             dA2 = self._new(y2.B, y2.H, y2.W, y2.C)
             ops.maxpool_bwd(dP, d_skips[i - 1] if d_skips is not None else None, y2, dA2, lv["s2"]["mean"], lv["s2"]["invstd"],
                             self._bn_ws(y2.C))
-            dA1 = self._convbn_bwd(sd, lv["s2"], dA2, grads, True, fused_stats=True)
+            dA1 = self._convbn_bwd(sd, lv["s2"], dA2, grads, True, fused_stats=True, next_bn=lv["s1"])
             dP = self._convbn_bwd(sd, lv["s1"], dA1, grads, i > 1)
         return None
 
@@ -275,8 +292,11 @@ class UNetEngine:
             ctx["logits"] = logits
         return ctx
 
-    def decoder_backward(self, sd, ctx, dlogits, grads, need_input_grads=True):
-        """Returns (d_latent Act, [d_skip Acts]) -- d_skip[i-1] is the right half of level i's concat gradient."""
+    def decoder_backward(self, sd, ctx, dlogits, grads, need_input_grads=True, latent_bn=None):
+        """Returns (d_latent Act, [d_skip Acts]) -- d_skip[i-1] is the right half of level i's concat gradient.
+        ``latent_bn``: saved state of the conv+BN layer that produced the latent, when d_latent goes straight into its
+        backward (no other gradient is added to it): the deepest ConvTranspose's data-gradient kernel then also produces
+        that layer's BN-backward partial sums."""
         prefix = ctx["prefix"]
         x = ctx["out"]
         K = sd[prefix + "conv_last.weight"].shape[0]
@@ -297,7 +317,7 @@ class UNetEngine:
             p = f"{prefix}up_conv{i}."
             cat = lv["cat"]
             Cup, Cs = cat["Cup"], cat["Cskip"]
-            dA1 = self._convbn_bwd(sd, lv["s2"], dA, grads, True, fused_stats=(fused and i == 1))
+            dA1 = self._convbn_bwd(sd, lv["s2"], dA, grads, True, fused_stats=(fused and i == 1), next_bn=lv["s1"])
             dcat = self._convbn_bwd(sd, lv["s1"], dA1, grads, True)
             d_skips[i - 1] = Act(dcat.buf, Cup, Cs)
             dleft = Act(dcat.buf, 0, Cup)
@@ -310,7 +330,14 @@ class UNetEngine:
             grads[p + "up_sample.bias"] = dbt
             if i < nup or need_input_grads:
                 dA = self._new(xu.B, xu.H, xu.W, xu.C)
-                ops.convT2x2_dgrad(dleft, self._wpT(p + "up_sample.", wt, 1), dA)
+                # the layer that produced this ConvTranspose's input: the next decoder level's second conv, or the latent's
+                tgt = ctx["levels"][i]["s2"] if i < nup else latent_bn
+                if tgt is not None and tgt["y"].buf is xu.buf and tgt["y"].coff == xu.coff and tgt["y"].C == xu.C:
+                    slab = self._tile_slab(tgt["y"])
+                    ops.convT2x2_dgrad_bn(dleft, self._wpT(p + "up_sample.", wt, 1), dA, tgt["y"], tgt["mean"], tgt["invstd"], slab)
+                    tgt["bstats"] = slab
+                else:
+                    ops.convT2x2_dgrad(dleft, self._wpT(p + "up_sample.", wt, 1), dA)
             else:
                 dA = None
         return dA, d_skips
@@ -328,6 +355,6 @@ class UNetEngine:
 
     def unet_backward(self, sd, ctx, dlogits):
         grads = {}
-        d_latent, d_skips = self.decoder_backward(sd, ctx["dec"], dlogits, grads, True)
+        d_latent, d_skips = self.decoder_backward(sd, ctx["dec"], dlogits, grads, True, latent_bn=ctx["enc"]["bott"]["s2"])
         self.encoder_backward(sd, ctx["enc"], d_latent, d_skips, grads)
         return grads

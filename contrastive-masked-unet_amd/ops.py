@@ -215,6 +215,26 @@ def bn_bwd_finalize(bn_ws, count, dgamma, dbeta, coef):
     call("cmu_bn_bwd_finalize", _p(bn_ws), int(count), _p(dgamma), _p(dbeta), _p(coef), coef.shape[1], _stream())
 
 
+def bn_bwd_finalize_tiles(bstats, count, dgamma, dbeta, coef, ws):
+    """Phase 1 of BatchNorm backward from the per-tile slab written by conv3x3_dgrad_bn / convT2x2_dgrad_bn."""
+    call("cmu_bn_bwd_finalize_tiles", _p(bstats), bstats.shape[0], int(count), _p(dgamma), _p(dbeta), _p(coef), coef.shape[1], _p(ws),
+         _stream())
+
+
+def conv3x3_dgrad_bn(dY, wpacked_flip, dX, y, save_mean, save_invstd, bstats):
+    """dX = data gradient of a 3x3 conv; ``y``: Act of the raw output (+ pending BN transform) of the layer whose activated
+    output is the conv's input -- its BatchNorm+ReLU backward partial sums go to ``bstats`` (new_stats shape)."""
+    call("cmu_conv3x3_dgrad_bn", dY.ptr(), dY.ld, _p(wpacked_flip), dX.ptr(), dX.ld, y.ptr(), y.ld, _p(y.scale), _p(y.shift),
+         _p(save_mean), _p(save_invstd), _p(bstats), dX.B, dX.H, dX.W, dY.C, dX.C, dX.dt, _stream(),
+         work=2.0 * 9 * dY.C * dX.C * dX.B * dX.H * dX.W)
+
+
+def convT2x2_dgrad_bn(dOut, wpacked_dgrad, dX, y, save_mean, save_invstd, bstats):
+    call("cmu_convT2x2_dgrad_bn", dOut.ptr(), dOut.ld, _p(wpacked_dgrad), dX.ptr(), dX.ld, y.ptr(), y.ld, _p(y.scale), _p(y.shift),
+         _p(save_mean), _p(save_invstd), _p(bstats), dX.B, dX.H, dX.W, dX.C, dOut.C, dX.dt, _stream(),
+         work=2.0 * 4 * dX.C * dOut.C * dX.B * dX.H * dX.W)
+
+
 def convT2x2_dgrad(dOut, wpacked_dgrad, dX):
     call("cmu_convT2x2_dgrad", dOut.ptr(), dOut.ld, _p(wpacked_dgrad), dX.ptr(), dX.ld, dX.B, dX.H, dX.W, dX.C, dOut.C,
          dX.dt, _stream(), work=2.0 * 4 * dX.C * dOut.C * dX.B * dX.H * dX.W)

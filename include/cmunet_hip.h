@@ -121,6 +121,17 @@ int cmu_bn_bwd_reduce(const void* dA, int64_t ldd, const void* y, int64_t ldy, c
 /* finalisation of a slab written by a fused producer (cmu_maxpool_bwd / cmu_conv1x1_head_bwd with bn_ws):
  * dgamma, dbeta (nullable) and coef[2][C], summed in row order (bitwise reproducible).                          */
 int cmu_bn_bwd_finalize(const void* bn_ws, int64_t count, float* dgamma, float* dbeta, float* coef, int C, void* stream);
+/* Same phase-1 result from a per-tile slab [cmu_conv_ntiles][2][C] written by cmu_conv3x3_dgrad_bn /
+ * cmu_convT2x2_dgrad_bn.  ws: cmu_bn_finalize_ws_bytes(C).                                                       */
+int cmu_bn_bwd_finalize_tiles(const float* bstats, int ntiles, int64_t count, float* dgamma, float* dbeta, float* coef, int C,
+                              void* ws, void* stream);
+/* Data gradient of Conv2d 3x3 (autograd of model.py:17,20): cmu_conv3x3_fwd on dY with the flipped pack, plus -- in the
+ * epilogue, from the stored dX and the raw output ``yraw`` of the conv+BN+ReLU layer that produced the conv's input --
+ * that layer's BatchNorm+ReLU backward partial sums (replaces a separate cmu_bn_bwd_reduce pass over dX and yraw).
+ * K = channels of dY, N = channels of dX.                                                                        */
+int cmu_conv3x3_dgrad_bn(const void* dY, int64_t ldd, const void* wpacked_flip, void* dX, int64_t ldx, const void* yraw, int64_t ldy,
+                         const float* scale, const float* shift, const float* save_mean, const float* save_invstd, float* bstats,
+                         int B, int H, int W, int K, int N, int dt, void* stream);
 /* phase 2: dY = scale * (dz - coef0 - xhat*coef1), written to dY (may alias dA). */
 int cmu_bn_bwd_apply(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift,
                      const float* save_mean, const float* save_invstd, const float* coef, void* dY, int64_t ldo,
@@ -151,6 +162,11 @@ int cmu_maxpool_bwd(const void* dP, int64_t ldp, const void* dSkip, int64_t lds,
  * weight: dW (Cin,Cout,2,2) and dbias (Cout) fp32, overwritten.                                    */
 int cmu_convT2x2_dgrad(const void* dOut, int64_t ldd, const void* wpacked_dgrad, void* dX, int64_t ldx,
                        int B, int H, int W, int Cin, int Cout, int dt, void* stream);
+/* cmu_convT2x2_dgrad + the BatchNorm+ReLU backward partial sums of the layer that produced the ConvTranspose's input
+ * (see cmu_conv3x3_dgrad_bn).                                                                                     */
+int cmu_convT2x2_dgrad_bn(const void* dOut, int64_t ldd, const void* wpacked_dgrad, void* dX, int64_t ldx, const void* yraw,
+                          int64_t ldy, const float* scale, const float* shift, const float* save_mean, const float* save_invstd,
+                          float* bstats, int B, int H, int W, int Cin, int Cout, int dt, void* stream);
 int64_t cmu_convT2x2_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int dt);
 int cmu_convT2x2_wgrad(const void* x, int64_t ldx, const float* in_scale, const float* in_shift, int relu_from,
                        const void* dOut, int64_t ldd, float* dW, float* dbias,

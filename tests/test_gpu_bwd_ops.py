@@ -302,3 +302,65 @@ def test_l2norm_ema_adam(ops):
             opt.step()
             ops.adam_step(pd, gr.cuda(), m, v, None, 1e-3, 0.9, 0.95, 1e-8, wd, decoupled, step)
         check(pd.cpu(), p.detach(), 1e-5, f"adam decoupled={decoupled} wd={wd}")
+
+
+def _bn_bwd_sums(dx_stored, y, scale, shift, mean, invstd):
+    """sum(gate*dX), sum(gate*dX*xhat) per channel, fp64, gate evaluated as the kernels do (fp32 scale/shift)."""
+    gate = (y.float() * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)) > 0
+    dz = dx_stored.double() * gate
+    xhat = (y.double() - mean.double().view(1, -1, 1, 1)) * invstd.double().view(1, -1, 1, 1)
+    return dz.sum((0, 2, 3)), (dz * xhat).sum((0, 2, 3))
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape", [(2, 18, 21, 24, 40), (1, 18, 37, 128, 64), (2, 16, 32, 64, 128), (1, 33, 40, 64, 256)])
+def test_conv3x3_dgrad_bn(ops, dt, shape):
+    """Data gradient + fused BatchNorm-backward partial sums of the producer layer (first and wide-tile kernels)."""
+    from cmunet_amd import _lib
+    B, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(31)
+    dy = q(torch.randn(B, Cout, H, W, generator=g), dt, ops)
+    w = q(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cout * 9) ** 0.5, dt, ops)
+    y = q(torch.randn(B, Cin, H, W, generator=g) * 1.5 + 0.2, dt, ops)          # raw output of the producer layer
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    mean, invstd, scale, shift = bn_consts(y, gamma, beta)
+    ya = to_act(y, dt, ops, ld=Cin + 16, coff=16).with_transform(scale.cuda(), shift.cuda(), 0)
+    dx = ops.new_act(B, H, W, Cin, dt, "cuda")
+    slab = ops.new_stats(B, H, W, Cin, "cuda")
+    ops.conv3x3_dgrad_bn(to_act(dy, dt, ops), ops.pack_conv3x3(w.cuda(), dt, transpose_flip=True), dx, ya, mean.cuda(), invstd.cuda(), slab)
+    ref = torch.nn.grad.conv2d_input((B, Cin, H, W), w.double(), dy.double(), padding=1)
+    check(from_act(dx), ref, TOL[dt], "dgrad dx")
+    s1, s2 = _bn_bwd_sums(from_act(dx), y, scale, shift, mean, invstd)
+    got = slab.double().sum(0).cpu()
+    check(got[0], s1, 2e-4, "sum gate*dX")
+    check(got[1], s2, 2e-4, "sum gate*dX*xhat")
+    # and the two-level finalisation of that slab
+    dgamma, dbeta, coef = torch.empty(Cin, device="cuda"), torch.empty(Cin, device="cuda"), torch.empty(2, Cin, device="cuda")
+    ops.bn_bwd_finalize_tiles(slab, B * H * W, dgamma, dbeta, coef, ws_bytes(_lib.lib().cmu_bn_finalize_ws_bytes(Cin)))
+    check(dbeta.cpu(), s1, 2e-4, "dbeta")
+    check(dgamma.cpu(), s2, 2e-4, "dgamma")
+    check(coef.cpu()[0], s1 / (B * H * W), 2e-4, "coef mean(dz)")
+    check(coef.cpu()[1], s2 / (B * H * W), 2e-4, "coef mean(dz*xhat)")
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape", [(2, 8, 8, 32, 16), (1, 5, 9, 64, 32), (2, 16, 16, 128, 64)])
+def test_convT2x2_dgrad_bn(ops, dt, shape):
+    B, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(33)
+    dout = q(torch.randn(B, Cout, 2 * H, 2 * W, generator=g), dt, ops)
+    w = q(torch.randn(Cin, Cout, 2, 2, generator=g) / (Cout * 4) ** 0.5, dt, ops)
+    y = q(torch.randn(B, Cin, H, W, generator=g) * 1.5 + 0.2, dt, ops)
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    mean, invstd, scale, shift = bn_consts(y, gamma, beta)
+    ya = to_act(y, dt, ops).with_transform(scale.cuda(), shift.cuda(), 0)
+    dx = ops.new_act(B, H, W, Cin, dt, "cuda")
+    slab = ops.new_stats(B, H, W, Cin, "cuda")
+    ops.convT2x2_dgrad_bn(to_act(dout, dt, ops, ld=2 * Cout, coff=0), ops.pack_convT2x2(w.cuda(), dt, 1), dx, ya, mean.cuda(),
+                          invstd.cuda(), slab)
+    ref = F.conv2d(dout.double(), w.double(), stride=2)
+    check(from_act(dx), ref, TOL[dt], "convT dgrad")
+    s1, s2 = _bn_bwd_sums(from_act(dx), y, scale, shift, mean, invstd)
+    got = slab.double().sum(0).cpu()
+    check(got[0], s1, 2e-4, "sum gate*dX")
+    check(got[1], s2, 2e-4, "sum gate*dX*xhat")
