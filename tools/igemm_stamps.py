@@ -58,6 +58,19 @@ if not hasattr(lib, "cmu_debug_ig_stamps"):
 buf = np.zeros(64 * NST * 8, dtype=np.uint64)
 rc = lib.cmu_debug_ig_stamps(buf.ctypes.data_as(ctypes.c_void_p))
 assert rc == 0
+GROUPS = int(sys.argv[9]) if len(sys.argv) > 9 else 1    # wide kernel: 2 (waves 0 and 4 stamp), 32 blocks
+if GROUPS == 2:
+    st2 = buf.reshape(32, 2, NST, 8).astype(np.int64)
+    for grp in range(2):
+        stg = st2[:, grp]
+        stg = stg[stg[:, 0, 0] > 0][:, :min(NST, int(sys.argv[8]))]
+        print(f"wave {4 * grp}: blocks {stg.shape[0]}")
+        nm = sys.argv[7].split(",")
+        for k in range(NPH - 1):
+            d = stg[:, 1:, k + 1] - stg[:, 1:, k]
+            print(f"  {nm[k]:12s} avg {d.mean():8.0f} cyc  (min {d.min()}, max {d.max()})")
+        print(f"  per-step total avg {(stg[:, 2:, 0] - stg[:, 1:-1, 0]).mean():.0f} cyc")
+    sys.exit(0)
 st = buf.reshape(64, NST, 8).astype(np.int64)
 names = sys.argv[7].split(",") if len(sys.argv) > 7 else ["barrier1", "store_stage", "barrier2", "load_issue", "mfma_phase", "loop"]
 ns = min(NST, int(sys.argv[8]) if len(sys.argv) > 8 else (Cin * 2 + 63) // 64)
