@@ -151,7 +151,8 @@ def main():
     if rank == 0 and prof is not None:
         summ = prof.summary()
         tot_ms = sum(v["ms"] for v in summ.values())
-        mf = {k: v for k, v in summ.items() if v["work"] > 0}
+        # the MFMA entries grouped by the kernel that served them (rocprofv3 lists kernels, not entry points)
+        mf = prof.by_kernel()
         name = max(mf, key=lambda k: mf[k]["ms"])
         d = mf[name]
         ach = d["work"] / (d["ms"] * 1e-3) / 1e12
@@ -167,11 +168,13 @@ def main():
         except (OSError, ValueError, KeyError):
             traffic = None
         out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "GB/launch (PMC, profiles/traffic.json)",
+                           "entries": sorted(d["entries"]), "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "GB/launch (PMC, profiles/traffic.json)",
                            "algorithmic_gflop_per_launch": round(d["work"] / d["calls"] / 1e9, 1),
                            "launches_per_step": d["calls"] // args.steps,
                            "avg_launch_ms": round(d["ms"] / d["calls"], 4),
                            "share_of_kernel_time": round(d["ms"] / tot_ms, 3)}
+        out["mfma_kernels"] = {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "launches_per_step": v["calls"] // args.steps,
+                                   "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in mf.items()}
         out["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
         flops_step = sum(v["work"] for v in summ.values()) / args.steps
         out["step_mfma_tflops"] = round(flops_step / (elapsed / args.steps) / 1e12, 2)

@@ -21,6 +21,7 @@ _F = ctypes.c_float
 # name -> (restype, argtypes); mirrors include/cmunet_hip.h one to one.
 _SIGS = {
     "cmu_last_error": (ctypes.c_char_p, []),
+    "cmu_last_kernel": (ctypes.c_char_p, []),
     "cmu_version": (_I, []),
     "cmu_dtype_size": (_I, [_I]),
     "cmu_pack_conv3x3_elems": (_L, [_I, _I, _I, _I]),
@@ -128,17 +129,32 @@ class EventProfiler:
     ``work`` is the algorithmic FLOP (or byte) count the caller attributes to the launch."""
 
     def __init__(self):
-        self.records = []      # (name, start_event, end_event, work)
+        self.records = []      # (name, start_event, end_event, work, kernel tag)
 
     def summary(self):
         import torch
         torch.cuda.synchronize()
         out = {}
-        for name, e0, e1, work in self.records:
+        for name, e0, e1, work, _ in self.records:
             d = out.setdefault(name, {"ms": 0.0, "calls": 0, "work": 0.0})
             d["ms"] += e0.elapsed_time(e1)
             d["calls"] += 1
             d["work"] += work
+        return out
+
+    def by_kernel(self):
+        """The MFMA entries (work > 0) grouped by the compute kernel that served them (cmu_last_kernel)."""
+        import torch
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1, work, tag in self.records:
+            if work <= 0 or not tag:
+                continue
+            d = out.setdefault(tag, {"ms": 0.0, "calls": 0, "work": 0.0, "entries": set()})
+            d["ms"] += e0.elapsed_time(e1)
+            d["calls"] += 1
+            d["work"] += work
+            d["entries"].add(name)
         return out
 
 
@@ -157,7 +173,7 @@ def call(name, *args, work=0.0):
         e0.record()
         rc = fn(*args)
         e1.record()
-        PROFILER.records.append((name, e0, e1, work))
+        PROFILER.records.append((name, e0, e1, work, l.cmu_last_kernel().decode() if work > 0 else ""))
     else:
         rc = fn(*args)
     if rc != 0:

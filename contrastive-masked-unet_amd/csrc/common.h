@@ -10,6 +10,7 @@
 // error plumbing
 // ---------------------------------------------------------------------------------------------
 void cmu_set_error(const char* fmt, ...);
+void cmu_set_kernel_tag(const char* tag);
 
 #define CMU_CHECK_ARG(cond, ...)                 \
     do {                                         \

@@ -476,6 +476,7 @@ static int launch_igemm(const IGParams& p, hipStream_t st, const char* name) {
         attr_set = true;
     }
     hipLaunchKernelGGL((conv_igemm_kernel<TR, MODE>), dim3((unsigned)p.total_blocks), dim3(256), C::LDS_BYTES, st, p);
+    cmu_set_kernel_tag("conv_igemm_kernel");
     CMU_CHECK_LAUNCH(name);
     return CMU_OK;
 }

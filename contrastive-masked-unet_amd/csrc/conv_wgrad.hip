@@ -464,6 +464,7 @@ static int wgradT_wide_t(WGParams p, float* dW, float* dbias, hipStream_t st) {
     pp.dty = (p.splitk / p.tilesX) % p.tilesY;
     pp.dtb = p.splitk / (p.tilesX * p.tilesY);
     hipLaunchKernelGGL((conv_wgradT2_kernel<TR>), dim3(p.nAB * p.nBB * p.splitk), dim3(512), C::LDS_BYTES, st, pp);
+    cmu_set_kernel_tag("conv_wgradT2_kernel");
     CMU_CHECK_LAUNCH("cmu_convT2x2_wgrad(wide)");
     const int64_t total = (int64_t)4 * p.CA * p.CB;
     const int grid = (int)(cmu_div_up64(total, 64) < 8192 ? cmu_div_up64(total, 64) : 8192);
@@ -493,6 +494,7 @@ static int wgrad3_wide_t(WGParams p, float* dW, hipStream_t st) {
     pp.dty = (p.splitk / p.tilesX) % p.tilesY;
     pp.dtb = p.splitk / (p.tilesX * p.tilesY);
     hipLaunchKernelGGL((conv_wgrad2_kernel<TR>), dim3(p.nAB * p.nBB * p.splitk), dim3(512), C::LDS_BYTES, st, pp);
+    cmu_set_kernel_tag("conv_wgrad2_kernel");
     CMU_CHECK_LAUNCH("cmu_conv3x3_wgrad(wide)");
     const int64_t total = (int64_t)9 * p.CA * p.CB;
     const int grid = (int)(cmu_div_up64(total, 64) < 8192 ? cmu_div_up64(total, 64) : 8192);
@@ -517,6 +519,7 @@ static int launch_wgrad(const WGParams& p, hipStream_t st, const char* name) {
     }
     const int grid = p.nAB * p.nBB * p.splitk * (MODE == MODE_WT ? 4 : 1);
     hipLaunchKernelGGL((conv_wgrad_kernel<TR, MODE>), dim3(grid), dim3(512), C::LDS_BYTES, st, p);
+    cmu_set_kernel_tag("conv_wgrad_kernel");
     CMU_CHECK_LAUNCH(name);
     return CMU_OK;
 }

@@ -18,6 +18,11 @@ void cmu_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* cmu_last_error(void) { return g_err; }
+// name of the compute kernel the calling thread launched last through a GEMM-shaped entry point (several kernels serve
+// cmu_conv3x3_fwd / _wgrad): lets a profiler attribute the entry's time to the kernel rocprofv3 will list
+static thread_local const char* g_kernel_tag = "";
+void cmu_set_kernel_tag(const char* tag) { g_kernel_tag = tag; }
+extern "C" const char* cmu_last_kernel(void) { return g_kernel_tag; }
 extern "C" int cmu_version(void) { return 100; }
 extern "C" int cmu_dtype_size(int dt) { return dt == CMU_F32 ? 4 : (dt == CMU_F16 || dt == CMU_BF16) ? 2 : 0; }
 

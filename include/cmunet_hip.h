@@ -38,6 +38,8 @@ typedef enum { CMU_F32 = 0, CMU_F16 = 1, CMU_BF16 = 2 } cmu_dtype;
 #define CMU_ERR_LAUNCH (-4)   /* hipGetLastError() != hipSuccess after a launch */
 
 const char* cmu_last_error(void);
+/* name of the compute kernel the calling thread's last GEMM-shaped entry launched ("" if none): for profilers */
+const char* cmu_last_kernel(void);
 int cmu_version(void);
 /* element size in bytes of a cmu_dtype */
 int cmu_dtype_size(int dt);

@@ -260,9 +260,11 @@ def test_bad_args_fail_loudly(ops):
         ops.conv3x3_fwd(a, w, o, None)
 
 
-def test_conv3x3_wide_tile_kernel_matches_first():
-    """The wide-tile kernel (conv_igemm3.inc) computes the same convolution as the first one, which CMU_CONV_WIDE=0
-    selects for every layer (different fp32 summation order only): run both in subprocesses and compare."""
+@pytest.mark.parametrize("chans,wide", [((256, 256), "1"), ((64, 64), "2"), ((128, 64), "2")])
+def test_conv3x3_wide_tile_kernel_matches_first(chans, wide):
+    """The wide-tile kernels (conv_igemm3.inc; CMU_CONV_WIDE=2 also sends 64-channel layers with few input channels to
+    the 32-byte-slice variant) compute the same convolution as the first kernel, which CMU_CONV_WIDE=0 selects for every
+    layer (different fp32 summation order only): run both in subprocesses and compare."""
     import os
     import subprocess
     import sys
@@ -275,7 +277,7 @@ import sys, torch
 sys.path.insert(0, %r)
 from cmunet_amd import ops
 g = torch.Generator().manual_seed(0)
-B, H, W, Cin, Cout = 2, 20, 33, 256, 256
+B, H, W, Cin, Cout = 2, 20, 33, %d, %d
 x = torch.randn(B, H, W, Cin, generator=g).to(torch.bfloat16).cuda()
 w = (torch.randn(Cout, Cin, 3, 3, generator=g) / 48).cuda()
 sc, sh = (torch.rand(Cin, generator=g) + 0.5).cuda(), (torch.randn(Cin, generator=g) * 0.3).cuda()
@@ -283,12 +285,12 @@ y = ops.new_act(B, H, W, Cout, "bf16", "cuda")
 st = ops.new_stats(B, H, W, Cout, "cuda")
 ops.conv3x3_fwd(ops.Act(x, 0, Cin, sc, sh, 0), ops.pack_conv3x3(w, "bf16"), y, st)
 torch.save({"y": y.buf.float().cpu(), "s": st.sum(0).cpu()}, sys.argv[1])
-''' % root
+''' % (root, chans[0], chans[1])
     outs = []
-    for wide in ("0", "1"):
+    for v in ("0", wide):
         with tempfile.NamedTemporaryFile(suffix=".pt", delete=False) as f:
             path = f.name
-        subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, CMU_CONV_WIDE=wide), timeout=300)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, CMU_CONV_WIDE=v), timeout=300)
         outs.append(torch.load(path))
         os.unlink(path)
     check(outs[1]["y"], outs[0]["y"], 8e-3, "wide vs first y (bf16 rounding of different fp32 sums)")
