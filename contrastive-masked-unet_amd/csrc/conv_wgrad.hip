@@ -395,12 +395,23 @@ __global__ void channel_sum_final_kernel(const float* __restrict__ ws, int nbloc
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
-static int wg_splitk(int nbase, int ntiles, int mult) {
-    // aim at ~512 workgroups (two rounds over 256 CUs); every split gets at least one tile
-    int s = 512 / (nbase * mult);
+static int wg_splitk(int nbase, int ntiles, int mult, int target = 512) {
+    // aim at ~target workgroups (512: two rounds over 256 CUs); every split gets at least one tile
+    int s = target / (nbase * mult);
     if (s < 1) s = 1;
     if (s > ntiles) s = ntiles;
     return s;
+}
+// the wide kernels hold one workgroup per CU (LDS): 256 workgroups are exactly one round over the chip, and every
+// workgroup writes its whole accumulator tile to the split-K slab -- half the workgroups is half the slab traffic of
+// the reduction (1.1 ms per bench step at 512).  CMU_WGRAD_BLOCKS overrides (A/B).
+static int cmu_wg_first_target() {
+    static const int v = []() { const char* e = getenv("CMU_WGRAD_BLOCKS1"); const int n = e ? atoi(e) : 512; return n >= 8 ? n : 512; }();
+    return v;
+}
+static int cmu_wg_wide_target() {
+    static const int v = []() { const char* e = getenv("CMU_WGRAD_BLOCKS"); const int n = e ? atoi(e) : 256; return n >= 8 ? n : 256; }();
+    return v;
 }
 static void wg_geometry(int B, int H, int W, int CA, int CB, int dt, int mult, WGParams& p) {
     const int CW = 128 / cmu_dtype_size(dt);
@@ -411,7 +422,7 @@ static void wg_geometry(int B, int H, int W, int CA, int CB, int dt, int mult, W
     p.nBB = cmu_div_up(CB, CW);
     p.CApad = p.nAB * CW;
     p.CBpad = p.nBB * CW;
-    p.splitk = wg_splitk(p.nAB * p.nBB, p.ntiles, mult);
+    p.splitk = wg_splitk(p.nAB * p.nBB, p.ntiles, mult, mult == 1 ? cmu_wg_first_target() : 512);
 }
 constexpr int CSUM_BLOCKS = 256;
 
@@ -429,7 +440,7 @@ static void wg2_geometry(int B, int H, int W, int CA, int CB, WGParams& p) {
     p.nBB = CB / 64;
     p.CApad = CA;
     p.CBpad = CB;
-    p.splitk = wg_splitk(p.nAB * p.nBB, p.ntiles, 1);
+    p.splitk = wg_splitk(p.nAB * p.nBB, p.ntiles, 1, cmu_wg_wide_target());
 }
 static bool wgT2_shape_ok(int CA, int CB, int dt) {
     static const bool on = []() { const char* e = getenv("CMU_WGRAD_WIDE"); return !(e && e[0] == '0'); }();
@@ -443,7 +454,7 @@ static void wgT2_geometry(int B, int H, int W, int CA, int CB, WGParams& p) {
     p.nBB = CB / 128;
     p.CApad = CA;
     p.CBpad = CB;
-    p.splitk = wg_splitk(p.nAB * p.nBB, p.ntiles, 1);
+    p.splitk = wg_splitk(p.nAB * p.nBB, p.ntiles, 1, cmu_wg_wide_target());
 }
 template <class TR>
 static int wgradT_wide_t(WGParams p, float* dW, float* dbias, hipStream_t st) {
