@@ -353,8 +353,12 @@ class UNetEngine:
         dctx = self.decoder_forward(sd, ectx["latent"], ectx["skips"], training, "", cats, True)
         return dctx["logits"], {"enc": ectx, "dec": dctx}
 
-    def unet_backward(self, sd, ctx, dlogits):
+    def unet_backward(self, sd, ctx, dlogits, after_decoder=None):
+        """``after_decoder``: called when every decoder parameter gradient has been queued (data-parallel trainers start
+        the decoder's all-reduce there, under the encoder backward)."""
         grads = {}
         d_latent, d_skips = self.decoder_backward(sd, ctx["dec"], dlogits, grads, True, latent_bn=ctx["enc"]["bott"]["s2"])
+        if after_decoder is not None:
+            after_decoder()
         self.encoder_backward(sd, ctx["enc"], d_latent, d_skips, grads)
         return grads

@@ -71,6 +71,29 @@ class FlatParams:
         Returns the scale (1/world) the optimiser kernel folds into its gradient load."""
         return all_reduce_sum_scale(self.grad, group)
 
+    def tail_offset(self, prefixes):
+        """Element offset where the trailing run of parameters whose names start with one of ``prefixes`` begins
+        (the arena follows ``named_parameters`` order), or None when those parameters are not one contiguous tail.
+        The UNet's decoder (``up_conv*``, ``conv_last``) is such a tail: its gradients are complete when the decoder
+        backward returns, so their all-reduce can run under the encoder backward."""
+        prefixes = tuple(prefixes)
+        first = None
+        for n in self.names:
+            hit = n.startswith(prefixes)
+            if hit and first is None:
+                first = n
+            elif not hit and first is not None:
+                return None
+        return None if first is None else self.offsets[first][0]
+
+    def all_reduce_range_async(self, lo, hi, group=None):
+        """Start the SUM all-reduce of gradient elements [lo, hi); returns a work handle (``.wait()``) or None when
+        there is nothing to exchange.  On RCCL the collective runs on the process group's stream after the kernels
+        already queued on the current stream, concurrently with what is queued next."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 and hi > lo:
+            return dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True)
+        return None
+
 
 def no_decay_bias_norm(name, param):
     """cmunet_config.py:84-91 ('bias', 'ln', ... decay_mult=0) and the usual 1-D rule for norm weights."""

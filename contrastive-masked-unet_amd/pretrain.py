@@ -70,6 +70,10 @@ class MaskedReconPretrainer:
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._dlogits = None
         self._ws = None
+        # gradient exchange in two buckets: the decoder's parameters are the tail of the arena and their gradients are
+        # complete half-way through the backward pass
+        self._dec_off = self.flat.tail_offset(("up_conv", "conv_last"))
+        self._pending = None
 
     def broadcast_parameters(self, src=0):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
@@ -90,15 +94,36 @@ class MaskedReconPretrainer:
         ops.masked_mse_fwd_bwd(logits, self.pred_channel, img, mask, self.loss, self._dlogits,
                                self.rc_weight * self.loss_scale, self._ws)
         eng.grad_target, eng.grad_prefix = self.flat.grad_views, ""
+        self._pending = None
+
+        def decoder_done():
+            if self._dec_off is not None:
+                self._pending = self.flat.all_reduce_range_async(self._dec_off, self.flat.grad.numel(), self.group)
+
         try:
-            eng.unet_backward(self.sd, ctx, self._dlogits)
+            eng.unet_backward(self.sd, ctx, self._dlogits, after_decoder=decoder_done)
         finally:
             eng.grad_target = None
         return self.loss
 
+    def exchange_gradients(self):
+        """Finish the data-parallel gradient SUM (the decoder bucket may already be in flight) and return 1/world."""
+        world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+        if world <= 1:
+            return 1.0
+        if self._pending is not None:
+            rest = self.flat.all_reduce_range_async(0, self._dec_off, self.group)
+            self._pending.wait()
+            if rest is not None:
+                rest.wait()
+            self._pending = None
+        else:
+            self.flat.all_reduce_mean(self.group)
+        return 1.0 / world
+
     def step(self, img, mask):
         loss = self.forward_backward(img, mask)
-        scale = self.flat.all_reduce_mean(self.group) / self.loss_scale
+        scale = self.exchange_gradients() / self.loss_scale
         self.opt.step(grad_scale=scale)
         return loss
 

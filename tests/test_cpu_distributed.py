@@ -55,6 +55,24 @@ def _worker(rank, world, port, q):
         w2 = w.detach().clone().requires_grad_(True)
         ((x_all @ w2 - y_all) ** 2).mean().backward()
         assert torch.allclose(grad * scale, w2.grad, atol=1e-6)
+        # two-bucket exchange (decoder tail first, asynchronously) == one all-reduce of the whole arena
+        from cmunet_amd.optim import FlatParams
+        flat = FlatParams.__new__(FlatParams)      # the arena itself is GPU-only: exercise the bucket logic on a CPU stand-in
+        flat.names = ["down_conv1.w", "down_conv1.b", "double_conv.w", "up_conv1.w", "up_conv1.b", "conv_last.w"]
+        sizes, flat.offsets, o = [36, 8, 24, 12, 4, 8], {}, 0
+        for n, sz in zip(flat.names, sizes):
+            flat.offsets[n] = (o, sz)
+            o += sz
+        flat.grad = torch.zeros(o)
+        off = flat.tail_offset(("up_conv", "conv_last"))
+        assert off == 36 + 8 + 24 and flat.tail_offset(("double_conv",)) is None and flat.tail_offset(("nope",)) is None
+        flat.grad.copy_(torch.arange(flat.grad.numel(), dtype=torch.float32) * (rank + 1))
+        whole = flat.grad.clone()
+        dist.all_reduce(whole)
+        h1 = flat.all_reduce_range_async(off, flat.grad.numel())
+        h0 = flat.all_reduce_range_async(0, off)
+        h1.wait(); h0.wait()
+        assert torch.equal(flat.grad, whole)
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         q.put((rank, repr(e)))
