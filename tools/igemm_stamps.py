@@ -63,13 +63,19 @@ if GROUPS == 2:
     st2 = buf.reshape(32, 2, NST, 8).astype(np.int64)
     for grp in range(2):
         stg = st2[:, grp]
-        stg = stg[stg[:, 0, 0] > 0][:, :min(NST, int(sys.argv[8]))]
+        stg = stg[stg[:, 0, 0] > 0][:, :min(15, int(sys.argv[8]))]
         print(f"wave {4 * grp}: blocks {stg.shape[0]}")
         nm = sys.argv[7].split(",")
         for k in range(NPH - 1):
             d = stg[:, 1:, k + 1] - stg[:, 1:, k]
             print(f"  {nm[k]:12s} avg {d.mean():8.0f} cyc  (min {d.min()}, max {d.max()})")
         print(f"  per-step total avg {(stg[:, 2:, 0] - stg[:, 1:-1, 0]).mean():.0f} cyc")
+    ck = st2[:, 0, 15, :4]
+    ck = ck[ck[:, 0] > 0]
+    if len(ck):
+        mhz = (ck[:, 2] - ck[:, 0]) / np.maximum(ck[:, 3] - ck[:, 1], 1) * 100.0
+        print(f"shader clock inside the main loop: median {np.median(mhz):.0f} MHz (min {mhz.min():.0f}, max {mhz.max():.0f}); "
+              f"dense bf16 peak at that clock: {2500.0 * np.median(mhz) / 2400.0:.0f} TFLOP/s")
     sys.exit(0)
 st = buf.reshape(64, NST, 8).astype(np.int64)
 names = sys.argv[7].split(",") if len(sys.argv) > 7 else ["barrier1", "store_stage", "barrier2", "load_issue", "mfma_phase", "loop"]
