@@ -22,6 +22,8 @@ _F = ctypes.c_float
 _SIGS = {
     "cmu_last_error": (ctypes.c_char_p, []),
     "cmu_last_kernel": (ctypes.c_char_p, []),
+    "cmu_pack_desc_bytes": (_I, []),
+    "cmu_pack_batch": (_I, [_P, _I, _L, _I, _P]),
     "cmu_version": (_I, []),
     "cmu_dtype_size": (_I, [_I]),
     "cmu_pack_conv3x3_elems": (_L, [_I, _I, _I, _I]),

@@ -165,7 +165,7 @@ static inline int sp_shift_bits(int H, int f) {
 // spatial tile of the implicit-GEMM kernels
 constexpr int CMU_TH = 16;
 constexpr int CMU_TW = 16;
-static inline int cmu_div_up(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int cmu_div_up(int a, int b) { return (a + b - 1) / b; }
 // rows per (slice, tap) of the packed 3x3 weights: [K/32B][9][npad][32 B]; 64 for narrow layers, else a multiple of 128
-static inline int cmu_conv3x3_npad(int N) { return N <= 64 ? 64 : ((N + 127) / 128) * 128; }
+__host__ __device__ static inline int cmu_conv3x3_npad(int N) { return N <= 64 ? 64 : ((N + 127) / 128) * 128; }
 static inline int64_t cmu_div_up64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -97,7 +97,7 @@ __global__ void pack_convT_kernel(const float* __restrict__ w, typename TR::elem
         out[o] = TR::from_float(v);
     }
 }
-static int64_t convT_pack_elems(int Cin, int Cout, int es, int mode, int* npad_out, int* cpi_out) {
+__host__ __device__ static int64_t convT_pack_elems(int Cin, int Cout, int es, int mode, int* npad_out, int* cpi_out) {
     const int KC = 64 / es;
     int64_t slices;
     int npad, cpi = cmu_div_up(Cout, KC);
@@ -125,6 +125,90 @@ extern "C" int64_t cmu_pack_convT2x2_elems(int Cin, int Cout, int dt, int mode) 
 extern "C" int cmu_pack_convT2x2(const float* w, void* out, int Cin, int Cout, int dt, int mode, void* stream) {
     CMU_CHECK_ARG(w && out && Cin > 0 && Cout > 0 && (mode == 0 || mode == 1), "cmu_pack_convT2x2: bad args");
     CMU_DISPATCH_DT(dt, pack_convT_t, w, out, Cin, Cout, mode, (hipStream_t)stream);
+}
+
+// All packs of a step in ONE launch (a trainer repacks every weight after each optimiser step: 42 launches of 5-40 us
+// otherwise).  Descriptor table in device memory; workgroup -> descriptor by its first-block prefix.
+struct CmuPackDescDev {
+    const float* w;
+    void* out;
+    int Cin, Cout, mode, kind;   // kind 0: conv3x3 (mode = transpose_flip), 1: convT2x2 (mode 0 / 1)
+    int64_t total;               // elements of the packed array
+    int64_t block0;              // first workgroup of this descriptor (4096 elements per workgroup)
+};
+template <class TR>
+__global__ __launch_bounds__(256) void pack_batch_kernel(const CmuPackDescDev* __restrict__ descs, int ndesc) {
+    typedef typename TR::elem_t elem_t;
+    __shared__ int sd;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = ndesc - 1;
+        while (lo < hi) {   // last descriptor with block0 <= blockIdx.x
+            const int mid = (lo + hi + 1) >> 1;
+            if (descs[mid].block0 <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        sd = lo;
+    }
+    __syncthreads();
+    const CmuPackDescDev d = descs[sd];
+    const int Cin = d.Cin, Cout = d.Cout;
+    elem_t* out = reinterpret_cast<elem_t*>(d.out);
+    const int64_t o0 = ((int64_t)blockIdx.x - d.block0) * 4096;
+    if (d.kind == 0) {
+        constexpr int KC = 32 / (int)sizeof(elem_t);
+        const int K = d.mode ? Cout : Cin, N = d.mode ? Cin : Cout;
+        const int npad = cmu_conv3x3_npad(N);
+        for (int i = 0; i < 16; ++i) {
+            const int64_t o = o0 + i * 256 + threadIdx.x;
+            if (o >= d.total) break;
+            const int k = (int)(o % KC);
+            const int n = (int)((o / KC) % npad);
+            const int t = (int)((o / ((int64_t)KC * npad)) % 9);
+            const int s = (int)(o / ((int64_t)KC * npad * 9));
+            const int c = s * KC + k;
+            float v = 0.f;
+            if (n < N && c < K) {
+                const int kh = t / 3, kw = t % 3;
+                if (!d.mode) v = d.w[(((int64_t)n * Cin + c) * 3 + kh) * 3 + kw];
+                else v = d.w[(((int64_t)c * Cin + n) * 3 + (2 - kh)) * 3 + (2 - kw)];
+            }
+            out[o] = TR::from_float(v);
+        }
+    } else {
+        constexpr int KC = 64 / (int)sizeof(elem_t);
+        int npad, cpi;
+        convT_pack_elems(Cin, Cout, (int)sizeof(elem_t), d.mode, &npad, &cpi);
+        for (int i = 0; i < 16; ++i) {
+            const int64_t o = o0 + i * 256 + threadIdx.x;
+            if (o >= d.total) break;
+            const int k = (int)(o % KC);
+            const int n = (int)((o / KC) % npad);
+            const int s = (int)(o / ((int64_t)KC * npad));
+            float v = 0.f;
+            if (d.mode == 0) {
+                const int ci = s * KC + k;
+                if (n < 4 * Cout && ci < Cin) {
+                    const int ij = n / Cout, co = n % Cout;
+                    v = d.w[(((int64_t)ci * Cout + co) * 2 + (ij >> 1)) * 2 + (ij & 1)];
+                }
+            } else {
+                const int ij = s / cpi, cc = s % cpi;
+                const int co = cc * KC + k;
+                if (n < Cin && co < Cout) v = d.w[(((int64_t)n * Cout + co) * 2 + (ij >> 1)) * 2 + (ij & 1)];
+            }
+            out[o] = TR::from_float(v);
+        }
+    }
+}
+template <class TR>
+static int pack_batch_t(const void* descs, int ndesc, int64_t total_blocks, hipStream_t st) {
+    hipLaunchKernelGGL((pack_batch_kernel<TR>), dim3((unsigned)total_blocks), dim3(256), 0, st, (const CmuPackDescDev*)descs, ndesc);
+    CMU_CHECK_LAUNCH("cmu_pack_batch");
+    return CMU_OK;
+}
+extern "C" int cmu_pack_desc_bytes(void) { return (int)sizeof(CmuPackDescDev); }
+extern "C" int cmu_pack_batch(const void* descs_dev, int ndesc, int64_t total_blocks, int dt, void* stream) {
+    CMU_CHECK_ARG(descs_dev && ndesc > 0 && total_blocks > 0 && total_blocks < (1ll << 31), "cmu_pack_batch: bad args");
+    CMU_DISPATCH_DT(dt, pack_batch_t, descs_dev, ndesc, total_blocks, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -85,6 +85,32 @@ class UNetEngine:
     def _f32(self, *shape):
         return torch.empty(shape, dtype=torch.float32, device=self.device)
 
+    def prepack(self, sd):
+        """Repack every 3x3 / conv-transpose weight of ``sd`` in one launch and mark the per-layer caches fresh (a
+        trainer calls this once per step, after the optimiser rewrote the parameter arena)."""
+        plan = getattr(self, "_pack_plan", None)
+        if plan is None or plan[0] != tuple((k, v.data_ptr()) for k, v in sd.items() if k.endswith("weight") and v.dim() == 4):
+            keys, items = [], []
+            for k, v in sd.items():
+                if not (k.endswith("weight") and v.dim() == 4):
+                    continue
+                name = k[:-len("weight")]
+                if v.shape[2:] == (3, 3) and v.shape[1] > 1:
+                    for flip in (False, True):
+                        keys.append((name, flip)); items.append((v.detach(), 0, int(flip)))
+                elif v.shape[2:] == (2, 2):
+                    for mode in (0, 1):
+                        keys.append((name, "T", mode)); items.append((v.detach(), 1, mode))
+            if not items:
+                return
+            sig = tuple((k, v.data_ptr()) for k, v in sd.items() if k.endswith("weight") and v.dim() == 4)
+            plan = (sig, keys, ops.PackPlan(items, self.dt), [sd[k[0] + "weight"] for k in keys])
+            self._pack_plan = plan
+        _, keys, pp, params = plan
+        pp.run()
+        for key, out, prm in zip(keys, pp.outs, params):
+            self.packs.items[key] = ((prm._version, ops.PARAM_GENERATION), prm.data_ptr(), out)
+
     def _wp(self, name, w, flip):
         return self.packs.get((name, flip), w, lambda: ops.pack_conv3x3(w.detach(), self.dt, flip))
 

@@ -109,6 +109,41 @@ def pack_convT2x2(w, dt, mode):
     return out
 
 
+class PackPlan:
+    """Every conv / conv-transpose weight pack of a model as ONE launch (cmu_pack_batch).  ``items``: list of
+    (weight fp32 tensor, kind 0 conv3x3 / 1 convT2x2, mode) -- conv3x3 mode = transpose_flip, convT mode 0 fwd / 1 dgrad.
+    ``outs[i]`` is the packed tensor of item i (allocated once; the weights must keep their storage, as the flat parameter
+    arena guarantees)."""
+
+    def __init__(self, items, dt):
+        import struct
+        dt = dt_code(dt)
+        l = _lib.lib()
+        assert l.cmu_pack_desc_bytes() == 48
+        self.dt, self.outs, recs, block = dt, [], [], 0
+        dev = items[0][0].device
+        for w, kind, mode in items:
+            assert w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 4
+            if kind == 0:
+                Cout, Cin = w.shape[0], w.shape[1]
+                n = l.cmu_pack_conv3x3_elems(Cin, Cout, dt, int(mode))
+            else:
+                Cin, Cout = w.shape[0], w.shape[1]
+                n = l.cmu_pack_convT2x2_elems(Cin, Cout, dt, int(mode))
+            out = torch.empty(n, dtype=TORCH_DT[dt], device=dev)
+            self.outs.append(out)
+            recs.append(struct.pack("<QQiiiiqq", w.data_ptr(), out.data_ptr(), Cin, Cout, int(mode), kind, n, block))
+            block += (n + 4095) // 4096
+        self.ptrs = [w.data_ptr() for w, _, _ in items]
+        self.items = items
+        self.total_blocks = block
+        self.descs = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(dev)
+
+    def run(self):
+        assert all(w.data_ptr() == q for (w, _, _), q in zip(self.items, self.ptrs)), "a packed weight moved"
+        call("cmu_pack_batch", _p(self.descs), len(self.items), self.total_blocks, self.dt, _stream())
+
+
 # ------------------------------------------------------------------------------------------------
 # forward
 # ------------------------------------------------------------------------------------------------

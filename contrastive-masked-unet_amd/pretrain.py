@@ -87,6 +87,7 @@ class MaskedReconPretrainer:
         returns the loss tensor (1,) on the device (no host sync)."""
         eng = self.engine
         B, H, W = img.shape
+        eng.prepack(self.sd)      # all weight packs of the step in one launch
         logits, ctx = eng.unet_forward(self.sd, img, True, mask, mask_per_sample=not self.ref_compat)
         if self._dlogits is None or self._dlogits.shape != logits.shape:
             self._dlogits = torch.empty_like(logits)

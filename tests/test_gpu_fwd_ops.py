@@ -295,3 +295,18 @@ torch.save({"y": y.buf.float().cpu(), "s": st.sum(0).cpu()}, sys.argv[1])
         os.unlink(path)
     check(outs[1]["y"], outs[0]["y"], 8e-3, "wide vs first y (bf16 rounding of different fp32 sums)")
     check(outs[1]["s"], outs[0]["s"], 1e-4, "wide vs first stats")
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_pack_batch_matches_single_packs(ops, dt):
+    """cmu_pack_batch (all packs of a step in one launch) writes exactly what the per-weight entries write."""
+    g = torch.Generator().manual_seed(23)
+    ws = [torch.randn(40, 24, 3, 3, generator=g).cuda(), torch.randn(128, 64, 3, 3, generator=g).cuda(),
+          torch.randn(64, 32, 2, 2, generator=g).cuda(), torch.randn(8, 8, 3, 3, generator=g).cuda()]
+    items = [(ws[0], 0, 0), (ws[0], 0, 1), (ws[1], 0, 0), (ws[1], 0, 1), (ws[2], 1, 0), (ws[2], 1, 1), (ws[3], 0, 1)]
+    plan = ops.PackPlan(items, dt)
+    plan.run()
+    torch.cuda.synchronize()
+    for (w, kind, mode), out in zip(items, plan.outs):
+        ref = ops.pack_conv3x3(w, dt, transpose_flip=bool(mode)) if kind == 0 else ops.pack_convT2x2(w, dt, mode)
+        assert torch.equal(out.view(torch.uint8), ref.view(torch.uint8)), (kind, mode, tuple(w.shape))
