@@ -344,7 +344,9 @@ def test_conv3x3_dgrad_bn(ops, dt, shape):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("shape", [(2, 8, 8, 32, 16), (1, 5, 9, 64, 32), (2, 16, 16, 128, 64)])
+@pytest.mark.parametrize("shape", [(2, 8, 8, 32, 16), (1, 5, 9, 64, 32), (2, 16, 16, 128, 64),
+                                   # Cin % 256 == 0 and Cout a whole number of 128-byte steps -> GEMM kernel (conv_gemm.inc)
+                                   (1, 5, 9, 256, 64), (2, 20, 17, 512, 128)])
 def test_convT2x2_dgrad_bn(ops, dt, shape):
     B, H, W, Cin, Cout = shape
     g = torch.Generator().manual_seed(33)
