@@ -56,6 +56,7 @@ struct IGParams {
     int64_t ldbx;
     const float *b_scale, *b_shift, *b_mean, *b_invstd;
     float* bstats;        // slab [cmu_conv_ntiles][2][N]
+    int buf_ok;           // first kernel, 3x3 mode: one image and the weight pack fit buffer descriptors
 };
 
 template <class TR, int MODE>
@@ -176,6 +177,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IGParams p) {
         w_t[it] = t;
     }
 
+    // ---- 3x3 mode: raw buffer loads (see conv_igemm3.inc): loop-invariant per-thread offsets, the slice advance is a
+    // scalar offset, pixels outside the image (and the chunks of a ragged last slice) point past num_records and read
+    // as zero -- no per-load address arithmetic, no predicated loads, no branches around them.  The address path of the
+    // ConvTranspose modes depends on the slice per thread and keeps plain loads.
+    constexpr unsigned OOBV = 0x7fff0000u;
+    unsigned a_voff[C::A_ITERS], w_voff[C::W_ITERS];
+    const bool use_buf = C::C3 && p.buf_ok;
+    // (descriptors are built for every mode -- the type has no default state -- and only used by the 3x3 buffer path)
+    const int64_t img_b = (int64_t)p.H * p.W * p.ldx * (int64_t)sizeof(elem_t);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(xb) + (use_buf ? b * img_b : 0), 0,
+        (int)(unsigned)((((int64_t)p.H * p.W - 1) * p.ldx + p.K) * (int64_t)sizeof(elem_t)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(wb), 0, (int)(unsigned)((int64_t)p.nslices32 * 9 * p.npad * 32), 0x00020000);
+    if (C::C3) {
+#pragma unroll
+        for (int it = 0; it < C::A_ITERS; ++it)
+            a_voff[it] = ((a_inb >> it) & 1u) ? (unsigned)((a_goff[it] - ((int64_t)b * p.H * p.W) * p.ldx + cg * C::EPC) * (int64_t)sizeof(elem_t)) : OOBV;
+#pragma unroll
+        for (int it = 0; it < C::W_ITERS; ++it)
+            w_voff[it] = (it * 256 + tid < C::W_CHUNKS) ? (unsigned)(((int64_t)((cg >> 1) * 9 + w_t[it]) * p.npad + w_n[it]) * 32 + (cg & 1) * 16) : OOBV;
+    }
+
     // ---- prefetch registers -----------------------------------------------------------------------
     u32x4 areg[C::A_ITERS];
     u32x4 wreg[C::W_ITERS];
@@ -183,7 +207,30 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IGParams p) {
     bool relu = false, chan_ok = false;
     const bool has_tf = (p.in_scale != nullptr);
 
+    float lo_relu = 0.f;
     auto load_stage = [&](int s) {
+        if (C::C3 && use_buf) {
+            const int c0 = s * C::KC + cg * C::EPC;
+            chan_ok = c0 < p.K;
+#pragma unroll
+            for (int it = 0; it < C::A_ITERS; ++it)
+                areg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(chan_ok ? a_voff[it] : OOBV), s * 64, 0));
+            if (has_tf) {
+                const int cc = chan_ok ? c0 : 0;
+#pragma unroll
+                for (int e = 0; e < C::EPC; ++e) {
+                    sc[e] = p.in_scale[cc + e];
+                    sh[e] = p.in_shift[cc + e];
+                }
+                lo_relu = (c0 >= p.relu_from) ? 0.f : -__builtin_inff();
+            }
+            const bool w_ok = (2 * s + (cg >> 1)) < p.nslices32;
+            const unsigned wso = (unsigned)(2 * s * 9) * (unsigned)p.npad * 32u;
+#pragma unroll
+            for (int it = 0; it < C::W_ITERS; ++it)
+                wreg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(w_ok ? w_voff[it] : OOBV), (int)wso, 0));
+            return;
+        }
         // channel slice handled by this thread in stage s
         const int kslice = C::C3 ? s : s * C::TAPS + aslice;
         int c0;         // first channel of this thread's chunk (within the input tensor)
@@ -233,6 +280,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IGParams p) {
     };
 
     auto store_stage = [&]() {
+        if (C::C3 && use_buf) {
+#pragma unroll
+            for (int it = 0; it < C::A_ITERS; ++it) {
+                u32x4 v = areg[it];
+                if (has_tf) {
+                    float f[C::EPC];
+                    TR::unpack(v, f);
+#pragma unroll
+                    for (int e = 0; e < C::EPC; ++e) f[e] = fmaxf(fmaf(f[e], sc[e], sh[e]), lo_relu);
+                    v = TR::pack(f);
+                    if (!(chan_ok && ((a_inb >> it) & 1u))) v = u32x4{0u, 0u, 0u, 0u};
+                }
+                if (it * 256 + tid < C::A_CHUNKS) *reinterpret_cast<u32x4*>(smem + a_lds[it]) = v;
+            }
+#pragma unroll
+            for (int it = 0; it < C::W_ITERS; ++it)
+                if (it * 256 + tid < C::W_CHUNKS) *reinterpret_cast<u32x4*>(smem + w_lds[it]) = wreg[it];
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < C::A_ITERS; ++it) {
             if (it * 256 + tid < C::A_CHUNKS) {
@@ -499,6 +565,9 @@ static int conv3x3_fwd_t(IGParams p, hipStream_t st) {
     p.nslices = cmu_div_up(p.K, C::KC);
     p.nslices32 = cmu_div_up(p.K, C::KC / 2);
     p.npad = cmu_conv3x3_npad(p.N);
+    static const bool bufload = []() { const char* e = getenv("CMU_CONV_BUFLOAD"); return !(e && e[0] == '0'); }();
+    p.buf_ok = bufload && ((int64_t)p.H * p.W * p.ldx + p.K) * (int64_t)sizeof(typename TR::elem_t) < 0x7fff0000ll &&
+               (int64_t)p.nslices32 * 9 * p.npad * 32 < 0x7fff0000ll;
     return launch_igemm<TR, MODE_CONV3>(p, st, "cmu_conv3x3_fwd");
 }
 template <class TR>
