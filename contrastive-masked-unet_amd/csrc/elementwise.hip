@@ -364,9 +364,20 @@ __global__ __launch_bounds__(256) void conv3x3_c1_fwd_kernel(const float* __rest
     __shared__ float halo[18 * 18];
     __shared__ float red[2][256];
     const int tid = threadIdx.x;
-    const int tile = blockIdx.x;
+    const int nchunk = Cout / EPC;
+    const int ppi = 256 / nchunk;  // pixels per iteration
+    const int chunk = tid % nchunk, prow = tid / nchunk;
+    const bool active = prow < ppi;
+    float wr[EPC][9];   // this thread's 8 (4) filters: loaded once, the workgroup walks several tiles
+#pragma unroll
+    for (int e = 0; e < EPC; ++e)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[e][t] = active ? w[(chunk * EPC + e) * 9 + t] : 0.f;
+    const int ntile = B * tilesX * tilesY;
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     const int tx = tile % tilesX, ty = (tile / tilesX) % tilesY, b = tile / (tilesX * tilesY);
     const int ty0 = ty * 16, tx0 = tx * 16;
+    __syncthreads();   // the previous tile's halo / reduction buffers are free
     for (int i = tid; i < 18 * 18; i += 256) {
         const int gy = ty0 - 1 + i / 18, gx = tx0 - 1 + i % 18;
         float v = 0.f;
@@ -376,15 +387,6 @@ __global__ __launch_bounds__(256) void conv3x3_c1_fwd_kernel(const float* __rest
         }
         halo[i] = v;
     }
-    const int nchunk = Cout / EPC;
-    const int ppi = 256 / nchunk;  // pixels per iteration
-    const int chunk = tid % nchunk, prow = tid / nchunk;
-    const bool active = prow < ppi;
-    float wr[EPC][9];
-#pragma unroll
-    for (int e = 0; e < EPC; ++e)
-#pragma unroll
-        for (int t = 0; t < 9; ++t) wr[e][t] = active ? w[(chunk * EPC + e) * 9 + t] : 0.f;
     __syncthreads();
     float s1[EPC], s2[EPC];
 #pragma unroll
@@ -410,8 +412,39 @@ __global__ __launch_bounds__(256) void conv3x3_c1_fwd_kernel(const float* __rest
             st_global16(reinterpret_cast<unsigned char*>(y) + ((((int64_t)b * H + gy) * W + gx) * ldy + chunk * EPC) * sizeof(typename TR::elem_t),
                         TR::pack(o));
         }
-    if (stats == nullptr) return;
-    // combine the threads that share a channel chunk (same tid % nchunk): fixed-order tree over prow
+    if (stats == nullptr) continue;
+    if ((nchunk & (nchunk - 1)) == 0 && nchunk <= 32) {
+        // threads sharing a channel chunk sit nchunk lanes apart: fold inside the wave (fixed xor order), then the four
+        // waves through LDS -- one barrier instead of sixteen and no serial 32-term sums by eight threads
+        float* wred = &red[0][0];   // [4 waves][Cout <= 128][2]
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float a = s1[e], q = s2[e];
+            for (int o = nchunk; o < 64; o <<= 1) {
+                a += __shfl_xor(a, o, 64);
+                q += __shfl_xor(q, o, 64);
+            }
+            if ((tid & 63) < nchunk && nchunk * EPC <= 64) {
+                wred[((tid >> 6) * 64 + (tid & 63) * EPC + e) * 2 + 0] = a;
+                wred[((tid >> 6) * 64 + (tid & 63) * EPC + e) * 2 + 1] = q;
+            }
+        }
+        if (nchunk * EPC <= 64) {
+            __syncthreads();
+            if (tid < Cout) {
+                float a = 0.f, q = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) {
+                    a += wred[(wv * 64 + tid) * 2 + 0];
+                    q += wred[(wv * 64 + tid) * 2 + 1];
+                }
+                stats[((int64_t)tile * 2 + 0) * Cout + tid] = a;
+                stats[((int64_t)tile * 2 + 1) * Cout + tid] = q;
+            }
+            continue;
+        }
+    }
+    // general shapes: combine the threads that share a channel chunk (same tid % nchunk): fixed-order tree over prow
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
         __syncthreads();
@@ -428,13 +461,15 @@ __global__ __launch_bounds__(256) void conv3x3_c1_fwd_kernel(const float* __rest
             stats[((int64_t)tile * 2 + 1) * Cout + tid * EPC + e] = q;
         }
     }
+    }   // tiles
 }
 
 template <class TR>
 static int conv3x3_c1_fwd_t(const float* x, const uint8_t* mask, int mps, const float* w, void* y, int64_t ldy, float* stats,
                             int B, int H, int W, int Cout, hipStream_t st) {
     const int tilesX = cmu_div_up(W, 16), tilesY = cmu_div_up(H, 16);
-    hipLaunchKernelGGL((conv3x3_c1_fwd_kernel<TR>), dim3(B * tilesX * tilesY), dim3(256), 0, st, x, mask, mps, w,
+    const int ntile = B * tilesX * tilesY;
+    hipLaunchKernelGGL((conv3x3_c1_fwd_kernel<TR>), dim3(ntile < 4096 ? ntile : 4096), dim3(256), 0, st, x, mask, mps, w,
                        (typename TR::elem_t*)y, ldy, stats, B, H, W, Cout, tilesX, tilesY);
     CMU_CHECK_LAUNCH("cmu_conv3x3_c1_fwd");
     return CMU_OK;
