@@ -544,50 +544,61 @@ extern "C" int cmu_bnrelu_maxpool_fwd(const void* y, int64_t ldy, const float* s
 // 1x1 head: logits (B,K,H,W) fp32 NCHW from the raw NHWC tensor + pending transform
 // ---------------------------------------------------------------------------------------------
 constexpr int HEAD_MAX_K = 8;
-template <class TR>
+template <class TR, int KT>   // KT = compiled class count (2 for the reference's heads, HEAD_MAX_K otherwise)
 __global__ void conv1x1_head_fwd_kernel(const unsigned char* __restrict__ x, int64_t ldx, const float* __restrict__ scale,
                                         const float* __restrict__ shift, const float* __restrict__ w, const float* __restrict__ bias,
                                         float* __restrict__ logits, int B, int H, int W, int C, int K, int64_t npix) {
     constexpr int EPC = TR::EPC;
     constexpr int ES = (int)sizeof(typename TR::elem_t);
+    constexpr int U = 4;         // pixels per thread and trip: four 16-byte loads in flight (this pass is HBM-bound)
     const int nchunk = C / EPC;  // power of two <= 64 (checked on the host)
     const int ch = threadIdx.x % nchunk;
     const int ppb = blockDim.x / nchunk;
-    float sc[EPC], sh[EPC], wk[HEAD_MAX_K][EPC];
+    float sc[EPC], sh[EPC], wk[KT][EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
         sc[e] = scale ? scale[ch * EPC + e] : 1.f;
         sh[e] = scale ? shift[ch * EPC + e] : 0.f;
     }
 #pragma unroll
-    for (int k = 0; k < HEAD_MAX_K; ++k)
+    for (int k = 0; k < KT; ++k)
 #pragma unroll
         for (int e = 0; e < EPC; ++e) wk[k][e] = (k < K) ? w[k * C + ch * EPC + e] : 0.f;
+    const float lo = scale ? 0.f : -__builtin_inff();
     const int64_t HW = (int64_t)H * W;
-    for (int64_t p0 = (int64_t)blockIdx.x * ppb; p0 < npix; p0 += (int64_t)gridDim.x * ppb) {
-        const int64_t pix = p0 + threadIdx.x / nchunk;
-        const bool ok = pix < npix;
-        float f[EPC];
-        if (ok) TR::unpack(ld_global16(x + (pix * ldx + ch * EPC) * ES), f);
-        float acc[HEAD_MAX_K];
+    for (int64_t p0 = (int64_t)blockIdx.x * ppb * U; p0 < npix; p0 += (int64_t)gridDim.x * ppb * U) {
+        u32x4 q[U];
+        bool ok[U];
 #pragma unroll
-        for (int k = 0; k < HEAD_MAX_K; ++k) acc[k] = 0.f;
-        if (ok) {
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                float a = fmaf(f[e], sc[e], sh[e]);
-                if (scale) a = fmaxf(a, 0.f);
-#pragma unroll
-                for (int k = 0; k < HEAD_MAX_K; ++k) acc[k] = fmaf(a, wk[k][e], acc[k]);
-            }
+        for (int u = 0; u < U; ++u) {
+            const int64_t pix = p0 + u * ppb + threadIdx.x / nchunk;
+            ok[u] = pix < npix;
+            q[u] = ok[u] ? ld_global16(x + (pix * ldx + ch * EPC) * ES) : u32x4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
-        for (int k = 0; k < HEAD_MAX_K; ++k)
-            if (k < K)
-                for (int o = 1; o < nchunk; o <<= 1) acc[k] += __shfl_xor(acc[k], o, 64);
-        if (ok && ch == 0) {
-            const int64_t b = pix / HW, r = pix % HW;
-            for (int k = 0; k < K; ++k) logits[(b * K + k) * HW + r] = acc[k] + bias[k];
+        for (int u = 0; u < U; ++u) {
+            const int64_t pix = p0 + u * ppb + threadIdx.x / nchunk;
+            float f[EPC];
+            TR::unpack(q[u], f);
+            float acc[KT];
+#pragma unroll
+            for (int k = 0; k < KT; ++k) acc[k] = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float a = fmaxf(fmaf(f[e], sc[e], sh[e]), lo);
+#pragma unroll
+                for (int k = 0; k < KT; ++k) acc[k] = fmaf(a, wk[k][e], acc[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < KT; ++k)
+                if (k < K)
+                    for (int o = 1; o < nchunk; o <<= 1) acc[k] += __shfl_xor(acc[k], o, 64);
+            if (ok[u] && ch == 0) {
+                const int64_t b = pix / HW, r = pix % HW;
+#pragma unroll
+                for (int k = 0; k < KT; ++k)
+                    if (k < K) logits[(b * K + k) * HW + r] = acc[k] + bias[k];
+            }
         }
     }
 }
@@ -597,10 +608,14 @@ static int conv1x1_head_fwd_t(const void* x, int64_t ldx, const float* scale, co
     const int nchunk = C / TR::EPC;
     const int64_t npix = (int64_t)B * H * W;
     const int ppb = 256 / nchunk;
-    const int64_t nb = cmu_div_up64(npix, ppb);
+    const int64_t nb = cmu_div_up64(npix, ppb * 4);
     const int grid = (int)(nb < 8192 ? nb : 8192);
-    hipLaunchKernelGGL((conv1x1_head_fwd_kernel<TR>), dim3(grid), dim3(256), 0, st, (const unsigned char*)x, ldx, scale, shift, w, bias,
-                       logits, B, H, W, C, K, npix);
+    if (K <= 2)
+        hipLaunchKernelGGL((conv1x1_head_fwd_kernel<TR, 2>), dim3(grid), dim3(256), 0, st, (const unsigned char*)x, ldx, scale, shift, w,
+                           bias, logits, B, H, W, C, K, npix);
+    else
+        hipLaunchKernelGGL((conv1x1_head_fwd_kernel<TR, HEAD_MAX_K>), dim3(grid), dim3(256), 0, st, (const unsigned char*)x, ldx, scale,
+                           shift, w, bias, logits, B, H, W, C, K, npix);
     CMU_CHECK_LAUNCH("cmu_conv1x1_head_fwd");
     return CMU_OK;
 }
