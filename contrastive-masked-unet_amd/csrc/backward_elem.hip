@@ -359,7 +359,7 @@ extern "C" int cmu_maxpool_bwd(const void* dP, int64_t ldp, const void* dSkip, i
 // 1x1 head backward (autograd of model.py:130)
 // ---------------------------------------------------------------------------------------------
 constexpr int HEAD_MAX_K = 8;
-template <class TR>
+template <class TR, int KT>   // KT = compiled class count (2 for the reference's heads, KT otherwise)
 __global__ __launch_bounds__(256) void conv1x1_head_bwd_kernel(const float* __restrict__ dlogits, const unsigned char* __restrict__ x,
                                                               int64_t ldx, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, const float* __restrict__ w,
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void conv1x1_head_bwd_kernel(const float* __re
     const int ch = tid % nchunk;
     const int ppb = 256 / nchunk;
     const int prow = tid / nchunk;
-    float sc[EPC], sh[EPC], wk[HEAD_MAX_K][EPC], dw[HEAD_MAX_K][EPC], db[HEAD_MAX_K], mu[EPC], is[EPC], s1[EPC], s2[EPC];
+    float sc[EPC], sh[EPC], wk[KT][EPC], dw[KT][EPC], db[KT], mu[EPC], is[EPC], s1[EPC], s2[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
         sc[e] = scale ? scale[ch * EPC + e] : 1.f;
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void conv1x1_head_bwd_kernel(const float* __re
         s1[e] = s2[e] = 0.f;
     }
 #pragma unroll
-    for (int k = 0; k < HEAD_MAX_K; ++k) {
+    for (int k = 0; k < KT; ++k) {
         db[k] = 0.f;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
@@ -396,17 +396,17 @@ __global__ __launch_bounds__(256) void conv1x1_head_bwd_kernel(const float* __re
     const int64_t HW = (int64_t)H * W;
     for (int64_t pix = (int64_t)blockIdx.x * ppb + prow; pix < npix; pix += (int64_t)gridDim.x * ppb) {
         const int64_t b = pix / HW, r = pix % HW;
-        float f[EPC], o[EPC], dl[HEAD_MAX_K];
+        float f[EPC], o[EPC], dl[KT];
         TR::unpack(ld_global16(x + (pix * ldx + ch * EPC) * ES), f);
 #pragma unroll
-        for (int k = 0; k < HEAD_MAX_K; ++k) dl[k] = (k < K) ? dlogits[(b * K + k) * HW + r] : 0.f;
+        for (int k = 0; k < KT; ++k) dl[k] = (k < K) ? dlogits[(b * K + k) * HW + r] : 0.f;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             float a = fmaf(f[e], sc[e], sh[e]);
             if (scale) a = fmaxf(a, 0.f);
             float d = 0.f;
 #pragma unroll
-            for (int k = 0; k < HEAD_MAX_K; ++k) {
+            for (int k = 0; k < KT; ++k) {
                 d = fmaf(dl[k], wk[k][e], d);
                 dw[k][e] = fmaf(dl[k], a, dw[k][e]);
             }
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void conv1x1_head_bwd_kernel(const float* __re
         }
         if (ch == 0) {
 #pragma unroll
-            for (int k = 0; k < HEAD_MAX_K; ++k) db[k] += dl[k];
+            for (int k = 0; k < KT; ++k) db[k] += dl[k];
         }
         const u32x4 packed = TR::pack(o);
         if (dX) st_global16(dX + (pix * ldo + ch * EPC) * ES, packed);
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void conv1x1_head_bwd_kernel(const float* __re
     }
     float* out = ws + (int64_t)blockIdx.x * (K * C + K);
 #pragma unroll
-    for (int k = 0; k < HEAD_MAX_K; ++k) {
+    for (int k = 0; k < KT; ++k) {
         if (k >= K) break;   // K is uniform; indices stay compile-time constants after unrolling
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
@@ -482,8 +482,12 @@ static int conv1x1_head_bwd_t(const float* dlogits, const void* x, int64_t ldx, 
     const int64_t npix = (int64_t)B * H * W;
     int gx = (int)(cmu_div_up64(npix, ppb * 4) < RED_MAX_BLOCKS ? cmu_div_up64(npix, ppb * 4) : RED_MAX_BLOCKS);
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL((conv1x1_head_bwd_kernel<TR>), dim3(gx), dim3(256), 0, st, dlogits, (const unsigned char*)x, ldx, scale, shift, w,
-                       (unsigned char*)dX, ldo, (float*)ws, B, H, W, C, K, npix, mean, invstd, (float*)bn_ws);
+    if (K <= 2)
+        hipLaunchKernelGGL((conv1x1_head_bwd_kernel<TR, 2>), dim3(gx), dim3(256), 0, st, dlogits, (const unsigned char*)x, ldx, scale, shift, w,
+                           (unsigned char*)dX, ldo, (float*)ws, B, H, W, C, K, npix, mean, invstd, (float*)bn_ws);
+    else
+        hipLaunchKernelGGL((conv1x1_head_bwd_kernel<TR, HEAD_MAX_K>), dim3(gx), dim3(256), 0, st, dlogits, (const unsigned char*)x, ldx, scale,
+                           shift, w, (unsigned char*)dX, ldo, (float*)ws, B, H, W, C, K, npix, mean, invstd, (float*)bn_ws);
     CMU_CHECK_LAUNCH("cmu_conv1x1_head_bwd");
     const int64_t n = (int64_t)K * C + K;
     hipLaunchKernelGGL(sum_slab_kernel, dim3((unsigned)cmu_div_up64(n, 16)), dim3(256), 0, st, (const float*)ws, gx, n, dW, (int64_t)K * C,
