@@ -51,7 +51,7 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 20
 fl = 2.0 * B * H * W * Cin * Cout * 9
-print(f"layer {Cin}->{Cout} @ {H}x{W} B={B}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TFLOP/s"))
+print(f"layer {Cin}->{Cout} @ {H}x{W} B={B}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TFLOP/s")
 
 if not hasattr(lib, "cmu_debug_ig_stamps"):
     sys.exit(0)
