@@ -62,6 +62,42 @@ def cpu_baseline(H, W, seconds_budget=25.0):
             "sample": f"oracle (torch CPU fp32 restatement of the reference step) bs={bs} {H}x{W}, {n} timed step(s) after 1 warm-up"}
 
 
+def step_roofline(B, H, W, dtype, img_s):
+    """Whole-step rooflines of SURVEY 8(d) for the reference UNet (base 64, depth 5): per layer F = algorithmic FLOPs,
+    bytes = (in + out + weights) * sizeof(storage dtype), training convention x3 (forward + data gradient + weight
+    gradient); composite = sum over layers of max(F / MFMA peak, bytes / HBM peak)."""
+    es = 4 if dtype == "f32" else 2
+    peak = PEAK_TFLOPS[dtype] * 1e12
+    bw = 8.0e12
+    layers = []   # (flops, bytes) per image, forward
+
+    def conv(cin, cout, s, k):
+        layers.append((2.0 * k * k * cin * cout * s * s, (cin * s * s + cout * s * s + k * k * cin * cout) * es))
+
+    chans, s = [64, 128, 256, 512], H
+    cin = 1
+    for c in chans:
+        conv(cin, c, s, 3); conv(c, c, s, 3)
+        layers.append((3.0 * c * (s // 2) ** 2, (c * s * s + c * (s // 2) ** 2) * es))      # max-pool
+        cin, s = c, s // 2
+    conv(512, 1024, s, 3); conv(1024, 1024, s, 3)
+    cin = 1024
+    for c in reversed(chans):
+        s *= 2
+        layers.append((2.0 * cin * c * s * s, (cin * (s // 2) ** 2 + c * s * s + 4 * cin * c) * es))   # ConvTranspose 2x2 s2
+        conv(2 * c, c, s, 3); conv(c, c, s, 3)
+        cin = c
+    conv(64, 2, s, 1)
+    f = 3.0 * sum(l[0] for l in layers)
+    by = 3.0 * sum(l[1] for l in layers)
+    t_comp = 3.0 * sum(max(l[0] / peak, l[1] / bw) for l in layers)
+    return {"gflop_per_image": round(f / 1e9, 1), "mb_per_image": round(by / 1e6, 1),
+            "mfma_only_img_s": round(peak / f, 1), "hbm_only_img_s": round(bw / by, 1), "composite_img_s": round(1.0 / t_comp, 1),
+            "frac_of_mfma_only": round(img_s * f / peak, 4), "frac_of_hbm_only": round(img_s * by / bw, 4),
+            "frac_of_composite": round(img_s * t_comp, 4),
+            "note": "SURVEY 8(d): algorithmic FLOPs / bytes per layer, x3 for training; peaks 2.5 PFLOP/s (16-bit) and 8 TB/s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,6 +214,7 @@ def main():
         out["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
         flops_step = sum(v["work"] for v in summ.values()) / args.steps
         out["step_mfma_tflops"] = round(flops_step / (elapsed / args.steps) / 1e12, 2)
+        out["step_roofline"] = step_roofline(B, H, W, args.dtype, out["value"] / world)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(H, W)
