@@ -22,6 +22,10 @@ _F = ctypes.c_float
 _SIGS = {
     "cmu_last_error": (ctypes.c_char_p, []),
     "cmu_last_kernel": (ctypes.c_char_p, []),
+    "cmu_sgd_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _L, _F, _P]),
+    "cmu_lamb_block_elems": (_I, []),
+    "cmu_lamb_ws_bytes": (_L, [_I, _I]),
+    "cmu_lamb_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _F, _F, _F, _F, _I, _I, _F, _I, _I, _L, _F, _P, _P]),
     "cmu_pack_desc_bytes": (_I, []),
     "cmu_pack_batch": (_I, [_P, _I, _L, _I, _P]),
     "cmu_version": (_I, []),

@@ -383,3 +383,21 @@ def adam_step(p, g, m, v, wd_mask, lr, beta1, beta2, eps, weight_decay, decouple
     call("cmu_adam_step", _p(_f32c(p)), _p(_f32c(g)), _p(_f32c(m)), _p(_f32c(v)), _p(wd_mask), p.numel(), float(lr),
          float(beta1), float(beta2), float(eps), float(weight_decay), int(decoupled), int(step), float(grad_scale),
          _stream())
+
+
+def sgd_step(p, g, buf, wd_mask, lr, momentum, dampening, weight_decay, nesterov, step, grad_scale=1.0):
+    global PARAM_GENERATION
+    PARAM_GENERATION += 1
+    call("cmu_sgd_step", _p(_f32c(p)), _p(_f32c(g)), _p(buf), _p(wd_mask), p.numel(), float(lr), float(momentum), float(dampening),
+         float(weight_decay), int(nesterov), int(step), float(grad_scale), _stream())
+
+
+def lamb_step(p, g, m, v, u, tables, lr, beta1, beta2, eps, bias_correction, grad_averaging, max_grad_norm, trust_clip,
+              always_adapt, step, grad_scale, ws):
+    """``tables`` = (blk_start int64, blk_count int32, blk_tensor int32, t_blk0 int32 [T+1], t_wd float32 [T]) on the device."""
+    global PARAM_GENERATION
+    PARAM_GENERATION += 1
+    bs, bc, bt, t0, twd = tables
+    call("cmu_lamb_step", _p(_f32c(p)), _p(_f32c(g)), _p(m), _p(v), _p(u), _p(bs), _p(bc), _p(bt), bs.numel(), _p(t0), _p(twd),
+         twd.numel(), float(lr), float(beta1), float(beta2), float(eps), int(bias_correction), int(grad_averaging),
+         float(max_grad_norm), int(trust_clip), int(always_adapt), int(step), float(grad_scale), _p(ws), _stream())

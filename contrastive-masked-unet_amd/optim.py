@@ -129,3 +129,72 @@ class FusedAdam:
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])
         self.step_count = int(sd["step"])
+
+
+class FusedSGD:
+    """torch.optim.SGD semantics (momentum, dampening, Nesterov, L2 weight decay) over a FlatParams arena in one launch
+    (cmu_sgd_step) -- MoCo's optimiser (moco2_module.py:339-344: lr, momentum 0.9, weight_decay 1e-4)."""
+
+    def __init__(self, flat, lr, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, decay_filter=None):
+        if nesterov and (momentum <= 0 or dampening != 0):
+            raise ValueError("Nesterov momentum requires a momentum and zero dampening")   # torch.optim.SGD's own check
+        self.flat = flat
+        self.lr, self.momentum, self.dampening, self.weight_decay, self.nesterov = lr, momentum, dampening, weight_decay, nesterov
+        self.buf = torch.zeros_like(flat.arena) if momentum != 0 else None
+        self.wd_mask = flat.wd_mask(decay_filter) if (decay_filter is not None and weight_decay != 0.0) else None
+        self.step_count = 0
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.flat.params.values():
+            p.grad = None
+
+    def step(self, grad_scale=1.0):
+        self.step_count += 1
+        ops.sgd_step(self.flat.arena, self.flat.grad, self.buf, self.wd_mask, self.lr, self.momentum, self.dampening,
+                     self.weight_decay, self.nesterov, self.step_count, grad_scale)
+
+
+class FusedLAMB:
+    """LAMB as the reference's SparK pretraining uses it (Pretraining/Spark/utils/lamb.py:67-159) over a FlatParams arena:
+    global gradient-norm clip, Adam moments, per-tensor trust ratio -- five small launches, no host synchronisation.
+    ``decay_filter(name, param) -> bool`` selects the tensors that get ``weight_decay`` (the others also skip the trust
+    ratio unless ``always_adapt``), as the reference's two parameter groups do."""
+
+    def __init__(self, flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01, bias_correction=True, grad_averaging=True,
+                 max_grad_norm=2.0, trust_clip=False, always_adapt=False, decay_filter=None):
+        from . import _lib
+        self.flat = flat
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.bias_correction, self.grad_averaging, self.max_grad_norm = bias_correction, grad_averaging, max_grad_norm
+        self.trust_clip, self.always_adapt = trust_clip, always_adapt
+        dev = flat.arena.device
+        blk = _lib.lib().cmu_lamb_block_elems()
+        starts, counts, tens, t0, twd = [], [], [], [0], []
+        for t, n in enumerate(flat.names):
+            off, cnt = flat.offsets[n]
+            for s in range(0, cnt, blk):
+                starts.append(off + s); counts.append(min(blk, cnt - s)); tens.append(t)
+            t0.append(len(starts))
+            twd.append(weight_decay if (decay_filter is None or decay_filter(n, flat.params[n])) else 0.0)
+        self.tables = (torch.tensor(starts, dtype=torch.int64, device=dev), torch.tensor(counts, dtype=torch.int32, device=dev),
+                       torch.tensor(tens, dtype=torch.int32, device=dev), torch.tensor(t0, dtype=torch.int32, device=dev),
+                       torch.tensor(twd, dtype=torch.float32, device=dev))
+        self.m, self.v, self.u = torch.zeros_like(flat.arena), torch.zeros_like(flat.arena), torch.empty_like(flat.arena)
+        self.ws = torch.empty(_lib.lib().cmu_lamb_ws_bytes(len(starts), len(twd)), dtype=torch.uint8, device=dev)
+        self.step_count = 0
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.flat.params.values():
+            p.grad = None
+
+    @property
+    def global_grad_norm(self):
+        """The reference exposes this for logging (lamb.py:91); reading it synchronises."""
+        n = len(self.tables[0])
+        return float(self.ws.view(torch.float32)[3 * n + len(self.tables[4])])
+
+    def step(self, grad_scale=1.0):
+        self.step_count += 1
+        ops.lamb_step(self.flat.arena, self.flat.grad, self.m, self.v, self.u, self.tables, self.lr, self.betas[0], self.betas[1],
+                      self.eps, self.bias_correction, self.grad_averaging, self.max_grad_norm, self.trust_clip, self.always_adapt,
+                      self.step_count, grad_scale, self.ws)

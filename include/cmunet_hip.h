@@ -274,6 +274,24 @@ int cmu_adam_step(float* p, const float* g, float* m, float* v, const uint8_t* w
                   float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled,
                   int64_t step, float grad_scale, void* stream);
 
+/* Fused SGD step over a flat fp32 arena (torch.optim.SGD; MoCo: moco2_module.py:339-344, momentum 0.9, weight decay 1e-4).
+ * g' = g*grad_scale + wd*p (where wd_mask != 0 or wd_mask == NULL); buf = g' on step 1, else momentum*buf + (1-dampening)*g';
+ * p -= lr * (nesterov ? g' + momentum*buf : buf); momentum == 0: p -= lr*g' (buf may be NULL).                        */
+int cmu_sgd_step(float* p, const float* g, float* buf, const uint8_t* wd_mask, int64_t n, float lr, float momentum,
+                 float dampening, float weight_decay, int nesterov, int64_t step, float grad_scale, void* stream);
+
+/* Fused LAMB step (Pretraining/Spark/utils/lamb.py:67-159) over a flat fp32 arena cut into blocks of at most
+ * cmu_lamb_block_elems() elements that never straddle a parameter tensor: blk_start / blk_count / blk_tensor [nblocks]
+ * (device), t_blk0 [ntensors+1] first block of each tensor, t_wd [ntensors] its weight decay (0 = excluded; such tensors
+ * skip the trust ratio unless always_adapt).  u: scratch arena of the parameters' size; ws: cmu_lamb_ws_bytes.
+ * Global gradient-norm clip (max_grad_norm <= 0: off), moments, per-tensor trust ratio, update -- no host sync.          */
+int cmu_lamb_block_elems(void);
+int64_t cmu_lamb_ws_bytes(int nblocks, int ntensors);
+int cmu_lamb_step(float* p, const float* g, float* m, float* v, float* u, const int64_t* blk_start, const int* blk_count,
+                  const int* blk_tensor, int nblocks, const int* t_blk0, const float* t_wd, int ntensors, float lr, float beta1,
+                  float beta2, float eps, int bias_correction, int grad_averaging, float max_grad_norm, int trust_clip,
+                  int always_adapt, int64_t step, float grad_scale, void* ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

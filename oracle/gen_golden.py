@@ -168,6 +168,56 @@ def gen_spark(ref):
          bott_running_var=rv)
 
 
+def gen_optim():
+    """LAMB: the reference's own class (Pretraining/Spark/utils/lamb.py, pure torch); SGD: torch.optim.SGD as MoCo configures it."""
+    import importlib.util
+    from oracle import optim as OO
+    spec = importlib.util.spec_from_file_location("ref_lamb", os.path.join(REF, "Pretraining", "Spark", "utils", "lamb.py"))
+    ref_lamb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_lamb)
+    g = torch.Generator().manual_seed(91)
+    shapes = [(24, 8, 3, 3), (24,), (5000,), (16, 24)]
+    p0 = [torch.randn(s, generator=g) * 0.3 for s in shapes]
+    grads = [[torch.randn(s, generator=g) * (3.0 if k == 0 else 0.2) for s in shapes] for k in range(3)]   # step 1 gets clipped
+    wds = [0.05, 0.0, 0.05, 0.0]
+    out = {"shapes": np.array([list(s) + [0] * (4 - len(s)) for s in shapes]), "wds": np.array(wds)}
+    for i, t in enumerate(p0):
+        out[f"p0.{i}"] = t
+    for k in range(3):
+        for i, t in enumerate(grads[k]):
+            out[f"g{k}.{i}"] = t
+    for tag, kw in (("a", dict(trust_clip=False, always_adapt=False)), ("b", dict(trust_clip=True, always_adapt=True))):
+        ps = [torch.nn.Parameter(t.clone()) for t in p0]
+        opt = ref_lamb.TheSameAsTimmLAMB([{"params": [ps[0], ps[2]], "weight_decay": 0.05}, {"params": [ps[1], ps[3]], "weight_decay": 0.0}],
+                                        lr=2e-2, betas=(0.9, 0.98), eps=1e-6, max_grad_norm=2.0, **kw)
+        om = [t.clone() for t in p0]
+        ms, vs = [torch.zeros_like(t) for t in p0], [torch.zeros_like(t) for t in p0]
+        for k in range(3):
+            for prm, gr in zip(ps, grads[k]):
+                prm.grad = gr.clone()
+            opt.step()
+            OO.lamb_step(om, grads[k], ms, vs, 2e-2, wds, betas=(0.9, 0.98), eps=1e-6, max_grad_norm=2.0, step=k + 1, **kw)
+            for i in range(len(ps)):
+                close(om[i], ps[i].detach(), tol=2e-6, what=f"lamb {tag} step {k} tensor {i}")
+        for i, prm in enumerate(ps):
+            out[f"lamb_{tag}.{i}"] = prm.detach().clone()
+    for tag, kw in (("a", dict(momentum=0.9, weight_decay=1e-4)), ("b", dict(momentum=0.9, weight_decay=1e-2, nesterov=True)),
+                    ("c", dict(momentum=0.0, weight_decay=0.0))):
+        ps = [torch.nn.Parameter(t.clone()) for t in p0]
+        opt = torch.optim.SGD(ps, lr=0.03, **kw)
+        om, bufs = [t.clone() for t in p0], [torch.zeros_like(t) for t in p0]
+        for k in range(3):
+            for prm, gr in zip(ps, grads[k]):
+                prm.grad = gr.clone()
+            opt.step()
+            OO.sgd_step(om, grads[k], bufs, 0.03, step=k + 1, **kw)
+            for i in range(len(ps)):
+                close(om[i], ps[i].detach(), tol=2e-6, what=f"sgd {tag} step {k} tensor {i}")
+        for i, prm in enumerate(ps):
+            out[f"sgd_{tag}.{i}"] = prm.detach().clone()
+    save("optim_traces", **out)
+
+
 def main():
     from oracle import unet as OU, losses as OL
     ref, M = import_reference()
@@ -175,6 +225,9 @@ def main():
     torch.set_num_threads(4)
     if "--only-spark" in sys.argv:      # regenerate tests/golden/spark_unet.npz alone
         gen_spark(ref)
+        return
+    if "--only-optim" in sys.argv:      # regenerate tests/golden/optim_traces.npz alone
+        gen_optim()
         return
 
     def load(mod, sd):
@@ -378,6 +431,7 @@ def main():
          dlogits=logits.grad, bad_mode_msg=np.array(bad_mode_msg))
     # ---- 7. SparK (sparse masked conv) -- reference imported behind the stubs of SURVEY Appendix C-3 ---------
     gen_spark(ref)
+    gen_optim()
     print("all fixtures written; oracle == reference on every case")
 
 

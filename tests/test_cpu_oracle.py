@@ -177,3 +177,29 @@ def test_spark_golden(golden_dir):
     assert abs(float(loss) - float(d["loss"])) < 1e-5 and rec.shape == (2, 1, 64, 64)
     a = OS.make_active(3, 16, 0.6, torch.Generator().manual_seed(0))
     assert a.shape == (3, 1, 16, 16) and a.view(3, -1).sum(1).tolist() == [round(256 * 0.4)] * 3     # spark.py:29,82-86
+
+
+def test_optimizer_traces_golden(golden_dir):
+    """oracle/optim.py (SGD as MoCo configures it, LAMB as SparK does) against traces of torch.optim.SGD and of the
+    reference's own LAMB class (oracle/gen_golden.py)."""
+    import numpy as np
+    import torch
+    from oracle import optim as OO
+    d = np.load(f"{golden_dir}/optim_traces.npz")
+    wds = [float(w) for w in d["wds"]]
+    n = len(wds)
+    p0 = [torch.from_numpy(d[f"p0.{i}"]) for i in range(n)]
+    grads = [[torch.from_numpy(d[f"g{k}.{i}"]) for i in range(n)] for k in range(3)]
+    for tag, kw in (("a", dict(trust_clip=False, always_adapt=False)), ("b", dict(trust_clip=True, always_adapt=True))):
+        ps, ms, vs = [t.clone() for t in p0], [torch.zeros_like(t) for t in p0], [torch.zeros_like(t) for t in p0]
+        for k in range(3):
+            OO.lamb_step(ps, grads[k], ms, vs, 2e-2, wds, betas=(0.9, 0.98), eps=1e-6, max_grad_norm=2.0, step=k + 1, **kw)
+        for i in range(n):
+            assert torch.allclose(ps[i], torch.from_numpy(d[f"lamb_{tag}.{i}"]), atol=2e-6), (tag, i)
+    for tag, kw in (("a", dict(momentum=0.9, weight_decay=1e-4)), ("b", dict(momentum=0.9, weight_decay=1e-2, nesterov=True)),
+                    ("c", dict(momentum=0.0, weight_decay=0.0))):
+        ps, bufs = [t.clone() for t in p0], [torch.zeros_like(t) for t in p0]
+        for k in range(3):
+            OO.sgd_step(ps, grads[k], bufs, 0.03, step=k + 1, **kw)
+        for i in range(n):
+            assert torch.allclose(ps[i], torch.from_numpy(d[f"sgd_{tag}.{i}"]), atol=2e-6), (tag, i)

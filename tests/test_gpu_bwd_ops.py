@@ -366,3 +366,45 @@ def test_convT2x2_dgrad_bn(ops, dt, shape):
     got = slab.double().sum(0).cpu()
     check(got[0], s1, 2e-4, "sum gate*dX")
     check(got[1], s2, 2e-4, "sum gate*dX*xhat")
+
+
+def test_fused_sgd_and_lamb_vs_reference_traces(golden_dir):
+    """FusedSGD / FusedLAMB on the flat arena against three-step traces of torch.optim.SGD and of the reference's LAMB class
+    (tests/golden/optim_traces.npz), including the clipped first step, excluded tensors, trust clipping."""
+    import numpy as np
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cmunet_amd.optim import FlatParams, FusedLAMB, FusedSGD
+    d = np.load(f"{golden_dir}/optim_traces.npz")
+    wds = [float(w) for w in d["wds"]]
+    n = len(wds)
+    shapes = [tuple(int(v) for v in row if v) for row in d["shapes"]]
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.ps = torch.nn.ParameterList([torch.nn.Parameter(torch.from_numpy(d[f"p0.{i}"]).clone().view(shapes[i])) for i in range(n)])
+
+    def load_grads(flat, k):
+        for i, name in enumerate(flat.names):
+            flat.grad_views[name].copy_(torch.from_numpy(d[f"g{k}.{i}"]).view(shapes[i]))
+
+    decay = lambda name, prm: wds[int(name.split(".")[-1])] != 0.0
+    for tag, kw in (("a", dict(trust_clip=False, always_adapt=False)), ("b", dict(trust_clip=True, always_adapt=True))):
+        flat = FlatParams(Holder().cuda())
+        opt = FusedLAMB(flat, lr=2e-2, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05, max_grad_norm=2.0, decay_filter=decay, **kw)
+        for k in range(3):
+            load_grads(flat, k)
+            opt.step()
+        for i, name in enumerate(flat.names):
+            check(flat.views[name].cpu().flatten(), torch.from_numpy(d[f"lamb_{tag}.{i}"]).flatten(), 2e-5, f"lamb {tag} tensor {i}")
+        assert opt.global_grad_norm > 0
+    for tag, kw in (("a", dict(momentum=0.9, weight_decay=1e-4)), ("b", dict(momentum=0.9, weight_decay=1e-2, nesterov=True)),
+                    ("c", dict(momentum=0.0, weight_decay=0.0))):
+        flat = FlatParams(Holder().cuda())
+        opt = FusedSGD(flat, lr=0.03, **kw)
+        for k in range(3):
+            load_grads(flat, k)
+            opt.step()
+        for i, name in enumerate(flat.names):
+            check(flat.views[name].cpu().flatten(), torch.from_numpy(d[f"sgd_{tag}.{i}"]).flatten(), 2e-6, f"sgd {tag} tensor {i}")
