@@ -239,6 +239,51 @@ def remap_checkpoint(checkpoint, path):
     return sd, label
 
 
+def export_checkpoint(state_dict, path, layout, epoch=0, optimizer_state=None, extra=None):
+    """Writer for the foreign layouts ``remap_checkpoint`` reads, so that weights trained here load into the
+    reference's own ``load_model`` (train.py:240-308) and its pretraining drivers:
+      'spark'   .pth  {'module': sparse_encoder.sp_cnn.* + dense_decoder.*, 'args', 'input_size', 'arch', 'epoch',
+                       'performance_desc', 'optimizer', 'is_pretrain'}        (Spark/utils/misc.py:143-162)
+      'cmunet'  .pth  {'meta': {'mmengine_version', ...}, 'state_dict': backbone.* + pixel_decoder.*}   (mmengine CheckpointHook)
+      'encoder' .pth  raw encoder dict (down_conv* / double_conv*), optionally DataParallel-prefixed via extra={'prefix': 'module.'}
+      'moco'    .ckpt {'state_dict': encoder_q.*, 'epoch', ...}                (Lightning ModelCheckpoint)
+      'genesis' .pt   {'epoch', 'state_dict': module.*, 'optimizer_state_dict'} (Genesis_Chest_CT.py:165-169)
+    ``state_dict``: this UNet's key names.  The file extension must match the layout (it is what the reader dispatches on)."""
+    extra = dict(extra or {})
+    sd = {k: v.detach().cpu() if torch.is_tensor(v) else v for k, v in state_dict.items()}
+    enc = {k: v for k, v in sd.items() if k.startswith(("down_conv", "double_conv"))}
+    dec = {k: v for k, v in sd.items() if k.startswith(("up_conv", "conv_last"))}
+    ext = {"spark": ".pth", "cmunet": ".pth", "encoder": ".pth", "moco": ".ckpt", "genesis": ".pt"}
+    if layout not in ext:
+        raise ValueError(f"unknown checkpoint layout {layout!r}; one of {sorted(ext)}")
+    if not path.endswith(ext[layout]):
+        raise ValueError(f"layout {layout!r} is written to a '{ext[layout]}' file (the reader dispatches on the extension)")
+    if layout == "spark":
+        module = {"sparse_encoder.sp_cnn." + k: v for k, v in enc.items()}
+        module.update({"dense_decoder." + k: v for k, v in dec.items()})
+        ck = {"args": extra.get("args", {}), "input_size": extra.get("input_size", 512), "arch": extra.get("arch", "unet_sparse"),
+              "epoch": epoch, "performance_desc": extra.get("performance_desc", ""), "module": module,
+              "optimizer": optimizer_state, "is_pretrain": True}
+    elif layout == "cmunet":
+        out = {"backbone." + k: v for k, v in enc.items()}
+        out.update({"pixel_decoder." + k: v for k, v in dec.items()})
+        ck = {"meta": {"mmengine_version": extra.get("mmengine_version", "0.10.5"), "epoch": epoch, "iter": extra.get("iter", 0)},
+              "state_dict": out}
+        if optimizer_state is not None:
+            ck["optimizer"] = optimizer_state
+    elif layout == "encoder":
+        pre = extra.get("prefix", "")
+        ck = {pre + k: v for k, v in enc.items()}
+    elif layout == "moco":
+        ck = {"epoch": epoch, "global_step": extra.get("global_step", 0), "state_dict": {"encoder_q." + k: v for k, v in enc.items()}}
+        if optimizer_state is not None:
+            ck["optimizer_states"] = [optimizer_state]
+    else:
+        ck = {"epoch": epoch, "state_dict": {"module." + k: v for k, v in sd.items()}, "optimizer_state_dict": optimizer_state}
+    torch.save(ck, path)
+    return path
+
+
 def load_model(args, map_location="cpu"):
     """train.py:240-308: UNet() initialised from ``args.pretrained`` (strict=False, head dropped)."""
     model = UNet(dtype=getattr(args, "dtype", "bf16"))

@@ -69,6 +69,35 @@ def test_load_model_checkpoint_layouts(tmp_path):
     assert sum(p.numel() for p in m.parameters()) == 31042434
 
 
+def test_export_checkpoint_round_trips(tmp_path):
+    """export_checkpoint writes each foreign layout so that the reader (the reference's load_model dispatch, restated in
+    remap_checkpoint) recovers exactly the tensors that layout carries."""
+    from cmunet_amd import train as T
+    sd = OU.make_state_dict(base_ch=16, depth=3, seed=4)
+    enc_keys = [k for k in sd if k.startswith(("down_conv", "double_conv"))]
+    dec_keys = [k for k in sd if k.startswith("up_conv")]
+    for layout, name, has_dec in (("spark", "a.pth", True), ("cmunet", "b.pth", True), ("encoder", "c.pth", False),
+                                  ("moco", "d.ckpt", False), ("genesis", "e.pt", True)):
+        path = T.export_checkpoint(sd, str(tmp_path / name), layout, epoch=7, optimizer_state={"lr": 0.1})
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        got, label = T.remap_checkpoint(ck, path)
+        assert label == layout
+        for k in enc_keys:
+            assert torch.equal(got[k], sd[k]), (layout, k)
+        for k in dec_keys:
+            assert (k in got and torch.equal(got[k], sd[k])) == has_dec, (layout, k)
+        assert "conv_last.weight" not in got
+    ck = torch.load(str(tmp_path / "a.pth"), weights_only=False)
+    assert {"args", "input_size", "arch", "epoch", "performance_desc", "module", "optimizer", "is_pretrain"} <= set(ck) and ck["epoch"] == 7
+    assert torch.load(str(tmp_path / "b.pth"), weights_only=False)["meta"]["mmengine_version"]
+    pre = T.export_checkpoint(sd, str(tmp_path / "f.pth"), "encoder", extra={"prefix": "module."})
+    assert all(k.startswith("module.") for k in torch.load(pre, weights_only=False))
+    with pytest.raises(ValueError):
+        T.export_checkpoint(sd, str(tmp_path / "x.pt"), "spark")
+    with pytest.raises(ValueError):
+        T.export_checkpoint(sd, str(tmp_path / "x.pth"), "nope")
+
+
 def test_cli_flags_and_meter():
     from cmunet_amd import train as T
     a = T.get_args(["-e", "3", "-b", "2,4", "-l", "0.001", "-n", "x", "-r", "0.5"])
