@@ -22,6 +22,11 @@ _F = ctypes.c_float
 _SIGS = {
     "cmu_last_error": (ctypes.c_char_p, []),
     "cmu_last_kernel": (ctypes.c_char_p, []),
+    "cmu_softmax2_threshold": (_I, [_P, _F, _P, _I, _I, _I, _P]),
+    "cmu_soft_skeleton_ws_bytes": (_L, [_L]),
+    "cmu_soft_skeleton": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "cmu_cldice_sums_ws_bytes": (_L, []),
+    "cmu_cldice_sums": (_I, [_P, _P, _P, _P, _L, _P, _P, _P]),
     "cmu_sgd_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _L, _F, _P]),
     "cmu_lamb_block_elems": (_I, []),
     "cmu_lamb_ws_bytes": (_L, [_I, _I]),

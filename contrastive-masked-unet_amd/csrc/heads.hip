@@ -535,3 +535,123 @@ extern "C" int cmu_gap_bwd(const float* dout, void* dA, int64_t ldd, int B, int 
     CMU_CHECK_ARG(cmu_dtype_size(dt) > 0 && dout && dA && B > 0 && H > 0 && W > 0 && C > 0 && ldd >= C, "cmu_gap_bwd: bad args");
     CMU_DISPATCH_DT(dt, gap_bwd_t, dout, dA, ldd, B, H * W, C, (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------------------------------------
+// soft-clDice (Finetuning/metrics.py:401-492): soft skeletonisation by iterated min/max pooling on fp32
+// (planes, H, W) stacks.  With img_{j+1} = erode(img_j) the reference's soft_open(img_j) is dilate(img_{j+1}), so one erode
+// and one fused dilate+update per level (it runs two erodes); pooling pads with the identity of min / max.
+//   erode:  out = min( min over the 3x1 column window, min over the 1x3 row window )      (metrics.py:456-459)
+//   update: delta = relu(img - dilate3x3(next)); skel = first ? delta : skel + relu(delta - skel*delta)   (:476-486)
+// ---------------------------------------------------------------------------------------------
+__global__ void soft_erode_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, int64_t total) {
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(o % W), y = (int)((o / W) % H);
+        const float c = in[o];
+        float m = c;
+        if (y > 0) m = fminf(m, in[o - W]);
+        if (y + 1 < H) m = fminf(m, in[o + W]);
+        if (x > 0) m = fminf(m, in[o - 1]);
+        if (x + 1 < W) m = fminf(m, in[o + 1]);
+        out[o] = m;
+    }
+}
+__global__ void soft_skel_update_kernel(const float* __restrict__ img, const float* __restrict__ next, float* __restrict__ skel, int H,
+                                        int W, int64_t total, int first) {
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(o % W), y = (int)((o / W) % H);
+        float d = next[o];
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = y + dy, xx = x + dx;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) d = fmaxf(d, next[o + (int64_t)dy * W + dx]);
+            }
+        const float delta = fmaxf(img[o] - d, 0.f);
+        skel[o] = first ? delta : skel[o] + fmaxf(delta - skel[o] * delta, 0.f);
+    }
+}
+// four sums for clDice: sum(skel_pred*y_true), sum(skel_pred), sum(skel_true*y_pred), sum(skel_true) -> out[4] (fp64 combine)
+__global__ __launch_bounds__(256) void cldice_sums_kernel(const float* __restrict__ sp, const float* __restrict__ yt,
+                                                         const float* __restrict__ stt, const float* __restrict__ yp, int64_t n,
+                                                         float* __restrict__ part) {
+    __shared__ float red[4][4];
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        a[0] = fmaf(sp[i], yt[i], a[0]);
+        a[1] += sp[i];
+        a[2] = fmaf(stt[i], yp[i], a[2]);
+        a[3] += stt[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        a[k] = wave_sum(a[k]);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = a[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) part[(int64_t)blockIdx.x * 4 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+__global__ void cldice_final_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ out) {
+    const int k = threadIdx.x;
+    if (k >= 4) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += (double)part[(int64_t)b * 4 + k];
+    out[k] = (float)s;
+}
+constexpr int CLD_BLOCKS = 512;
+extern "C" int64_t cmu_soft_skeleton_ws_bytes(int64_t n) { return 2 * n * (int64_t)sizeof(float); }
+extern "C" int cmu_soft_skeleton(const float* img, float* skel, int planes, int H, int W, int num_iter, void* ws, void* stream) {
+    CMU_CHECK_ARG(img && skel && ws && planes > 0 && H > 0 && W > 0 && num_iter >= 0, "cmu_soft_skeleton: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = (int64_t)planes * H * W;
+    const int grid = (int)(cmu_div_up64(n, 256) < 4096 ? cmu_div_up64(n, 256) : 4096);
+    float* a = (float*)ws;
+    float* b = a + n;
+    // level 0: cur = img, nxt = erode(img)
+    const float* cur = img;
+    float* nxt = a;
+    hipLaunchKernelGGL(soft_erode_kernel, dim3(grid), dim3(256), 0, st, cur, nxt, H, W, n);
+    CMU_CHECK_LAUNCH("cmu_soft_skeleton(erode)");
+    hipLaunchKernelGGL(soft_skel_update_kernel, dim3(grid), dim3(256), 0, st, cur, (const float*)nxt, skel, H, W, n, 1);
+    CMU_CHECK_LAUNCH("cmu_soft_skeleton(update)");
+    for (int j = 0; j < num_iter; ++j) {
+        cur = nxt;                       // img_{j+1}
+        nxt = (cur == a) ? b : a;        // img_{j+2} = erode(img_{j+1})
+        hipLaunchKernelGGL(soft_erode_kernel, dim3(grid), dim3(256), 0, st, cur, nxt, H, W, n);
+        CMU_CHECK_LAUNCH("cmu_soft_skeleton(erode)");
+        hipLaunchKernelGGL(soft_skel_update_kernel, dim3(grid), dim3(256), 0, st, cur, (const float*)nxt, skel, H, W, n, 0);
+        CMU_CHECK_LAUNCH("cmu_soft_skeleton(update)");
+    }
+    return CMU_OK;
+}
+extern "C" int64_t cmu_cldice_sums_ws_bytes(void) { return (int64_t)CLD_BLOCKS * 4 * (int64_t)sizeof(float); }
+extern "C" int cmu_cldice_sums(const float* skel_pred, const float* y_true, const float* skel_true, const float* y_pred, int64_t n,
+                               float* out4, void* ws, void* stream) {
+    CMU_CHECK_ARG(skel_pred && y_true && skel_true && y_pred && out4 && ws && n > 0, "cmu_cldice_sums: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (int)(cmu_div_up64(n, 1024) < CLD_BLOCKS ? cmu_div_up64(n, 1024) : CLD_BLOCKS);
+    hipLaunchKernelGGL(cldice_sums_kernel, dim3(grid), dim3(256), 0, st, skel_pred, y_true, skel_true, y_pred, n, (float*)ws);
+    CMU_CHECK_LAUNCH("cmu_cldice_sums");
+    hipLaunchKernelGGL(cldice_final_kernel, dim3(1), dim3(64), 0, st, (const float*)ws, grid, out4);
+    CMU_CHECK_LAUNCH("cmu_cldice_sums(final)");
+    return CMU_OK;
+}
+// (softmax(logits, dim=1)[:, 1] > threshold) as fp32 for 2-class logits (B,2,H,W): the binarised foreground the reference's
+// metrics take after Activation('softmax') + _threshold + _take_channels(ignore_channels=[0]) (metrics.py:84-133)
+__global__ void softmax2_threshold_kernel(const float* __restrict__ logits, float thr, float* __restrict__ out, int64_t HW, int64_t total) {
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = o / HW, r = o % HW;
+        const float l0 = logits[(b * 2 + 0) * HW + r], l1 = logits[(b * 2 + 1) * HW + r];
+        const float mx = fmaxf(l0, l1);
+        const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
+        out[o] = (e1 / (e0 + e1) > thr) ? 1.f : 0.f;
+    }
+}
+extern "C" int cmu_softmax2_threshold(const float* logits, float threshold, float* out, int B, int H, int W, void* stream) {
+    CMU_CHECK_ARG(logits && out && B > 0 && H > 0 && W > 0, "cmu_softmax2_threshold: bad args");
+    const int64_t HW = (int64_t)H * W, total = HW * B;
+    const int grid = (int)(cmu_div_up64(total, 256) < 4096 ? cmu_div_up64(total, 256) : 4096);
+    hipLaunchKernelGGL(softmax2_threshold_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, threshold, out, HW, total);
+    CMU_CHECK_LAUNCH("cmu_softmax2_threshold");
+    return CMU_OK;
+}

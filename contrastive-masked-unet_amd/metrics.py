@@ -156,3 +156,42 @@ class DiceMetric(Metric):
 
     def forward(self, y_pr, y_gt):
         return seg_stats(y_pr, y_gt)[1].detach().double()
+
+
+class soft_cldice(Loss):
+    """Soft clDice (metrics.py:401-431) evaluated on the device: binarised foreground -> soft skeletons of prediction and
+    target by ten rounds of min/max pooling (cmu_soft_skeleton) -> four sums (cmu_cldice_sums) -> 1 - 2*tprec*tsens/(tprec+tsens).
+    The configuration of the reference's driver (train.py:464: activation 'softmax', threshold 0.5, ignore_channels [0],
+    two classes) runs on the HIP path; other settings raise.  Thresholded -> no gradient, as in the reference."""
+    __name__ = "soft_clDice"
+
+    def __init__(self, iter_=3, smooth=1., exclude_background=False, threshold=0.5, activation=None, ignore_channels=None):
+        super().__init__()
+        if activation not in ("softmax", "softmax2d") or threshold is None or list(ignore_channels or []) != [0] or exclude_background:
+            raise NotImplementedError("soft_cldice: only the reference driver's configuration (activation='softmax', a threshold, "
+                                      "ignore_channels=[0]) is implemented on the HIP path")
+        self.iter, self.smooth, self.threshold, self.num_iter = iter_, smooth, float(threshold), 10
+
+    def forward(self, y_pred, y_true):
+        if not y_pred.is_cuda:
+            raise RuntimeError("soft_cldice runs on the GPU only (no CPU fallback)")
+        B, K, H, W = y_pred.shape
+        if K != 2:
+            raise NotImplementedError("soft_cldice: two-class logits expected")
+        lib = _lib.lib()
+        logits = y_pred.detach().float().contiguous()
+        yt = y_true[:, 1].detach().float().contiguous()
+        yp = torch.empty(B, H, W, dtype=torch.float32, device=y_pred.device)
+        _lib.call("cmu_softmax2_threshold", ops._p(logits), self.threshold, ops._p(yp), B, H, W, ops._stream())
+        n = B * H * W
+        ws = torch.empty(lib.cmu_soft_skeleton_ws_bytes(n), dtype=torch.uint8, device=y_pred.device)
+        sp, st = torch.empty_like(yp), torch.empty_like(yp)
+        _lib.call("cmu_soft_skeleton", ops._p(yp), ops._p(sp), B, H, W, self.num_iter, ops._p(ws), ops._stream())
+        _lib.call("cmu_soft_skeleton", ops._p(yt), ops._p(st), B, H, W, self.num_iter, ops._p(ws), ops._stream())
+        out4 = torch.empty(4, dtype=torch.float32, device=y_pred.device)
+        ws2 = torch.empty(lib.cmu_cldice_sums_ws_bytes(), dtype=torch.uint8, device=y_pred.device)
+        _lib.call("cmu_cldice_sums", ops._p(sp), ops._p(yt), ops._p(st), ops._p(yp), n, ops._p(out4), ops._p(ws2), ops._stream())
+        s = out4.double()
+        tprec = (s[0] + self.smooth) / (s[1] + self.smooth)
+        tsens = (s[2] + self.smooth) / (s[3] + self.smooth)
+        return 1. - 2.0 * (tprec * tsens) / (tprec + tsens)

@@ -274,6 +274,16 @@ int cmu_adam_step(float* p, const float* g, float* m, float* v, const uint8_t* w
                   float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled,
                   int64_t step, float grad_scale, void* stream);
 
+/* soft-clDice building blocks (Finetuning/metrics.py:401-492): soft skeleton of an fp32 (planes, H, W) stack by num_iter
+ * rounds of min/max pooling (the reference uses 10), and the four sums sum(skel_pred*y_true), sum(skel_pred),
+ * sum(skel_true*y_pred), sum(skel_true) -> out4 (device), from which clDice = 1 - 2*tprec*tsens/(tprec+tsens).        */
+int cmu_softmax2_threshold(const float* logits /*(B,2,H,W)*/, float threshold, float* out /*(B,H,W) 0/1*/, int B, int H, int W, void* stream);
+int64_t cmu_soft_skeleton_ws_bytes(int64_t n);
+int cmu_soft_skeleton(const float* img, float* skel, int planes, int H, int W, int num_iter, void* ws, void* stream);
+int64_t cmu_cldice_sums_ws_bytes(void);
+int cmu_cldice_sums(const float* skel_pred, const float* y_true, const float* skel_true, const float* y_pred, int64_t n,
+                    float* out4, void* ws, void* stream);
+
 /* Fused SGD step over a flat fp32 arena (torch.optim.SGD; MoCo: moco2_module.py:339-344, momentum 0.9, weight decay 1e-4).
  * g' = g*grad_scale + wd*p (where wd_mask != 0 or wd_mask == NULL); buf = g' on step 1, else momentum*buf + (1-dampening)*g';
  * p -= lr * (nesterov ? g' + momentum*buf : buf); momentum == 0: p -= lr*g' (buf may be NULL).                        */

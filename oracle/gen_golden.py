@@ -168,6 +168,27 @@ def gen_spark(ref):
          bott_running_var=rv)
 
 
+def gen_cldice(M):
+    """soft_cldice of the reference (metrics.py:401-431, the driver's configuration train.py:464) on vessel-like masks."""
+    from oracle import losses as OL
+    g = torch.Generator().manual_seed(77)
+    B, H, W = 2, 48, 56
+    # curvilinear foreground: thresholded smooth noise + a few thin lines
+    base = torch.nn.functional.avg_pool2d(torch.randn(B, 1, H, W, generator=g), 5, 1, 2)
+    fg = (base[:, 0] > base.flatten(1).quantile(0.88, dim=1).view(B, 1, 1))
+    fg[:, 10, :] = True
+    fg[:, :, 23] = True
+    y1h = torch.stack([~fg, fg], 1).double()
+    logits = torch.randn(B, 2, H, W, generator=g) * 0.8 + (y1h.float() * 2 - 1) * torch.tensor([1.0, 1.6]).view(1, 2, 1, 1)
+    ref = M.soft_cldice(threshold=0.5, activation="softmax", ignore_channels=[0])(logits, y1h)
+    mine = OL.soft_cldice(logits, y1h)
+    close(mine.float(), ref.float(), what="soft clDice")
+    yp = (torch.softmax(logits, 1) > 0.5).float()[:, 1:2]
+    skel = M.SoftSkeletonize(num_iter=10)(yp)
+    close(OL.soft_skel(yp, 10), skel, what="soft skeleton")
+    save("cldice", logits=logits, y1h=y1h, cldice=ref.detach(), skel_pred=skel, metric_name=np.array(M.soft_cldice().__name__))
+
+
 def gen_optim():
     """LAMB: the reference's own class (Pretraining/Spark/utils/lamb.py, pure torch); SGD: torch.optim.SGD as MoCo configures it."""
     import importlib.util
@@ -228,6 +249,9 @@ def main():
         return
     if "--only-optim" in sys.argv:      # regenerate tests/golden/optim_traces.npz alone
         gen_optim()
+        return
+    if "--only-cldice" in sys.argv:
+        gen_cldice(M)
         return
 
     def load(mod, sd):
@@ -432,6 +456,7 @@ def main():
     # ---- 7. SparK (sparse masked conv) -- reference imported behind the stubs of SURVEY Appendix C-3 ---------
     gen_spark(ref)
     gen_optim()
+    gen_cldice(M)
     print("all fixtures written; oracle == reference on every case")
 
 

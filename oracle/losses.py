@@ -51,3 +51,34 @@ def cross_entropy_prob(logits, y):
 def dice_ce_loss(logits, y):
     """train.py:455 -- the finetuning criterion 'dice_loss + cross_entropy_loss'."""
     return dice_loss(logits, y) + cross_entropy_prob(logits, y)
+
+
+def soft_skel(img, num_iter=10):
+    """metrics.py:448-490 (SoftSkeletonize): iterated min/max pooling; img (B,C,H,W)."""
+    import torch.nn.functional as F
+
+    def erode(x):
+        p1 = -F.max_pool2d(-x, (3, 1), (1, 1), (1, 0))
+        p2 = -F.max_pool2d(-x, (1, 3), (1, 1), (0, 1))
+        return torch.min(p1, p2)
+
+    def opened(x):
+        return F.max_pool2d(erode(x), (3, 3), (1, 1), (1, 1))
+
+    skel = F.relu(img - opened(img))
+    for _ in range(num_iter):
+        img = erode(img)
+        delta = F.relu(img - opened(img))
+        skel = skel + F.relu(delta - skel * delta)
+    return skel
+
+
+def soft_cldice(logits, y_true, smooth=1.0, threshold=0.5, num_iter=10):
+    """metrics.py:401-431 in the driver's configuration (train.py:464: activation 'softmax', threshold 0.5,
+    ignore_channels [0]): binarised foreground vs the one-hot target's channel 1."""
+    y_pred = (torch.softmax(logits, dim=1) > threshold).to(logits.dtype)[:, 1:2]
+    yt = y_true[:, 1:2].to(logits.dtype)
+    sp, st = soft_skel(y_pred, num_iter), soft_skel(yt, num_iter)
+    tprec = ((sp * yt).sum() + smooth) / (sp.sum() + smooth)
+    tsens = ((st * y_pred).sum() + smooth) / (st.sum() + smooth)
+    return 1.0 - 2.0 * (tprec * tsens) / (tprec + tsens)

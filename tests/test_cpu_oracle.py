@@ -203,3 +203,16 @@ def test_optimizer_traces_golden(golden_dir):
             OO.sgd_step(ps, grads[k], bufs, 0.03, step=k + 1, **kw)
         for i in range(n):
             assert torch.allclose(ps[i], torch.from_numpy(d[f"sgd_{tag}.{i}"]), atol=2e-6), (tag, i)
+
+
+def test_soft_cldice_golden(golden_dir):
+    """oracle/losses.py soft skeleton / soft clDice against the reference's own classes (fixture from gen_golden.py)."""
+    import numpy as np
+    import torch
+    from oracle import losses as OL
+    d = np.load(f"{golden_dir}/cldice.npz")
+    logits, y1h = torch.from_numpy(d["logits"]), torch.from_numpy(d["y1h"])
+    assert abs(float(OL.soft_cldice(logits, y1h)) - float(d["cldice"])) < 1e-6
+    yp = (torch.softmax(logits, 1) > 0.5).float()[:, 1:2]
+    assert torch.allclose(OL.soft_skel(yp, 10), torch.from_numpy(d["skel_pred"]), atol=1e-6)
+    assert str(d["metric_name"]) == "soft_clDice"

@@ -70,3 +70,27 @@ def test_finetune_unet_small_vs_oracle(golden_dir):
     net.eval(); net2.eval()
     with torch.no_grad():
         assert torch.equal(net(x), net2.cuda()(x))
+
+
+def test_soft_cldice_vs_reference_fixture(golden_dir):
+    """Device soft-clDice (skeleton kernels + sums) against the value and the skeleton the reference's classes produced."""
+    import numpy as np
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cmunet_amd import _lib, metrics as PM, ops
+    d = np.load(f"{golden_dir}/cldice.npz")
+    logits, y1h = torch.from_numpy(d["logits"]).cuda(), torch.from_numpy(d["y1h"]).cuda()
+    m = PM.soft_cldice(threshold=0.5, activation="softmax", ignore_channels=[0])
+    assert m.__name__ == str(d["metric_name"])
+    got = float(m(logits, y1h))
+    assert abs(got - float(d["cldice"])) <= 1e-5, (got, float(d["cldice"]))
+    # the skeleton itself
+    B, _, H, W = logits.shape
+    yp = torch.empty(B, H, W, device="cuda")
+    _lib.call("cmu_softmax2_threshold", ops._p(logits.float().contiguous()), 0.5, ops._p(yp), B, H, W, ops._stream())
+    ws = torch.empty(_lib.lib().cmu_soft_skeleton_ws_bytes(B * H * W), dtype=torch.uint8, device="cuda")
+    sk = torch.empty_like(yp)
+    _lib.call("cmu_soft_skeleton", ops._p(yp), ops._p(sk), B, H, W, 10, ops._p(ws), ops._stream())
+    assert torch.allclose(sk.cpu(), torch.from_numpy(d["skel_pred"])[:, 0], atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        PM.soft_cldice(activation=None)
