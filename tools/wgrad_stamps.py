@@ -43,14 +43,24 @@ if not hasattr(lib, "cmu_debug_wg_stamps"):
     sys.exit(0)
 buf = np.zeros(64 * 16 * 8, dtype=np.uint64)
 assert lib.cmu_debug_wg_stamps(buf.ctypes.data_as(vp)) == 0
+names = sys.argv[5].split(",") if len(sys.argv) > 5 else ["mfma", "barrierA", "stage", "barrierB"]
+if Cout % 128 == 0 and Cin % 64 == 0:      # wide kernel: waves 0 and 4 of 32 workgroups stamp through LDS
+    st2 = buf.reshape(32, 2, 16, 8).astype(np.int64)
+    for grp in range(2):
+        stg = st2[:, grp]
+        stg = stg[stg[:, 0, 0] > 0][:, :15]
+        nst = int((stg[0, :, 0] > 0).sum())
+        print(f"wave {4 * grp}: workgroups {stg.shape[0]}, tiles stamped {nst}")
+        for k, nm in enumerate(names):
+            d = stg[:, 1:nst - 1, k + 1] - stg[:, 1:nst - 1, k]
+            print(f"  {nm:11s} avg {d.mean():8.0f} cyc (min {d.min()}, max {d.max()})")
+        print(f"  per-tile total {(stg[:, 2:nst - 1, 0] - stg[:, 1:nst - 2, 0]).mean():.0f} cyc")
+    sys.exit(0)
 st = buf.reshape(64, 16, 8).astype(np.int64)
 st = st[st[:, 0, 0] > 0]
 nst = int((st[0, :, 0] > 0).sum()) - 1
 print("blocks", st.shape[0], "tiles/block stamped", nst + 1)
-for k, nm in enumerate((sys.argv[5].split(",") if len(sys.argv) > 5 else ["compute", "store_tile", "barrier", "load_issue"])):
+for k, nm in enumerate(["compute", "store_tile", "barrier", "load_issue"]):
     d = st[:, 1:nst, k + 1] - st[:, 1:nst, k]
     print(f"  {nm:11s} avg {d.mean():8.0f} cyc (min {d.min()}, max {d.max()})")
-if (st[:, 1:nst, 5] > 0).all():
-    d = st[:, 1:nst, 5] - st[:, 1:nst, 2]
-    print(f"  (stage: store part avg {d.mean():.0f} cyc, load-issue part avg {(st[:, 1:nst, 3] - st[:, 1:nst, 5]).mean():.0f} cyc)")
 print(f"  per-tile total {(st[:, 2:nst, 0] - st[:, 1:nst - 1, 0]).mean():.0f} cyc")
