@@ -524,7 +524,10 @@ template <class TR>
 __global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask,
                                                               int mask_per_sample, const unsigned char* __restrict__ dY, int64_t ldd,
                                                               float* __restrict__ ws, int B, int H, int W, int Cout, int tilesX,
-                                                              int tilesY, int ntiles) {
+                                                              int tilesY, int ntiles, const unsigned char* __restrict__ yraw, int64_t ldy,
+                                                              const float* __restrict__ bsc, const float* __restrict__ bsh,
+                                                              const float* __restrict__ bmu, const float* __restrict__ bis,
+                                                              const float* __restrict__ coef) {
     constexpr int EPC = TR::EPC;
     constexpr int ES = (int)sizeof(typename TR::elem_t);
     __shared__ float halo[18 * 18];
@@ -539,6 +542,16 @@ __global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __re
     for (int e = 0; e < EPC; ++e)
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[e][t] = 0.f;
+    // yraw != NULL: ``dY`` holds dA (gradient w.r.t. the activated output) and the BatchNorm+ReLU backward of this layer is
+    // applied on the fly (cmu_conv3x3_c1_wgrad_bn) -- the first layer has no data gradient, so dY is never materialised
+    float sc[EPC], sh[EPC], mu[EPC], is[EPC], c1[EPC], c2[EPC];
+    if (yraw != nullptr) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const int c = active ? chunk * EPC + e : 0;
+            sc[e] = bsc[c]; sh[e] = bsh[c]; mu[e] = bmu[c]; is[e] = bis[c]; c1[e] = coef[c]; c2[e] = coef[Cout + c];
+        }
+    }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tx = tile % tilesX, ty = (tile / tilesX) % tilesY, b = tile / (tilesX * tilesY);
         const int ty0 = ty * 16, tx0 = tx * 16;
@@ -560,6 +573,15 @@ __global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __re
                 if (gy >= H || gx >= W) continue;
                 float g[EPC];
                 TR::unpack(ld_global16(dY + ((((int64_t)b * H + gy) * W + gx) * ldd + chunk * EPC) * ES), g);
+                if (yraw != nullptr) {
+                    float v[EPC];
+                    TR::unpack(ld_global16(yraw + ((((int64_t)b * H + gy) * W + gx) * ldy + chunk * EPC) * ES), v);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const float dz = fmaf(v[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
+                        g[e] = sc[e] * (dz - c1[e] - (v[e] - mu[e]) * is[e] * c2[e]);
+                    }
+                }
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     const float xv = halo[(py + t / 3) * 18 + px + t % 3];
@@ -579,12 +601,14 @@ __global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __re
 }
 template <class TR>
 static int conv3x3_c1_wgrad_t(const float* x, const uint8_t* mask, int mps, const void* dY, int64_t ldd, float* dW, int B, int H, int W,
-                              int Cout, void* ws, hipStream_t st) {
+                              int Cout, void* ws, hipStream_t st, const void* yraw = nullptr, int64_t ldy = 0, const float* bsc = nullptr,
+                              const float* bsh = nullptr, const float* bmu = nullptr, const float* bis = nullptr,
+                              const float* coef = nullptr) {
     const int tilesX = cmu_div_up(W, 16), tilesY = cmu_div_up(H, 16);
     const int ntiles = B * tilesX * tilesY;
     const int grid = ntiles < C1W_MAX_BLOCKS ? ntiles : C1W_MAX_BLOCKS;
     hipLaunchKernelGGL((conv3x3_c1_wgrad_kernel<TR>), dim3(grid), dim3(256), 0, st, x, mask, mps, (const unsigned char*)dY, ldd, (float*)ws,
-                       B, H, W, Cout, tilesX, tilesY, ntiles);
+                       B, H, W, Cout, tilesX, tilesY, ntiles, (const unsigned char*)yraw, ldy, bsc, bsh, bmu, bis, coef);
     CMU_CHECK_LAUNCH("cmu_conv3x3_c1_wgrad");
     const int64_t n = (int64_t)Cout * 9;
     hipLaunchKernelGGL(sum_slab_kernel, dim3((unsigned)cmu_div_up64(n, 16)), dim3(256), 0, st, (const float*)ws, grid, n, dW, n, (float*)nullptr);
@@ -602,4 +626,18 @@ extern "C" int cmu_conv3x3_c1_wgrad(const float* x, const uint8_t* mask, int mas
     CMU_CHECK_ARG(Cout > 0 && Cout % epc == 0 && Cout / epc <= 256, "cmu_conv3x3_c1_wgrad: Cout=%d unsupported", Cout);
     CMU_CHECK_ARG(cmu_aligned16(dY) && ldd % epc == 0 && ldd >= Cout, "cmu_conv3x3_c1_wgrad: dY alignment / stride");
     CMU_DISPATCH_DT(dt, conv3x3_c1_wgrad_t, x, mask, mask_per_sample, dY, ldd, dW, B, H, W, Cout, ws, (hipStream_t)stream);
+}
+extern "C" int cmu_conv3x3_c1_wgrad_bn(const float* x, const uint8_t* mask, int mask_per_sample, const void* dA, int64_t ldd,
+                                       const void* yraw, int64_t ldy, const float* scale, const float* shift, const float* save_mean,
+                                       const float* save_invstd, const float* coef, float* dW, int B, int H, int W, int Cout, int dt,
+                                       void* ws, void* stream) {
+    const int es = cmu_dtype_size(dt);
+    CMU_CHECK_ARG(es > 0 && x && dA && yraw && scale && shift && save_mean && save_invstd && coef && dW && ws && B > 0 && H > 0 && W > 0,
+                  "cmu_conv3x3_c1_wgrad_bn: bad args");
+    const int epc = 16 / es;
+    CMU_CHECK_ARG(Cout > 0 && Cout % epc == 0 && Cout / epc <= 256, "cmu_conv3x3_c1_wgrad_bn: Cout=%d unsupported", Cout);
+    CMU_CHECK_ARG(cmu_aligned16(dA) && ldd % epc == 0 && ldd >= Cout && cmu_aligned16(yraw) && ldy % epc == 0 && ldy >= Cout,
+                  "cmu_conv3x3_c1_wgrad_bn: alignment / stride");
+    CMU_DISPATCH_DT(dt, conv3x3_c1_wgrad_t, x, mask, mask_per_sample, dA, ldd, dW, B, H, W, Cout, ws, (hipStream_t)stream, yraw, ldy, scale,
+                    shift, save_mean, save_invstd, coef);
 }

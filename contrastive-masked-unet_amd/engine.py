@@ -176,8 +176,10 @@ class UNetEngine:
             ops.bn_bwd_finalize(ws, B * H * W, dgamma, dbeta, coef)
         else:
             ops.bn_bwd_reduce(dA, y, s["mean"], s["invstd"], dgamma, dbeta, coef, ws)
+        first = s["x_img"] is not None                        # first layer: no data gradient, BN apply fused in its wgrad
         dY = Act(dA.buf, dA.coff, dA.C)                       # in place over dA
-        ops.bn_bwd_apply(dA, y, s["mean"], s["invstd"], coef, dY)
+        if not first:
+            ops.bn_bwd_apply(dA, y, s["mean"], s["invstd"], coef, dY)
         grads[s["pbn"] + "weight"] = dgamma
         grads[s["pbn"] + "bias"] = dbeta
         # conv bias: followed by training-mode BN, its gradient is identically zero (sum of dY over pixels)
@@ -187,13 +189,13 @@ class UNetEngine:
         dW = self._gbuf(s["pconv"] + "weight", w)
         if s["x_img"] is not None:
             wsb = self.scratch.get("wg", self.lib.cmu_conv3x3_c1_wgrad_ws_bytes(B, H, W, C))
-            ops.conv3x3_c1_wgrad(s["x_img"], dY, dW, wsb, s["mask"], s["mps"])
+            ops.conv3x3_c1_wgrad_bn(s["x_img"], dA, y, y.scale, y.shift, s["mean"], s["invstd"], coef, dW, wsb, s["mask"], s["mps"])
         else:
             Cin = w.shape[1]
             wsb = self.scratch.get("wg", self.lib.cmu_conv3x3_wgrad_ws_bytes(B, H, W, Cin, C, self.dt))
             ops.conv3x3_wgrad(s["x"], dY, dW, wsb)
         grads[s["pconv"] + "weight"] = dW
-        if not need_dx or s["x_img"] is not None:
+        if not need_dx or first:
             return None
         dX = dx_out if dx_out is not None else self._new(B, H, W, w.shape[1])
         if next_bn is not None and next_bn["y"].C == dX.C:

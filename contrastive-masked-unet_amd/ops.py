@@ -240,6 +240,15 @@ def conv3x3_c1_wgrad(x_bhw, dY, dW, ws, mask=None, mask_per_sample=False):
          B, H, W, dW.shape[0], dY.dt, _p(ws), _stream())
 
 
+def conv3x3_c1_wgrad_bn(x_bhw, dA, yraw, scale, shift, save_mean, save_invstd, coef, dW, ws, mask=None, mask_per_sample=False):
+    """First-layer weight gradient with the layer's BatchNorm+ReLU backward applied in registers (no dY in memory)."""
+    B, H, W = x_bhw.shape
+    assert dA.dt == yraw.dt
+    call("cmu_conv3x3_c1_wgrad_bn", _p(_f32c(x_bhw)), _p(mask), int(mask_per_sample), dA.ptr(), dA.ld, yraw.ptr(), yraw.ld,
+         _p(scale), _p(shift), _p(save_mean), _p(save_invstd), _p(coef), _p(_f32c(dW)), B, H, W, dW.shape[0], dA.dt, _p(ws),
+         _stream())
+
+
 def maxpool_bwd(dP, dSkip, y, dA, save_mean=None, save_invstd=None, bn_ws=None):
     call("cmu_maxpool_bwd", dP.ptr(), dP.ld, None if dSkip is None else dSkip.ptr(), 0 if dSkip is None else dSkip.ld,
          y.ptr(), y.ld, _p(y.scale), _p(y.shift), dA.ptr(), dA.ld, _p(save_mean), _p(save_invstd), _p(bn_ws),

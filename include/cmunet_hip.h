@@ -155,6 +155,13 @@ int cmu_conv3x3_wgrad(const void* x, int64_t ldx, const float* in_scale, const f
 int64_t cmu_conv3x3_c1_wgrad_ws_bytes(int B, int H, int W, int Cout);
 int cmu_conv3x3_c1_wgrad(const float* x, const uint8_t* mask, int mask_per_sample, const void* dY, int64_t ldd,
                          float* dW, int B, int H, int W, int Cout, int dt, void* ws, void* stream);
+/* Same with the layer's BatchNorm+ReLU backward applied on the fly: dA is the gradient w.r.t. the activated output, yraw the
+ * layer's raw conv output, coef the phase-1 coefficients (cmu_bn_bwd_finalize*).  The first layer has no data gradient, so
+ * its dY never has to exist in memory (no cmu_bn_bwd_apply pass for it).                                               */
+int cmu_conv3x3_c1_wgrad_bn(const float* x, const uint8_t* mask, int mask_per_sample, const void* dA, int64_t ldd,
+                            const void* yraw, int64_t ldy, const float* scale, const float* shift, const float* save_mean,
+                            const float* save_invstd, const float* coef, float* dW, int B, int H, int W, int Cout, int dt,
+                            void* ws, void* stream);
 
 /* MaxPool2d(2) backward fused with the skip-branch add: dA = unpool(dP) + dSkip (dSkip may be NULL).
  * The arg-max is recomputed from the raw output + transform (first max in row-major 2x2 order, as ATen). */

@@ -112,6 +112,34 @@ def test_conv3x3_c1_wgrad(ops, dt, masked):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("masked", [0, 2])
+def test_conv3x3_c1_wgrad_bn(ops, dt, masked):
+    """First-layer wgrad with the BN+ReLU backward applied on the fly == unfused (apply in f64, then wgrad)."""
+    from cmunet_amd import _lib
+    B, H, W, Cout = 2, 20, 37, 32
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, H, W, generator=g)
+    dA = q(torch.randn(B, Cout, H, W, generator=g), dt, ops)
+    yraw = q(torch.randn(B, Cout, H, W, generator=g), dt, ops)
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.3
+    mu, istd = torch.randn(Cout, generator=g) * 0.1, torch.rand(Cout, generator=g) + 0.5
+    coef = torch.randn(2, Cout, generator=g) * 0.1
+    mask, xin = None, x
+    if masked:
+        mask = (torch.rand(B, H, W, generator=g) > 0.5).to(torch.uint8)
+        xin = x * (1 - mask).float()
+    v = lambda t: t.double().view(1, -1, 1, 1)
+    dz = torch.where(yraw.double() * v(sc) + v(sh) > 0, dA.double(), torch.zeros((), dtype=torch.float64))
+    dy = v(sc) * (dz - v(coef[0]) - (yraw.double() - v(mu)) * v(istd) * v(coef[1]))
+    dW = torch.empty(Cout, 1, 3, 3, device="cuda")
+    ws = ws_bytes(_lib.lib().cmu_conv3x3_c1_wgrad_ws_bytes(B, H, W, Cout))
+    ops.conv3x3_c1_wgrad_bn(x.cuda(), to_act(dA, dt, ops), to_act(yraw, dt, ops), sc.cuda(), sh.cuda(), mu.cuda(), istd.cuda(),
+                            coef.cuda(), dW, ws, None if mask is None else mask.cuda(), masked == 2)
+    ref = torch.nn.grad.conv2d_weight(xin.double().unsqueeze(1), (Cout, 1, 3, 3), dy, padding=1)
+    check(dW.cpu(), ref, 1e-4, "dW c1 (fused BN backward)")
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("with_skip", [True, False])
 def test_maxpool_bwd(ops, dt, with_skip):
     B, C, H, W = 2, 32, 8, 12
