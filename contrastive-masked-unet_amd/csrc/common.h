@@ -116,6 +116,12 @@ struct BF16Traits {
     }
     __device__ static inline float to_float(__bf16 v) { return (float)v; }
     __device__ static inline __bf16 from_float(float v) { return (__bf16)v; }
+    // two conversions in one instruction (round to nearest even, same as the cast): a in the low half, b in the high half
+    __device__ static inline uint32_t pack2(float a, float b) {
+        uint32_t r;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    }
 };
 
 // dispatch a templated launcher on the runtime dtype

@@ -57,7 +57,16 @@ struct IGParams {
     const float *b_scale, *b_shift, *b_mean, *b_invstd;
     float* bstats;        // slab [cmu_conv_ntiles][2][N]
     int buf_ok;           // first kernel, 3x3 mode: one image and the weight pack fit buffer descriptors
+    // persistent wide kernel: division by nblk / tilesX / tilesY as (mulhi(n, M) + n) >> s (n < 2^31)
+    unsigned fd_nblk[2], fd_tx[2], fd_ty[2];
 };
+// round-up magic for unsigned division by d >= 1: s = ceil(log2 d), M = floor(2^32 * (2^s - d) / d) + 1
+static inline void cmu_fastdiv_init(unsigned d, unsigned* out) {
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    out[0] = (unsigned)((((1ull << s) - d) << 32) / d + 1);
+    out[1] = s;
+}
 
 template <class TR, int MODE>
 struct IGCfg {
@@ -524,6 +533,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IGParams p) {
 }
 
 #include "conv_igemm3.inc"
+#include "conv_igemm3p.inc"
 #include "conv_gemm.inc"
 
 // ---------------------------------------------------------------------------------------------------
@@ -561,7 +571,7 @@ template <class TR>
 static int conv3x3_fwd_t(IGParams p, hipStream_t st) {
     typedef IGCfg<TR, MODE_CONV3> C;
     // channel counts in whole 64-byte slices / 64-channel blocks: wide-tile kernel (conv_igemm3.inc); else the first kernel
-    if (igemm3_eligible<TR>(p)) return launch_igemm3<TR>(p, st);
+    if (igemm3_eligible<TR>(p)) return launch_igemm3_any<TR>(p, st);
     p.nslices = cmu_div_up(p.K, C::KC);
     p.nslices32 = cmu_div_up(p.K, C::KC / 2);
     p.npad = cmu_conv3x3_npad(p.N);
