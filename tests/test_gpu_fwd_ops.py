@@ -300,6 +300,59 @@ torch.save({"y": y.buf.float().cpu(), "s": st.sum(0).cpu()}, sys.argv[1])
     check(outs[1]["s"], outs[0]["s"], 1e-4, "wide vs first stats")
 
 
+@pytest.mark.parametrize("chans", [(64, 128), (128, 64), (64, 64)])
+def test_conv3x3_persistent_kernel_is_bit_identical(chans):
+    """The persistent wide kernel (conv_igemm3p.inc: one workgroup walks a list of tiles) against the one-tile-per-workgroup
+    kernel (CMU_CONV_PERSIST=0) on a whole-tile shape, with 13 workgroups forced so that every workgroup streams several
+    tiles and the per-XCD item ranges are uneven: same MFMA order per accumulator, same statistics folding order ->
+    identical bits, for the forward (pending transform + BN statistics), the plain data gradient and the data gradient
+    with fused BN-backward sums."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from cmunet_amd import ops
+g = torch.Generator().manual_seed(0)
+B, H, W, Cin, Cout = 3, 48, 96, %d, %d
+x = torch.randn(B, H, W, Cin, generator=g).to(torch.bfloat16).cuda()
+w = (torch.randn(Cout, Cin, 3, 3, generator=g) / 48).cuda()
+sc, sh = (torch.rand(Cin, generator=g) + 0.5).cuda(), (torch.randn(Cin, generator=g) * 0.3).cuda()
+out = {}
+y = ops.new_act(B, H, W, Cout, "bf16", "cuda")
+st = ops.new_stats(B, H, W, Cout, "cuda")
+ops.conv3x3_fwd(ops.Act(x, 0, Cin, sc, sh, 0), ops.pack_conv3x3(w, "bf16"), y, st)
+out["y"], out["s"] = y.buf.clone(), st.clone()
+y2 = ops.new_act(B, H, W, Cout, "bf16", "cuda")
+ops.conv3x3_fwd(ops.Act(x, 0, Cin), ops.pack_conv3x3(w, "bf16"), y2, None)
+out["y2"] = y2.buf.clone()
+# data gradient into a conv+BN layer with raw output xr (Cout channels after the transposed-flipped pack)
+xr = torch.randn(B, H, W, Cout, generator=g).to(torch.bfloat16).cuda()
+bsc, bsh = (torch.rand(Cout, generator=g) + 0.5).cuda(), (torch.randn(Cout, generator=g) * 0.3).cuda()
+mu, istd = (torch.randn(Cout, generator=g) * 0.1).cuda(), (torch.rand(Cout, generator=g) + 0.5).cuda()
+wt = (torch.randn(Cin, Cout, 3, 3, generator=g) / 48).cuda()       # the layer dY belongs to: Cout -> Cin
+dX = ops.new_act(B, H, W, Cout, "bf16", "cuda")
+slab = ops.new_stats(B, H, W, Cout, "cuda")
+ops.conv3x3_dgrad_bn(ops.Act(x, 0, Cin), ops.pack_conv3x3(wt, "bf16", transpose_flip=True), dX, ops.Act(xr, 0, Cout, bsc, bsh, 0), mu, istd, slab)
+out["dx"], out["slab"] = dX.buf.clone(), slab.clone()
+torch.save({k: v.cpu() for k, v in out.items()}, sys.argv[1])
+''' % (root, chans[0], chans[1])
+    outs = []
+    for env in ({"CMU_CONV_PERSIST": "0"}, {"CMU_CONV_PERSIST": "1", "CMU_CONV_PERSIST_GRID": "13"}):
+        with tempfile.NamedTemporaryFile(suffix=".pt", delete=False) as f:
+            path = f.name
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, CMU_CONV_WIDE="2", **env), timeout=300)
+        outs.append(torch.load(path))
+        os.unlink(path)
+    for k in outs[0]:
+        assert torch.equal(outs[0][k].view(torch.uint8), outs[1][k].view(torch.uint8)), k
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_pack_batch_matches_single_packs(ops, dt):
     """cmu_pack_batch (all packs of a step in one launch) writes exactly what the per-weight entries write."""
