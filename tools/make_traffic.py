@@ -15,7 +15,7 @@ go = os.path.join(root, "gpurun_out")
 
 
 def one_step(pattern):
-    f = glob.glob(os.path.join(go, pattern, "*", "*_counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(go, pattern, "*", "*_counter_collection.csv")), key=os.path.getmtime)   # newest run
     disp = collections.OrderedDict()
     for r in csv.DictReader(open(f)):
         e = disp.setdefault(r["Dispatch_Id"], {"name": r["Kernel_Name"], "c": {}})
@@ -59,5 +59,5 @@ for base, d in tj.items():
 json.dump(out, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
 st = glob.glob(os.path.join(go, f"prof_{tag}", "*", "*_kernel_stats.csv"))
 if st:
-    shutil.copy(st[0], os.path.join(root, "profiles", f"{tag}_kernel_stats.csv"))
+    shutil.copy(max(st, key=os.path.getmtime), os.path.join(root, "profiles", f"{tag}_kernel_stats.csv"))
 print("wrote profiles/ for", tag, "-", ", ".join(f"{k}: {v['hbm_bytes_per_launch'] / 1e9:.2f} GB/launch x {v['launches_per_step']}" for k, v in out.items()))
