@@ -17,6 +17,7 @@ _P = ctypes.c_void_p
 _I = ctypes.c_int
 _L = ctypes.c_int64
 _F = ctypes.c_float
+_U64 = ctypes.c_uint64
 
 # name -> (restype, argtypes); mirrors include/cmunet_hip.h one to one.
 _SIGS = {
@@ -31,6 +32,10 @@ _SIGS = {
     "cmu_sgd_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _L, _F, _P]),
     "cmu_lamb_block_elems": (_I, []),
     "cmu_lamb_ws_bytes": (_L, [_I, _I]),
+    "cmu_resize_bicubic_ws_bytes": (_L, [_I, _I, _I, _I, _I]),
+    "cmu_resize_bicubic": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P]),
+    "cmu_two_view": (_I, [_P, _I, _I, _P, _P, _U64, _P, _P, _I, _P]),
+    "cmu_philox_normal": (_I, [_P, _L, _U64, _U64, _P]),
     "cmu_lamb_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _F, _F, _F, _F, _I, _I, _F, _I, _I, _L, _F, _P, _P]),
     "cmu_pack_desc_bytes": (_I, []),
     "cmu_pack_batch": (_I, [_P, _I, _L, _I, _P]),

@@ -106,3 +106,62 @@ class SyntheticTwoViewDataset(Dataset):
     def __getitem__(self, idx):
         it = two_view_item(self.base[idx], self.rng, self.pixel, self.out)
         return {k: torch.from_numpy(v) for k, v in it.items()}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the same pipeline on the device: batches of raw images resident in HBM -> the two views of a step
+# ---------------------------------------------------------------------------------------------------------------------
+def random_resized_crop_params(h, w, rng, crop_ratio_range=(0.2, 1.0), aspect_ratio_range=(3. / 4., 4. / 3.), max_attempts=10):
+    """Crop window of mmcv's RandomResizedCrop (the transform configs/cmunet_config.py:49 names; mmcv itself is a third-party
+    dependency absent from /root/reference): up to ``max_attempts`` draws of (area ratio uniform, aspect ratio log-uniform),
+    the first that fits wins, else the central crop with the aspect ratio clamped.  Returns (x0, y0, cw, ch)."""
+    area = h * w
+    lo, hi = np.log(aspect_ratio_range[0]), np.log(aspect_ratio_range[1])
+    for _ in range(max_attempts):
+        target_area = rng.uniform(*crop_ratio_range) * area
+        aspect = np.exp(rng.uniform(lo, hi))
+        cw, ch = int(round(np.sqrt(target_area * aspect))), int(round(np.sqrt(target_area / aspect)))
+        if 0 < cw <= w and 0 < ch <= h:
+            return int(rng.randint(0, w - cw + 1)), int(rng.randint(0, h - ch + 1)), cw, ch
+    in_ratio = w / h
+    if in_ratio < aspect_ratio_range[0]:
+        cw, ch = w, int(round(w / aspect_ratio_range[0]))
+    elif in_ratio > aspect_ratio_range[1]:
+        cw, ch = int(round(h * aspect_ratio_range[1])), h
+    else:
+        cw, ch = w, h
+    return (w - cw) // 2, (h - ch) // 2, cw, ch
+
+
+class DeviceTwoViewPipeline:
+    """CMUNetDataset.__getitem__ (cmunet_dataset.py:60-88) for a whole batch on the GPU: bicubic resize to ``size`` ->
+    RandomResizedCrop(size, crop_ratio (0.2, 1), bicubic) + RandomFlip(0.5) (cmunet_config.py:48-51) -> 'img' =
+    ShiftPixel(0) crop, 'img_t' = ShiftPixel(<= pixel) crop + GaussNoise.  The few random scalars per sample (window, flip,
+    shifts) are drawn on the host from a seeded numpy generator; the pixels never leave HBM (the noise comes from the
+    kernel's counter-based generator, keyed by (seed, call count)).  Requires the HIP library (no CPU fallback)."""
+
+    def __init__(self, size=256, out=224, pixel=31, crop_ratio_range=(0.2, 1.0), flip_prob=0.5, seed=0):
+        self.size, self.out, self.pixel = size, out, pixel
+        self.crop_ratio_range, self.flip_prob = crop_ratio_range, flip_prob
+        self.rng = np.random.RandomState(seed)
+        self.seed, self.calls = int(seed), 0
+
+    def draw(self, B):
+        """The random scalars of one batch: boxes (B,4) int32 (x0, y0, w, h), flips (B,) uint8, shifts (B,2) int32."""
+        boxes = np.array([random_resized_crop_params(self.size, self.size, self.rng, self.crop_ratio_range) for _ in range(B)], np.int32)
+        flips = (self.rng.uniform(size=B) < self.flip_prob).astype(np.uint8)
+        shifts = self.rng.randint(0, self.pixel + 1, size=(B, 2)).astype(np.int32) if self.pixel > 0 else np.zeros((B, 2), np.int32)
+        return boxes, flips, shifts
+
+    def __call__(self, raw, params=None, noise=None):
+        from . import ops
+        assert raw.is_cuda and raw.dtype == torch.float32 and raw.dim() == 3
+        raw = raw.contiguous()
+        B = raw.shape[0]
+        boxes, flips, shifts = params if params is not None else self.draw(B)
+        base = raw if tuple(raw.shape[1:]) == (self.size, self.size) else ops.resize_bicubic(raw, self.size, self.size)
+        crop = ops.resize_bicubic(base, self.size, self.size, torch.from_numpy(np.asarray(boxes)), torch.from_numpy(np.asarray(flips)))
+        self.calls += 1
+        img, img_t = ops.two_view(crop, torch.from_numpy(np.asarray(shifts)), self.out, noise=noise,
+                                  seed=(self.seed << 32) | (self.calls & 0xFFFFFFFF))
+        return {'img': img, 'img_t': img_t}

@@ -410,3 +410,46 @@ def lamb_step(p, g, m, v, u, tables, lr, beta1, beta2, eps, bias_correction, gra
     call("cmu_lamb_step", _p(_f32c(p)), _p(_f32c(g)), _p(m), _p(v), _p(u), _p(bs), _p(bc), _p(bt), bs.numel(), _p(t0), _p(twd),
          twd.numel(), float(lr), float(beta1), float(beta2), float(eps), int(bias_correction), int(grad_averaging),
          float(max_grad_norm), int(trust_clip), int(always_adapt), int(step), float(grad_scale), _p(ws), _stream())
+
+
+# ---- input pipeline on the device ---------------------------------------------------------------------
+def resize_bicubic(src, out_h, out_w, boxes=None, flip=None):
+    """Pillow-convention bicubic resize of per-sample crop windows (+ optional horizontal flip): src (B,H,W) f32 cuda,
+    boxes (B,4) int32 (x0, y0, w, h) or None, flip (B,) uint8/bool or None -> (B,out_h,out_w) f32."""
+    assert src.dtype == torch.float32 and src.dim() == 3 and src.is_contiguous()
+    B, H, W = src.shape
+    if boxes is not None:
+        bh = boxes.detach().cpu().to(torch.int64)
+        ok = (bh[:, 0] >= 0) & (bh[:, 1] >= 0) & (bh[:, 2] >= 1) & (bh[:, 3] >= 1) & (bh[:, 0] + bh[:, 2] <= W) & (bh[:, 1] + bh[:, 3] <= H)
+        if bh.shape != (B, 4) or not bool(ok.all()):
+            raise ValueError("resize_bicubic: crop windows must be (B,4) (x0, y0, w, h) inside the image")
+        boxes = boxes.to(device=src.device, dtype=torch.int32).contiguous()
+    if flip is not None:
+        flip = flip.to(device=src.device, dtype=torch.uint8).contiguous()
+    out = torch.empty(B, out_h, out_w, dtype=torch.float32, device=src.device)
+    ws = torch.empty(_lib.lib().cmu_resize_bicubic_ws_bytes(B, H, W, out_h, out_w), dtype=torch.uint8, device=src.device)
+    call("cmu_resize_bicubic", _p(src), B, H, W, _p(boxes), _p(flip), _p(out), out_h, out_w, _p(ws), _stream())
+    return out
+
+
+def two_view(src, shifts, out=224, noise=None, seed=0):
+    """ShiftPixel crops + GaussNoise: src (B,S,S) f32 cuda, shifts (B,2) int (dy, dx) -> (img, img_t) (B,out,out) f32.
+    ``noise``: (B,out,out) float64 standard-normal draws, or None for the in-kernel Philox generator keyed by ``seed``."""
+    assert src.dtype == torch.float32 and src.dim() == 3 and src.shape[1] == src.shape[2] and src.is_contiguous()
+    B, S = src.shape[0], src.shape[1]
+    sh = shifts.detach().cpu().to(torch.int64)
+    if sh.shape != (B, 2) or bool((sh < 0).any()) or bool((sh + out > S).any()):
+        raise ValueError("two_view: shifts must be (B,2) with 0 <= d and d + out <= S")      # processing.py:112-113 asserts
+    shifts = shifts.to(device=src.device, dtype=torch.int32).contiguous()
+    if noise is not None:
+        assert noise.dtype == torch.float64 and tuple(noise.shape) == (B, out, out) and noise.is_contiguous()
+    img = torch.empty(B, out, out, dtype=torch.float32, device=src.device)
+    img_t = torch.empty_like(img)
+    call("cmu_two_view", _p(src), B, S, _p(shifts), _p(noise), int(seed) & (2 ** 64 - 1), _p(img), _p(img_t), out, _stream())
+    return img, img_t
+
+
+def philox_normal(n, offset=0, seed=0, device="cuda"):
+    out = torch.empty(n, dtype=torch.float64, device=device)
+    call("cmu_philox_normal", _p(out), n, int(offset), int(seed) & (2 ** 64 - 1), _stream())
+    return out

@@ -309,6 +309,24 @@ int cmu_lamb_step(float* p, const float* g, float* m, float* v, float* u, const 
                   float beta2, float eps, int bias_correction, int grad_averaging, float max_grad_norm, int trust_clip,
                   int always_adapt, int64_t step, float grad_scale, void* ws, void* stream);
 
+/* ---- input pipeline on the device (Pretraining/CM-UNet/cmae/datasets/cmunet_dataset.py:60-88) -------------
+ * cmu_resize_bicubic: Pillow-convention bicubic resize (mode 'F': Keys a = -0.5, antialiased support, double accumulation,
+ * float32 store after each of the two passes, horizontal first) of a per-sample integer crop window to (Ho, Wo), then an
+ * optional horizontal flip -- cmunet_dataset.py:74-75 (boxes == NULL: whole image) and RandomResizedCrop + RandomFlip of
+ * configs/cmunet_config.py:49-50.  src (B,Hs,Ws) f32; boxes (B,4) int32 device (x0, y0, w, h) or NULL; flip (B) u8 device
+ * or NULL; out (B,Ho,Wo) f32; ws: cmu_resize_bicubic_ws_bytes.  Bit-identical to Pillow 12.2 on finite inputs.             */
+int64_t cmu_resize_bicubic_ws_bytes(int B, int Hs, int Ws, int Ho, int Wo);
+int cmu_resize_bicubic(const float* src, int B, int Hs, int Ws, const int* boxes, const uint8_t* flip, float* out, int Ho, int Wo,
+                       void* ws, void* stream);
+/* cmu_two_view: 'img' = src[b, :out, :out] (ShiftPixel(0), pipelines/processing.py:97-127); 'img_t' = src[b, dy:dy+out,
+ * dx:dx+out] + (max of that crop / 10) * z evaluated in float64 and cast to float32 (GaussNoise,
+ * pipelines/auto_augment.py:1136-1153).  shifts (B,2) int32 device (dy, dx); z = noise (B,out,out) f64 device, or, when
+ * noise == NULL, the in-kernel generator: Philox4x32-10 with counter (element index, 0, 0) and key `seed`, Box-Muller on
+ * its first two words (cmu_philox_normal returns the same draws).                                                        */
+int cmu_two_view(const float* src, int B, int S, const int* shifts, const double* noise, uint64_t seed, float* img, float* img_t,
+                 int out, void* stream);
+int cmu_philox_normal(double* out, int64_t n, uint64_t offset, uint64_t seed, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

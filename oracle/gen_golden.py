@@ -239,8 +239,40 @@ def gen_optim():
     save("optim_traces", **out)
 
 
+def gen_augment():
+    """Input pipeline: expected outputs of Pillow itself (``Image.fromarray(f32).resize(size, BICUBIC)``, the
+    call of cmunet_dataset.py:74-75) on small seeded arrays -- the pin of oracle/augment.py's restatement -- and of the
+    reference's ShiftPixel / GaussNoise arithmetic (processing.py:118, auto_augment.py:1149-1153) written out with numpy."""
+    from PIL import Image
+    import PIL
+    from oracle import augment as OA
+    rng = np.random.RandomState(123)
+    out = {"pillow_version": np.array(PIL.__version__)}
+    for i, (h, w, oh, ow) in enumerate([(40, 56, 32, 24), (64, 64, 32, 32), (20, 30, 48, 40), (33, 33, 33, 20), (97, 15, 16, 16)]):
+        a = (rng.standard_normal((h, w)) * 2 + 0.3).astype(np.float32)
+        ref = np.asarray(Image.fromarray(a).resize((ow, oh), resample=Image.BICUBIC))
+        assert np.array_equal(OA.resize_bicubic(a, oh, ow).view(np.uint32), ref.view(np.uint32)), (h, w, oh, ow)
+        out[f"resize{i}.in"], out[f"resize{i}.out"] = a, ref
+    # ShiftPixel + GaussNoise exactly as the reference's lines evaluate them
+    img = rng.standard_normal((2, 40, 40)).astype(np.float32)
+    shifts = np.array([[3, 7], [8, 0]], np.int32)
+    noise = rng.standard_normal((2, 32, 32))
+    exp_t = []
+    for b in range(2):
+        v = img[b][0 + shifts[b, 0]:shifts[b, 0] + 32, 0 + shifts[b, 1]:shifts[b, 1] + 32]       # processing.py:118
+        sigma = np.max(v) / 10                                                                  # auto_augment.py:1149
+        exp_t.append(np.array(v + sigma * noise[b], dtype=v.dtype))                             # :1151-1152
+    o_img, o_t = OA.two_view(img, shifts, noise, 32)
+    assert np.array_equal(o_t, np.stack(exp_t)) and np.array_equal(o_img, img[:, :32, :32])
+    out.update(tv_in=img, tv_shifts=shifts, tv_noise=noise, tv_img_t=np.stack(exp_t))
+    save("augment", **out)
+
+
 def main():
     from oracle import unet as OU, losses as OL
+    if "--only-augment" in sys.argv:    # needs Pillow only, not the reference
+        gen_augment()
+        return
     ref, M = import_reference()
     torch.manual_seed(0)
     torch.set_num_threads(4)

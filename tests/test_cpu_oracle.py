@@ -216,3 +216,43 @@ def test_soft_cldice_golden(golden_dir):
     yp = (torch.softmax(logits, 1) > 0.5).float()[:, 1:2]
     assert torch.allclose(OL.soft_skel(yp, 10), torch.from_numpy(d["skel_pred"]), atol=1e-6)
     assert str(d["metric_name"]) == "soft_clDice"
+
+
+def test_augment_oracle_against_pillow_fixture_and_live(golden_dir):
+    """oracle/augment.py: the bicubic resize restatement reproduces Pillow's own outputs bit for bit (committed fixture made
+    by oracle/gen_golden.py --only-augment; and Pillow itself when it is importable here), the ShiftPixel / GaussNoise
+    arithmetic matches the reference's lines, and the in-kernel generator is Philox4x32-10 (Random123 known answers)."""
+    from oracle import augment as OA
+    z = np.load(os.path.join(golden_dir, "augment.npz"))
+    i = 0
+    while f"resize{i}.in" in z:
+        a, ref = z[f"resize{i}.in"], z[f"resize{i}.out"]
+        assert np.array_equal(OA.resize_bicubic(a, *ref.shape).view(np.uint32), ref.view(np.uint32)), i
+        i += 1
+    assert i == 5
+    _, t = OA.two_view(z["tv_in"], z["tv_shifts"], z["tv_noise"], 32)
+    assert np.array_equal(t.view(np.uint32), z["tv_img_t"].view(np.uint32))
+    try:
+        from PIL import Image
+    except ImportError:
+        Image = None
+    if Image is not None:
+        rng = np.random.RandomState(9)
+        for (h, w, oh, ow) in [(300, 200, 256, 256), (51, 77, 256, 256), (512, 512, 256, 256)]:
+            a = rng.standard_normal((h, w)).astype(np.float32)
+            ref = np.asarray(Image.fromarray(a).resize((ow, oh), resample=Image.BICUBIC))
+            assert np.array_equal(OA.resize_bicubic(a, oh, ow).view(np.uint32), ref.view(np.uint32))
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for c, k, exp in kat:
+        assert tuple(int(v) for v in OA.philox4x32_10(np.array([c], dtype=np.uint64), k)[0]) == exp
+
+
+def test_random_resized_crop_params_contract():
+    from cmunet_amd.dataset import random_resized_crop_params
+    rng = np.random.RandomState(0)
+    for _ in range(500):
+        x0, y0, cw, ch = random_resized_crop_params(256, 256, rng)
+        assert 0 <= x0 and 0 <= y0 and cw >= 1 and ch >= 1 and x0 + cw <= 256 and y0 + ch <= 256
+        assert 0.18 <= cw * ch / 65536 <= 1.0 and 0.70 <= cw / ch <= 1.40

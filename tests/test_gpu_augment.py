@@ -1,0 +1,107 @@
+"""Device input pipeline against the oracle (oracle/augment.py, itself pinned bit-for-bit to Pillow in
+tests/test_cpu_oracle.py): the HIP kernels must reproduce Pillow's bicubic resize and the reference's ShiftPixel +
+GaussNoise arithmetic EXACTLY (float32 outputs compared as bits)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cmunet_amd import ops as o
+    return o
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("shape,out", [((3, 512, 512), (256, 256)), ((2, 300, 200), (256, 256)), ((2, 51, 77), (256, 256)),
+                                       ((2, 256, 256), (256, 256)), ((1, 100, 100), (64, 48)), ((2, 37, 512), (256, 256)),
+                                       ((1, 1024, 640), (256, 256))])
+def test_resize_bicubic_whole_image_matches_pillow_convention(ops, shape, out):
+    from oracle.augment import resize_bicubic
+    rng = np.random.RandomState(1)
+    a = (rng.standard_normal(shape) * 3 + 0.5).astype(np.float32)
+    got = ops.resize_bicubic(torch.from_numpy(a).cuda(), out[0], out[1]).cpu().numpy()
+    ref = np.stack([resize_bicubic(x, out[0], out[1]) for x in a])
+    assert np.array_equal(_bits(got), _bits(ref)), float(np.abs(got - ref).max())
+
+
+def test_resize_bicubic_crop_windows_and_flip(ops):
+    """RandomResizedCrop + RandomFlip: ragged windows (1-pixel, full-size, thin, equal-to-output) per sample."""
+    from oracle.augment import resize_bicubic_crop
+    rng = np.random.RandomState(2)
+    B, S = 8, 256
+    a = rng.standard_normal((B, S, S)).astype(np.float32)
+    boxes = np.array([[0, 0, 256, 256], [10, 20, 100, 57], [255, 255, 1, 1], [0, 100, 256, 3], [17, 0, 51, 256], [3, 5, 200, 250],
+                      [0, 0, 256, 128], [128, 0, 128, 256]], np.int32)
+    flips = np.array([0, 1, 0, 1, 1, 0, 1, 0], np.uint8)
+    got = ops.resize_bicubic(torch.from_numpy(a).cuda(), 256, 256, torch.from_numpy(boxes), torch.from_numpy(flips)).cpu().numpy()
+    ref = resize_bicubic_crop(a, boxes, flips, 256, 256)
+    assert np.array_equal(_bits(got), _bits(ref)), float(np.abs(got - ref).max())
+    with pytest.raises(ValueError):
+        ops.resize_bicubic(torch.from_numpy(a).cuda(), 256, 256, torch.tensor([[0, 0, 257, 10]] * B))
+
+
+def test_two_view_with_explicit_noise_is_exact(ops):
+    from oracle.augment import two_view
+    rng = np.random.RandomState(3)
+    B, S, out = 5, 256, 224
+    a = (rng.standard_normal((B, S, S)) * 2).astype(np.float32)
+    a[3] = -np.abs(a[3]) - 1.0                              # all-negative sample: sigma = max/10 is negative, as numpy has it
+    shifts = np.array([[0, 0], [31, 31], [7, 19], [32, 0], [1, 32]], np.int32)
+    noise = rng.standard_normal((B, out, out))
+    img, img_t = ops.two_view(torch.from_numpy(a).cuda(), torch.from_numpy(shifts), out, noise=torch.from_numpy(noise).cuda())
+    r_img, r_img_t = two_view(a, shifts, noise, out)
+    assert np.array_equal(_bits(img.cpu().numpy()), _bits(r_img))
+    assert np.array_equal(_bits(img_t.cpu().numpy()), _bits(r_img_t))
+    with pytest.raises(ValueError):
+        ops.two_view(torch.from_numpy(a).cuda(), torch.tensor([[33, 0]] * B), out)      # dy + 224 > 256 (processing.py:112)
+
+
+def test_philox_generator_matches_oracle(ops):
+    """Counter-based draws: the integer stream is Philox4x32-10 (known answers in the CPU suite); the normals agree with the
+    numpy restatement to rounding of log / cos / sqrt (1e-12), at an offset that crosses the 32-bit counter word."""
+    from oracle.augment import philox_normal
+    for off, seed in ((0, 0), (2 ** 32 - 100, 0x1234_5678_9ABC_DEF0)):
+        got = ops.philox_normal(5000, off, seed).cpu().numpy()
+        ref = philox_normal(5000, off, seed)
+        assert np.abs(got - ref).max() < 1e-12
+    z = ops.philox_normal(1 << 20, 0, 7).cpu().numpy()
+    assert abs(z.mean()) < 5e-3 and abs(z.std() - 1) < 5e-3
+
+
+def test_two_view_in_kernel_noise_equals_explicit_draws(ops):
+    rng = np.random.RandomState(4)
+    B, S, out = 3, 256, 224
+    a = rng.standard_normal((B, S, S)).astype(np.float32)
+    shifts = torch.tensor([[3, 4], [0, 31], [31, 0]])
+    x = torch.from_numpy(a).cuda()
+    z = ops.philox_normal(B * out * out, 0, 99).view(B, out, out)
+    _, t_explicit = ops.two_view(x, shifts, out, noise=z)
+    _, t_kernel = ops.two_view(x, shifts, out, seed=99)
+    assert torch.equal(t_explicit, t_kernel)
+
+
+def test_device_pipeline_equals_host_pipeline_on_the_same_draws(ops):
+    """The whole device pipeline against Pillow-convention resize + numpy crops on the host, same random scalars."""
+    from cmunet_amd.dataset import DeviceTwoViewPipeline
+    from oracle.augment import resize_bicubic, resize_bicubic_crop, two_view
+    rng = np.random.RandomState(5)
+    raw = rng.standard_normal((4, 384, 384)).astype(np.float32)
+    pipe = DeviceTwoViewPipeline(seed=11)
+    boxes, flips, shifts = pipe.draw(4)
+    noise = rng.standard_normal((4, 224, 224))
+    got = pipe(torch.from_numpy(raw).cuda(), params=(boxes, flips, shifts), noise=torch.from_numpy(noise).cuda())
+    base = np.stack([resize_bicubic(x, 256, 256) for x in raw])
+    crop = resize_bicubic_crop(base, boxes, flips, 256, 256)
+    r_img, r_img_t = two_view(crop, shifts, noise, 224)
+    assert np.array_equal(_bits(got['img'].cpu().numpy()), _bits(r_img))
+    assert np.array_equal(_bits(got['img_t'].cpu().numpy()), _bits(r_img_t))
+    out = pipe(torch.from_numpy(raw).cuda())                  # fully random call: shapes / dtype / finiteness
+    assert out['img'].shape == (4, 224, 224) and out['img_t'].dtype == torch.float32 and bool(torch.isfinite(out['img_t']).all())
