@@ -566,27 +566,46 @@ __global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __re
             halo[i] = v;
         }
         __syncthreads();
+        // four pixels per trip: their 16-byte loads (dY, and the raw output when the BN backward is fused) go out together --
+        // one or two loads in flight per wave left this pass latency-bound at ~2.6 TB/s
+        constexpr int U = 4;
         if (active)
-            for (int pix = prow; pix < 256; pix += ppi) {
-                const int py = pix >> 4, px = pix & 15;
-                const int gy = ty0 + py, gx = tx0 + px;
-                if (gy >= H || gx >= W) continue;
-                float g[EPC];
-                TR::unpack(ld_global16(dY + ((((int64_t)b * H + gy) * W + gx) * ldd + chunk * EPC) * ES), g);
-                if (yraw != nullptr) {
-                    float v[EPC];
-                    TR::unpack(ld_global16(yraw + ((((int64_t)b * H + gy) * W + gx) * ldy + chunk * EPC) * ES), v);
+            for (int pix0 = prow; pix0 < 256; pix0 += ppi * U) {
+                u32x4 gq[U], vq[U];
+                bool ok[U];
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) {
-                        const float dz = fmaf(v[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
-                        g[e] = sc[e] * (dz - c1[e] - (v[e] - mu[e]) * is[e] * c2[e]);
+                for (int u = 0; u < U; ++u) {
+                    const int pix = pix0 + u * ppi;
+                    const int gy = ty0 + (pix >> 4), gx = tx0 + (pix & 15);
+                    ok[u] = pix < 256 && gy < H && gx < W;
+                    gq[u] = vq[u] = u32x4{0u, 0u, 0u, 0u};
+                    if (ok[u]) {
+                        gq[u] = ld_global16(dY + ((((int64_t)b * H + gy) * W + gx) * ldd + chunk * EPC) * ES);
+                        if (yraw != nullptr) vq[u] = ld_global16(yraw + ((((int64_t)b * H + gy) * W + gx) * ldy + chunk * EPC) * ES);
                     }
                 }
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const float xv = halo[(py + t / 3) * 18 + px + t % 3];
+                for (int u = 0; u < U; ++u) {
+                    if (!ok[u]) continue;
+                    const int pix = pix0 + u * ppi;
+                    const int py = pix >> 4, px = pix & 15;
+                    float g[EPC];
+                    TR::unpack(gq[u], g);
+                    if (yraw != nullptr) {
+                        float v[EPC];
+                        TR::unpack(vq[u], v);
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) acc[e][t] = fmaf(g[e], xv, acc[e][t]);
+                        for (int e = 0; e < EPC; ++e) {
+                            const float dz = fmaf(v[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
+                            g[e] = sc[e] * (dz - c1[e] - (v[e] - mu[e]) * is[e] * c2[e]);
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const float xv = halo[(py + t / 3) * 18 + px + t % 3];
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) acc[e][t] = fmaf(g[e], xv, acc[e][t]);
+                    }
                 }
             }
     }
