@@ -70,6 +70,7 @@ struct F32Traits {
     }
     __device__ static inline float to_float(float v) { return v; }
     __device__ static inline float from_float(float v) { return v; }
+    __device__ static inline uint32_t pack2(float a, float) { return __float_as_uint(a); }   // (16-bit paths only; never called)
 };
 
 struct F16Traits {
@@ -92,6 +93,9 @@ struct F16Traits {
     }
     __device__ static inline float to_float(_Float16 v) { return (float)v; }
     __device__ static inline _Float16 from_float(float v) { return (_Float16)v; }
+    __device__ static inline uint32_t pack2(float a, float b) {   // a in the low half, b in the high half
+        return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)a) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)b) << 16);
+    }
 };
 
 struct BF16Traits {
