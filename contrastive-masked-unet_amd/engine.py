@@ -67,6 +67,9 @@ class UNetEngine:
         self.scratch = _Scratch(self.device)
         self.packs = _PackCache()
         self.lib = _lib.lib()
+        self._zero_bias_done = set()
+        self._cats, self._cats_busy = None, False
+        self._nbt, self._nbt_defer = [], 0
         self.grad_target = None      # optional dict name -> preallocated fp32 tensor (FlatParams.grad_views)
         self.grad_prefix = ""
 
@@ -120,7 +123,18 @@ class UNetEngine:
         return self.packs.get((name, "T", mode), w, lambda: ops.pack_convT2x2(w.detach(), self.dt, mode))
 
     # one Conv3x3 + BatchNorm2d(+ReLU pending): returns the saved state needed by backward
-    def _convbn_fwd(self, sd, pconv, pbn, x, out, training, x_img=None, mask=None, mask_per_sample=False):
+    def flush_counters(self):
+        """``num_batches_tracked += 1`` of every BatchNorm the forward went through, as ONE multi-tensor launch (18 one-element
+        launches per UNet forward otherwise)."""
+        if self._nbt_defer > 0:
+            return
+        pend, self._nbt = self._nbt, []
+        if pend:
+            torch._foreach_add_(pend, 1)
+
+    def _convbn_fwd(self, sd, pconv, pbn, x, out, training, x_img=None, mask=None, mask_per_sample=False, affine_out=None):
+        """``affine_out``: optional (scale, shift) views the pending transform is written into (a skip that lives in a concat
+        buffer gets the buffer's own arrays: no copy later)."""
         w = sd[pconv + "weight"]
         Cout = w.shape[0]
         B, H, W = out.B, out.H, out.W
@@ -129,24 +143,25 @@ class UNetEngine:
             ops.conv3x3_c1_fwd(x_img, w.detach(), out, stats, mask, mask_per_sample)
         else:
             ops.conv3x3_fwd(x, self._wp(pconv, w, False), out, stats)
-        scale, shift = self._f32(Cout), self._f32(Cout)
+        scale, shift = affine_out if affine_out is not None else (self._f32(Cout), self._f32(Cout))
         mean, invstd = self._f32(Cout), self._f32(Cout)
         ws = self.scratch.get("bnfin", self.lib.cmu_bn_finalize_ws_bytes(Cout))
         ops.bn_finalize(stats, B * H * W, sd[pconv + "bias"].detach(), sd[pbn + "weight"].detach(),
                         sd[pbn + "bias"].detach(), sd[pbn + "running_mean"], sd[pbn + "running_var"], BN_MOMENTUM,
                         BN_EPS, training, scale, shift, mean, invstd, ws)
         if training and (pbn + "num_batches_tracked") in sd:
-            sd[pbn + "num_batches_tracked"] += 1
+            self._nbt.append(sd[pbn + "num_batches_tracked"])
         return {"pconv": pconv, "pbn": pbn, "x": x, "x_img": x_img, "mask": mask, "mps": mask_per_sample,
                 "y": out.with_transform(scale, shift, 0), "mean": mean, "invstd": invstd}
 
-    def _double_conv_fwd(self, sd, prefix, x, out2, training, x_img=None, mask=None, mask_per_sample=False):
+    def _double_conv_fwd(self, sd, prefix, x, out2, training, x_img=None, mask=None, mask_per_sample=False, affine_out2=None):
         """DoubleConv (model.py:16-26).  ``out2``: where the second conv writes its raw output."""
         w1 = sd[prefix + "0.weight"]
         B, H, W = out2.B, out2.H, out2.W
         y1 = self._new(B, H, W, w1.shape[0])
         s1 = self._convbn_fwd(sd, prefix + "0.", prefix + "1.", x, y1, training, x_img, mask, mask_per_sample)
-        s2 = self._convbn_fwd(sd, prefix + "3.", prefix + "4.", s1["y"], out2, training)
+        s2 = self._convbn_fwd(sd, prefix + "3.", prefix + "4.", s1["y"], out2, training, affine_out=affine_out2)
+        self.flush_counters()            # (a no-op inside encoder_forward / decoder_forward, which flush once at their end)
         return s1, s2
 
     # backward of one Conv3x3+BN+ReLU given dA (gradient w.r.t. the activated output); returns dX act or None
@@ -186,7 +201,11 @@ class UNetEngine:
         grads[s["pbn"] + "bias"] = dbeta
         # conv bias: followed by training-mode BN, its gradient is identically zero (sum of dY over pixels)
         gb = self._gbuf(s["pconv"] + "bias", sd[s["pconv"] + "bias"])
-        gb.zero_()
+        zk = (s["pconv"], gb.data_ptr())
+        if self.grad_target is None or zk not in self._zero_bias_done:     # arena views: written here and nowhere else
+            gb.zero_()
+            if self.grad_target is not None:
+                self._zero_bias_done.add(zk)
         grads[s["pconv"] + "bias"] = gb
         dW = self._gbuf(s["pconv"] + "weight", w)
         if s["x_img"] is not None:
@@ -218,20 +237,22 @@ class UNetEngine:
             n += 1
         return n
 
-    def encoder_forward(self, sd, x_bhw, training, prefix="", mask=None, mask_per_sample=False, skip_out=None):
+    def encoder_forward(self, sd, x_bhw, training, prefix="", mask=None, mask_per_sample=False, skip_out=None, skip_affine=None):
         """x (B,H,W) fp32 cuda.  ``skip_out[i]``: optional Act (right half of a concat buffer) where level i's
         raw skip is written.  Returns ctx with 'latent' (raw Act + pending transform) and 'skips'."""
         B, H, W = x_bhw.shape
         nd = self.n_down(sd, prefix)
         assert H % (1 << nd) == 0 and W % (1 << nd) == 0, f"H,W must be multiples of {1 << nd}"
         ctx = {"levels": [], "prefix": prefix}
+        self._nbt_defer += 1
         x_act, x_img = None, x_bhw.contiguous()
         h, w_ = H, W
         for i in range(1, nd + 1):
             p = f"{prefix}down_conv{i}.double_conv.double_conv."
             C = sd[p + "0.weight"].shape[0]
             out2 = skip_out[i - 1] if skip_out is not None else self._new(B, h, w_, C)
-            s1, s2 = self._double_conv_fwd(sd, p, x_act, out2, training, x_img, mask if i == 1 else None, mask_per_sample)
+            s1, s2 = self._double_conv_fwd(sd, p, x_act, out2, training, x_img, mask if i == 1 else None, mask_per_sample,
+                                           affine_out2=skip_affine[i - 1] if skip_affine is not None else None)
             pooled = self._new(B, h // 2, w_ // 2, C)
             ops.bnrelu_maxpool_fwd(s2["y"], pooled)
             ctx["levels"].append({"s1": s1, "s2": s2, "pooled": pooled})
@@ -243,6 +264,8 @@ class UNetEngine:
         ctx["bott"] = {"s1": s1, "s2": s2}
         ctx["latent"] = s2["y"]
         ctx["skips"] = [lv["s2"]["y"] for lv in ctx["levels"]]
+        self._nbt_defer -= 1
+        self.flush_counters()
         return ctx
 
     def encoder_backward(self, sd, ctx, d_latent, d_skips, grads):
@@ -288,6 +311,7 @@ class UNetEngine:
         if cats is None:
             cats = self.decoder_alloc(sd, B, skips[0].H, skips[0].W, prefix)
         ctx = {"levels": [None] * nup, "prefix": prefix, "cats": cats}
+        self._nbt_defer += 1
         x = latent
         for i in range(nup, 0, -1):
             p = f"{prefix}up_conv{i}."
@@ -299,8 +323,9 @@ class UNetEngine:
             if not (sk.buf is cat["buf"] and sk.coff == Cup):
                 right.buf[..., Cup:].copy_(sk.buf[..., sk.coff:sk.coff + sk.C])   # split encoder/decoder: one strided copy
             if sk.scale is not None:
-                cat["scale"][Cup:].copy_(sk.scale)
-                cat["shift"][Cup:].copy_(sk.shift)
+                if sk.scale.data_ptr() != cat["scale"][Cup:].data_ptr():
+                    cat["scale"][Cup:].copy_(sk.scale)
+                    cat["shift"][Cup:].copy_(sk.shift)
                 relu_from = Cup
             else:                      # already-activated skip handed over at a module boundary: identity, no ReLU
                 cat["scale"][Cup:].fill_(1.0)
@@ -320,6 +345,8 @@ class UNetEngine:
             logits = self._f32(B, K, x.H, x.W)
             ops.conv1x1_head_fwd(x, sd[prefix + "conv_last.weight"].detach().reshape(K, -1), sd[prefix + "conv_last.bias"].detach(), logits)
             ctx["logits"] = logits
+        self._nbt_defer -= 1
+        self.flush_counters()
         return ctx
 
     def decoder_backward(self, sd, ctx, dlogits, grads, need_input_grads=True, latent_bn=None):
@@ -377,9 +404,19 @@ class UNetEngine:
     # ------------------------------------------------------------------------------------------
     def unet_forward(self, sd, x_bhw, training, mask=None, mask_per_sample=False):
         B, H, W = x_bhw.shape
-        cats = self.decoder_alloc(sd, B, H, W, "")
+        # concat buffers + affine arrays of the last shape are reused from step to step (no per-step fills) unless a
+        # training forward is still waiting for its backward: that one keeps them, this call gets fresh ones
+        key = (B, H, W, self.tdt)
+        if self._cats_busy:
+            cats = self.decoder_alloc(sd, B, H, W, "")
+        else:
+            if self._cats is None or self._cats[0] != key:
+                self._cats = (key, self.decoder_alloc(sd, B, H, W, ""))
+            cats = self._cats[1]
+            self._cats_busy = bool(training)
         skip_out = [Act(c["buf"], c["Cup"], c["Cskip"]) for c in cats]
-        ectx = self.encoder_forward(sd, x_bhw, training, "", mask, mask_per_sample, skip_out)
+        skip_affine = [(c["scale"][c["Cup"]:], c["shift"][c["Cup"]:]) for c in cats]
+        ectx = self.encoder_forward(sd, x_bhw, training, "", mask, mask_per_sample, skip_out, skip_affine)
         dctx = self.decoder_forward(sd, ectx["latent"], ectx["skips"], training, "", cats, True)
         return dctx["logits"], {"enc": ectx, "dec": dctx}
 
@@ -391,4 +428,6 @@ class UNetEngine:
         if after_decoder is not None:
             after_decoder()
         self.encoder_backward(sd, ctx["enc"], d_latent, d_skips, grads)
+        if self._cats is not None and ctx["dec"]["cats"] is self._cats[1]:
+            self._cats_busy = False
         return grads
