@@ -320,6 +320,21 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WGParams p) {
 #include "conv_wgrad2.inc"
 
 // partial slabs -> parameter-gradient layout, summed in split order
+// sum over the split slabs k = part, part + 4, ... (fixed order), eight loads in flight per trip
+__device__ static inline float sum_split(const float* __restrict__ p, int64_t stride, int part, int splitk) {
+    constexpr int U = 8;
+    float s = 0.f;
+    int k = part;
+    for (; k + 4 * (U - 1) < splitk; k += 4 * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = p[(int64_t)(k + 4 * u) * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) s += v[u];
+    }
+    for (; k < splitk; k += 4) s += p[(int64_t)k * stride];
+    return s;
+}
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splitk, int T, int CApad, int CBpad, int CA,
                                                           int CB, float* __restrict__ dW, int mode) {
     // 64 outputs x 4 split-parts per block; the parts are combined through LDS in a fixed order
@@ -335,10 +350,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         if (mode == 2) {   // wide ConvTranspose kernel: slabs are [split][ij][c][n], n fastest
             n = (int)(o % CA);
             c = (int)((o / CA) % CB);
-            if (o < total)
-                for (int k = part; k < splitk; k += 4) s += ws[(((int64_t)k * T + t) * CB + c) * CA + n];
+            if (o < total) s = sum_split(ws + ((int64_t)t * CB + c) * CA + n, (int64_t)T * CB * CA, part, splitk);
         } else if (o < total)
-            for (int k = part; k < splitk; k += 4) s += ws[(((int64_t)k * T + t) * CApad + n) * CBpad + c];
+            s = sum_split(ws + ((int64_t)t * CApad + n) * CBpad + c, (int64_t)T * CApad * CBpad, part, splitk);
         __syncthreads();
         red[part][ol] = s;
         __syncthreads();
