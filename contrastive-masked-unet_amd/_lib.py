@@ -36,6 +36,11 @@ _SIGS = {
     "cmu_resize_bicubic": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P]),
     "cmu_two_view": (_I, [_P, _I, _I, _P, _P, _U64, _P, _P, _I, _P]),
     "cmu_philox_normal": (_I, [_P, _L, _U64, _U64, _P]),
+    "cmu_skinny_gemm_ws_bytes": (_L, [_I, _I, _L]),
+    "cmu_skinny_gemm_fwd": (_I, [_P, _P, _P, _P, _I, _I, _L, _P, _P]),
+    "cmu_skinny_gemm_bwd_ws_bytes": (_L, [_I, _I]),
+    "cmu_skinny_gemm_dgrad": (_I, [_P, _P, _P, _I, _I, _L, _P, _P]),
+    "cmu_skinny_gemm_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _L, _P]),
     "cmu_lamb_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _F, _F, _F, _F, _I, _I, _F, _I, _I, _L, _F, _P, _P]),
     "cmu_pack_desc_bytes": (_I, []),
     "cmu_pack_batch": (_I, [_P, _I, _L, _I, _P]),

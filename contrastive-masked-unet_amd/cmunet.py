@@ -222,6 +222,35 @@ class MUNetPretrainDecoder(_EngineOwner, nn.Module):
         return _DecoderFn.apply(self, len(skip), names, x, *skip, *params)
 
 
+class _SkinnyLinearFn(torch.autograd.Function):
+    """nn.Linear on <= 32 rows through the weight-streaming kernels (csrc/skinny.hip): one pass over the weights for the
+    forward, one for the input gradient, one write of the weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return ops.skinny_gemm_fwd(x.detach(), weight.detach(), None if bias is None else bias.detach())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = ops.skinny_gemm_dgrad(dy, weight.detach()) if ctx.needs_input_grad[0] else None
+        dw, db = (ops.skinny_gemm_wgrad(dy, x.detach(), ctx.has_bias) if ctx.needs_input_grad[1] else (None, None))
+        if ctx.has_bias and db is None and ctx.needs_input_grad[2]:
+            db = dy.sum(0)
+        return dx, dw, db
+
+
+def neck_linear(fc, x):
+    """``fc(x)`` for the necks' Linear layers (nonlinear_neck.py:63-66, 95-101): skinny kernels for <= 32 fp32 rows, else the
+    library GEMM (rocBLAS through torch) that a plain tall product is."""
+    if ops.skinny_eligible(x, fc.weight):
+        return _SkinnyLinearFn.apply(x, fc.weight, fc.bias)
+    return fc(x)
+
+
 class NonLinearNeck(nn.Module):
     """fc0 -> BN(eps 1e-6) -> [ReLU -> fc_i (-> BN)]* (nonlinear_neck.py:35-102).  ``norm_cfg`` type 'SyncBN'
     becomes nn.SyncBatchNorm when a process group with more than one rank exists, else BatchNorm1d."""
@@ -283,11 +312,11 @@ class NonLinearNeck(nn.Module):
         else:
             x = x[:, 0, :]
         x = x.reshape(x.size(0), -1)
-        x = self.fc0(x)
+        x = neck_linear(self.fc0, x)
         x = self._bn(self.bn0, x)
         for fc_name, bn_name in zip(self.fc_names, self.bn_names):
             x = self.relu(x)
-            x = getattr(self, fc_name)(x)
+            x = neck_linear(getattr(self, fc_name), x)
             if bn_name is not None:
                 x = self._bn(getattr(self, bn_name), x)
         return x.unsqueeze(dim=1)

@@ -1,0 +1,222 @@
+// skinny.hip -- weight-streaming GEMMs of the CM-UNet projector / predictor necks (SURVEY row a9, 8(b) `cmu_skinny_gemm_*`):
+// NonLinearNeck's first Linear maps a whole feature image to 1,536 units (Pretraining/CM-UNet/cmae/models/necks/
+// nonlinear_neck.py:63-66 with configs/cmunet_config.py:18-26: in_channels = H*W = 50,176 at 224^2, 262,144 at 512^2), i.e.
+// 77-403 M fp32 weights for a batch of 32 rows per GPU.  All three products of a training step are bound by ONE pass over
+// those 0.3-1.6 GB (reading W forward and for the input gradient, writing dW), the arithmetic is 64 FLOP per weight:
+//   fwd    y  (M,N) = x (M,K) . w (N,K)^T (+ bias)     [nn.Linear]
+//   dgrad  dx (M,K) = dy (M,N) . w (N,K)
+//   wgrad  dw (N,K) = dy^T (N,M) . x (M,K),  dbias (N) = sum_m dy
+// for M <= 32 rows (one 32-row MFMA tile; more rows are a plain library GEMM and stay with rocBLAS on the host side).
+// fp32 in, fp32 out on `v_mfma_f32_32x32x2_f32` (exact f32 products, f32 accumulation -- the reference computes these layers
+// in fp32): per wave 16-byte loads straight from HBM into the MFMA operand registers (lane l: row or column l & 31, four
+// consecutive k of half l >> 5, so MFMA j of a step contracts k = kb + j and kb + 4 + j), no LDS.  Each wave streams its own
+// 32 weight rows (fwd) or 128 weight columns (dgrad, wgrad); the other operand (x, dy: <= 32 rows) comes from L2.
+// Split-K partial sums (fwd) go through a slab and a fixed-order second kernel: no atomics, bitwise reproducible.
+#include "common.h"
+
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+
+__device__ static inline f32x4s sk_ld4(const float* p, bool ok) {
+    return ok ? *reinterpret_cast<const f32x4s*>(p) : f32x4s{0.f, 0.f, 0.f, 0.f};
+}
+__device__ static inline f32x16 sk_zero() {
+    f32x16 z;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) z[e] = 0.f;
+    return z;
+}
+
+// ---- forward: block = 4 waves = 4 x 32 rows of w over one K range; grid (ceil(N/128), splits) -------------------------------------
+constexpr int SKF_STEP = 8;      // k per load pair (two halves x four floats)
+constexpr int SKF_UNROLL = 4;    // load pairs in flight per wave
+__global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ slab,
+                                                        int M, int N, int64_t K, int64_t kchunk) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int n = (blockIdx.x * 4 + wave) * 32 + c;           // w row of this lane (B operand column)
+    const int64_t k0 = (int64_t)blockIdx.y * kchunk, k1 = k0 + kchunk < K ? k0 + kchunk : K;
+    const bool nok = n < N, mok = c < M;
+    const float* wp = w + (int64_t)(nok ? n : 0) * K + 4 * h;
+    const float* xp = x + (int64_t)(mok ? c : 0) * K + 4 * h;
+    f32x16 acc = sk_zero();
+    for (int64_t kb = k0; kb < k1; kb += SKF_STEP * SKF_UNROLL) {
+        f32x4s wv[SKF_UNROLL], xv[SKF_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SKF_UNROLL; ++u) {
+            const int64_t k = kb + u * SKF_STEP;
+            wv[u] = sk_ld4(wp + k, nok && k < k1);
+            xv[u] = sk_ld4(xp + k, mok && k < k1);
+        }
+#pragma unroll
+        for (int u = 0; u < SKF_UNROLL; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[u][j], wv[u][j], acc, 0, 0, 0);
+    }
+    // D[m][n]: lane holds column n (its w row), rows m = (e & 3) + 8 (e >> 2) + 4 h
+    float* out = slab + (int64_t)blockIdx.y * M * N;
+    if (nok) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (m < M) out[(int64_t)m * N + n] = acc[e];
+        }
+    }
+}
+__global__ void skinny_fwd_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias, float* __restrict__ y, int M, int N,
+                                         int splits) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)M * N) return;
+    float s = bias ? bias[i % N] : 0.f;
+    for (int k = 0; k < splits; ++k) s += slab[(int64_t)k * M * N + i];
+    y[i] = s;
+}
+static int skf_splits(int N, int64_t K, int64_t* kchunk) {
+    const int nblk = cmu_div_up(N, 128);
+    int splits = (int)cmu_div_up64(1024, nblk);                       // ~4 workgroups per CU
+    int64_t kc = cmu_div_up64(K, splits);
+    kc = cmu_div_up64(kc, SKF_STEP * SKF_UNROLL) * (SKF_STEP * SKF_UNROLL);
+    if (kc < SKF_STEP * SKF_UNROLL) kc = SKF_STEP * SKF_UNROLL;
+    *kchunk = kc;
+    return (int)cmu_div_up64(K, kc);
+}
+extern "C" int64_t cmu_skinny_gemm_ws_bytes(int M, int N, int64_t K) {
+    int64_t kc;
+    return (int64_t)skf_splits(N, K, &kc) * M * N * (int64_t)sizeof(float);
+}
+extern "C" int cmu_skinny_gemm_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int64_t K, void* ws, void* stream) {
+    CMU_CHECK_ARG(x && w && y && ws && M >= 1 && M <= 32 && N >= 1 && K >= 8 && K % 8 == 0, "cmu_skinny_gemm_fwd: needs 1 <= M <= 32, K %% 8 == 0 (M=%d, K=%lld)",
+                  M, (long long)K);
+    CMU_CHECK_ARG(cmu_aligned16(x) && cmu_aligned16(w), "cmu_skinny_gemm_fwd: x / w must be 16-byte aligned");
+    int64_t kc;
+    const int splits = skf_splits(N, K, &kc);
+    hipLaunchKernelGGL(skinny_fwd_kernel, dim3(cmu_div_up(N, 128), splits), dim3(256), 0, (hipStream_t)stream, x, w, (float*)ws, M, N, K, kc);
+    CMU_CHECK_LAUNCH("cmu_skinny_gemm_fwd");
+    hipLaunchKernelGGL(skinny_fwd_reduce_kernel, dim3((unsigned)cmu_div_up64((int64_t)M * N, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)ws, bias, y, M, N, splits);
+    CMU_CHECK_LAUNCH("cmu_skinny_gemm_fwd(reduce)");
+    return CMU_OK;
+}
+
+// ---- input gradient: block = 128 columns of w (four 32-column MFMA tiles: lane c holds columns 4c .. 4c+3); its four waves take
+// a quarter of the N rows each and combine through LDS in wave order (one 128-column tile per wave alone leaves K / 512
+// workgroups: 98 at K = 50,176 for 256 CUs).
+// dyt: dy transposed (N, M) so that the A operand (lane r: dy[m = r][n + h]) is a contiguous 128-byte read per n
+constexpr int SKD_UNROLL = 8;    // n pairs in flight per wave
+__global__ __launch_bounds__(256) void skinny_dgrad_kernel(const float* __restrict__ dyt, const float* __restrict__ w, float* __restrict__ dx,
+                                                          int M, int N, int64_t K) {
+    __shared__ float red[4][4][16][64];                                       // [wave][tile j][e][lane]: 64 KB
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t kcol = (int64_t)blockIdx.x * 128 + 4 * c;                   // first of this lane's four columns
+    const bool kok = kcol < K, mok = c < M;
+    const int nq = ((N + 3) / 4 + 1) & ~1;                                    // rows per wave (even: n pairs)
+    const int nbeg = wave * nq, nend = nbeg + nq < N ? nbeg + nq : N;
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = sk_zero();
+    for (int n0 = nbeg; n0 < nend; n0 += 2 * SKD_UNROLL) {
+        f32x4s wv[SKD_UNROLL];
+        float av[SKD_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SKD_UNROLL; ++u) {
+            const int n = n0 + 2 * u + h;
+            wv[u] = sk_ld4(w + (int64_t)(n < nend ? n : 0) * K + kcol, kok && n < nend);
+            av[u] = (mok && n < nend) ? dyt[(int64_t)n * M + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < SKD_UNROLL; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], wv[u][j], acc[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[wave][j][e][lane] = acc[j][e];
+    __syncthreads();
+    // wave q sums accumulator elements e = 4q .. 4q+3 of all four tiles over the waves, in wave order
+    if (kok) {
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) {
+            const int e = 4 * wave + ee;
+            const int m = (e & 3) + 8 * (e >> 2) + 4 * h;
+            f32x4s v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ((red[0][j][e][lane] + red[1][j][e][lane]) + red[2][j][e][lane]) + red[3][j][e][lane];
+            if (m < M) *reinterpret_cast<f32x4s*>(dx + (int64_t)m * K + kcol) = v;
+        }
+    }
+}
+__global__ void skinny_transpose_kernel(const float* __restrict__ a, float* __restrict__ at, int M, int N) {   // (M,N) -> (N,M)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (int64_t)M * N) at[(i % N) * M + i / N] = a[i];
+}
+extern "C" int64_t cmu_skinny_gemm_bwd_ws_bytes(int M, int N) { return (int64_t)M * N * (int64_t)sizeof(float); }
+extern "C" int cmu_skinny_gemm_dgrad(const float* dy, const float* w, float* dx, int M, int N, int64_t K, void* ws, void* stream) {
+    CMU_CHECK_ARG(dy && w && dx && ws && M >= 1 && M <= 32 && N >= 1 && K >= 4 && K % 4 == 0, "cmu_skinny_gemm_dgrad: needs 1 <= M <= 32, K %% 4 == 0 (M=%d, K=%lld)",
+                  M, (long long)K);
+    CMU_CHECK_ARG(cmu_aligned16(w) && cmu_aligned16(dx), "cmu_skinny_gemm_dgrad: w / dx must be 16-byte aligned");
+    hipLaunchKernelGGL(skinny_transpose_kernel, dim3((unsigned)cmu_div_up64((int64_t)M * N, 256)), dim3(256), 0, (hipStream_t)stream, dy, (float*)ws, M, N);
+    CMU_CHECK_LAUNCH("cmu_skinny_gemm_dgrad(transpose)");
+    hipLaunchKernelGGL(skinny_dgrad_kernel, dim3((unsigned)cmu_div_up64(K, 128)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, w, dx, M, N, K);
+    CMU_CHECK_LAUNCH("cmu_skinny_gemm_dgrad");
+    return CMU_OK;
+}
+
+// ---- weight gradient: wave = 32 rows n x 128 columns k; contraction over the M <= 32 rows (16 MFMA k-pairs) -----------------------
+// A operand: lane r holds dy[m = 2p + h][n0 + r] for the 16 pairs p (contiguous 128-byte reads of dy rows); B: x[m][4c .. 4c+3]
+constexpr int SKW_NT = 2;        // 32-row n tiles per wave and x fragment (halves the passes over x)
+__global__ __launch_bounds__(256) void skinny_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw,
+                                                          int M, int N, int64_t K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t kcol = ((int64_t)blockIdx.x * 4 + wave) * 128 + 4 * c;
+    const bool kok = kcol < K;
+    const int nbase = blockIdx.y * 32 * SKW_NT;
+    f32x4s xv[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const int m = 2 * p + h;
+        xv[p] = sk_ld4(x + (int64_t)(m < M ? m : 0) * K + kcol, kok && m < M);
+    }
+#pragma unroll
+    for (int t = 0; t < SKW_NT; ++t) {
+        const int n = nbase + 32 * t + c;       // A operand row of this lane
+        f32x16 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = sk_zero();
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int m = 2 * p + h;
+            const float a = (n < N && m < M) ? dy[(int64_t)m * N + n] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xv[p][j], acc[j], 0, 0, 0);
+        }
+        if (kok) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int nr = nbase + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;      // output row (D row = A row)
+                if (nr < N) *reinterpret_cast<f32x4s*>(dw + (int64_t)nr * K + kcol) = f32x4s{acc[0][e], acc[1][e], acc[2][e], acc[3][e]};
+            }
+        }
+    }
+}
+__global__ void skinny_colsum_kernel(const float* __restrict__ dy, float* __restrict__ dbias, int M, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += dy[(int64_t)m * N + n];
+    dbias[n] = s;
+}
+extern "C" int cmu_skinny_gemm_wgrad(const float* dy, const float* x, float* dw, float* dbias, int M, int N, int64_t K, void* stream) {
+    CMU_CHECK_ARG(dy && x && dw && M >= 1 && M <= 32 && N >= 1 && K >= 4 && K % 4 == 0, "cmu_skinny_gemm_wgrad: needs 1 <= M <= 32, K %% 4 == 0 (M=%d, K=%lld)",
+                  M, (long long)K);
+    CMU_CHECK_ARG(cmu_aligned16(x) && cmu_aligned16(dw), "cmu_skinny_gemm_wgrad: x / dw must be 16-byte aligned");
+    hipLaunchKernelGGL(skinny_wgrad_kernel, dim3((unsigned)cmu_div_up64(K, 512), cmu_div_up(N, 32 * SKW_NT)), dim3(256), 0, (hipStream_t)stream, dy, x, dw,
+                       M, N, K);
+    CMU_CHECK_LAUNCH("cmu_skinny_gemm_wgrad");
+    if (dbias != nullptr) {
+        hipLaunchKernelGGL(skinny_colsum_kernel, dim3(cmu_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, dy, dbias, M, N);
+        CMU_CHECK_LAUNCH("cmu_skinny_gemm_wgrad(bias)");
+    }
+    return CMU_OK;
+}

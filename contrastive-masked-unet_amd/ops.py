@@ -453,3 +453,40 @@ def philox_normal(n, offset=0, seed=0, device="cuda"):
     out = torch.empty(n, dtype=torch.float64, device=device)
     call("cmu_philox_normal", _p(out), n, int(offset), int(seed) & (2 ** 64 - 1), _stream())
     return out
+
+
+# ---- skinny GEMMs of the necks ----------------------------------------------------------------------------------
+def skinny_eligible(x, weight):
+    """nn.Linear on <= 32 fp32 rows with K % 8 == 0: the weight-streaming kernels; anything else is a plain library GEMM."""
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2 and 1 <= x.shape[0] <= 32
+            and x.shape[1] % 8 == 0 and x.shape[1] >= 8)
+
+
+def skinny_gemm_fwd(x, weight, bias=None):
+    x, weight = _f32c(x), _f32c(weight)
+    M, K = x.shape
+    N = weight.shape[0]
+    y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    ws = torch.empty(_lib.lib().cmu_skinny_gemm_ws_bytes(M, N, K), dtype=torch.uint8, device=x.device)
+    call("cmu_skinny_gemm_fwd", _p(x), _p(weight), _p(None if bias is None else _f32c(bias)), _p(y), M, N, K, _p(ws), _stream())
+    return y
+
+
+def skinny_gemm_dgrad(dy, weight):
+    dy, weight = _f32c(dy), _f32c(weight)
+    M, N = dy.shape
+    K = weight.shape[1]
+    dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
+    ws = torch.empty(_lib.lib().cmu_skinny_gemm_bwd_ws_bytes(M, N), dtype=torch.uint8, device=dy.device)
+    call("cmu_skinny_gemm_dgrad", _p(dy), _p(weight), _p(dx), M, N, K, _p(ws), _stream())
+    return dx
+
+
+def skinny_gemm_wgrad(dy, x, with_bias=False):
+    dy, x = _f32c(dy), _f32c(x)
+    M, N = dy.shape
+    K = x.shape[1]
+    dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+    db = torch.empty(N, dtype=torch.float32, device=dy.device) if with_bias else None
+    call("cmu_skinny_gemm_wgrad", _p(dy), _p(x), _p(dw), _p(db), M, N, K, _stream())
+    return dw, db

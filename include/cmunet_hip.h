@@ -327,6 +327,18 @@ int cmu_two_view(const float* src, int B, int S, const int* shifts, const double
                  int out, void* stream);
 int cmu_philox_normal(double* out, int64_t n, uint64_t offset, uint64_t seed, void* stream);
 
+/* ---- skinny (weight-streaming) GEMMs of the projector / predictor necks (nonlinear_neck.py:63-66, 95-101 with
+ * cmunet_config.py:18-38: Linear(H*W -> 1536) on <= 32 rows per GPU) -- nn.Linear and its autograd, fp32, M <= 32:
+ *   fwd    y (M,N) = x (M,K) . w (N,K)^T + bias (or NULL)      K % 8 == 0; ws: cmu_skinny_gemm_ws_bytes (split-K slab)
+ *   dgrad  dx (M,K) = dy (M,N) . w (N,K)                        K % 4 == 0; ws: cmu_skinny_gemm_bwd_ws_bytes (dy transposed)
+ *   wgrad  dw (N,K) = dy^T . x, dbias (N) = sum_m dy (or NULL)  K % 4 == 0
+ * x, w, dx, dw 16-byte aligned, rows contiguous.  One pass over the weights each; v_mfma_f32_32x32x2_f32.                  */
+int64_t cmu_skinny_gemm_ws_bytes(int M, int N, int64_t K);
+int cmu_skinny_gemm_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int64_t K, void* ws, void* stream);
+int64_t cmu_skinny_gemm_bwd_ws_bytes(int M, int N);
+int cmu_skinny_gemm_dgrad(const float* dy, const float* w, float* dx, int M, int N, int64_t K, void* ws, void* stream);
+int cmu_skinny_gemm_wgrad(const float* dy, const float* x, float* dw, float* dbias, int M, int N, int64_t K, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
