@@ -200,11 +200,11 @@ def main():
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 tj = json.load(f).get(name)
             if tj and args.dtype == "bf16" and B == 32 and H == 512:
-                traffic = round(tj["hbm_bytes_per_launch"] / 1e9, 3)
+                traffic = int(round(tj["hbm_bytes_per_launch"]))
         except (OSError, ValueError, KeyError):
             traffic = None
         out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                           "entries": sorted(d["entries"]), "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "GB/launch (PMC, profiles/traffic.json)",
+                           "entries": sorted(d["entries"]), "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json)",
                            "algorithmic_gflop_per_launch": round(d["work"] / d["calls"] / 1e9, 1),
                            "launches_per_step": d["calls"] // args.steps,
                            "avg_launch_ms": round(d["ms"] / d["calls"], 4),
