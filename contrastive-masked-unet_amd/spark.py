@@ -13,7 +13,8 @@ models/__init__.py:40-49}).
 The module-global ``_cur_active`` of the reference (encoder.py:12) is an explicit argument here.  Round-1
 execution model (csrc/sparse.hip): the dense implicit-GEMM kernels compute every conv; sparse-BatchNorm
 statistics over the active positions, the masked BN+ReLU apply, the densify step and the loss are HBM-bound
-kernels with the patch mask looked up per pixel.  SparseSyncBatchNorm (``sbn=True``) is not implemented.
+kernels with the patch mask looked up per pixel.  ``sbn=True``: the bottleneck's two BatchNorms exchange their statistics
+(forward sums and counts, backward sums) over the default process group, as nn.SyncBatchNorm does for SparseSyncBatchNorm2d.
 """
 import torch
 import torch.nn as nn
@@ -47,8 +48,10 @@ class UNET_MAE_SPARSE(nn.Module):
 class SparseEncoder(nn.Module):
     def __init__(self, cnn, input_size, sbn=False, verbose=False):
         super().__init__()
-        if sbn:
-            raise NotImplementedError("SparseSyncBatchNorm2d (sbn=True) is not implemented on the HIP path")
+        # sbn: dense_model_to_sparse (encoder.py:181-192) turns the plain nn.BatchNorm2d modules into SparseSyncBatchNorm2d;
+        # in unet_sparse those are the two of the bottleneck DoubleConv only (custom.py:125-130 -- the down blocks are built
+        # from SparseBatchNorm2d directly; SURVEY A-10).  SparK._step exchanges their statistics over the process group.
+        self.sbn = bool(sbn)
         self.sp_cnn = cnn
         self.input_size, self.downsample_raito, self.enc_feat_map_chs = input_size, cnn.get_downsample_ratio(), cnn.get_feature_map_channels()
 
@@ -141,7 +144,12 @@ class SparK(_EngineOwner, nn.Module):
             cache[C] = (torch.ones(C, dtype=torch.float32, device=eng.device), torch.zeros(C, dtype=torch.float32, device=eng.device))
         return cache[C]
 
-    def _sp_convbn_fwd(self, eng, sd, pconv, pbn, x, x_img, inv_pix, active, count, B, H, W, training):
+    @staticmethod
+    def _sync_world():
+        import torch.distributed as dist
+        return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+    def _sp_convbn_fwd(self, eng, sd, pconv, pbn, x, x_img, inv_pix, active, count, B, H, W, training, sync=False):
         w = sd[pconv + "weight"]
         C = w.shape[0]
         y = eng._new(B, H, W, C)
@@ -151,6 +159,13 @@ class SparK(_EngineOwner, nn.Module):
             ops.conv3x3_fwd(x, eng._wp(pconv, w, False), y, None)
         scale, shift, mean, invstd = eng._f32(C), eng._f32(C), eng._f32(C), eng._f32(C)
         slab = ops.masked_channel_stats(y, active) if training else None          # statistics over ACTIVE pixels only
+        if sync and training and self._sync_world() > 1:
+            # SparseSyncBatchNorm2d (encoder.py:54-55 on nn.SyncBatchNorm): sums, sums of squares and counts of all ranks
+            import torch.distributed as dist
+            tot = torch.cat([slab.double().sum(0).reshape(-1), torch.tensor([float(count)], dtype=torch.float64, device=slab.device)])
+            dist.all_reduce(tot)
+            count = int(round(tot[-1].item()))
+            slab = tot[:-1].float().view(1, 2, C).contiguous()
         ws = eng.scratch.get("bnfin", eng.lib.cmu_bn_finalize_ws_bytes(C))
         ops.bn_finalize(slab, count, sd[pconv + "bias"].detach(), sd[pbn + "weight"].detach(), sd[pbn + "bias"].detach(),
                         sd[pbn + "running_mean"], sd[pbn + "running_var"], BN_MOMENTUM, BN_EPS, training, scale, shift, mean, invstd, ws)
@@ -160,7 +175,7 @@ class SparK(_EngineOwner, nn.Module):
         a = eng._new(B, H, W, C)
         ops.mask_select(yt, active, a, relu=True)                                  # BN + ReLU, zeros at masked positions
         return {"pconv": pconv, "pbn": pbn, "x": x, "x_img": x_img, "mask": inv_pix, "mps": True, "y": yt, "a": a,
-                "mean": mean, "invstd": invstd}
+                "mean": mean, "invstd": invstd, "sync": sync, "count_all": count}
 
     def _sp_convbn_bwd(self, eng, sd, s, dA, active, count, grads, need_dx):
         y = s["y"]
@@ -168,6 +183,13 @@ class SparK(_EngineOwner, nn.Module):
         w = sd[s["pconv"] + "weight"]
         dgamma, dbeta, coef = eng._f32(C), eng._f32(C), eng._f32(2, C)
         ops.bn_bwd_reduce_masked(dA, y, s["mean"], s["invstd"], dgamma, dbeta, coef, active, count, eng._bn_ws(C))
+        if s.get("sync") and self._sync_world() > 1:
+            # SyncBatchNorm backward: the input gradient uses the sums over ALL ranks; dgamma / dbeta stay local (the gradient
+            # exchange averages them like every other parameter gradient)
+            import torch.distributed as dist
+            tot = torch.stack([dbeta, dgamma]).double()
+            dist.all_reduce(tot)
+            coef.copy_((tot / float(s["count_all"])).float())
         dY = Act(dA.buf, dA.coff, dA.C)
         ops.bn_bwd_apply_masked(dA, y, s["mean"], s["invstd"], coef, dY, active)
         grads[s["pbn"] + "weight"], grads[s["pbn"] + "bias"] = dgamma, dbeta
@@ -214,8 +236,9 @@ class SparK(_EngineOwner, nn.Module):
             x, ximg, h, w_ = pooled, None, h // 2, w_ // 2
         p = f"{ep}double_conv.double_conv."
         cnt_b = n_cells * (h // f) * (w_ // f)
-        b1 = self._sp_convbn_fwd(eng, sd, p + "0.", p + "1.", x, ximg, None, active, cnt_b, B, h, w_, training)
-        b2 = self._sp_convbn_fwd(eng, sd, p + "3.", p + "4.", b1["a"], None, None, active, cnt_b, B, h, w_, training)
+        sbn = bool(getattr(self.sparse_encoder, "sbn", False))     # (SparK's own ``sbn`` only concerns the densify norms)
+        b1 = self._sp_convbn_fwd(eng, sd, p + "0.", p + "1.", x, ximg, None, active, cnt_b, B, h, w_, training, sync=sbn)
+        b2 = self._sp_convbn_fwd(eng, sd, p + "3.", p + "4.", b1["a"], None, None, active, cnt_b, B, h, w_, training, sync=sbn)
 
         # ---- densify (spark.py:98-111): feature maps from the smallest to the largest, mask_tokens[i] likewise ----
         feats = [b2["a"]] + [lv["s2"]["a"] for lv in reversed(levels)]

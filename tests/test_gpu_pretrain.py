@@ -227,3 +227,82 @@ def test_spark_step_vs_reference_fixture(cuda, golden_dir, dt):
     else:
         assert rel(tg, tg64) <= 0.3
     print(f"[spark {dt}] loss {float(loss):.5f} vs {float(d['loss']):.5f}, worst grad-norm err {worst:.2e}")
+
+
+def test_spark_sync_batchnorm_two_ranks(cuda):
+    """SparseSyncBatchNorm2d (sbn=True: the bottleneck's two BatchNorms, SURVEY A-10) on two ranks (gloo, both on cuda:0).
+    (i) Both ranks fed the SAME batch: the all-reduced sums and counts are twice the local ones, so loss, gradients and
+    running statistics must equal the single-process sbn=False step (to the float32 rounding of the exchanged totals).  (ii) Different batches per rank: the bottleneck's running
+    statistics come out identical on both ranks (they are the same all-reduced numbers) and differ from the unsynchronised
+    run, while a down block's stay per-rank."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, %r)
+import torch.distributed as dist
+from cmunet_amd import spark as S
+world = int(os.environ.get("WORLD_SIZE", "1"))
+rank = int(os.environ.get("RANK", "0"))
+if world > 1:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+mode, sbn, out = sys.argv[1], sys.argv[2] == "1", sys.argv[3]
+torch.manual_seed(5)
+enc = S.build_sparse_encoder("unet_sparse", input_size=64, sbn=sbn, base_ch=16, depth=3, dtype="f32")
+model = S.SparK(enc, S.UnetDecoder(base_ch=16, depth=3, dtype="f32"), mask_ratio=0.6, densify_norm="", dtype="f32").cuda().train()
+g = torch.Generator().manual_seed(11 if mode == "same" else 11 + rank)
+x = torch.randn(4, 1, 64, 64, generator=g)
+f = model.fmap_h
+active = torch.zeros(4, 1, f, f, dtype=torch.bool)
+for b in range(4):
+    idx = torch.randperm(f * f, generator=g)[:model.len_keep]
+    active[b, 0].view(-1)[idx] = True
+loss = model(x.cuda(), active_b1ff=active.cuda())
+loss.backward()
+sd = model.state_dict()
+bk = [k for k in sd if "sp_cnn.double_conv" in k and k.endswith("running_mean")]
+dk = [k for k in sd if "sp_cnn.down_conv1" in k and k.endswith("running_mean")]
+gp = dict(model.named_parameters())
+gk = [k for k in gp if "sp_cnn.double_conv.double_conv.0.weight" in k or "sp_cnn.down_conv1.double_conv.double_conv.3.weight" in k]
+torch.save({"loss": loss.detach().cpu(), "bott": [sd[k].cpu() for k in bk], "down": [sd[k].cpu() for k in dk],
+            "grads": [gp[k].grad.cpu() for k in gk]}, out + f".{rank}")
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+''' % root
+
+    def run(mode, sbn, world):
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "r")
+            procs = []
+            for rk in range(world):
+                env = dict(os.environ)
+                if world > 1:
+                    env.update(WORLD_SIZE=str(world), RANK=str(rk), MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+                else:
+                    for k in ("WORLD_SIZE", "RANK", "MASTER_ADDR", "MASTER_PORT"):
+                        env.pop(k, None)
+                procs.append(subprocess.Popen([sys.executable, "-c", code, mode, "1" if sbn else "0", out], env=env))
+            for p in procs:
+                assert p.wait(timeout=300) == 0
+            return [torch.load(out + f".{rk}") for rk in range(world)]
+
+    single = run("same", False, 1)[0]
+    same = run("same", True, 2)
+    def near(a, b, tol):
+        return (a.double() - b.double()).abs().max().item() <= tol * max(b.double().abs().max().item(), 1e-6)
+    for r in same:
+        assert near(r["loss"], single["loss"], 1e-6)
+        for a, b in zip(r["bott"] + r["down"], single["bott"] + single["down"]):
+            assert near(a, b, 1e-5)
+        for a, b in zip(r["grads"], single["grads"]):
+            assert near(a, b, 2e-4)
+    diff = run("diff", True, 2)
+    nosync = run("diff", False, 2)
+    for a, b in zip(diff[0]["bott"], diff[1]["bott"]):
+        assert torch.equal(a, b)                                  # synchronised statistics: the same numbers on both ranks
+    assert not torch.equal(diff[0]["down"][0], diff[1]["down"][0])   # the down blocks' SparseBatchNorm2d stay per-rank
+    assert not torch.equal(diff[0]["bott"][0], nosync[0]["bott"][0])
