@@ -300,12 +300,14 @@ torch.save({"y": y.buf.float().cpu(), "s": st.sum(0).cpu()}, sys.argv[1])
     check(outs[1]["s"], outs[0]["s"], 1e-4, "wide vs first stats")
 
 
-@pytest.mark.parametrize("chans", [(64, 128), (128, 64), (64, 64)])
-def test_conv3x3_persistent_kernel_is_bit_identical(chans):
+@pytest.mark.parametrize("chans,hw", [((64, 128), (48, 96)), ((128, 64), (48, 96)), ((64, 64), (48, 96)),
+                                      ((128, 64), (64, 96)), ((64, 64), (96, 64))])      # H % 32 == 0: the 32 x 32-pixel tiles
+def test_conv3x3_persistent_kernel_is_bit_identical(chans, hw):
     """The persistent wide kernel (conv_igemm3p.inc: one workgroup walks a list of tiles) against the one-tile-per-workgroup
     kernel (CMU_CONV_PERSIST=0) on a whole-tile shape, with 13 workgroups forced so that every workgroup streams several
     tiles and the per-XCD item ranges are uneven: same MFMA order per accumulator, same statistics folding order ->
-    identical bits, for the forward (pending transform + BN statistics), the plain data gradient and the data gradient
+    identical bits (with the 32 x 32-pixel tiles of the 64-channel layers the stored outputs are still identical; the
+    statistics are the same sums folded over 8 rows per wave instead of 4: compared to 2e-5), for the forward (pending transform + BN statistics), the plain data gradient and the data gradient
     with fused BN-backward sums."""
     import os
     import subprocess
@@ -319,7 +321,7 @@ import sys, torch
 sys.path.insert(0, %r)
 from cmunet_amd import ops
 g = torch.Generator().manual_seed(0)
-B, H, W, Cin, Cout = 3, 48, 96, %d, %d
+B, H, W, Cin, Cout = 3, %d, %d, %d, %d
 x = torch.randn(B, H, W, Cin, generator=g).to(torch.bfloat16).cuda()
 w = (torch.randn(Cout, Cin, 3, 3, generator=g) / 48).cuda()
 sc, sh = (torch.rand(Cin, generator=g) + 0.5).cuda(), (torch.randn(Cin, generator=g) * 0.3).cuda()
@@ -341,7 +343,7 @@ slab = ops.new_stats(B, H, W, Cout, "cuda")
 ops.conv3x3_dgrad_bn(ops.Act(x, 0, Cin), ops.pack_conv3x3(wt, "bf16", transpose_flip=True), dX, ops.Act(xr, 0, Cout, bsc, bsh, 0), mu, istd, slab)
 out["dx"], out["slab"] = dX.buf.clone(), slab.clone()
 torch.save({k: v.cpu() for k, v in out.items()}, sys.argv[1])
-''' % (root, chans[0], chans[1])
+''' % (root, hw[0], hw[1], chans[0], chans[1])
     outs = []
     for env in ({"CMU_CONV_PERSIST": "0"}, {"CMU_CONV_PERSIST": "1", "CMU_CONV_PERSIST_GRID": "13"}):
         with tempfile.NamedTemporaryFile(suffix=".pt", delete=False) as f:
@@ -349,8 +351,14 @@ torch.save({k: v.cpu() for k, v in out.items()}, sys.argv[1])
         subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, CMU_CONV_WIDE="2", **env), timeout=300)
         outs.append(torch.load(path))
         os.unlink(path)
+    tall = hw[0] % 32 == 0 and chans[1] == 64      # 32 x 32-pixel tiles: a wave sums 8 rows instead of 4 before the slab
     for k in outs[0]:
-        assert torch.equal(outs[0][k].view(torch.uint8), outs[1][k].view(torch.uint8)), k
+        if tall and k in ("s", "slab"):
+            a, b = outs[0][k].double().sum(0), outs[1][k].double().sum(0)
+            assert (a - b).abs().max().item() <= 1e-5 * max(b.abs().max().item(), 1.0), k
+            assert (outs[0][k].double() - outs[1][k].double()).abs().max().item() <= 2e-5 * max(outs[0][k].abs().max().item(), 1.0), k
+        else:
+            assert torch.equal(outs[0][k].view(torch.uint8), outs[1][k].view(torch.uint8)), k
 
 
 @pytest.mark.parametrize("dt", DTS)

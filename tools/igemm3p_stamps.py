@@ -1,6 +1,6 @@
 """Diagnostic: s_memtime timeline of the persistent wide conv kernel around a tile boundary (build the stamps library with
 tools/igemm_stamps.sh).  Usage: python tools/igemm3p_stamps.py [H Cin Cout].  Prints, for waves 0 and 4, the cycles between the
-stamps of 16 consecutive iterations starting two slices before the first tile's last slice."""
+stamps of 12 consecutive iterations starting two slices before the first tile's last slice."""
 import ctypes
 import sys
 
@@ -32,8 +32,8 @@ for _ in range(5):
 torch.cuda.synchronize()
 buf = np.zeros(64 * 16 * 8, dtype=np.uint64)
 assert lib.cmu_debug_ig_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
-NIT = 16
-st = buf.reshape(32, 2, 16, 8)[:4].astype(np.int64)
+NIT = 12
+st = buf.reshape(32, 256)[:4, :2 * NIT * 8].reshape(4, 2, NIT, 8).astype(np.int64)
 nsl = Cin // 16
 names = ["mfma", "barrier1", "store_regs", "slab+epilogue", "issue", "barrier2"]
 for grp in range(2):
