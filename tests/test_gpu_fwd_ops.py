@@ -348,7 +348,8 @@ torch.save({k: v.cpu() for k, v in out.items()}, sys.argv[1])
     for env in ({"CMU_CONV_PERSIST": "0"}, {"CMU_CONV_PERSIST": "1", "CMU_CONV_PERSIST_GRID": "13"}):
         with tempfile.NamedTemporaryFile(suffix=".pt", delete=False) as f:
             path = f.name
-        subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, CMU_CONV_WIDE="2", **env), timeout=300)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, CMU_CONV_WIDE="2", CMU_CONV_TALL="1", **env),
+                       timeout=300)
         outs.append(torch.load(path))
         os.unlink(path)
     tall = hw[0] % 32 == 0 and chans[1] == 64      # 32 x 32-pixel tiles: a wave sums 8 rows instead of 4 before the slab
