@@ -36,6 +36,7 @@ _SIGS = {
     "cmu_resize_bicubic": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P]),
     "cmu_two_view": (_I, [_P, _I, _I, _P, _P, _U64, _P, _P, _I, _P]),
     "cmu_philox_normal": (_I, [_P, _L, _U64, _U64, _P]),
+    "cmu_random_patch_mask": (_I, [_P, _I, _I, _I, _I, _I, _U64, _U64, _P]),
     "cmu_skinny_gemm_ws_bytes": (_L, [_I, _I, _L]),
     "cmu_skinny_gemm_fwd": (_I, [_P, _P, _P, _P, _I, _I, _L, _P, _P]),
     "cmu_skinny_gemm_bwd_ws_bytes": (_L, [_I, _I]),

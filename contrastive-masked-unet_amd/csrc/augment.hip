@@ -189,3 +189,41 @@ extern "C" int cmu_philox_normal(double* out, int64_t n, uint64_t offset, uint64
     CMU_CHECK_LAUNCH("cmu_philox_normal");
     return CMU_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// random patch mask (backbones/UNet_encoder.py:106-139: per sample a random permutation of the patches, the first
+// floor(ratio*H*W / patch^2) of it masked).  One workgroup per sample: patch p draws the 32-bit key Philox(offset + b*P + p)
+// (first output word); it is masked iff (key, p) ranks among the n_mask smallest of the sample -- a uniformly random
+// n_mask-subset, reproducible from (seed, offset), with no sort and no host loop.  mask (B,H,W) u8, 1 = masked.
+// ---------------------------------------------------------------------------------------------
+constexpr int PM_MAX_PATCHES = 4096;
+__global__ __launch_bounds__(256) void patch_mask_kernel(uint8_t* __restrict__ mask, int H, int W, int patch, int n_mask, uint64_t seed,
+                                                        uint64_t offset) {
+    __shared__ unsigned long long key[PM_MAX_PATCHES];
+    __shared__ uint8_t flag[PM_MAX_PATCHES];
+    const int b = blockIdx.x, ph = H / patch, pw = W / patch, P = ph * pw;
+    for (int q = threadIdx.x; q < P; q += 256) {
+        uint32_t r[4];
+        const uint64_t e = offset + (uint64_t)b * P + q;
+        philox4x32_10((uint32_t)e, (uint32_t)(e >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+        key[q] = ((unsigned long long)r[0] << 32) | (unsigned)q;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < P; q += 256) {
+        const unsigned long long k = key[q];
+        int rank = 0;
+        for (int j = 0; j < P; ++j) rank += key[j] < k ? 1 : 0;
+        flag[q] = rank < n_mask ? 1 : 0;
+    }
+    __syncthreads();
+    uint8_t* m = mask + (int64_t)b * H * W;
+    for (int i = threadIdx.x; i < H * W; i += 256) m[i] = flag[(i / W / patch) * pw + (i % W) / patch];
+}
+extern "C" int cmu_random_patch_mask(uint8_t* mask, int B, int H, int W, int patch, int n_mask, uint64_t seed, uint64_t offset, void* stream) {
+    CMU_CHECK_ARG(mask && B > 0 && H > 0 && W > 0 && patch > 0 && H % patch == 0 && W % patch == 0, "cmu_random_patch_mask: bad shape");
+    const int P = (H / patch) * (W / patch);
+    CMU_CHECK_ARG(P <= PM_MAX_PATCHES && n_mask >= 0 && n_mask <= P, "cmu_random_patch_mask: %d patches (max %d), n_mask %d", P, PM_MAX_PATCHES, n_mask);
+    hipLaunchKernelGGL(patch_mask_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, mask, H, W, patch, n_mask, seed, offset);
+    CMU_CHECK_LAUNCH("cmu_random_patch_mask");
+    return CMU_OK;
+}

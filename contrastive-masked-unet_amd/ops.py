@@ -490,3 +490,12 @@ def skinny_gemm_wgrad(dy, x, with_bias=False):
     db = torch.empty(N, dtype=torch.float32, device=dy.device) if with_bias else None
     call("cmu_skinny_gemm_wgrad", _p(dy), _p(x), _p(dw), _p(db), M, N, K, _stream())
     return dw, db
+
+
+def random_patch_mask(B, H, W, patch_size=16, mask_ratio=0.65, seed=0, offset=0, device="cuda"):
+    """UNet_encoder.create_random_patch_mask (UNet_encoder.py:106-139) in one kernel: (B,H,W) uint8, 1 = masked,
+    floor(ratio*H*W / patch^2) patches per sample, reproducible from (seed, offset)."""
+    n_mask = int(mask_ratio * H * W) // (patch_size * patch_size)
+    m = torch.empty(B, H, W, dtype=torch.uint8, device=device)
+    call("cmu_random_patch_mask", _p(m), B, H, W, patch_size, n_mask, int(seed) & (2 ** 64 - 1), int(offset), _stream())
+    return m

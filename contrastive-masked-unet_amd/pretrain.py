@@ -39,9 +39,14 @@ def create_random_patch_mask(batch_size, img_size, patch_size=16, mask_ratio=0.6
     return np.repeat(np.repeat(mask, patch_size, axis=1), patch_size, axis=2)
 
 
-def random_patch_mask_device(batch_size, H, W, patch_size=16, mask_ratio=0.65, generator=None, device="cuda"):
+def random_patch_mask_device(batch_size, H, W, patch_size=16, mask_ratio=0.65, generator=None, device="cuda", seed=None, offset=0):
     """Same distribution, generated on the device: a random permutation of the patches per
-    sample, the first floor(ratio*H*W/patch^2) masked.  Returns uint8 (B,H,W), 1 = masked."""
+    sample, the first floor(ratio*H*W/patch^2) masked.  Returns uint8 (B,H,W), 1 = masked.
+    ``seed`` given: one launch of the counter-based kernel (``ops.random_patch_mask``; the caller advances ``offset`` by
+    B * patches per call); else torch's generator (rand + double argsort)."""
+    if seed is not None:
+        from . import ops
+        return ops.random_patch_mask(batch_size, H, W, patch_size, mask_ratio, seed, offset, device)
     ph, pw = H // patch_size, W // patch_size
     n_mask = int(mask_ratio * H * W) // (patch_size * patch_size)
     r = torch.rand(batch_size, ph * pw, generator=generator, device=device)

@@ -326,6 +326,10 @@ int cmu_resize_bicubic(const float* src, int B, int Hs, int Ws, const int* boxes
 int cmu_two_view(const float* src, int B, int S, const int* shifts, const double* noise, uint64_t seed, float* img, float* img_t,
                  int out, void* stream);
 int cmu_philox_normal(double* out, int64_t n, uint64_t offset, uint64_t seed, void* stream);
+/* Random patch mask of backbones/UNet_encoder.py:106-139 on the device: mask (B,H,W) u8, 1 = masked; per sample a uniformly
+ * random n_mask-subset of the (H/patch)*(W/patch) patches (<= 4096): patch p of sample b draws the first word of
+ * Philox4x32-10(counter = offset + b*P + p, key = seed) and is masked iff (key, p) is among the n_mask smallest.            */
+int cmu_random_patch_mask(uint8_t* mask, int B, int H, int W, int patch, int n_mask, uint64_t seed, uint64_t offset, void* stream);
 
 /* ---- skinny (weight-streaming) GEMMs of the projector / predictor necks (nonlinear_neck.py:63-66, 95-101 with
  * cmunet_config.py:18-38: Linear(H*W -> 1536) on <= 32 rows per GPU) -- nn.Linear and its autograd, fp32, M <= 32:

@@ -122,3 +122,17 @@ def philox_normal(n, offset, seed):
     r = philox4x32_10(c, (seed & 0xFFFFFFFF, seed >> 32)).astype(np.float64)
     u1, u2 = (r[:, 0] + 0.5) / 4294967296.0, (r[:, 1] + 0.5) / 4294967296.0
     return np.sqrt(-2.0 * np.log(u1)) * np.cos(6.283185307179586 * u2)
+
+
+def random_patch_mask(B, H, W, patch, n_mask, seed, offset=0):
+    """cmu_random_patch_mask restated: patch p of sample b draws the first Philox word of counter offset + b*P + p; the n_mask
+    smallest (key, p) pairs of a sample are masked.  Same distribution as UNet_encoder.py:106-139 (shuffle, take the first)."""
+    ph, pw = H // patch, W // patch
+    P = ph * pw
+    e = np.arange(B * P, dtype=np.uint64) + np.uint64(offset)
+    c = np.stack([e & np.uint64(0xFFFFFFFF), e >> np.uint64(32), np.zeros_like(e), np.zeros_like(e)], axis=1)
+    key = philox4x32_10(c, (seed & 0xFFFFFFFF, seed >> 32))[:, 0].astype(np.uint64).reshape(B, P)
+    full = (key << np.uint64(32)) | np.arange(P, dtype=np.uint64)[None, :]
+    rank = full.argsort(axis=1).argsort(axis=1)
+    m = (rank < n_mask).astype(np.uint8).reshape(B, ph, pw)
+    return np.repeat(np.repeat(m, patch, axis=1), patch, axis=2)

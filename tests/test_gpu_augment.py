@@ -105,3 +105,21 @@ def test_device_pipeline_equals_host_pipeline_on_the_same_draws(ops):
     assert np.array_equal(_bits(got['img_t'].cpu().numpy()), _bits(r_img_t))
     out = pipe(torch.from_numpy(raw).cuda())                  # fully random call: shapes / dtype / finiteness
     assert out['img'].shape == (4, 224, 224) and out['img_t'].dtype == torch.float32 and bool(torch.isfinite(out['img_t']).all())
+
+
+@pytest.mark.parametrize("shape,patch,ratio", [((4, 512, 512), 16, 0.6), ((3, 224, 224), 16, 0.65), ((2, 64, 96), 16, 0.75), ((2, 32, 32), 16, 0.0)])
+def test_random_patch_mask_kernel(ops, shape, patch, ratio):
+    """Device patch-mask generator: identical to the numpy restatement (same Philox keys, same ranking), the reference's count
+    of masked patches per sample (UNet_encoder.py:113), whole patches only, fresh draws at another offset."""
+    from oracle.augment import random_patch_mask
+    B, H, W = shape
+    n_mask = int(ratio * H * W) // (patch * patch)
+    got = ops.random_patch_mask(B, H, W, patch, ratio, seed=77, offset=12345).cpu().numpy()
+    ref = random_patch_mask(B, H, W, patch, n_mask, 77, 12345)
+    assert np.array_equal(got, ref)
+    blocks = got.reshape(B, H // patch, patch, W // patch, patch)
+    assert (blocks.min(axis=(2, 4)) == blocks.max(axis=(2, 4))).all()
+    assert (blocks[:, :, 0, :, 0].reshape(B, -1).sum(1) == n_mask).all()
+    if n_mask:
+        other = ops.random_patch_mask(B, H, W, patch, ratio, seed=77, offset=12345 + B * (H // patch) * (W // patch)).cpu().numpy()
+        assert not np.array_equal(other, got)
