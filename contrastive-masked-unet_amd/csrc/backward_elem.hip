@@ -210,15 +210,15 @@ __global__ void bn_bwd_apply_kernel(const unsigned char* __restrict__ dA, int64_
             continue;
         }
         float g[EPC], v[EPC], o[EPC];
-        TR::unpack(ld_global16(dA + (p * ldd + ch * EPC) * ES), g);
-        TR::unpack(ld_global16(y + (p * ldy + ch * EPC) * ES), v);
+        TR::unpack(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(dA + (p * ldd + ch * EPC) * ES)), g);
+        TR::unpack(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(y + (p * ldy + ch * EPC) * ES)), v);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             const float dz = fmaf(v[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
             const float xh = (v[e] - mu[e]) * is[e];
             o[e] = sc[e] * (dz - c1[e] - xh * c2[e]);
         }
-        st_global16(dY + (p * ldo + ch * EPC) * ES, TR::pack(o));
+        __builtin_nontemporal_store(TR::pack(o), reinterpret_cast<u32x4*>(dY + (p * ldo + ch * EPC) * ES));
     }
 }
 template <class TR>
