@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
             const int xo = (int)(pp % Wo), yo = (int)((pp / Wo) % Ho), b = (int)(pp / ((int64_t)Wo * Ho));
             float best[EPC], g[EPC], f[4][EPC];
             int arg[EPC];
-            TR::unpack(ld_global16(dP + (pp * ldp + ch * EPC) * ES), g);
+            TR::unpack(ld_global16_nt(dP + (pp * ldp + ch * EPC) * ES), g);
             int64_t src[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float d[EPC];
-                if (dS) TR::unpack(ld_global16(dS + (src[q] * lds + ch * EPC) * ES), d);
+                if (dS) TR::unpack(ld_global16_nt(dS + (src[q] * lds + ch * EPC) * ES), d);
                 else {
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) d[e] = 0.f;
@@ -598,8 +598,8 @@ __global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __re
                     ok[u] = pix < 256 && gy < H && gx < W;
                     gq[u] = vq[u] = u32x4{0u, 0u, 0u, 0u};
                     if (ok[u]) {
-                        gq[u] = ld_global16(dY + ((((int64_t)b * H + gy) * W + gx) * ldd + chunk * EPC) * ES);
-                        if (yraw != nullptr) vq[u] = ld_global16(yraw + ((((int64_t)b * H + gy) * W + gx) * ldy + chunk * EPC) * ES);
+                        gq[u] = ld_global16_nt(dY + ((((int64_t)b * H + gy) * W + gx) * ldd + chunk * EPC) * ES);
+                        if (yraw != nullptr) vq[u] = ld_global16_nt(yraw + ((((int64_t)b * H + gy) * W + gx) * ldy + chunk * EPC) * ES);
                     }
                 }
 #pragma unroll

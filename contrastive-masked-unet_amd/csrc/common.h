@@ -144,6 +144,9 @@ struct BF16Traits {
 // ---------------------------------------------------------------------------------------------
 __device__ static inline u32x4 ld_global16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ static inline void st_global16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
+// streaming variants: data that is dead after this read / not read again soon (no reason to keep it in L2)
+__device__ static inline u32x4 ld_global16_nt(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
+__device__ static inline void st_global16_nt(void* p, const u32x4& v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p)); }
 
 __device__ static inline float wave_sum(float v) {
 #pragma unroll

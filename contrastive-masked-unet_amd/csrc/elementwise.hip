@@ -512,7 +512,7 @@ __global__ void bnrelu_maxpool_kernel(const unsigned char* __restrict__ y, int64
         for (int q = 0; q < 4; ++q) {
             const int64_t src = (((int64_t)b * H + 2 * yo + (q >> 1)) * W + 2 * xo + (q & 1)) * ldy + ch * EPC;
             float f[EPC];
-            TR::unpack(ld_global16(y + src * ES), f);
+            TR::unpack(ld_global16_nt(y + src * ES), f);   // the skip is not read again before the decoder
 #pragma unroll
             for (int e = 0; e < EPC; ++e) m[e] = fmaxf(m[e], fmaf(f[e], sc[e], sh[e]));
         }
