@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void conv3x3_c1_fwd_kernel(const float* __rest
                 s1[e] += a;
                 s2[e] = fmaf(a, a, s2[e]);
             }
-            st_global16(reinterpret_cast<unsigned char*>(y) + ((((int64_t)b * H + gy) * W + gx) * ldy + chunk * EPC) * sizeof(typename TR::elem_t),
+            st_global16_nt(reinterpret_cast<unsigned char*>(y) + ((((int64_t)b * H + gy) * W + gx) * ldy + chunk * EPC) * sizeof(typename TR::elem_t),
                         TR::pack(o));
         }
     if (stats == nullptr) continue;
