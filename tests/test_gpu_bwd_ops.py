@@ -341,7 +341,9 @@ def _bn_bwd_sums(dx_stored, y, scale, shift, mean, invstd):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("shape", [(2, 18, 21, 24, 40), (1, 18, 37, 128, 64), (2, 16, 32, 64, 128), (1, 33, 40, 64, 256)])
+@pytest.mark.parametrize("shape", [(2, 18, 21, 24, 40), (1, 18, 37, 128, 64), (2, 16, 32, 64, 128), (1, 33, 40, 64, 256),
+                                   # whole-tile shapes: the persistent kernel (several channel blocks, long K, 64-channel form)
+                                   (2, 32, 64, 256, 256), (1, 48, 32, 128, 512), (3, 16, 96, 64, 64)])
 def test_conv3x3_dgrad_bn(ops, dt, shape):
     """Data gradient + fused BatchNorm-backward partial sums of the producer layer (first and wide-tile kernels)."""
     from cmunet_amd import _lib

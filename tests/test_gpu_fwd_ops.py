@@ -59,6 +59,13 @@ CONV_CASES = [
     (2, 35, 70, 64, 64, 0, 0, True),
     (1, 17, 40, 96, 64, 0, 32, False),
     (1, 48, 64, 32, 384, 0, 0, True),
+    # whole tiles (H % 16 == 0, W % 32 == 0): the persistent kernel -- several items per workgroup list, several channel
+    # blocks, long K (table of 1024 channels), channel-sliced input and output buffers, no transform
+    (2, 32, 64, 256, 256, 0, 64, True),
+    (1, 48, 32, 512, 128, 32, 0, True),
+    (1, 16, 64, 1024, 128, 0, 0, True),
+    (3, 32, 32, 128, 64, 0, 0, False),
+    (2, 16, 96, 64, 64, 64, 64, True),
     # not eligible (N = 192 is not a multiple of 128; K = 136 has a ragged slice): first kernel
     (2, 16, 16, 256, 192, 0, 64, True),
     (1, 7, 9, 136, 256, 8, 0, False),
