@@ -229,7 +229,7 @@ static int bn_bwd_apply_t(const void* dA, int64_t ldd, const void* y, int64_t ld
     chunk_geometry(C / TR::EPC, &cpb, &ppb, &gy);
     const int64_t npix = (int64_t)B * H * W;
     const int sbits = active ? sp_shift_bits(H, f) : 0;
-    int gx = (int)(cmu_div_up64(npix, ppb * 2) < 4096 ? cmu_div_up64(npix, ppb * 2) : 4096);
+    int gx = (int)(cmu_div_up64(npix, ppb * 2) < 16384 ? cmu_div_up64(npix, ppb * 2) : 16384);
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL((bn_bwd_apply_kernel<TR>), dim3(gx, gy), dim3(256), 0, st, (const unsigned char*)dA, ldd,
                        (const unsigned char*)y, ldy, scale, shift, mean, invstd, coef, (unsigned char*)dY, ldo, npix, C, cpb, ppb, active, f,
