@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libcmunet_hip.so")
+LIB_PATH = os.environ.get("CMU_LIB_PATH") or os.path.join(CSRC, "libcmunet_hip.so")   # CMU_LIB_PATH: diagnostic builds (tools/)
 
 F32, F16, BF16 = 0, 1, 2
 

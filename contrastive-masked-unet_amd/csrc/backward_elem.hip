@@ -6,7 +6,10 @@
 // that a second tiny kernel adds in a fixed order (bitwise reproducible, no float atomics).
 #include "common.h"
 
-constexpr int RED_MAX_BLOCKS = 2048;
+constexpr int RED_MAX_BLOCKS = 2048;     // rows of the partial-sum slabs (workspace sizes)
+// measured on the bench step: the max-pool backward is fastest with 2048 workgroups (1.22 ms; 1.34 at 1024, 1.38 at 8192), the
+// head backward with 1024 (0.47 ms; 0.54 at 2048, 0.76 at 8192) -- each workgroup ends with a cross-wave fold of its sums
+constexpr int POOLB_MAX_BLOCKS = 2048, HEADB_MAX_BLOCKS = 1024;
 // BN-backward partial-sum slab ("bn_ws"): int32 header word 0 = number of rows written by the producer kernel
 // (device side, no host sync), then float rows [row][2][C] from byte 16 on.  Producers: cmu_bn_bwd_reduce,
 // cmu_maxpool_bwd, cmu_conv1x1_head_bwd (fused); consumer: bn_bwd_final_kernel.
@@ -229,7 +232,8 @@ static int bn_bwd_apply_t(const void* dA, int64_t ldd, const void* y, int64_t ld
     chunk_geometry(C / TR::EPC, &cpb, &ppb, &gy);
     const int64_t npix = (int64_t)B * H * W;
     const int sbits = active ? sp_shift_bits(H, f) : 0;
-    int gx = (int)(cmu_div_up64(npix, ppb * 2) < 16384 ? cmu_div_up64(npix, ppb * 2) : 16384);
+    // two pixel chunks per thread, no grid cap: 3.4 ms per bench step against 4.1 with 4,096 workgroups looping 64 times
+    int gx = (int)(cmu_div_up64(npix, ppb * 2) < (1 << 20) ? cmu_div_up64(npix, ppb * 2) : (1 << 20));
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL((bn_bwd_apply_kernel<TR>), dim3(gx, gy), dim3(256), 0, st, (const unsigned char*)dA, ldd,
                        (const unsigned char*)y, ldy, scale, shift, mean, invstd, coef, (unsigned char*)dY, ldo, npix, C, cpb, ppb, active, f,
@@ -352,7 +356,7 @@ static int maxpool_bwd_t(const void* dP, int64_t ldp, const void* dS, int64_t ld
     int cpb, ppb, gy;
     chunk_geometry(C / TR::EPC, &cpb, &ppb, &gy);
     const int64_t npool = (int64_t)B * (H / 2) * (W / 2);
-    int gx = (int)(cmu_div_up64(npool, ppb * 2) < RED_MAX_BLOCKS ? cmu_div_up64(npool, ppb * 2) : RED_MAX_BLOCKS);
+    int gx = (int)(cmu_div_up64(npool, ppb * 2) < POOLB_MAX_BLOCKS ? cmu_div_up64(npool, ppb * 2) : POOLB_MAX_BLOCKS);
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL((maxpool_bwd_kernel<TR>), dim3(gx, gy), dim3(256), 0, st, (const unsigned char*)dP, ldp, (const unsigned char*)dS,
                        lds, (const unsigned char*)y, ldy, scale, shift, (unsigned char*)dA, lda, B, H, W, C, cpb, ppb, mean, invstd,
@@ -498,7 +502,7 @@ static int conv1x1_head_bwd_t(const float* dlogits, const void* x, int64_t ldx, 
     const int nchunk = C / TR::EPC;
     const int ppb = 256 / nchunk;
     const int64_t npix = (int64_t)B * H * W;
-    int gx = (int)(cmu_div_up64(npix, ppb * 4) < RED_MAX_BLOCKS ? cmu_div_up64(npix, ppb * 4) : RED_MAX_BLOCKS);
+    int gx = (int)(cmu_div_up64(npix, ppb * 4) < HEADB_MAX_BLOCKS ? cmu_div_up64(npix, ppb * 4) : HEADB_MAX_BLOCKS);
     if (gx < 1) gx = 1;
     if (K <= 2)
         hipLaunchKernelGGL((conv1x1_head_bwd_kernel<TR, 2>), dim3(gx), dim3(256), 0, st, dlogits, (const unsigned char*)x, ldx, scale, shift, w,
@@ -537,7 +541,10 @@ extern "C" int cmu_conv1x1_head_bwd(const float* dlogits, const void* x, int64_t
 // ---------------------------------------------------------------------------------------------
 // first layer weight gradient: dW (Cout,1,3,3) = sum_p dY[p][n] * xm[p + tap]
 // ---------------------------------------------------------------------------------------------
-constexpr int C1W_MAX_BLOCKS = 1024;
+#ifndef CMU_C1W_BLOCKS
+#define CMU_C1W_BLOCKS 512
+#endif
+constexpr int C1W_MAX_BLOCKS = CMU_C1W_BLOCKS;
 template <class TR>
 __global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask,
                                                               int mask_per_sample, const unsigned char* __restrict__ dY, int64_t ldd,

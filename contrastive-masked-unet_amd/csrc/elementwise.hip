@@ -469,7 +469,10 @@ static int conv3x3_c1_fwd_t(const float* x, const uint8_t* mask, int mps, const 
                             int B, int H, int W, int Cout, hipStream_t st) {
     const int tilesX = cmu_div_up(W, 16), tilesY = cmu_div_up(H, 16);
     const int ntile = B * tilesX * tilesY;
-    hipLaunchKernelGGL((conv3x3_c1_fwd_kernel<TR>), dim3(ntile < 4096 ? ntile : 4096), dim3(256), 0, st, x, mask, mps, w,
+#ifndef CMU_C1F_CAP
+#define CMU_C1F_CAP 4096
+#endif
+    hipLaunchKernelGGL((conv3x3_c1_fwd_kernel<TR>), dim3(ntile < CMU_C1F_CAP ? ntile : CMU_C1F_CAP), dim3(256), 0, st, x, mask, mps, w,
                        (typename TR::elem_t*)y, ldy, stats, B, H, W, Cout, tilesX, tilesY);
     CMU_CHECK_LAUNCH("cmu_conv3x3_c1_fwd");
     return CMU_OK;
@@ -523,7 +526,10 @@ template <class TR>
 static int bnrelu_maxpool_t(const void* y, int64_t ldy, const float* scale, const float* shift, void* out, int64_t ldo, int B, int H,
                             int W, int C, hipStream_t st) {
     const int64_t total = (int64_t)B * (H / 2) * (W / 2) * (C / TR::EPC);
-    const int grid = (int)(cmu_div_up64(total, 256) < 8192 ? cmu_div_up64(total, 256) : 8192);
+#ifndef CMU_POOLF_CAP
+#define CMU_POOLF_CAP 65536
+#endif
+    const int grid = (int)(cmu_div_up64(total, 256) < CMU_POOLF_CAP ? cmu_div_up64(total, 256) : CMU_POOLF_CAP);
     hipLaunchKernelGGL((bnrelu_maxpool_kernel<TR>), dim3(grid), dim3(256), 0, st, (const unsigned char*)y, ldy, scale, shift,
                        (unsigned char*)out, ldo, B, H, W, C, total);
     CMU_CHECK_LAUNCH("cmu_bnrelu_maxpool_fwd");
@@ -609,7 +615,10 @@ static int conv1x1_head_fwd_t(const void* x, int64_t ldx, const float* scale, co
     const int64_t npix = (int64_t)B * H * W;
     const int ppb = 256 / nchunk;
     const int64_t nb = cmu_div_up64(npix, ppb * 4);
-    const int grid = (int)(nb < 8192 ? nb : 8192);
+#ifndef CMU_HEADF_CAP
+#define CMU_HEADF_CAP 8192
+#endif
+    const int grid = (int)(nb < CMU_HEADF_CAP ? nb : CMU_HEADF_CAP);
     if (K <= 2)
         hipLaunchKernelGGL((conv1x1_head_fwd_kernel<TR, 2>), dim3(grid), dim3(256), 0, st, (const unsigned char*)x, ldx, scale, shift, w,
                            bias, logits, B, H, W, C, K, npix);
