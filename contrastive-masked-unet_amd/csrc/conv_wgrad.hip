@@ -320,6 +320,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WGParams p) {
 #include "conv_wgrad2.inc"
 
 // partial slabs -> parameter-gradient layout, summed in split order
+#ifndef CMU_WGR_CAP
+#define CMU_WGR_CAP 8192
+#endif
 // sum over the split slabs k = part, part + 4, ... (fixed order), eight loads in flight per trip
 __device__ static inline float sum_split(const float* __restrict__ p, int64_t stride, int part, int splitk) {
     constexpr int U = 8;
@@ -492,7 +495,7 @@ static int wgradT_wide_t(WGParams p, float* dW, float* dbias, hipStream_t st) {
     cmu_set_kernel_tag("conv_wgradT2_kernel");
     CMU_CHECK_LAUNCH("cmu_convT2x2_wgrad(wide)");
     const int64_t total = (int64_t)4 * p.CA * p.CB;
-    const int grid = (int)(cmu_div_up64(total, 64) < 8192 ? cmu_div_up64(total, 64) : 8192);
+    const int grid = (int)(cmu_div_up64(total, 64) < CMU_WGR_CAP ? cmu_div_up64(total, 64) : CMU_WGR_CAP);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)p.ws, p.splitk, 4, p.CApad, p.CBpad, p.CA, p.CB, dW, 2);
     CMU_CHECK_LAUNCH("cmu_convT2x2_wgrad(reduce)");
     const float* ws_sum = p.ws + (int64_t)p.splitk * 4 * p.CB * p.CA;
@@ -522,7 +525,7 @@ static int wgrad3_wide_t(WGParams p, float* dW, hipStream_t st) {
     cmu_set_kernel_tag("conv_wgrad2_kernel");
     CMU_CHECK_LAUNCH("cmu_conv3x3_wgrad(wide)");
     const int64_t total = (int64_t)9 * p.CA * p.CB;
-    const int grid = (int)(cmu_div_up64(total, 64) < 8192 ? cmu_div_up64(total, 64) : 8192);
+    const int grid = (int)(cmu_div_up64(total, 64) < CMU_WGR_CAP ? cmu_div_up64(total, 64) : CMU_WGR_CAP);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)p.ws, p.splitk, 9, p.CApad, p.CBpad, p.CA, p.CB, dW,
                        (int)MODE_W3);
     CMU_CHECK_LAUNCH("cmu_conv3x3_wgrad(reduce)");
@@ -553,7 +556,7 @@ static int wgrad3_t(WGParams p, float* dW, hipStream_t st) {
     int rc = launch_wgrad<TR, MODE_W3>(p, st, "cmu_conv3x3_wgrad");
     if (rc) return rc;
     const int64_t total = (int64_t)9 * p.CA * p.CB;
-    const int grid = (int)(cmu_div_up64(total, 64) < 8192 ? cmu_div_up64(total, 64) : 8192);
+    const int grid = (int)(cmu_div_up64(total, 64) < CMU_WGR_CAP ? cmu_div_up64(total, 64) : CMU_WGR_CAP);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)p.ws, p.splitk, 9, p.CApad, p.CBpad, p.CA, p.CB, dW,
                        (int)MODE_W3);
     CMU_CHECK_LAUNCH("cmu_conv3x3_wgrad(reduce)");
@@ -564,7 +567,7 @@ static int wgradT_t(WGParams p, float* dW, float* dbias, float* ws_sum, hipStrea
     int rc = launch_wgrad<TR, MODE_WT>(p, st, "cmu_convT2x2_wgrad");
     if (rc) return rc;
     const int64_t total = (int64_t)4 * p.CA * p.CB;
-    const int grid = (int)(cmu_div_up64(total, 64) < 8192 ? cmu_div_up64(total, 64) : 8192);
+    const int grid = (int)(cmu_div_up64(total, 64) < CMU_WGR_CAP ? cmu_div_up64(total, 64) : CMU_WGR_CAP);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)p.ws, p.splitk, 4, p.CApad, p.CBpad, p.CA, p.CB, dW,
                        (int)MODE_WT);
     CMU_CHECK_LAUNCH("cmu_convT2x2_wgrad(reduce)");

@@ -5,5 +5,5 @@ for L in "$@"; do
   python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
 d = json.loads([l for l in sys.stdin if l.startswith('{')][-1]); k = d['kernel_ms_per_step']
-print('$L', d['value'], ' '.join(f'{n[4:]}={k[n]}' for n in ('cmu_bnrelu_maxpool_fwd', 'cmu_conv1x1_head_fwd', 'cmu_conv3x3_c1_fwd', 'cmu_conv3x3_c1_wgrad_bn', 'cmu_bn_bwd_apply', 'cmu_maxpool_bwd', 'cmu_conv1x1_head_bwd')))"
+print('$L', d['value'], ' '.join(f'{n[4:]}={k[n]}' for n in ('cmu_bnrelu_maxpool_fwd', 'cmu_conv1x1_head_fwd', 'cmu_conv3x3_c1_fwd', 'cmu_conv3x3_c1_wgrad_bn', 'cmu_bn_bwd_apply', 'cmu_maxpool_bwd', 'cmu_conv1x1_head_bwd', 'cmu_conv3x3_wgrad', 'cmu_convT2x2_wgrad')))"
 done
