@@ -232,8 +232,12 @@ static int bn_bwd_apply_t(const void* dA, int64_t ldd, const void* y, int64_t ld
     chunk_geometry(C / TR::EPC, &cpb, &ppb, &gy);
     const int64_t npix = (int64_t)B * H * W;
     const int sbits = active ? sp_shift_bits(H, f) : 0;
-    // two pixel chunks per thread, no grid cap: 3.4 ms per bench step against 4.1 with 4,096 workgroups looping 64 times
-    int gx = (int)(cmu_div_up64(npix, ppb * 2) < (1 << 20) ? cmu_div_up64(npix, ppb * 2) : (1 << 20));
+    // four pixel chunks per thread, no grid cap: 3.4 ms per bench step against 4.1 with 4,096 workgroups looping 64 times (A/B: 1 chunk
+    // per thread 4.6 ms, 2: 3.5, 8: 3.6)
+#ifndef CMU_APPLY_PPT
+#define CMU_APPLY_PPT 4
+#endif
+    int gx = (int)(cmu_div_up64(npix, ppb * CMU_APPLY_PPT) < (1 << 20) ? cmu_div_up64(npix, ppb * CMU_APPLY_PPT) : (1 << 20));
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL((bn_bwd_apply_kernel<TR>), dim3(gx, gy), dim3(256), 0, st, (const unsigned char*)dA, ldd,
                        (const unsigned char*)y, ldy, scale, shift, mean, invstd, coef, (unsigned char*)dY, ldo, npix, C, cpb, ppb, active, f,
