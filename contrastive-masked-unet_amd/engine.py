@@ -27,6 +27,9 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
 
+_FUSE_DGRAD_BN = os.environ.get("CMU_DGRAD_BN", "1")    # A/B: "0" = BN-backward sums as a separate pass, "64"/"128" = fused up to C
+
+
 class _Scratch:
     """Byte workspaces cached by purpose (grown on demand, reused across steps)."""
 
@@ -219,7 +222,8 @@ class UNetEngine:
         if not need_dx or first:
             return None
         dX = dx_out if dx_out is not None else self._new(B, H, W, w.shape[1])
-        if next_bn is not None and next_bn["y"].C == dX.C:
+        if next_bn is not None and next_bn["y"].C == dX.C and (_FUSE_DGRAD_BN == "1" or (_FUSE_DGRAD_BN == "64" and dX.C <= 64)
+                                                                or (_FUSE_DGRAD_BN == "128" and dX.C <= 128)):
             slab = self._tile_slab(next_bn["y"])
             ops.conv3x3_dgrad_bn(dY, self._wp(s["pconv"], w, True), dX, next_bn["y"], next_bn["mean"], next_bn["invstd"], slab)
             next_bn["bstats"] = slab
