@@ -247,6 +247,41 @@ def test_masked_mse(ops):
     check(dl.cpu(), lo.grad, 1e-5, "masked mse grad")
 
 
+@pytest.mark.parametrize("case", ["all_masked", "none_masked", "constant_rows", "one_pixel"])
+def test_masked_mse_edge_cases(ops, case):
+    """Edges of cmunet_head.py:62-70: every pixel masked; no pixel masked (0/0: the reference's loss is NaN -- so is ours, a
+    silent 0 would hide a broken mask); constant image rows (variance 0: the target is (x - mean) / sqrt(0 + 1e-6) = 0); one
+    masked pixel."""
+    from cmunet_amd import _lib
+    from oracle import cmunet as OC
+    B, K, H, W = 2, 2, 16, 32
+    g = torch.Generator().manual_seed(12)
+    logits = torch.randn(B, K, H, W, generator=g)
+    img = torch.randn(B, H, W, generator=g)
+    mask = (torch.rand(B, H, W, generator=g) > 0.5).to(torch.uint8)
+    if case == "all_masked":
+        mask[:] = 1
+    elif case == "none_masked":
+        mask[:] = 0
+    elif case == "constant_rows":
+        img[:, ::2, :] = 3.25
+    else:
+        mask[:] = 0
+        mask[1, 5, 7] = 1
+    lo = logits.clone().requires_grad_(True)
+    ref = OC.masked_mse(lo[:, 1], img, mask)
+    ref.backward()
+    loss = torch.empty(1, device="cuda")
+    dl = torch.empty(B, K, H, W, device="cuda")
+    ws = ws_bytes(_lib.lib().cmu_masked_mse_ws_bytes(B, H))
+    ops.masked_mse_fwd_bwd(logits.cuda(), 1, img.cuda(), mask.cuda(), loss, dl, 1.0, ws)
+    if case == "none_masked":
+        assert torch.isnan(ref) and torch.isnan(loss.cpu()).all()
+        return
+    check(loss.cpu(), ref.detach().view(1), 1e-5, "masked mse loss")
+    check(dl.cpu(), lo.grad, 1e-5, "masked mse grad")
+
+
 def test_softmax_ce_dice(ops, golden_dir):
     import numpy as np
     from cmunet_amd import _lib
