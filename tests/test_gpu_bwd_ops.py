@@ -299,6 +299,39 @@ def test_softmax_ce_dice(ops, golden_dir):
     check(dl.cpu(), torch.from_numpy(d["dlogits"]), 1e-5, "dlogits (CE only: Dice has no gradient, A-4)")
 
 
+@pytest.mark.parametrize("case", ["no_foreground", "all_foreground", "prediction_empty"])
+def test_softmax_ce_dice_edge_cases(ops, case):
+    """Degenerate masks of metrics.py:135-220: no foreground anywhere (Dice loss 1 - eps/eps = 0, IoU eps/eps = 1), everything
+    foreground, and a foreground target the prediction misses entirely (Dice loss ~1, IoU ~0)."""
+    from cmunet_amd import _lib
+    from oracle import losses as OL
+    B, K, H, W = 2, 2, 12, 20
+    g = torch.Generator().manual_seed(19)
+    logits = torch.randn(B, K, H, W, generator=g) * 0.3
+    fg = torch.rand(B, H, W, generator=g) > 0.7
+    if case == "no_foreground":
+        fg[:] = False
+        logits[:, 0] += 5.0                       # predicts background everywhere
+    elif case == "all_foreground":
+        fg[:] = True
+        logits[:, 1] += 5.0
+    else:
+        logits[:, 0] += 5.0                       # target has foreground, prediction has none
+    y1h = torch.stack([~fg, fg], 1).double()
+    lo = logits.clone().requires_grad_(True)
+    ce = OL.cross_entropy_prob(lo, y1h)
+    ce.backward()
+    out = torch.empty(6, device="cuda")
+    dl = torch.empty(B, K, H, W, device="cuda")
+    ws = ws_bytes(_lib.lib().cmu_softmax_ce_dice_ws_bytes(B, H, W))
+    ops.softmax_ce_dice_fwd_bwd(logits.cuda(), y1h.cuda(), out, dl, 1.0, ws)
+    o = out.cpu()
+    assert abs(o[0].item() - float(ce.detach())) < 1e-5 * max(1.0, float(ce.detach()))
+    assert abs(o[1].item() - float(OL.dice_loss(logits, y1h))) < 1e-6
+    assert abs(o[2].item() - (1.0 - float(OL.iou_loss(logits, y1h)))) < 1e-6 or abs(o[2].item() - float(OL.iou_loss(logits, y1h))) < 1e-6
+    check(dl.cpu(), lo.grad.float(), 1e-5, "dlogits")
+
+
 @pytest.mark.parametrize("rank,world", [(0, 1), (1, 4)])
 def test_infonce_inbatch(ops, rank, world):
     from oracle import cmunet as OC
