@@ -220,3 +220,28 @@ def test_unet_vs_oracle_masked(M, dt):
     ref = OU.unet_forward(x * (1 - mask[0]).float(), osd, training=True)
     e = rel_err(logits, ref)
     assert e <= TOLS[dt] * 2, f"{e:.3e}"
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16), (1, 32, 16), (1, 16, 48)])
+def test_unet_smallest_inputs_vs_oracle(M, shape):
+    """The smallest inputs a depth-5 UNet accepts (H, W multiples of 16): the bottleneck is 1 x 1 (or 2 x 1 / 1 x 3) pixels, so
+    its BatchNorm averages over as few as two values; batch 1 at 32 x 16.  f32 storage vs the CPU oracle, logits and gradients."""
+    from oracle import unet as OU
+    sd = OU.make_state_dict(base_ch=8, depth=5, seed=9)
+    m = M.UNet(base_ch=8, depth=5, dtype="f32")
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(*shape, generator=g)
+    go = torch.randn(shape[0], 2, shape[1], shape[2], generator=g)
+    logits = m(x.cuda())
+    (logits * go.cuda()).sum().backward()
+    osd = OU.clone_sd(sd, requires_grad=True)
+    ref = OU.unet_forward(x, osd, training=True)
+    (ref * go).sum().backward()
+    assert rel_err(logits, ref) <= 2e-3
+    for k in ("conv_last.weight", "down_conv1.double_conv.double_conv.0.weight", "double_conv.double_conv.3.weight", "up_conv4.up_sample.weight"):
+        e = rel_err(m.get_parameter(k).grad, osd[k].grad)
+        assert e <= 2e-2, f"d{k}: {e:.3e}"
+    with pytest.raises(AssertionError):
+        m(torch.randn(1, 24, 16).cuda())                     # not a multiple of 2^4
