@@ -22,7 +22,9 @@ def _bits(a):
 
 @pytest.mark.parametrize("shape,out", [((3, 512, 512), (256, 256)), ((2, 300, 200), (256, 256)), ((2, 51, 77), (256, 256)),
                                        ((2, 256, 256), (256, 256)), ((1, 100, 100), (64, 48)), ((2, 37, 512), (256, 256)),
-                                       ((1, 1024, 640), (256, 256))])
+                                       ((1, 1024, 640), (256, 256)),
+                                       # degenerate sources: one pixel, a 2 x 3 image, one row, output of one pixel
+                                       ((2, 1, 1), (8, 8)), ((1, 2, 3), (5, 7)), ((1, 1, 40), (16, 16)), ((1, 37, 29), (1, 1))])
 def test_resize_bicubic_whole_image_matches_pillow_convention(ops, shape, out):
     from oracle.augment import resize_bicubic
     rng = np.random.RandomState(1)

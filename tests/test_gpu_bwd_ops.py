@@ -332,10 +332,10 @@ def test_softmax_ce_dice_edge_cases(ops, case):
     check(dl.cpu(), lo.grad.float(), 1e-5, "dlogits")
 
 
-@pytest.mark.parametrize("rank,world", [(0, 1), (1, 4)])
-def test_infonce_inbatch(ops, rank, world):
+@pytest.mark.parametrize("rank,world,B", [(0, 1, 8), (1, 4, 8), (0, 1, 1), (2, 3, 5)])
+def test_infonce_inbatch(ops, rank, world, B):
     from oracle import cmunet as OC
-    B, D = 8, 256
+    D = 256
     g = torch.Generator().manual_seed(13)
     pred = torch.randn(B, D, generator=g)
     keys = F.normalize(torch.randn(B * world, D, generator=g), dim=1)
