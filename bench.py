@@ -1,21 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the CM-UNet hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): reference UNet (base 64, depth 5, 31.04 M parameters)
+Default workload (BASELINE.json configs[1]): reference UNet (base 64, depth 5, 31.04 M parameters)
 as CM-UNet masked-reconstruction pretraining (rc_weight=1, ct_weight=0, mask_ratio 0.6, patch 16) on synthetic
-512x512 grayscale batches, bs 32 per GPU.  One step = patch mask fused into the first conv + encoder +
-pixel decoder forward + masked MSE + full backward + gradient all-reduce (N>1) + fused AdamW, all on the
-hand-written HIP path.  Inputs (images and masks) are resident in HBM before the timed region.
+512x512 grayscale batches, bs 32 per GPU, in the reference's arithmetic for this configuration: fp16 operands with
+fp32 accumulation and dynamic loss scaling (AmpOptimWrapper, cmunet_config.py:76-78).  One step = patch mask fused into
+the first conv + encoder + pixel decoder forward + masked MSE + full backward + gradient all-reduce (N>1) + inf/nan
+check + fused AdamW + loss-scale update, all on the hand-written HIP path.  Inputs (images and masks) are resident in
+HBM before the timed region.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W [--workload recon|moco|joint|spark] [--dtype f16|bf16|f32]
 
-Rank 0 prints ONE JSON line: metric images/sec (whole job), roofline of the dominant kernel (algorithmic FLOPs
-of its launches / their HIP-event time, measured inside the timed region) and the CPU baseline (the oracle's
-torch-CPU restatement of the same step on a bounded sample, N=1 only).
+N > 1: one rank per GPU over RCCL.  Either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the
+environment) or directly -- then this process only spawns its N ranks (it never touches the GPU itself) and exits with
+the first non-zero child status.
+
+Other workloads (same bs 32 / GPU, 512x512; BASELINE configs 3-5):
+    moco   Moco_v2 (K = 4096, tau = 0.2, emb 1024, m = 0.999), key all-gather, fused InfoNCE + enqueue, SGD-momentum
+    joint  CM_UNet contrastive + masked reconstruction (projector in = 262,144), AdamW, EMA of the target networks
+    spark  SparK sparse masked-conv encoder (mask 0.75: 256 of 1,024 patches active) + UNet decoder, LAMB
+
+Rank 0 prints ONE JSON line: metric images/sec (whole job), roofline of the dominant kernel (algorithmic FLOPs of its
+launches / their HIP-event time, measured inside the timed region) and the CPU baseline (the oracle's torch-CPU
+restatement of the same step on a bounded sample, N=1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,33 +37,116 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12
 
 
-def cpu_baseline(H, W, seconds_budget=25.0):
+# ---------------------------------------------------------------------------------------------------------------------
+# host description for the CPU baseline
+# ---------------------------------------------------------------------------------------------------------------------
+def host_cpu_info():
+    """(model string, physical cores of the machine, CPUs this process may use)."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name") and model == "unknown":
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+    except OSError:
+        pass
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        avail = os.cpu_count() or 1
+    try:                                           # cgroup v2 CPU quota of the container
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max":
+            avail = max(1, min(avail, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    physical = len(cores) if cores else (os.cpu_count() or 1)
+    return model, physical, avail
+
+
+def cpu_baseline(workload, H, W, seconds_budget=25.0):
     """Oracle (CPU restatement pinned to the reference, oracle/) timed on the host cores: same step, bs 2."""
+    import numpy as np
     import torch
     from oracle import cmunet as OC, unet as OU
     from cmunet_amd.pretrain import create_random_patch_mask
-    import numpy as np
+    model, physical, avail = host_cpu_info()
+    threads = max(1, min(physical, avail))
+    torch.set_num_threads(threads)
     torch.manual_seed(0)
-    threads = torch.get_num_threads()
     bs = 2
-    sd = OU.make_state_dict(base_ch=64, depth=5, seed=0)
-    params = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
-    decay = [v for k, v in params.items() if not (k.endswith(".bias") or v.dim() <= 1)]
-    no_decay = [v for k, v in params.items() if k.endswith(".bias") or v.dim() <= 1]
-    opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.05}, {"params": no_decay, "weight_decay": 0.0}],
-                            lr=1.5e-4, betas=(0.9, 0.95))
-    x = torch.randn(bs, H, W, generator=torch.Generator().manual_seed(1234))
-    mask = torch.from_numpy(create_random_patch_mask(bs, H, 16, 0.6, np.random.RandomState(0)))
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(bs, H, W, generator=g)
 
-    def step():
-        opt.zero_grad()
-        xm = x * (1 - mask[0]).float()
-        logits = OU.unet_forward(xm, sd, training=True)
-        loss = OC.masked_mse(logits[:, 1], x, mask)
-        loss.backward()
-        opt.step()
+    def grouped_adamw(params, lr=1.5e-4):
+        decay = [v for k, v in params.items() if not (k.endswith(".bias") or v.dim() <= 1)]
+        no_decay = [v for k, v in params.items() if k.endswith(".bias") or v.dim() <= 1]
+        return torch.optim.AdamW([{"params": decay, "weight_decay": 0.05}, {"params": no_decay, "weight_decay": 0.0}], lr=lr, betas=(0.9, 0.95))
+
+    if workload == "recon":
+        sd = OU.make_state_dict(base_ch=64, depth=5, seed=0)
+        params = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+        opt = grouped_adamw(params)
+        mask = torch.from_numpy(create_random_patch_mask(bs, H, 16, 0.6, np.random.RandomState(0)))
+
+        def step():
+            opt.zero_grad()
+            logits = OU.unet_forward(x * (1 - mask[0]).float(), sd, training=True)
+            OC.masked_mse(logits[:, 1], x, mask).backward()
+            opt.step()
+        what = "masked-reconstruction step"
+    elif workload == "moco":
+        from oracle import moco as OM
+        enc = {k: v for k, v in OU.make_state_dict(base_ch=64, depth=5, seed=0).items() if k.startswith(("down_conv", "double_conv"))}
+        sd = {"encoder_q." + k: v.clone() for k, v in enc.items()}
+        sd.update({"encoder_k." + k: v.clone() for k, v in enc.items()})
+        params = [v.requires_grad_(True) for k, v in sd.items() if k.startswith("encoder_q.") and v.is_floating_point() and "running" not in k]
+        opt = torch.optim.SGD(params, lr=0.03, momentum=0.9, weight_decay=1e-4)
+        queue, ptr = OM.init_queue(1024, 4096), torch.zeros(1, dtype=torch.long)
+        xk = torch.randn(bs, H, W, generator=g)
+
+        def step():
+            opt.zero_grad()
+            loss, _, _ = OM.training_step(x.unsqueeze(1), xk.unsqueeze(1), sd, queue, ptr, 0.2, 0.999)
+            loss.backward()
+            opt.step()
+        what = "MoCo-v2 step (K 4096)"
+    elif workload == "spark":
+        from oracle import spark as OS
+        full = OU.make_state_dict(base_ch=64, depth=5, seed=0)
+        sd = {}
+        for k, v in full.items():
+            if "up_conv" in k or "conv_last" in k:
+                sd["dense_decoder." + k] = v[:1].clone() if "conv_last" in k else v
+            else:
+                sd["sparse_encoder.sp_cnn." + k] = v
+        toks = [torch.zeros(1, c, 1, 1).normal_(0, 0.02, generator=g).requires_grad_(True) for c in (1024, 512, 256, 128, 64)]
+        params = [v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k] + toks
+        opt = torch.optim.AdamW(params, lr=2e-4, betas=(0.9, 0.95), weight_decay=0.04)      # (stand-in for LAMB: same passes)
+        active = OS.make_active(bs, H // 16, 0.75, g)
+
+        def step():
+            opt.zero_grad()
+            loss, _ = OS.forward(x.unsqueeze(1), active, sd, toks)
+            loss.backward()
+            opt.step()
+        what = "SparK step (mask 0.75; AdamW standing in for LAMB)"
+    else:
+        return {"value": None, "unit": "images/sec", "cores": threads, "kind": "port",
+                "sample": "not timed for this workload (the 403 M-parameter projector step takes minutes per image on the host)"}
 
     step()                                   # warm-up
     t0, n = time.time(), 0
@@ -58,44 +154,159 @@ def cpu_baseline(H, W, seconds_budget=25.0):
         step()
         n += 1
     dt = (time.time() - t0) / n
-    return {"value": round(bs / dt, 4), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"oracle (torch CPU fp32 restatement of the reference step) bs={bs} {H}x{W}, {n} timed step(s) after 1 warm-up"}
+    return {"value": round(bs / dt, 4), "unit": "images/sec", "cores": threads, "kind": "port", "cpu_model": model,
+            "physical_cores": physical, "cpus_available": avail,
+            "sample": f"oracle (torch CPU fp32 restatement of the reference's {what}) bs={bs} {H}x{W}, {n} timed step(s) after 1 warm-up, "
+                      f"torch.set_num_threads({threads})"}
 
 
-def step_roofline(B, H, W, dtype, img_s):
-    """Whole-step rooflines of SURVEY 8(d) for the reference UNet (base 64, depth 5): per layer F = algorithmic FLOPs,
-    bytes = (in + out + weights) * sizeof(storage dtype), training convention x3 (forward + data gradient + weight
-    gradient); composite = sum over layers of max(F / MFMA peak, bytes / HBM peak)."""
-    es = 4 if dtype == "f32" else 2
-    peak = PEAK_TFLOPS[dtype] * 1e12
-    bw = 8.0e12
-    layers = []   # (flops, bytes) per image, forward
+# ---------------------------------------------------------------------------------------------------------------------
+# whole-step rooflines
+# ---------------------------------------------------------------------------------------------------------------------
+def unet_layers(H, es):
+    """(flops, bytes) per image and forward pass of every layer of the reference UNet, split into
+    encoder and decoder lists."""
+    enc, dec = [], []
 
-    def conv(cin, cout, s, k):
-        layers.append((2.0 * k * k * cin * cout * s * s, (cin * s * s + cout * s * s + k * k * cin * cout) * es))
+    def conv(lst, cin, cout, s, k):
+        lst.append((2.0 * k * k * cin * cout * s * s, (cin * s * s + cout * s * s + k * k * cin * cout) * es))
 
     chans, s = [64, 128, 256, 512], H
     cin = 1
     for c in chans:
-        conv(cin, c, s, 3); conv(c, c, s, 3)
-        layers.append((3.0 * c * (s // 2) ** 2, (c * s * s + c * (s // 2) ** 2) * es))      # max-pool
+        conv(enc, cin, c, s, 3); conv(enc, c, c, s, 3)
+        enc.append((3.0 * c * (s // 2) ** 2, (c * s * s + c * (s // 2) ** 2) * es))      # max-pool
         cin, s = c, s // 2
-    conv(512, 1024, s, 3); conv(1024, 1024, s, 3)
+    conv(enc, 512, 1024, s, 3); conv(enc, 1024, 1024, s, 3)
     cin = 1024
     for c in reversed(chans):
         s *= 2
-        layers.append((2.0 * cin * c * s * s, (cin * (s // 2) ** 2 + c * s * s + 4 * cin * c) * es))   # ConvTranspose 2x2 s2
-        conv(2 * c, c, s, 3); conv(c, c, s, 3)
+        dec.append((2.0 * cin * c * s * s, (cin * (s // 2) ** 2 + c * s * s + 4 * cin * c) * es))   # ConvTranspose 2x2 s2
+        conv(dec, 2 * c, c, s, 3); conv(dec, c, c, s, 3)
         cin = c
-    conv(64, 2, s, 1)
-    f = 3.0 * sum(l[0] for l in layers)
-    by = 3.0 * sum(l[1] for l in layers)
-    t_comp = 3.0 * sum(max(l[0] / peak, l[1] / bw) for l in layers)
+    conv(dec, 64, 2, s, 1)
+    return enc, dec
+
+
+def step_roofline(workload, H, dtype, img_s):
+    """Whole-step rooflines of SURVEY 8(d): per layer F = algorithmic FLOPs, bytes = (in + out + weights) * sizeof(storage
+    dtype); a trained pass counts x3 (forward + data gradient + weight gradient), a forward-only pass x1; composite = sum over
+    layers of max(F / MFMA peak, bytes / HBM peak).  recon: encoder + decoder trained.  moco: query encoder trained + key
+    encoder forward.  joint: online encoder + two decoders trained, target encoder forward, projector / target projector /
+    predictor as 3 + 1 passes over 2*H*W*1536 FLOP and H*W*1536 fp32 weights.  spark: as recon (dense-equivalent work; the
+    sparse encoder's useful share is its active fraction)."""
+    es = 4 if dtype == "f32" else 2
+    peak = PEAK_TFLOPS[dtype] * 1e12
+    enc, dec = unet_layers(H, es)
+    parts = {"recon": [(enc, 3), (dec, 3)], "spark": [(enc, 3), (dec, 3)], "moco": [(enc, 3), (enc, 1)],
+             "joint": [(enc, 3), (dec, 3), (dec, 3), (enc, 1)]}[workload]
+    f = sum(m * sum(l[0] for l in lst) for lst, m in parts)
+    by = sum(m * sum(l[1] for l in lst) for lst, m in parts)
+    t_comp = sum(m * sum(max(l[0] / peak, l[1] / HBM_PEAK) for l in lst) for lst, m in parts)
+    if workload == "joint":        # projector (trained: 3 weight passes) + target projector (1 pass), fp32 weights, per BATCH of 32
+        wbytes = H * H * 1536 * 4.0
+        t_comp += 4 * wbytes / HBM_PEAK / 32.0
+        by += 4 * wbytes / 32.0
+        f += 4 * 2.0 * H * H * 1536
     return {"gflop_per_image": round(f / 1e9, 1), "mb_per_image": round(by / 1e6, 1),
-            "mfma_only_img_s": round(peak / f, 1), "hbm_only_img_s": round(bw / by, 1), "composite_img_s": round(1.0 / t_comp, 1),
-            "frac_of_mfma_only": round(img_s * f / peak, 4), "frac_of_hbm_only": round(img_s * by / bw, 4),
+            "mfma_only_img_s": round(peak / f, 1), "hbm_only_img_s": round(HBM_PEAK / by, 1), "composite_img_s": round(1.0 / t_comp, 1),
+            "frac_of_mfma_only": round(img_s * f / peak, 4), "frac_of_hbm_only": round(img_s * by / HBM_PEAK, 4),
             "frac_of_composite": round(img_s * t_comp, 4),
-            "note": "SURVEY 8(d): algorithmic FLOPs / bytes per layer, x3 for training; peaks 2.5 PFLOP/s (16-bit) and 8 TB/s"}
+            "note": "SURVEY 8(d): algorithmic FLOPs / bytes per layer (x3 for a trained pass); peaks 2.5 PFLOP/s (16-bit) and 8 TB/s"}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# self-launch (python bench.py --gpus N without a launcher)
+# ---------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n, argv):
+    """Start one child per GPU with the torch.distributed environment and wait.  This parent never initialises the GPU (no
+    torch import, no HIP call) and never replaces itself with another program; a failing rank ends the others."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rk in range(n):
+        env = dict(os.environ, RANK=str(rk), LOCAL_RANK=str(rk), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "8")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for rk in sorted(pending):
+                r = procs[rk].poll()
+                if r is None:
+                    continue
+                pending.discard(rk)
+                if r != 0 and rc == 0:
+                    rc = r
+                    for other in pending:          # a rank failed: its peers would wait in a collective for ever
+                        procs[other].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+            p.wait()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# workloads: each returns (step callable -> loss tensor, description dict)
+# ---------------------------------------------------------------------------------------------------------------------
+def build_workload(name, args, dev, rank, world):
+    import torch
+    from cmunet_amd import model as M
+    from cmunet_amd import pretrain as P
+    B, H, W = args.batch, args.size, args.size
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    nb = 2                                                          # distinct pre-staged synthetic batches
+    torch.manual_seed(0)                                            # same initial weights on every rank (+ broadcast below)
+    lr_rule = B * world / 256.0                                     # cmunet_config.py:70-73 / arg_util.py:133: base_lr * batch * gpus / 256
+    if name == "recon":
+        net = M.UNet(out_classes=2, dtype=args.dtype).to(dev)
+        tr = P.MaskedReconPretrainer(net, lr=1.5e-4 * lr_rule, betas=(0.9, 0.95), weight_decay=0.05, amp=(args.dtype == "f16"))
+        tr.broadcast_parameters()
+        imgs = [torch.randn(B, H, W, generator=g, device=dev) for _ in range(nb)]
+        masks = [P.random_patch_mask_device(B, H, W, 16, 0.6, g, dev) for _ in range(nb)]
+        return (lambda i: tr.step(imgs[i % nb], masks[i % nb])), {
+            "workload": f"cmunet_masked_recon_unet64x5_{H}x{W}_bs{B}_mask0.6", "optimizer": "AdamW(fused)",
+            "amp": "dynamic loss scale (device-side GradScaler protocol)" if tr.amp is not None else "off"}, tr
+    if name == "moco":
+        from cmunet_amd import moco as MO
+        m = MO.Moco_v2(emb_dim=1024, num_negatives=4096, softmax_temperature=0.2, encoder_momentum=0.999, dtype=args.dtype).to(dev)
+        tr = P.MocoPretrainer(m, lr=0.03 * lr_rule)
+        tr.broadcast_parameters()
+        xs = [(torch.randn(B, 1, H, W, generator=g, device=dev), torch.randn(B, 1, H, W, generator=g, device=dev)) for _ in range(nb)]
+        return (lambda i: tr.step(*xs[i % nb])), {
+            "workload": f"moco_v2_unet64x5_encoder_{H}x{W}_bs{B}_K4096_tau0.2", "optimizer": "SGD-momentum(fused)"}, tr
+    if name == "joint":
+        from cmunet_amd import cmunet as C
+        m = C.build_model(C.cmunet_config(img_size=H, dtype=args.dtype, mask_ratio=0.6)).to(dev)
+        m.init_weights()
+        tr = P.JointPretrainer(m, lr=1.5e-4 * lr_rule)
+        tr.broadcast_parameters()
+        xs = [(torch.randn(B, H, W, generator=g, device=dev), torch.randn(B, H, W, generator=g, device=dev)) for _ in range(nb)]
+        masks = [P.random_patch_mask_device(B, H, W, 16, 0.6, g, dev) for _ in range(nb)]
+
+        def step(i):
+            l = tr.step(xs[i % nb][0], xs[i % nb][1], masks[i % nb])
+            return l["loss_ct"] + l["loss_rc"]
+        return step, {"workload": f"cmunet_joint_ct+rc_unet64x5_{H}x{W}_bs{B}_mask0.6_projector{H * W}x1536", "optimizer": "AdamW(fused) + EMA"}, tr
+    if name == "spark":
+        from cmunet_amd import spark as S
+        enc = S.build_sparse_encoder("unet_sparse", input_size=H, dtype=args.dtype)
+        m = S.SparK(enc, S.UnetDecoder(dtype=args.dtype), mask_ratio=0.75, densify_norm="", dtype=args.dtype).to(dev)
+        tr = P.SparKPretrainer(m, lr=2e-4 * lr_rule)
+        tr.broadcast_parameters()
+        xs = [torch.randn(B, 1, H, W, generator=g, device=dev) for _ in range(nb)]
+        acts = [m.mask(B, dev, torch.Generator().manual_seed(77 + rank + 1000 * i)) for i in range(nb)]
+        ls = 1024.0 if args.dtype == "f16" else 1.0     # static loss scale: the patch-normalised loss has O(1) gradients per patch
+        return (lambda i: tr.step(xs[i % nb], acts[i % nb], loss_scale=ls)), {
+            "workload": f"spark_sparse_unet64x5_{H}x{W}_bs{B}_mask0.75_keep{m.len_keep}of{m.fmap_h * m.fmap_w}", "optimizer": "LAMB(fused)"}, tr
+    raise SystemExit(f"unknown workload {name}")
 
 
 def main():
@@ -105,15 +316,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--dtype", default="f16", choices=["bf16", "f16", "f32"],
+                    help="activation / MFMA operand type (f16 = the reference's AMP arithmetic, cmunet_config.py:76-78)")
+    ap.add_argument("--workload", default="recon", choices=["recon", "moco", "joint", "spark"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (pure throughput run)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     import torch
     import torch.distributed as dist
-    from cmunet_amd import _lib, model as M
-    from cmunet_amd.pretrain import MaskedReconPretrainer, random_patch_mask_device
+    from cmunet_amd import _lib
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -122,26 +337,19 @@ def main():
     backend = os.environ.get("CMU_DIST_BACKEND", "nccl")
     single_dev = os.environ.get("CMU_SINGLE_DEVICE", "0") == "1"
     dev_index = 0 if (world == 1 or single_dev) else local_rank
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if world > 1:
         torch.cuda.set_device(dev_index)
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))   # RCCL over xGMI
         else:
             dist.init_process_group(backend=backend)
-    assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
     B, H, W = args.batch, args.size, args.size
-    torch.manual_seed(0)
-    net = M.UNet(out_classes=2, dtype=args.dtype).to(dev)           # reference structure, random init (same seed on all ranks)
-    # lr rule of cmunet_config.py:70-73: base_lr * batch * gpus / 256
-    tr = MaskedReconPretrainer(net, lr=1.5e-4 * B * world / 256.0, betas=(0.9, 0.95), weight_decay=0.05)
-    tr.broadcast_parameters()
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    nb = 2                                                          # distinct pre-staged synthetic batches
-    imgs = [torch.randn(B, H, W, generator=g, device=dev) for _ in range(nb)]
-    masks = [random_patch_mask_device(B, H, W, 16, 0.6, g, dev) for _ in range(nb)]
+    step, desc, tr = build_workload(args.workload, args, dev, rank, world)
 
     def sync():
         torch.cuda.synchronize()
@@ -150,7 +358,7 @@ def main():
             torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        tr.step(imgs[i % nb], masks[i % nb])
+        step(i)
     prof = None
     if not args.no_kernel_events:
         prof = _lib.EventProfiler()
@@ -158,7 +366,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = tr.step(imgs[i % nb], masks[i % nb])
+        loss = step(i)
     sync()
     elapsed = time.perf_counter() - t0
     _lib.PROFILER = None
@@ -166,10 +374,20 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss_val = float(loss.item())
+    loss_val = float(loss.reshape(-1)[0].item())
 
+    metric = {"recon": "pretrain images/sec/node at 512x512 (CM-UNet masked-reconstruction step)",
+              "moco": "pretrain images/sec/node at 512x512 (MoCo-v2 step on the UNet encoder)",
+              "joint": "pretrain images/sec/node at 512x512 (CM-UNet joint contrastive + masked-reconstruction step)",
+              "spark": "pretrain images/sec/node at 512x512 (SparK sparse masked-conv step)"}[args.workload]
+    cfg = dict(desc)
+    cfg.update({"global_batch": B * world, "image": [H, W], "parallelism": f"dp{world}", "loss": float(f"{loss_val:.6g}")})
+    amp = getattr(tr, "amp", None)
+    if amp is not None and rank == 0:
+        sc, _, _, good, skipped = amp.read()
+        cfg["amp_state"] = {"scale": sc, "updates": good, "skipped": skipped}
     out = {
-        "metric": "pretrain images/sec/node at 512x512 (CM-UNet masked-reconstruction step)",
+        "metric": metric,
         "value": round(B * world * args.steps / elapsed, 3),
         "unit": "images/sec",
         "n_gpus": world,
@@ -181,8 +399,7 @@ def main():
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic (seeded randn images, random 16x16 patch masks; random-init weights)",
-        "config": {"workload": f"cmunet_masked_recon_unet64x5_{H}x{W}_bs{B}_mask0.6", "global_batch": B * world,
-                   "image": [H, W], "parallelism": f"dp{world}", "optimizer": "AdamW(fused)", "loss": float(f"{loss_val:.6g}")},
+        "config": cfg,
     }
     if rank == 0 and prof is not None:
         summ = prof.summary()
@@ -198,13 +415,15 @@ def main():
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                tj = json.load(f).get(name)
-            if tj and args.dtype == "bf16" and B == 32 and H == 512:
-                traffic = int(round(tj["hbm_bytes_per_launch"]))
-        except (OSError, ValueError, KeyError):
+                tj = json.load(f)
+            ent = tj.get(name)
+            if ent and tj.get("_command", {}).get("dtype", "bf16") == args.dtype and args.workload == "recon" and B == 32 and H == 512:
+                traffic = int(round(ent["hbm_bytes_per_launch"]))
+        except (OSError, ValueError, KeyError, AttributeError):
             traffic = None
         out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                           "entries": sorted(d["entries"]), "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json)",
+                           "entries": sorted(d["entries"]), "frac": round(ach / peak, 4), "traffic": traffic,
+                           "traffic_unit": "HBM bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE from a separate rocprofv3 --pmc run, profiles/traffic.json)",
                            "algorithmic_gflop_per_launch": round(d["work"] / d["calls"] / 1e9, 1),
                            "launches_per_step": d["calls"] // args.steps,
                            "avg_launch_ms": round(d["ms"] / d["calls"], 4),
@@ -214,10 +433,11 @@ def main():
         out["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
         flops_step = sum(v["work"] for v in summ.values()) / args.steps
         out["step_mfma_tflops"] = round(flops_step / (elapsed / args.steps) / 1e12, 2)
-        out["step_roofline"] = step_roofline(B, H, W, args.dtype, out["value"] / world)
+        if H == W:
+            out["step_roofline"] = step_roofline(args.workload, H, args.dtype, out["value"] / world)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(H, W)
+            out["cpu_baseline"] = cpu_baseline(args.workload, H, W)
         except Exception as e:  # the baseline must never take the GPU number down with it
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
     if rank == 0:

@@ -80,7 +80,7 @@ _SIGS = {
     "cmu_conv1x1_head_bwd_ws_bytes": (_L, [_I, _I, _I, _I, _I]),
     "cmu_conv1x1_head_bwd": (_I, [_P, _P, _L, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "cmu_masked_mse_ws_bytes": (_L, [_I, _I]),
-    "cmu_masked_mse_fwd_bwd": (_I, [_P, _I, _I, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P]),
+    "cmu_masked_mse_fwd_bwd": (_I, [_P, _I, _I, _P, _P, _P, _P, _F, _P, _I, _I, _I, _P, _P]),
     "cmu_softmax_ce_dice_ws_bytes": (_L, [_I, _I, _I]),
     "cmu_softmax_ce_dice_fwd_bwd": (_I, [_P, _P, _P, _P, _F, _I, _I, _I, _P, _P]),
     "cmu_infonce_inbatch_fwd_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
@@ -97,7 +97,11 @@ _SIGS = {
     "cmu_gap_fwd": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cmu_gap_bwd": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "cmu_ema_update": (_I, [_P, _P, _L, _F, _P]),
-    "cmu_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _L, _F, _P]),
+    "cmu_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _L, _F, _P, _P]),
+    "cmu_amp_state_bytes": (_I, []),
+    "cmu_amp_init": (_I, [_P, _F, _P]),
+    "cmu_amp_check_finite": (_I, [_P, _L, _P, _P]),
+    "cmu_amp_update": (_I, [_P, _F, _F, _I, _P]),
 }
 
 EXPORTS = tuple(_SIGS.keys())
@@ -184,12 +188,56 @@ class EventProfiler:
 PROFILER = None
 
 
+class DevPtr(ctypes.c_void_p):
+    """A device pointer that remembers which GPU owns it (``dev``): ``call`` binds the launch to that device."""
+
+
+class _StreamOfArgs:
+    """Placeholder for "the current stream of the device that owns this call's tensors" (resolved inside ``call``)."""
+
+
+STREAM = _StreamOfArgs()
+
+
+def devptr(addr, dev):
+    p = DevPtr(addr)
+    p.dev = dev
+    return p
+
+
 def call(name, *args, work=0.0):
-    """Call an int-returning entry point; raise CmuError with cmu_last_error() on failure."""
+    """Call an int-returning entry point; raise CmuError with cmu_last_error() on failure.
+
+    Device binding: every ``DevPtr`` argument must live on ONE device; the launch is issued with that device current and on
+    that device's current PyTorch stream (the ``STREAM`` placeholder), whatever the process's current device is -- a model on
+    ``cuda:1`` (the reference's own choice, Finetuning/train.py:246,451) runs there, not on device 0's stream."""
     l = lib()
     fn = getattr(l, name, None)
     if fn is None:
         raise CmuError(f"{name} is not exported by {LIB_PATH}")
+    import torch
+    dev, si = None, -1
+    for i, a in enumerate(args):
+        if type(a) is DevPtr:
+            if dev is None:
+                dev = a.dev
+            elif a.dev != dev:
+                raise CmuError(f"{name}: tensors on different devices (cuda:{dev} and cuda:{a.dev})")
+        elif a is STREAM:
+            si = i
+    cur = torch.cuda.current_device()
+    if dev is None:
+        dev = cur
+    if si >= 0:
+        args = list(args)
+        args[si] = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    if dev != cur:
+        with torch.cuda.device(dev):
+            return _call_bound(l, fn, name, args, work)
+    return _call_bound(l, fn, name, args, work)
+
+
+def _call_bound(l, fn, name, args, work):
     if PROFILER is not None:
         import torch
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -31,6 +31,36 @@ void cmu_set_kernel_tag(const char* tag);
 
 static inline bool cmu_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// the calling thread's current HIP device (the one its launches go to)
+static inline int cmu_current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev;
+}
+// one flag per device for work that has to be done once on each device the process launches on (function attributes
+// such as the dynamic LDS limit are per device, not per process)
+struct CmuPerDevice {
+    unsigned long long mask[4] = {0ull, 0ull, 0ull, 0ull};   // up to 256 devices
+    bool done() const {
+        const int d = cmu_current_device() & 255;
+        return (__atomic_load_n(&mask[d >> 6], __ATOMIC_ACQUIRE) >> (d & 63)) & 1ull;
+    }
+    void mark() {
+        const int d = cmu_current_device() & 255;
+        __atomic_fetch_or(&mask[d >> 6], 1ull << (d & 63), __ATOMIC_RELEASE);
+    }
+};
+
+// device-resident state of the dynamic loss scaler (cmu_amp_*; 32 bytes, see include/cmunet_hip.h)
+struct CmuAmpState {
+    float scale;          // current loss scale
+    float found_inf;      // 1 when the gradients of the step in flight hold an inf / nan
+    int growth_tracker;   // consecutive clean steps since the last change of the scale
+    int good_steps;       // optimiser updates actually taken (the step number of Adam's bias corrections)
+    int skipped_steps;
+    int pad[3];
+};
+
 // ---------------------------------------------------------------------------------------------
 // vector types
 // ---------------------------------------------------------------------------------------------

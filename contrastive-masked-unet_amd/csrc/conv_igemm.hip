@@ -542,15 +542,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IGParams p) {
 template <class TR, int MODE>
 static int launch_igemm(const IGParams& p, hipStream_t st, const char* name) {
     typedef IGCfg<TR, MODE> C;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static CmuPerDevice attr_set;   // hipFuncSetAttribute is per device
+    if (!attr_set.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<TR, MODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) {
             cmu_set_error("%s: hipFuncSetAttribute(%d B LDS): %s", name, C::LDS_BYTES, hipGetErrorString(e));
             return CMU_ERR_LAUNCH;
         }
-        attr_set = true;
+        attr_set.mark();
     }
     hipLaunchKernelGGL((conv_igemm_kernel<TR, MODE>), dim3((unsigned)p.total_blocks), dim3(256), C::LDS_BYTES, st, p);
     cmu_set_kernel_tag("conv_igemm_kernel");

@@ -476,15 +476,15 @@ static void wgT2_geometry(int B, int H, int W, int CA, int CB, WGParams& p) {
 template <class TR>
 static int wgradT_wide_t(WGParams p, float* dW, float* dbias, hipStream_t st) {
     typedef WGT2Cfg<TR> C;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static CmuPerDevice attr_set;   // hipFuncSetAttribute is per device
+    if (!attr_set.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgradT2_kernel<TR>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            C::LDS_BYTES);
         if (e != hipSuccess) {
             cmu_set_error("cmu_convT2x2_wgrad(wide): hipFuncSetAttribute(%d B LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
             return CMU_ERR_LAUNCH;
         }
-        attr_set = true;
+        attr_set.mark();
     }
     WG2Params pp;
     pp.g = p;
@@ -506,15 +506,15 @@ static int wgradT_wide_t(WGParams p, float* dW, float* dbias, hipStream_t st) {
 template <class TR>
 static int wgrad3_wide_t(WGParams p, float* dW, hipStream_t st) {
     typedef WG2Cfg<TR> C;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static CmuPerDevice attr_set;   // hipFuncSetAttribute is per device
+    if (!attr_set.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad2_kernel<TR>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            C::LDS_BYTES);
         if (e != hipSuccess) {
             cmu_set_error("cmu_conv3x3_wgrad(wide): hipFuncSetAttribute(%d B LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
             return CMU_ERR_LAUNCH;
         }
-        attr_set = true;
+        attr_set.mark();
     }
     WG2Params pp;
     pp.g = p;
@@ -535,15 +535,15 @@ static int wgrad3_wide_t(WGParams p, float* dW, hipStream_t st) {
 template <class TR, int MODE>
 static int launch_wgrad(const WGParams& p, hipStream_t st, const char* name) {
     typedef WGCfg<TR, MODE> C;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static CmuPerDevice attr_set;   // hipFuncSetAttribute is per device
+    if (!attr_set.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<TR, MODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) {
             cmu_set_error("%s: hipFuncSetAttribute(%d B LDS): %s", name, C::LDS_BYTES, hipGetErrorString(e));
             return CMU_ERR_LAUNCH;
         }
-        attr_set = true;
+        attr_set.mark();
     }
     const int grid = p.nAB * p.nBB * p.splitk * (MODE == MODE_WT ? 4 : 1);
     hipLaunchKernelGGL((conv_wgrad_kernel<TR, MODE>), dim3(grid), dim3(512), C::LDS_BYTES, st, p);

@@ -89,8 +89,9 @@ __global__ __launch_bounds__(256) void mmse_final_kernel(float* __restrict__ ws,
 }
 __global__ void mmse_grad_kernel(const float* __restrict__ logits, int K, int channel, const float* __restrict__ img,
                                  const uint8_t* __restrict__ mask, const float* __restrict__ ws, float* __restrict__ dlogits,
-                                 float loss_scale, int B, int H, int W, int64_t total) {
+                                 float loss_scale, const CmuAmpState* __restrict__ amp, int B, int H, int W, int64_t total) {
     const int rows = B * H;
+    if (amp != nullptr) loss_scale *= amp->scale;      // dynamic loss scale (power of two: exact)
     const float k = 2.f * loss_scale / ws[rows * 4 + 1];
     for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
         const int x = (int)(o % W), yy = (int)((o / W) % H), c = (int)((o / ((int64_t)W * H)) % K), b = (int)(o / ((int64_t)W * H * K));
@@ -105,7 +106,8 @@ __global__ void mmse_grad_kernel(const float* __restrict__ logits, int K, int ch
 }
 extern "C" int64_t cmu_masked_mse_ws_bytes(int B, int H) { return ((int64_t)B * H * 4 + 4) * (int64_t)sizeof(float); }
 extern "C" int cmu_masked_mse_fwd_bwd(const float* logits, int K, int channel, const float* img, const uint8_t* mask, float* loss,
-                                      float* dlogits, float loss_scale, int B, int H, int W, void* ws, void* stream) {
+                                      float* dlogits, float loss_scale, const void* amp_state, int B, int H, int W, void* ws,
+                                      void* stream) {
     CMU_CHECK_ARG(logits && img && mask && loss && ws && B > 0 && H > 0 && W > 0 && K > 0 && channel >= 0 && channel < K,
                   "cmu_masked_mse_fwd_bwd: bad args");
     hipStream_t st = (hipStream_t)stream;
@@ -117,7 +119,7 @@ extern "C" int cmu_masked_mse_fwd_bwd(const float* logits, int K, int channel, c
         const int64_t total = (int64_t)B * K * H * W;
         const int grid = (int)(cmu_div_up64(total, 256) < 8192 ? cmu_div_up64(total, 256) : 8192);
         hipLaunchKernelGGL(mmse_grad_kernel, dim3(grid), dim3(256), 0, st, logits, K, channel, img, mask, (const float*)ws, dlogits,
-                           loss_scale, B, H, W, total);
+                           loss_scale, (const CmuAmpState*)amp_state, B, H, W, total);
         CMU_CHECK_LAUNCH("cmu_masked_mse(grad)");
     }
     return CMU_OK;
@@ -406,11 +408,11 @@ extern "C" int cmu_moco_infonce_enqueue(const float* q_raw, const float* k_raw, 
     hipError_t e = hipMemsetAsync(ws, 0, 16, st);
     if (e != hipSuccess) { cmu_set_error("cmu_moco_infonce_enqueue: memset: %s", hipGetErrorString(e)); return CMU_ERR_LAUNCH; }
     const size_t lds = (size_t)(2 * D + K) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static CmuPerDevice attr_set;   // hipFuncSetAttribute is per device
+    if (!attr_set.done()) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&moco_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
         if (e != hipSuccess) { cmu_set_error("cmu_moco_infonce_enqueue: LDS attribute: %s", hipGetErrorString(e)); return CMU_ERR_LAUNCH; }
-        attr_set = true;
+        attr_set.mark();
     }
     hipLaunchKernelGGL(moco_kernel, dim3(B), dim3(256), lds, st, q_raw, k_raw, keys_all, Nk, queue, queue_ptr, loss, dq, k_norm_out, B, D, K,
                        temperature, (unsigned*)ws, (float*)((char*)ws + 16));
@@ -447,7 +449,16 @@ extern "C" int cmu_ema_update(float* target, const float* online, int64_t n, flo
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             const uint8_t* __restrict__ wd_mask, int64_t n, float lr, float b1, float b2, float eps, float wd,
-                            int decoupled, float bc1, float bc2_sqrt, float gscale) {
+                            int decoupled, float bc1, float bc2_sqrt, float gscale, const CmuAmpState* __restrict__ amp) {
+    if (amp != nullptr) {
+        // GradScaler.step: skip the whole update when the gradients hold an inf / nan; else unscale.  The step number of the
+        // bias corrections is the count of updates actually taken (a skipped step never reaches optimizer.step()).
+        if (amp->found_inf != 0.f) return;
+        gscale /= amp->scale;
+        const double t = (double)(amp->good_steps + 1);
+        bc1 = (float)(1.0 - pow((double)b1, t));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float pi = p[i], gi = g[i] * gscale;
         const float w = (wd_mask == nullptr || wd_mask[i]) ? wd : 0.f;
@@ -462,15 +473,76 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 extern "C" int cmu_adam_step(float* p, const float* g, float* m, float* v, const uint8_t* wd_mask, int64_t n, float lr, float beta1,
-                             float beta2, float eps, float weight_decay, int decoupled, int64_t step, float grad_scale, void* stream) {
+                             float beta2, float eps, float weight_decay, int decoupled, int64_t step, float grad_scale,
+                             const void* amp_state, void* stream) {
     CMU_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "cmu_adam_step: bad args");
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     const int64_t nb = cmu_div_up64(n, 256);
     const int grid = (int)(nb < 8192 ? nb : 8192);
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, wd_mask, n, lr, beta1, beta2, eps,
-                       weight_decay, decoupled, (float)bc1, (float)sqrt(bc2), grad_scale);
+                       weight_decay, decoupled, (float)bc1, (float)sqrt(bc2), grad_scale, (const CmuAmpState*)amp_state);
     CMU_CHECK_LAUNCH("cmu_adam_step");
+    return CMU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dynamic loss scaling (AmpOptimWrapper(loss_scale='dynamic') of cmunet_config.py:76-78 = torch.cuda.amp.GradScaler):
+// the state lives on the device, nothing here synchronises with the host.
+// ---------------------------------------------------------------------------------------------
+__global__ void amp_init_kernel(CmuAmpState* s, float init_scale) {
+    s->scale = init_scale;
+    s->found_inf = 0.f;
+    s->growth_tracker = 0;
+    s->good_steps = 0;
+    s->skipped_steps = 0;
+    s->pad[0] = s->pad[1] = s->pad[2] = 0;
+}
+__global__ __launch_bounds__(256) void amp_check_kernel(const float* __restrict__ g, int64_t n, CmuAmpState* __restrict__ s) {
+    const int64_t n4 = n >> 2;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(g)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bad |= !(fabsf(a[e]) <= 3.4028234664e38f);    // inf or nan
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) bad |= !(fabsf(g[(n4 << 2) + threadIdx.x]) <= 3.4028234664e38f);
+    if (__any(bad) && (threadIdx.x & 63) == 0) s->found_inf = 1.f;     // every writer stores the same value
+}
+__global__ void amp_update_kernel(CmuAmpState* s, float growth, float backoff, int interval) {
+    if (s->found_inf != 0.f) {
+        s->scale *= backoff;
+        s->growth_tracker = 0;
+        s->skipped_steps += 1;
+    } else {
+        s->good_steps += 1;
+        if (++s->growth_tracker == interval) {
+            s->scale *= growth;
+            s->growth_tracker = 0;
+        }
+    }
+    s->found_inf = 0.f;
+}
+extern "C" int cmu_amp_state_bytes(void) { return (int)sizeof(CmuAmpState); }
+extern "C" int cmu_amp_init(void* state, float init_scale, void* stream) {
+    CMU_CHECK_ARG(state && init_scale > 0.f, "cmu_amp_init: bad args");
+    hipLaunchKernelGGL(amp_init_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (CmuAmpState*)state, init_scale);
+    CMU_CHECK_LAUNCH("cmu_amp_init");
+    return CMU_OK;
+}
+extern "C" int cmu_amp_check_finite(const float* g, int64_t n, void* state, void* stream) {
+    CMU_CHECK_ARG(g && state && n > 0 && cmu_aligned16(g), "cmu_amp_check_finite: bad args / alignment");
+    const int64_t nb = cmu_div_up64(n >> 2, 256);
+    const int grid = (int)(nb < 8192 ? (nb < 1 ? 1 : nb) : 8192);
+    hipLaunchKernelGGL(amp_check_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, n, (CmuAmpState*)state);
+    CMU_CHECK_LAUNCH("cmu_amp_check_finite");
+    return CMU_OK;
+}
+extern "C" int cmu_amp_update(void* state, float growth_factor, float backoff_factor, int growth_interval, void* stream) {
+    CMU_CHECK_ARG(state && growth_factor >= 1.f && backoff_factor > 0.f && backoff_factor <= 1.f && growth_interval >= 1, "cmu_amp_update: bad args");
+    hipLaunchKernelGGL(amp_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (CmuAmpState*)state, growth_factor, backoff_factor,
+                       growth_interval);
+    CMU_CHECK_LAUNCH("cmu_amp_update");
     return CMU_OK;
 }
 

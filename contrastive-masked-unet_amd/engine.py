@@ -17,6 +17,7 @@ serves ``UNet`` (model.py), ``UNet_encoder`` (UNet_encoder.py:51-84) and ``MUNet
 (munet_neck.py:52-82).  There is no eager/CPU fallback here: every arithmetic step is a C-ABI call.
 """
 import os
+import weakref
 
 import torch
 
@@ -62,6 +63,12 @@ class _PackCache:
         return packed
 
 
+class _Ctx(dict):
+    """Saved state of a forward pass (a dict that can be weakly referenced: the engine watches whether the training
+    forward that owns the cached concat buffers is still waiting for its backward)."""
+    __slots__ = ("__weakref__",)
+
+
 class UNetEngine:
     def __init__(self, dt="bf16", device="cuda"):
         self.dt = ops.dt_code(dt)
@@ -70,8 +77,8 @@ class UNetEngine:
         self.scratch = _Scratch(self.device)
         self.packs = _PackCache()
         self.lib = _lib.lib()
-        self._zero_bias_done = set()
-        self._cats, self._cats_busy = None, False
+        self._zero_pending = []
+        self._cats, self._cats_busy, self._cats_owner = None, False, None
         self._nbt, self._nbt_defer = [], 0
         self.grad_target = None      # optional dict name -> preallocated fp32 tensor (FlatParams.grad_views)
         self.grad_prefix = ""
@@ -134,6 +141,12 @@ class UNetEngine:
         pend, self._nbt = self._nbt, []
         if pend:
             torch._foreach_add_(pend, 1)
+
+    def flush_zero_bias(self):
+        """Zero the conv-bias gradients collected by ``_convbn_bwd`` in one multi-tensor launch."""
+        pend, self._zero_pending = self._zero_pending, []
+        if pend:
+            torch._foreach_zero_(pend)
 
     def _convbn_fwd(self, sd, pconv, pbn, x, out, training, x_img=None, mask=None, mask_per_sample=False, affine_out=None):
         """``affine_out``: optional (scale, shift) views the pending transform is written into (a skip that lives in a concat
@@ -203,12 +216,10 @@ class UNetEngine:
         grads[s["pbn"] + "weight"] = dgamma
         grads[s["pbn"] + "bias"] = dbeta
         # conv bias: followed by training-mode BN, its gradient is identically zero (sum of dY over pixels)
+        # (zeroed every step -- the arena is also written by the autograd / drop-in path -- but as ONE multi-tensor fill for all
+        # layers of the pass, see flush_zero_bias)
         gb = self._gbuf(s["pconv"] + "bias", sd[s["pconv"] + "bias"])
-        zk = (s["pconv"], gb.data_ptr())
-        if self.grad_target is None or zk not in self._zero_bias_done:     # arena views: written here and nowhere else
-            gb.zero_()
-            if self.grad_target is not None:
-                self._zero_bias_done.add(zk)
+        self._zero_pending.append(gb)
         grads[s["pconv"] + "bias"] = gb
         dW = self._gbuf(s["pconv"] + "weight", w)
         if s["x_img"] is not None:
@@ -285,6 +296,7 @@ class UNetEngine:
                             self._bn_ws(y2.C))
             dA1 = self._convbn_bwd(sd, lv["s2"], dA2, grads, True, fused_stats=True, next_bn=lv["s1"])
             dP = self._convbn_bwd(sd, lv["s1"], dA1, grads, i > 1)
+        self.flush_zero_bias()
         return None
 
     # ------------------------------------------------------------------------------------------
@@ -401,6 +413,7 @@ class UNetEngine:
                     ops.convT2x2_dgrad(dleft, self._wpT(p + "up_sample.", wt, 1), dA)
             else:
                 dA = None
+        self.flush_zero_bias()
         return dA, d_skips
 
     # ------------------------------------------------------------------------------------------
@@ -411,6 +424,9 @@ class UNetEngine:
         # concat buffers + affine arrays of the last shape are reused from step to step (no per-step fills) unless a
         # training forward is still waiting for its backward: that one keeps them, this call gets fresh ones
         key = (B, H, W, self.tdt)
+        if self._cats_busy and (self._cats_owner is None or self._cats_owner() is None):
+            self._cats_busy = False           # the forward that held them was dropped without a backward
+        owns = False
         if self._cats_busy:
             cats = self.decoder_alloc(sd, B, H, W, "")
         else:
@@ -418,11 +434,15 @@ class UNetEngine:
                 self._cats = (key, self.decoder_alloc(sd, B, H, W, ""))
             cats = self._cats[1]
             self._cats_busy = bool(training)
+            owns = True
         skip_out = [Act(c["buf"], c["Cup"], c["Cskip"]) for c in cats]
         skip_affine = [(c["scale"][c["Cup"]:], c["shift"][c["Cup"]:]) for c in cats]
         ectx = self.encoder_forward(sd, x_bhw, training, "", mask, mask_per_sample, skip_out, skip_affine)
         dctx = self.decoder_forward(sd, ectx["latent"], ectx["skips"], training, "", cats, True)
-        return dctx["logits"], {"enc": ectx, "dec": dctx}
+        ctx = _Ctx(enc=ectx, dec=dctx)
+        if owns and training:
+            self._cats_owner = weakref.ref(ctx)
+        return dctx["logits"], ctx
 
     def unet_backward(self, sd, ctx, dlogits, after_decoder=None):
         """``after_decoder``: called when every decoder parameter gradient has been queued (data-parallel trainers start

@@ -11,6 +11,7 @@ Only the configuration the reference's driver uses is implemented on the HIP pat
 The Dice term has no gradient, exactly like the reference's thresholded version (SURVEY A-4).
 """
 import re
+import weakref
 
 import torch
 import torch.nn as nn
@@ -97,7 +98,15 @@ class _SegStatsFn(torch.autograd.Function):
         return dl * g[0], None
 
 
-_cache = {"key": None, "out": None}
+# The loss and each metric object are called with the SAME (prediction, target) tensors one after the other
+# (train.py:127-136); the fused pass runs once for the pair.  The pair is recognised by object identity through weak
+# references (an address + version key would also match a LATER batch that the caching allocator placed at the same
+# address once the earlier tensors were freed -- e.g. the first test batch after the last validation batch).
+_cache = {"pr": None, "gt": None, "ver": None, "out": None}
+
+
+def clear_seg_cache():
+    _cache.update(pr=None, gt=None, ver=None, out=None)
 
 
 def seg_stats(y_pr, y_gt):
@@ -105,10 +114,12 @@ def seg_stats(y_pr, y_gt):
         raise RuntimeError("metrics: the HIP path needs CUDA/ROCm tensors (no CPU fallback)")
     if y_pr.dim() != 4 or y_pr.shape[1] != 2 or y_gt.shape != y_pr.shape:
         raise NotImplementedError("fused segmentation losses support (B,2,H,W) logits with one-hot targets of the same shape")
-    y = y_gt if y_gt.dtype == torch.float64 else y_gt.double()
-    key = (y_pr.data_ptr(), y_pr._version, y_gt.data_ptr(), y_gt._version, tuple(y_pr.shape), y_pr.requires_grad)
-    if _cache["key"] != key:
-        _cache["key"], _cache["out"] = key, _SegStatsFn.apply(y_pr.float(), y)
+    ver = (y_pr._version, y_gt._version, y_pr.requires_grad and torch.is_grad_enabled())
+    pr, gt = _cache["pr"], _cache["gt"]
+    if pr is None or pr() is not y_pr or gt() is not y_gt or _cache["ver"] != ver:
+        y = y_gt if y_gt.dtype == torch.float64 else y_gt.double()
+        out = _SegStatsFn.apply(y_pr.float(), y)
+        _cache.update(pr=weakref.ref(y_pr), gt=weakref.ref(y_gt), ver=ver, out=out)
     return _cache["out"]
 
 

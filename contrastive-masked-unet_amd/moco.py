@@ -90,6 +90,10 @@ class Moco_v2(nn.Module):
     @torch.no_grad()
     def _momentum_update_key_encoder(self):
         em = self.hparams["encoder_momentum"]
+        arenas = getattr(self, "_ema_arenas", None)      # set by pretrain.MocoPretrainer: both encoders live in flat arenas
+        if arenas is not None:
+            ops.ema_update(arenas[0], arenas[1], em)
+            return
         for pq, pk in zip(self.encoder_q.parameters(), self.encoder_k.parameters()):
             ops.ema_update(pk.data.view(-1), pq.data.view(-1), em)
 

@@ -207,6 +207,7 @@ class _BlockFn(torch.autograd.Function):
         dA1 = eng._convbn_bwd(sd, s2, dA2, grads, True)
         first_has_dx = s1["x_img"] is None
         dX = eng._convbn_bwd(sd, s1, dA1, grads, first_has_dx)
+        eng.flush_zero_bias()
         gx, gskip = None, None
         if kind == "up":
             _, _, x_act, Cup, Cs = ctx.saved

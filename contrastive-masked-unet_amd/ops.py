@@ -28,14 +28,15 @@ def dt_code(dt):
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The launch stream: resolved by ``_lib.call`` to the current stream of the device that owns the call's tensors."""
+    return _lib.STREAM
 
 
 def _p(t):
     if t is None:
         return None
     assert t.is_cuda, "HIP path: tensor must live on the GPU"
-    return ctypes.c_void_p(t.data_ptr())
+    return _lib.devptr(t.data_ptr(), t.device.index)
 
 
 def _f32c(t):
@@ -75,7 +76,7 @@ class Act:
         return DT_OF[self.buf.dtype]
 
     def ptr(self):
-        return ctypes.c_void_p(self.buf.data_ptr() + self.coff * self.buf.element_size())
+        return _lib.devptr(self.buf.data_ptr() + self.coff * self.buf.element_size(), self.buf.device.index)
 
     def with_transform(self, scale, shift, relu_from=0):
         return Act(self.buf, self.coff, self.C, scale, shift, relu_from)
@@ -300,10 +301,10 @@ def conv1x1_head_bwd(dlogits, x, w, dX, dW, dbias, ws, save_mean=None, save_invs
 # ------------------------------------------------------------------------------------------------
 # losses / heads / optimiser
 # ------------------------------------------------------------------------------------------------
-def masked_mse_fwd_bwd(logits, channel, img, mask, loss, dlogits, loss_scale, ws):
+def masked_mse_fwd_bwd(logits, channel, img, mask, loss, dlogits, loss_scale, ws, amp=None):
     B, K, H, W = logits.shape
     call("cmu_masked_mse_fwd_bwd", _p(_f32c(logits)), K, channel, _p(_f32c(img)), _p(mask), _p(loss), _p(dlogits),
-         float(loss_scale), B, H, W, _p(ws), _stream())
+         float(loss_scale), _p(None if amp is None else amp.state), B, H, W, _p(ws), _stream())
 
 
 def softmax_ce_dice_fwd_bwd(logits, y1h, out, dlogits, loss_scale, ws):
@@ -386,12 +387,35 @@ def ema_update(target, online, momentum):
     call("cmu_ema_update", _p(_f32c(target)), _p(_f32c(online)), target.numel(), float(momentum), _stream())
 
 
-def adam_step(p, g, m, v, wd_mask, lr, beta1, beta2, eps, weight_decay, decoupled, step, grad_scale=1.0):
+def adam_step(p, g, m, v, wd_mask, lr, beta1, beta2, eps, weight_decay, decoupled, step, grad_scale=1.0, amp=None):
     global PARAM_GENERATION
     PARAM_GENERATION += 1
     call("cmu_adam_step", _p(_f32c(p)), _p(_f32c(g)), _p(_f32c(m)), _p(_f32c(v)), _p(wd_mask), p.numel(), float(lr),
          float(beta1), float(beta2), float(eps), float(weight_decay), int(decoupled), int(step), float(grad_scale),
-         _stream())
+         _p(None if amp is None else amp.state), _stream())
+
+
+class AmpScaler:
+    """Dynamic loss scaler with its state on the device (cmu_amp_*): torch.cuda.amp.GradScaler's protocol -- what mmengine's
+    AmpOptimWrapper(loss_scale='dynamic') wraps (cmunet_config.py:76-78) -- without the per-step host read of found_inf."""
+
+    def __init__(self, device, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+        self.state = torch.zeros(_lib.lib().cmu_amp_state_bytes(), dtype=torch.uint8, device=device)
+        call("cmu_amp_init", _p(self.state), float(init_scale), _stream())
+
+    def check(self, grad_arena):
+        call("cmu_amp_check_finite", _p(_f32c(grad_arena)), grad_arena.numel(), _p(self.state), _stream())
+
+    def update(self):
+        call("cmu_amp_update", _p(self.state), float(self.growth_factor), float(self.backoff_factor), int(self.growth_interval), _stream())
+
+    def read(self):
+        """(scale, found_inf, growth_tracker, good_steps, skipped_steps) -- synchronises; for logging and tests."""
+        raw = self.state.cpu()
+        f = raw[:8].view(torch.float32)
+        i = raw[8:20].view(torch.int32)
+        return float(f[0]), float(f[1]), int(i[0]), int(i[1]), int(i[2])
 
 
 def sgd_step(p, g, buf, wd_mask, lr, momentum, dampening, weight_decay, nesterov, step, grad_scale=1.0):

@@ -86,6 +86,17 @@ class FlatParams:
                 return None
         return None if first is None else self.offsets[first][0]
 
+    def prefix_range(self, prefix):
+        """[lo, hi) element range of the parameters whose names start with ``prefix`` when they form one contiguous run of the
+        arena (padding included), else None."""
+        idx = [i for i, n in enumerate(self.names) if n.startswith(prefix)]
+        if not idx or idx != list(range(idx[0], idx[-1] + 1)):
+            return None
+        lo = self.offsets[self.names[idx[0]]][0]
+        last = self.names[idx[-1]]
+        hi = self.offsets[last][0] + ((self.offsets[last][1] + 3) // 4) * 4
+        return lo, hi
+
     def all_reduce_range_async(self, lo, hi, group=None):
         """Start the SUM all-reduce of gradient elements [lo, hi); returns a work handle (``.wait()``) or None when
         there is nothing to exchange.  On RCCL the collective runs on the process group's stream after the kernels
@@ -116,10 +127,12 @@ class FusedAdam:
         for p in self.flat.params.values():
             p.grad = None
 
-    def step(self, grad_scale=1.0):
+    def step(self, grad_scale=1.0, amp=None):
+        """``amp``: an ``ops.AmpScaler`` -- the kernel then skips / unscales from its device state (and takes the step number
+        of the bias corrections from it)."""
         self.step_count += 1
         ops.adam_step(self.flat.arena, self.flat.grad, self.m, self.v, self.wd_mask, self.lr, self.betas[0],
-                      self.betas[1], self.eps, self.weight_decay, self.decoupled, self.step_count, grad_scale)
+                      self.betas[1], self.eps, self.weight_decay, self.decoupled, self.step_count, grad_scale, amp)
         # ops.adam_step bumps ops.PARAM_GENERATION: the engine's packed-weight caches see the raw-kernel write
 
     def state_dict(self):

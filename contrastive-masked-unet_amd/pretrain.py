@@ -15,13 +15,14 @@ AmpOptimWrapper.update_params -> AdamW.step, cmunet_config.py:76-91) is ONE kern
 exactly the "masked-recon only" configuration SURVEY 8(d)-(2) names; the joint step lives in cmunet.py.
 """
 import math
+import os
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
 from . import _lib, ops
-from .optim import FlatParams, FusedAdam, no_decay_bias_norm
+from .optim import FlatParams, FusedAdam, FusedLAMB, FusedSGD, no_decay_bias_norm
 
 
 def create_random_patch_mask(batch_size, img_size, patch_size=16, mask_ratio=0.65, rng=None):
@@ -59,7 +60,10 @@ class MaskedReconPretrainer:
     """One object = model + flat arenas + fused AdamW + (optional) data-parallel group."""
 
     def __init__(self, model, lr=1.5e-4, betas=(0.9, 0.95), weight_decay=0.05, eps=1e-8, rc_weight=1.0,
-                 ref_compat=True, pred_channel=1, process_group=None, loss_scale=1.0):
+                 ref_compat=True, pred_channel=1, process_group=None, loss_scale=1.0, amp=None):
+        """``amp``: True (or an ``ops.AmpScaler``) turns on the dynamic loss scaling of the reference's AmpOptimWrapper
+        (cmunet_config.py:76-78; needed with f16 activations: a masked-MSE gradient is ~1e-7 per pixel at bs 32 x 512 x 512,
+        below f16's smallest normal) -- state and decisions stay on the device."""
         assert next(model.parameters()).is_cuda, "move the model to the GPU first"
         self.model = model.train()
         self.device = next(model.parameters()).device
@@ -72,12 +76,14 @@ class MaskedReconPretrainer:
         self.rc_weight, self.ref_compat, self.pred_channel = rc_weight, ref_compat, pred_channel
         self.group = process_group
         self.loss_scale = loss_scale
+        self.amp = ops.AmpScaler(self.device) if amp is True else (amp or None)
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._dlogits = None
         self._ws = None
         # gradient exchange in two buckets: the decoder's parameters are the tail of the arena and their gradients are
         # complete half-way through the backward pass
-        self._dec_off = self.flat.tail_offset(("up_conv", "conv_last"))
+        # (CMU_DDP_OVERLAP=0: one all-reduce of the whole arena after the backward pass -- A/B and fallback switch)
+        self._dec_off = self.flat.tail_offset(("up_conv", "conv_last")) if os.environ.get("CMU_DDP_OVERLAP", "1") != "0" else None
         self._pending = None
 
     def broadcast_parameters(self, src=0):
@@ -98,7 +104,7 @@ class MaskedReconPretrainer:
             self._dlogits = torch.empty_like(logits)
             self._ws = torch.empty(_lib.lib().cmu_masked_mse_ws_bytes(B, H), dtype=torch.uint8, device=self.device)
         ops.masked_mse_fwd_bwd(logits, self.pred_channel, img, mask, self.loss, self._dlogits,
-                               self.rc_weight * self.loss_scale, self._ws)
+                               self.rc_weight * self.loss_scale, self._ws, self.amp)
         eng.grad_target, eng.grad_prefix = self.flat.grad_views, ""
         self._pending = None
 
@@ -130,8 +136,151 @@ class MaskedReconPretrainer:
     def step(self, img, mask):
         loss = self.forward_backward(img, mask)
         scale = self.exchange_gradients() / self.loss_scale
-        self.opt.step(grad_scale=scale)
+        if self.amp is not None:
+            self.amp.check(self.flat.grad)         # after the exchange: every rank sees the same inf / nan
+        self.opt.step(grad_scale=scale, amp=self.amp)
+        if self.amp is not None:
+            self.amp.update()
         return loss
+
+
+class ArenaTrainer:
+    """Data-parallel trainer for the autograd-wrapped pretraining models (``CM_UNet``, ``Moco_v2``, ``SparK``): what the
+    reference gets from DistributedDataParallel + an optimiser object (Spark/main.py:102,130-140; dist_train.sh:9-17 with
+    cmunet_config.py:76-91,120; Lightning's DDP for moco2_module.py:339-344) is here
+
+        trainable parameters re-homed into ONE fp32 arena (frozen momentum / target networks stay outside)
+        loss.backward() through the module's fused autograd node(s)
+        gradients gathered into the gradient arena; parameters that received no gradient (SparK's ``densify_projs`` of
+            the full UNet, SURVEY A-10 -- they would trip the reference's own DDP(find_unused_parameters=False)) count as zero
+        ONE RCCL all-reduce (SUM) over the arena, 1/world folded into the optimiser kernel's gradient load
+        ONE fused optimiser launch (AdamW / SGD-momentum / LAMB, csrc/heads.hip + optim.hip).
+
+    Embedding all-gathers and SyncBN exchanges stay inside the models (cmunet.py, moco.py, spark.py); all of them use the
+    default process group, as the reference's do."""
+
+    def __init__(self, model, optimizer, process_group=None):
+        self.model = model
+        self.group = process_group
+        self.flat = optimizer.flat
+        self.opt = optimizer
+        self.device = self.flat.arena.device
+
+    @staticmethod
+    def trainable(model):
+        want = {n for n, p in model.named_parameters() if p.requires_grad}
+        return FlatParams(model, names=lambda n: n in want)
+
+    def world(self):
+        return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+
+    def broadcast_parameters(self, src=0):
+        """Rank ``src``'s parameters and floating-point buffers to every rank (DDP does this at construction)."""
+        if self.world() <= 1:
+            return
+        dist.broadcast(self.flat.arena, src=src, group=self.group)
+        held = {id(p) for p in self.flat.params.values()}
+        for p in self.model.parameters():
+            if id(p) not in held:
+                dist.broadcast(p.data, src=src, group=self.group)
+        for b in self.model.buffers():
+            if b.is_floating_point():
+                dist.broadcast(b, src=src, group=self.group)
+
+    def backward_and_step(self, loss, loss_scale=1.0):
+        """``loss``: scalar tensor from the model's forward (already multiplied by ``loss_scale`` if one is used)."""
+        for p in self.flat.params.values():
+            p.grad = None
+        loss.backward()
+        self.flat.gather_autograd_grads()
+        scale = 1.0
+        if self.world() > 1:
+            dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)
+            scale = 1.0 / self.world()
+        self.opt.step(grad_scale=scale / loss_scale)
+        for p in self.flat.params.values():       # the arena holds them; drop the per-tensor copies autograd made
+            p.grad = None
+
+
+class JointPretrainer(ArenaTrainer):
+    """Joint contrastive + masked-reconstruction step of CM-UNet (BASELINE config 4; cmunet.py:108-135 under
+    cmunet_config.py:76-114): AdamW(lr, betas (0.9, 0.95), wd 0.05, no decay on bias / norm parameters), then the EMA of the
+    target backbone + projector (MomentumUpdateHook.after_train_iter) as two launches between two arenas."""
+
+    def __init__(self, model, lr=1.5e-4, betas=(0.9, 0.95), weight_decay=0.05, eps=1e-8, process_group=None):
+        model.train()
+        flat = self.trainable(model)
+        opt = FusedAdam(flat, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decoupled=True, decay_filter=no_decay_bias_norm)
+        super().__init__(model, opt, process_group)
+        tnames = {n for n, _ in model.named_parameters() if n.startswith(("target_backbone.", "target_projector."))}
+        self.tflat = FlatParams(model, names=lambda n: n in tnames)
+        # identical layouts: (backbone, projector) inside the online arena <-> (target_backbone, target_projector)
+        self._ema = []
+        for src, dst in (("backbone.", "target_backbone."), ("projector.", "target_projector.")):
+            a, b = self.flat.prefix_range(src), self.tflat.prefix_range(dst)
+            assert a is not None and b is not None and a[1] - a[0] == b[1] - b[0], "online / target layouts differ"
+            self._ema.append((a, b))
+
+    def momentum_update(self):
+        for (a0, a1), (b0, b1) in self._ema:
+            ops.ema_update(self.tflat.arena[b0:b1], self.flat.arena[a0:a1], self.model.momentum)
+
+    def step(self, img, img_t, mask=None, cur_iter=None, max_iter=None, **kw):
+        if cur_iter is not None and max_iter:
+            from .cmunet import momentum_schedule
+            self.model.momentum = momentum_schedule(cur_iter, max_iter, self.model.base_momentum, getattr(self.model, "end_momentum", self.model.base_momentum))
+        losses = self.model(img, mode="loss", img_t=img_t, mask=mask, **kw)
+        self.backward_and_step(losses["loss_ct"] + losses["loss_rc"])
+        self.momentum_update()
+        return {k: v.detach() for k, v in losses.items()}
+
+
+class MocoPretrainer(ArenaTrainer):
+    """MoCo-v2 step (BASELINE config 3; moco2_module.py:287-309,339-344): SGD(lr, momentum 0.9, weight decay 1e-4) on the
+    query encoder; the key encoder's EMA (before the forward, A-8) is one launch between two arenas."""
+
+    def __init__(self, model, lr=None, momentum=None, weight_decay=None, process_group=None):
+        model.train()
+        hp = model.hparams
+        flat = self.trainable(model)
+        opt = FusedSGD(flat, lr=hp["learning_rate"] if lr is None else lr, momentum=hp["momentum"] if momentum is None else momentum,
+                       weight_decay=hp["weight_decay"] if weight_decay is None else weight_decay)
+        super().__init__(model, opt, process_group)
+        knames = {n for n, _ in model.named_parameters() if n.startswith("encoder_k.")}
+        self.kflat = FlatParams(model, names=lambda n: n in knames)
+        a, b = self.flat.prefix_range("encoder_q."), self.kflat.prefix_range("encoder_k.")
+        assert a is not None and b is not None and a[1] - a[0] == b[1] - b[0]
+        model._ema_arenas = (self.kflat.arena[b[0]:b[1]], self.flat.arena[a[0]:a[1]])     # used by _momentum_update_key_encoder
+
+    def step(self, img_q, img_k):
+        loss = self.model.training_step((img_q, img_k))
+        self.backward_and_step(loss)
+        return loss.detach()
+
+
+class SparKPretrainer(ArenaTrainer):
+    """SparK step (BASELINE config 5; Spark/main.py:178-227 with utils/lamb.py): LAMB (betas (0.9, 0.95), wd 0.04, global
+    gradient-norm clip) over every parameter, the unused ``densify_projs`` included (zero gradient)."""
+
+    def __init__(self, model, lr=2e-4, betas=(0.9, 0.95), weight_decay=0.04, clip=5.0, process_group=None):
+        model.train()
+        flat = self.trainable(model)
+        # lr_control.get_param_groups (lr_control.py:32-53) with main.py:107's nowd_keys
+        nowd = ("cls_token", "pos_embed", "mask_token", "gamma")
+        opt = FusedLAMB(flat, lr=lr, betas=betas, weight_decay=weight_decay, max_grad_norm=clip,
+                        decay_filter=lambda n, p: not (p.dim() == 1 or n.endswith(".bias") or any(k in n for k in nowd)))
+        super().__init__(model, opt, process_group)
+
+    def step(self, inp_bchw, active_b1ff=None, loss_scale=1.0):
+        """``loss_scale``: static scale applied to the loss gradient INSIDE the fused step (the activations' gradients are
+        stored in the model's dtype) and divided out again by the optimiser kernel."""
+        self.model.grad_scale = float(loss_scale)
+        try:
+            loss = self.model(inp_bchw, active_b1ff=active_b1ff)
+            self.backward_and_step(loss, loss_scale)
+        finally:
+            self.model.grad_scale = 1.0
+        return loss.detach()
 
 
 def cosine_warmup_lr(base_lr, it, warmup_iters, total_iters, start_factor=1e-4):

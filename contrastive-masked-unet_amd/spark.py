@@ -107,6 +107,9 @@ class SparK(_EngineOwner, nn.Module):
         self.sbn = sbn
         self.hierarchy = len(sparse_encoder.enc_feat_map_chs)
         self.densify_norm_str = densify_norm.lower()
+        # static loss scale of the fused step (set by pretrain.SparKPretrainer for f16 storage: a per-pixel loss gradient is
+        # ~3e-7 at bs 32 x 512 x 512, below f16's normal range); the parameter gradients come out multiplied by it
+        self.grad_scale = 1.0
         self.densify_projs = nn.ModuleList()
         self.mask_tokens = nn.ParameterList()
         e_widths, d_width = list(sparse_encoder.enc_feat_map_chs), dense_decoder.width
@@ -256,7 +259,7 @@ class SparK(_EngineOwner, nn.Module):
         loss = torch.empty(1, dtype=torch.float32, device=eng.device)
         drec = torch.empty_like(rec) if need_grads else None
         ws = eng.scratch.get("sploss", eng.lib.cmu_spark_loss_ws_bytes(B, f))
-        ops.spark_loss_fwd_bwd(rec.view(B, H, W), x_img, active, loss, drec, 1.0, r, ws)
+        ops.spark_loss_fwd_bwd(rec.view(B, H, W), x_img, active, loss, drec, float(self.grad_scale), r, ws)
         if not need_grads:
             return loss[0], None
 

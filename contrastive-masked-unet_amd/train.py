@@ -16,58 +16,15 @@ import sys
 import numpy as np
 import torch
 
+from . import metrics as metrics_mod
 from .model import UNet
 
 
-class Meter(object):
-    def reset(self):
-        pass
-
-    def add(self, value):
-        pass
-
-    def value(self):
-        pass
-
-
-class AverageValueMeter(Meter):
-    """Running mean / std with the reference's update rule (train.py:43-79)."""
-
-    def __init__(self):
-        super().__init__()
-        self.reset()
-        self.val = 0
-
-    def add(self, value, n=1):
-        self.val = value
-        self.sum += value
-        self.var += value * value
-        self.n += n
-        if self.n == 0:
-            self.mean, self.std = np.nan, np.nan
-        elif self.n == 1:
-            self.mean = 0.0 + self.sum
-            self.std = np.inf
-            self.mean_old = self.mean
-            self.m_s = 0.0
-        else:
-            self.mean = self.mean_old + (value - n * self.mean_old) / float(self.n)
-            self.m_s += (value - self.mean_old) * (value - self.mean)
-            self.mean_old = self.mean
-            self.std = np.sqrt(self.m_s / (self.n - 1.0))
-
-    def value(self):
-        return self.mean, self.std
-
-    def reset(self):
-        self.n = 0
-        self.sum = 0.0
-        self.var = 0.0
-        self.val = 0.0
-        self.mean = np.nan
-        self.mean_old = 0.0
-        self.m_s = 0.0
-        self.std = np.nan
+def _epoch_means(table):
+    """Mean of every column of the (batches, values) table of an epoch: the ``.mean`` the reference's per-key meters
+    hold when ``Epoch.run`` returns (train.py:129-140).  The whole table is on the host by then, so no running update."""
+    table = np.asarray(table, dtype=np.float64)
+    return table.sum(axis=0) / table.shape[0]
 
 
 class Epoch:
@@ -99,6 +56,7 @@ class Epoch:
         """Same logs contract as train.py:109-145 ({loss name: mean, metric name: mean}); per-batch values are
         kept on the device and fetched once at the end of the epoch."""
         self.on_epoch_start()
+        metrics_mod.clear_seg_cache()
         names = [self.loss.__name__] + [m.__name__ for m in self.metrics]
         per_batch = []
         for x, y in dataloader:
@@ -111,11 +69,7 @@ class Epoch:
         logs = {}
         if per_batch:
             table = torch.stack(per_batch).cpu().numpy()          # the only device -> host copy of the epoch
-            meters = [AverageValueMeter() for _ in names]
-            for row in table:
-                for m, v in zip(meters, row):
-                    m.add(v)
-            logs = {k: m.mean for k, m in zip(names, meters)}
+            logs = {k: float(v) for k, v in zip(names, _epoch_means(table))}
         if self.verbose:
             print(f"{self.stage_name}: {self._format_logs(logs)}", file=sys.stdout)
         return logs

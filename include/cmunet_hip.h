@@ -202,8 +202,10 @@ int cmu_conv1x1_head_bwd(const float* dlogits, const void* x, int64_t ldx, const
  * and, if dlogits != NULL, d loss*loss_scale / d logits (B,K,H,W) (zero on the other channels).
  * mask uint8 (B,H,W).  ws: cmu_masked_mse_ws_bytes(B,H).                                            */
 int64_t cmu_masked_mse_ws_bytes(int B, int H);
+/* amp_state (nullable): a cmu_amp_* state whose current scale multiplies loss_scale in dlogits (loss stays unscaled).  */
 int cmu_masked_mse_fwd_bwd(const float* logits, int K, int channel, const float* img, const uint8_t* mask,
-                           float* loss, float* dlogits, float loss_scale, int B, int H, int W, void* ws, void* stream);
+                           float* loss, float* dlogits, float loss_scale, const void* amp_state, int B, int H, int W, void* ws,
+                           void* stream);
 
 /* Finetune criterion (train.py:455; metrics.py:135-180,503): softmax over 2 classes, CE with one-hot
  * (probability) targets averaged over B*H*W, Dice/IoU counters on softmax[:,1] > 0.5 (no gradient: A-4).
@@ -276,10 +278,25 @@ int cmu_ema_update(float* target, const float* online, int64_t n, float momentum
 /* Fused Adam/AdamW step over a flat fp32 arena (torch.optim.Adam, train.py:341; AdamW cmunet_config.py:79-83).
  * decoupled != 0: AdamW (p *= 1 - lr*wd) else L2 (g += wd*p).  wd_mask (nullable, uint8 per element):
  * weight decay applies where mask != 0 (bias / norm parameters are excluded, cmunet_config.py:84-91).
- * grad_scale multiplies the gradient first (loss-scale removal / DP mean).                          */
+ * grad_scale multiplies the gradient first (loss-scale removal / DP mean).
+ * amp_state (nullable, cmu_amp_*): the update is skipped when the state's found_inf flag is set, the gradient is divided
+ * by the state's scale, and the step number of the bias corrections is the state's count of updates taken + 1 (``step``
+ * is ignored) -- GradScaler.step / unscale_ without a host round trip.                               */
 int cmu_adam_step(float* p, const float* g, float* m, float* v, const uint8_t* wd_mask, int64_t n,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled,
-                  int64_t step, float grad_scale, void* stream);
+                  int64_t step, float grad_scale, const void* amp_state, void* stream);
+
+/* Dynamic loss scaling: AmpOptimWrapper(loss_scale='dynamic') of Pretraining/CM-UNet/configs/cmunet_config.py:76-78, i.e.
+ * torch.cuda.amp.GradScaler(init_scale 2^16, growth 2, backoff 0.5, growth_interval 2000), with the state on the device
+ * (cmu_amp_state_bytes() = 32 bytes: float scale, float found_inf, int32 growth_tracker, int32 good_steps,
+ * int32 skipped_steps, pad): no host synchronisation per step.  Per step: the loss kernel scales its gradient by
+ * state.scale; after the gradient exchange cmu_amp_check_finite raises found_inf if any gradient is inf / nan; the
+ * optimiser kernel skips or unscales (see cmu_adam_step); cmu_amp_update halves the scale after a skipped step or doubles
+ * it after growth_interval clean ones, and clears found_inf.                                                      */
+int cmu_amp_state_bytes(void);
+int cmu_amp_init(void* state, float init_scale, void* stream);
+int cmu_amp_check_finite(const float* g, int64_t n, void* state, void* stream);
+int cmu_amp_update(void* state, float growth_factor, float backoff_factor, int growth_interval, void* stream);
 
 /* soft-clDice building blocks (Finetuning/metrics.py:401-492): soft skeleton of an fp32 (planes, H, W) stack by num_iter
  * rounds of min/max pooling (the reference uses 10), and the four sums sum(skel_pred*y_true), sum(skel_pred),

@@ -101,15 +101,24 @@ def import_spark():
     return sp_encoder, sp_decoder, sp_spark, build_sparse_encoder
 
 
-def gen_spark(ref):
+_SPARK_MODS = None
+
+
+def gen_spark(ref, S=64, ratio=0.6, name="spark_unet", seed=71):
+    """``S`` = image side (f = S/16 patches per side; the reference model is size-agnostic), ``ratio`` = mask ratio.
+    spark_unet: 64 px, ratio 0.6 (6 of 16 patches active).  spark_unet_m75: 128 px at BASELINE config 5's ratio 0.75
+    (16 of 64 patches active per image; arg_util.py:30 / spark.py:82-86)."""
+    global _SPARK_MODS
     from oracle import unet as OU, spark as OS
-    enc_mod, dec_mod, spark_mod, build_sparse_encoder = import_spark()
+    if _SPARK_MODS is None:
+        _SPARK_MODS = import_spark()
+    enc_mod, dec_mod, spark_mod, build_sparse_encoder = _SPARK_MODS
     torch.manual_seed(0)
-    S, B = 64, 2                                  # f = 4 patches per side; the reference model is size-agnostic
+    B, f = 2, S // 16
     senc = build_sparse_encoder("unet_sparse", input_size=S, sbn=False)
-    model = spark_mod.SparK(sparse_encoder=senc, dense_decoder=dec_mod.UnetDecoder(), mask_ratio=0.6, densify_norm='', sbn=False)
-    assert model.fmap_h == 4 and model.len_keep == round(16 * 0.4) and model.hierarchy == 5
-    sd = OU.make_state_dict(base_ch=64, depth=5, seed=71)
+    model = spark_mod.SparK(sparse_encoder=senc, dense_decoder=dec_mod.UnetDecoder(), mask_ratio=ratio, densify_norm='', sbn=False)
+    assert model.fmap_h == f and model.len_keep == round(f * f * (1 - ratio)) and model.hierarchy == 5
+    sd = OU.make_state_dict(base_ch=64, depth=5, seed=seed)
     msd = model.state_dict()
     for k, v in sd.items():
         if "up_conv" in k or "conv_last" in k:
@@ -122,14 +131,15 @@ def gen_spark(ref):
             kk = "sparse_encoder.sp_cnn." + k
         assert kk in msd and tuple(msd[kk].shape) == tuple(v.shape), (kk, tuple(v.shape))
         msd[kk] = v.clone()
-    g = torch.Generator().manual_seed(72)
+    g = torch.Generator().manual_seed(seed + 1)
     tokens = [0.3 * torch.randn_like(p, generator=None) for p in model.mask_tokens]
     for i, t in enumerate(tokens):
         msd[f"mask_tokens.{i}"] = t
     model.load_state_dict(msd)
     model.train()
     x = torch.randn(B, 1, S, S, generator=g)
-    active = OS.make_active(B, 4, 0.6, g)
+    active = OS.make_active(B, f, ratio, g)
+    assert int(active.sum()) == B * model.len_keep
     loss = model(x, active_b1ff=active)
     loss.backward()
     # oracle restatement
@@ -159,7 +169,7 @@ def gen_spark(ref):
     extra = {"grad64." + k: n64[k].grad for k in spot}
     extra["token_grads64_flat"] = torch.cat([p.grad.flatten() for p in m64.mask_tokens])
     extra["grad_norms64"] = torch.stack([n64[k].grad.norm() for k in gkeys])
-    save("spark_unet", **extra, x=x, active=active.to(torch.uint8), loss=loss.detach(), seed=np.array(71),
+    save(name, **extra, x=x, active=active.to(torch.uint8), loss=loss.detach(), seed=np.array(seed), mask_ratio=np.array(ratio),
          tokens_flat=torch.cat([t.flatten() for t in tokens]),
          grad_norm_keys=np.array(gkeys), grad_norms=torch.stack([named[k].grad.norm() for k in gkeys]),
          token_grads_flat=torch.cat([p.grad.flatten() for p in model.mask_tokens]),
@@ -276,6 +286,9 @@ def main():
     ref, M = import_reference()
     torch.manual_seed(0)
     torch.set_num_threads(4)
+    if "--only-spark75" in sys.argv:    # tests/golden/spark_unet_m75.npz alone (BASELINE config 5's mask ratio)
+        gen_spark(None, S=128, ratio=0.75, name="spark_unet_m75", seed=171)
+        return
     if "--only-spark" in sys.argv:      # regenerate tests/golden/spark_unet.npz alone
         gen_spark(ref)
         return
@@ -487,6 +500,7 @@ def main():
          dlogits=logits.grad, bad_mode_msg=np.array(bad_mode_msg))
     # ---- 7. SparK (sparse masked conv) -- reference imported behind the stubs of SURVEY Appendix C-3 ---------
     gen_spark(ref)
+    gen_spark(ref, S=128, ratio=0.75, name="spark_unet_m75", seed=171)
     gen_optim()
     gen_cldice(M)
     print("all fixtures written; oracle == reference on every case")

@@ -1,0 +1,115 @@
+"""Child process of tests/test_gpu_dataparallel.py (not a test module): one data-parallel rank of a pretraining trainer.
+
+    python dp_child.py <mode> <out_prefix> [key=value ...]
+
+Runs under gloo with every rank on cuda:0 (the one-GPU box) -- or RCCL with one device per rank when CMU_DIST_BACKEND=nccl
+and enough GPUs exist.  Every rank is fed the SAME seeded batch unless data=rank; the result (losses, a selection of updated
+parameters, buffers) goes to <out_prefix>.<rank>.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np      # noqa: E402
+import torch            # noqa: E402
+import torch.distributed as dist   # noqa: E402
+
+
+def main():
+    mode, out = sys.argv[1], sys.argv[2]
+    opts = dict(kv.split("=", 1) for kv in sys.argv[3:])
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    backend = os.environ.get("CMU_DIST_BACKEND", "gloo")
+    dev = torch.device("cuda", rank if (backend == "nccl" and torch.cuda.device_count() > rank) else 0)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    from cmunet_amd import pretrain as P
+    from oracle import unet as OU
+    steps = int(opts.get("steps", "2"))
+    dseed = 100 + (rank if opts.get("data") == "rank" else 0)
+    g = torch.Generator().manual_seed(dseed)
+    res = {}
+    if mode == "recon":
+        from cmunet_amd import model as M
+        net = M.UNet(base_ch=16, depth=3, dtype=opts.get("dtype", "f32"))
+        net.load_state_dict(OU.make_state_dict(base_ch=16, depth=3, seed=9))
+        tr = P.MaskedReconPretrainer(net.to(dev), lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05, amp=opts.get("amp") == "1")
+        tr.broadcast_parameters()
+        losses = []
+        for it in range(steps):
+            x = torch.randn(2, 32, 64, generator=g).to(dev)
+            mask = torch.from_numpy(P.create_random_patch_mask(2, 32, 16, 0.5, np.random.RandomState(dseed + it))).to(dev)
+            mask = torch.cat([mask, mask], 2).contiguous()
+            losses.append(float(tr.step(x, mask)))
+        res = {"losses": losses, "arena": tr.flat.arena.cpu(), "bufs": {n: b.cpu() for n, b in net.named_buffers()}}
+    elif mode == "joint":
+        from cmunet_amd import cmunet as C
+        torch.manual_seed(0)
+        B, S = 4, 32
+        model = C.build_model(C.cmunet_config(img_size=S, dtype="f32", base_ch=16, depth=3)).to(dev).train()
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if p.dim() == 1 and ("bn" in n or ".1." in n or ".4." in n):
+                    p.add_(0.2 * torch.randn_like(p))
+            for pb, pm in zip(model.backbone.parameters(), model.target_backbone.parameters()):
+                pm.copy_(pb * 0.9)
+            for pb, pm in zip(model.projector.parameters(), model.target_projector.parameters()):
+                pm.copy_(pb * 1.1)
+        res["init"] = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        tr = P.JointPretrainer(model, lr=1e-3)
+        tr.broadcast_parameters()
+        img, img_t = torch.randn(B, S, S, generator=g), torch.randn(B, S, S, generator=g)
+        mask = torch.from_numpy(P.create_random_patch_mask(B, S, 16, 0.65, np.random.RandomState(2)))
+        Cr = model.reduced_channels()
+        gw = torch.Generator().manual_seed(7)
+        rw, rb = torch.randn(Cr, 64, 1, 1, generator=gw) * 0.1, torch.randn(Cr, generator=gw) * 0.1
+        model.momentum = 0.9
+        l = tr.step(img.to(dev), img_t.to(dev), mask.to(dev), reduce_w=rw.to(dev), reduce_b=rb.to(dev))
+        res.update({"loss_ct": float(l["loss_ct"]), "loss_rc": float(l["loss_rc"]), "img": img, "img_t": img_t, "mask": mask, "rw": rw, "rb": rb,
+                    "final": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}})
+    elif mode == "moco":
+        from cmunet_amd import moco as MO
+        torch.manual_seed(0)
+        B, S, K, T = 4, 32, 64, 0.2
+        m = MO.Moco_v2(emb_dim=64, num_negatives=K, softmax_temperature=T, encoder_momentum=0.99, learning_rate=0.05, dtype="f32",
+                       base_ch=16, depth=3).to(dev).train()
+        with torch.no_grad():
+            for pk in m.encoder_k.parameters():
+                pk.mul_(0.95)
+        res["init"] = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        tr = P.MocoPretrainer(m)
+        tr.broadcast_parameters()
+        xq, xk = torch.randn(B, 1, S, S, generator=g), torch.randn(B, 1, S, S, generator=g)
+        loss = tr.step(xq.to(dev), xk.to(dev))
+        res.update({"loss": float(loss), "xq": xq, "xk": xk, "final": {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}})
+    elif mode == "spark":
+        from cmunet_amd import spark as S
+        torch.manual_seed(5)
+        enc = S.build_sparse_encoder("unet_sparse", input_size=64, sbn=False, base_ch=16, depth=3, dtype="f32")
+        model = S.SparK(enc, S.UnetDecoder(base_ch=16, depth=3, dtype="f32"), mask_ratio=0.6, densify_norm="", dtype="f32").to(dev).train()
+        tr = P.SparKPretrainer(model, lr=1e-2)
+        tr.broadcast_parameters()
+        losses = []
+        for it in range(steps):
+            x = torch.randn(4, 1, 64, 64, generator=g)
+            f = model.fmap_h
+            active = torch.zeros(4, 1, f, f, dtype=torch.bool)
+            for b in range(4):
+                active[b, 0].view(-1)[torch.randperm(f * f, generator=g)[:model.len_keep]] = True
+            losses.append(float(tr.step(x.to(dev), active.to(dev), loss_scale=float(opts.get("loss_scale", "1")))))
+        res = {"losses": losses, "arena": tr.flat.arena.cpu(), "names": list(tr.flat.names)}
+    else:
+        raise SystemExit(f"unknown mode {mode}")
+    torch.save(res, f"{out}.{rank}")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -65,3 +65,26 @@ def test_lr_schedule_and_mask_device_free_logic():
     assert abs(cosine_warmup_lr(1.0, 0, 40, 300) - 1e-4) < 1e-12
     assert abs(cosine_warmup_lr(1.0, 40, 40, 300) - 1.0) < 1e-12
     assert cosine_warmup_lr(1.0, 300, 40, 300) < 1e-12
+
+
+def test_call_refuses_tensors_on_different_devices():
+    """Device binding of the C-ABI launches: pointers carry their device; a call mixing two devices is refused
+    before anything is launched (checked here without a GPU, with hand-made device pointers)."""
+    from cmunet_amd import _lib
+    a, b = _lib.devptr(0x1000, 0), _lib.devptr(0x2000, 1)
+    with pytest.raises(_lib.CmuError, match="different devices"):
+        _lib.call("cmu_ema_update", a, b, 16, 0.5, _lib.STREAM)
+    assert isinstance(a, __import__("ctypes").c_void_p) and a.dev == 0 and a.value == 0x1000
+
+
+def test_bench_self_launch_propagates_rank_failure():
+    """`python bench.py --gpus 2` without a launcher starts its own two ranks and never touches the GPU itself; here (no GPU)
+    both ranks fail at start-up: the parent must come back promptly with a non-zero status, not hang or re-exec."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert '"metric"' not in r.stdout

@@ -159,10 +159,12 @@ def test_oracle_vs_imported_reference():
         assert close(OU.unet_forward(x, OU.clone_sd(sd), training=True), m(x), 1e-4)
 
 
-def test_spark_golden(golden_dir):
-    """oracle/spark.py reproduces the loss the reference's SparK produced (fixture written by gen_golden.py)."""
+@pytest.mark.parametrize("fixture", ["spark_unet", "spark_unet_m75"])
+def test_spark_golden(golden_dir, fixture):
+    """oracle/spark.py reproduces the loss the reference's SparK produced (fixtures written by gen_golden.py: 64 px at mask
+    ratio 0.6, 128 px at BASELINE config 5's ratio 0.75)."""
     from oracle import spark as OS
-    d = np.load(f"{golden_dir}/spark_unet.npz")
+    d = np.load(f"{golden_dir}/{fixture}.npz")
     sd = OU.make_state_dict(base_ch=64, depth=5, seed=int(d["seed"]))
     osd = {}
     for k, v in sd.items():
@@ -174,7 +176,9 @@ def test_spark_golden(golden_dir):
     for c in (1024, 512, 256, 128, 64):
         toks.append(tok[off:off + c].view(1, c, 1, 1)); off += c
     loss, rec = OS.forward(torch.from_numpy(d["x"]), torch.from_numpy(d["active"]).bool(), osd, toks)
-    assert abs(float(loss) - float(d["loss"])) < 1e-5 and rec.shape == (2, 1, 64, 64)
+    assert abs(float(loss) - float(d["loss"])) < 1e-5 and rec.shape == tuple(d["x"].shape)
+    if fixture == "spark_unet_m75":
+        assert float(d["mask_ratio"]) == 0.75 and int(d["active"].sum()) == 2 * 16
     a = OS.make_active(3, 16, 0.6, torch.Generator().manual_seed(0))
     assert a.shape == (3, 1, 16, 16) and a.view(3, -1).sum(1).tolist() == [round(256 * 0.4)] * 3     # spark.py:29,82-86
 

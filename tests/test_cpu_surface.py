@@ -104,10 +104,9 @@ def test_cli_flags_and_meter():
     assert a.epochs == [3] and a.batch_size == [2, 4] and a.lr == [0.001] and a.name == "x" and a.ratio == 0.5
     d = T.get_args([])
     assert d.epochs == [2] and d.batch_size == [16, 32] and d.lr == [0.1, 1e-2, 1e-3, 1e-4, 1e-5, 1e-6] and d.pretrained is None
-    m = T.AverageValueMeter()
-    for v in (1.0, 2.0, 4.0):
-        m.add(v)
-    assert abs(m.mean - 7.0 / 3) < 1e-12 and abs(m.std - np.std([1, 2, 4], ddof=1)) < 1e-12
+    # the logs contract of Epoch.run (train.py:129-140): per key, the mean over the epoch's batches
+    means = T._epoch_means([[1.0, 10.0], [2.0, 20.0], [4.0, 60.0]])
+    assert abs(means[0] - 7.0 / 3) < 1e-12 and abs(means[1] - 30.0) < 1e-12
 
 
 def test_loss_algebra_names(golden_dir):

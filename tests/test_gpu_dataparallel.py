@@ -1,0 +1,223 @@
+"""Data-parallel trainers on the GPU: two ranks of every pretraining trainer against one rank and against the
+oracle.  Ranks run as child processes (tests/dp_child.py) over gloo with both ranks on cuda:0 -- the collectives, the arena
+exchange, the embedding all-gather with B*rank label offsets and the SyncBN exchange are the code paths RCCL takes on a
+multi-GPU node; with >= 2 GPUs and CMU_DIST_BACKEND=nccl the same tests run over RCCL.
+
+Reference semantics: DistributedDataParallel gradient MEAN (Spark/main.py:102; dist_train.sh:9-17 + cmunet_config.py:120;
+Lightning DDP for MoCo), concat_all_gather of the keys (cmunet_head.py:77-85, moco2_module.py:160-175), per-GPU encoder
+BatchNorm (UNet_encoder.py:22,25), SyncBN in the necks (nonlinear_neck.py:45,58)."""
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def cuda():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_ranks(mode, world, extra_env=None, **opts):
+    """Start ``world`` ranks of dp_child.py, wait, return their result dicts.  Every child is reaped (and killed if a peer
+    failed or the wait times out), so a failing rank cannot leave a process holding the GPU."""
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "r")
+        port = _free_port()
+        procs = []
+        try:
+            for rk in range(world):
+                env = dict(os.environ)
+                for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+                    env.pop(k, None)
+                if world > 1:
+                    env.update(WORLD_SIZE=str(world), RANK=str(rk), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                env.update(extra_env or {})
+                argv = [sys.executable, os.path.join(HERE, "dp_child.py"), mode, out] + [f"{k}={v}" for k, v in opts.items()]
+                procs.append(subprocess.Popen(argv, env=env))
+            for p in procs:
+                rc = p.wait(timeout=420)
+                assert rc == 0, f"rank exited with {rc}"
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+                p.wait()
+        return [torch.load(f"{out}.{rk}", weights_only=False) for rk in range(world)]
+
+
+def rel(got, ref):
+    return (got.double() - ref.double()).abs().max().item() / max(ref.double().abs().max().item(), 1e-9)
+
+
+def test_masked_recon_two_ranks_same_batch_equals_one_rank(cuda):
+    """Both ranks fed the same batches: SUM over ranks x 1/world == the local gradient exactly (2g * 0.5), so parameters after
+    two steps are bit-identical to the single-process trainer -- with the overlapped two-bucket exchange and without."""
+    one = run_ranks("recon", 1)[0]
+    for overlap in ("1", "0"):
+        two = run_ranks("recon", 2, extra_env={"CMU_DDP_OVERLAP": overlap})
+        for r in two:
+            assert r["losses"] == one["losses"]
+            assert torch.equal(r["arena"], one["arena"]), f"overlap={overlap}: max diff {(r['arena'] - one['arena']).abs().max().item():.3e}"
+            for k, v in one["bufs"].items():
+                assert torch.equal(r["bufs"][k], v), k
+
+
+def test_masked_recon_two_ranks_amp_and_f16(cuda):
+    """The same with f16 storage and the dynamic loss scaler: the inf / nan check runs on the exchanged gradients, so both
+    ranks take the same decision and stay bit-identical to each other and to one rank."""
+    one = run_ranks("recon", 1, dtype="f16", amp="1")[0]
+    two = run_ranks("recon", 2, dtype="f16", amp="1")
+    assert torch.equal(two[0]["arena"], two[1]["arena"])
+    assert torch.equal(two[0]["arena"], one["arena"])
+    assert all(np.isfinite(one["losses"]))
+
+
+def test_masked_recon_two_ranks_different_batches_vs_oracle(cuda):
+    """Different data per rank: the updated parameters follow the MEAN of the two ranks' gradients, each computed with its own
+    per-GPU BatchNorm statistics (oracle: one CPU forward/backward per rank, then torch AdamW on the averaged gradient)."""
+    from cmunet_amd.pretrain import create_random_patch_mask
+    from oracle import cmunet as OC, unet as OU
+    two = run_ranks("recon", 2, data="rank", steps=1)
+    assert torch.equal(two[0]["arena"], two[1]["arena"])
+    sd = OU.make_state_dict(base_ch=16, depth=3, seed=9)
+    names = [k for k, v in sd.items() if v.is_floating_point() and "running" not in k]
+    grads, losses = {k: 0.0 for k in names}, []
+    for rk in range(2):
+        osd = OU.clone_sd(sd, requires_grad=True)
+        g = torch.Generator().manual_seed(100 + rk)
+        x = torch.randn(2, 32, 64, generator=g)
+        m = torch.from_numpy(create_random_patch_mask(2, 32, 16, 0.5, np.random.RandomState(100 + rk)))
+        m = torch.cat([m, m], 2)
+        logits = OU.unet_forward(x * (1 - m[0]).float(), osd, training=True)
+        loss = OC.masked_mse(logits[:, 1], x, m)
+        loss.backward()
+        losses.append(float(loss))
+        for k in names:
+            grads[k] = grads[k] + osd[k].grad / 2
+    for rk in range(2):
+        assert abs(two[rk]["losses"][0] - losses[rk]) <= 1e-5 * max(1.0, abs(losses[rk]))
+    # first AdamW step from the averaged gradient: p*(1 - lr*wd) - lr*g/(|g| + eps); compare where the sign of g is not in doubt
+    off, checked = 0, 0
+    for k in names:
+        p0, g = sd[k], grads[k]
+        n = p0.numel()
+        got = two[0]["arena"][off:off + n].view_as(p0)
+        off += ((n + 3) // 4) * 4
+        wd = 0.0 if (k.endswith(".bias") or p0.dim() <= 1) else 0.05
+        exp = p0 * (1 - 1e-3 * wd) - 1e-3 * g / (g.abs() + 1e-8)
+        sure = g.abs() > 2e-3 * g.abs().max()
+        if ".0.bias" in k or ".3.bias" in k or not bool(sure.any()):
+            continue
+        assert (got - exp)[sure].abs().max().item() <= 2e-6, k
+        checked += int(sure.sum())
+    assert checked > 10000
+
+
+def _joint_oracle(r, gather_dup, rank=0):
+    from oracle import cmunet as OC
+    sd = r["init"]
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and not k.startswith("target_") else v.clone())
+           for k, v in sd.items()}
+    gather = (lambda t: torch.cat([t, t], 0)) if gather_dup else None
+    ref = OC.forward_train(r["img"], r["img_t"], r["mask"].numpy(), r["rw"], r["rb"], osd, temperature=0.07, ct_weight=1.0, rc_weight=1.0,
+                           gather=gather, rank=rank)
+    (ref["loss_ct"] + ref["loss_rc"]).backward()
+    return ref, osd
+
+
+def _check_joint(r, ref, osd, lr=1e-3, momentum=0.9):
+    assert abs(r["loss_rc"] - float(ref["loss_rc"])) <= 2e-4 * max(1, abs(float(ref["loss_rc"])))
+    assert abs(r["loss_ct"] - float(ref["loss_ct"])) <= 2e-3 * max(1, abs(float(ref["loss_ct"])))
+    init, final = r["init"], r["final"]
+    checked = 0
+    for k, v in osd.items():
+        if not (torch.is_tensor(v) and v.requires_grad) or v.grad is None or ".0.bias" in k or ".3.bias" in k:
+            continue
+        g = v.grad
+        if g.abs().max() < 1e-6:
+            continue
+        wd = 0.0 if (k.endswith(".bias") or v.dim() <= 1) else 0.05
+        exp = init[k] * (1 - lr * wd) - lr * g / (g.abs() + 1e-8)
+        sure = g.abs() > 2e-2 * g.abs().max()            # (gradient parity is 5e-3 of the max norm: test_gpu_pretrain)
+        assert (final[k] - exp)[sure].abs().max().item() <= 5e-6, k
+        checked += int(sure.sum())
+    assert checked > 5000
+    # EMA after the optimiser step (MomentumUpdateHook.after_train_iter): target = m*target + (1-m)*online_new
+    for src, dst in (("backbone.", "target_backbone."), ("projector.", "target_projector.")):
+        for k in final:
+            if k.startswith(src) and final[k].is_floating_point() and "running" not in k:
+                kt = dst + k[len(src):]
+                assert rel(final[kt], init[kt] * momentum + final[k] * (1 - momentum)) <= 1e-6, kt
+
+
+def test_joint_trainer_one_and_two_ranks_vs_oracle(cuda):
+    """CM-UNet joint step through JointPretrainer (AdamW arena + EMA arenas).  One rank against the oracle; two ranks fed the
+    same batch against the oracle with the key all-gather emulated (2B keys, labels i + B*rank) -- SyncBN over duplicated rows
+    has the single-rank statistics, so everything but the contrastive loss's denominator is unchanged."""
+    one = run_ranks("joint", 1)[0]
+    ref, osd = _joint_oracle(one, False)
+    _check_joint(one, ref, osd)
+    two = run_ranks("joint", 2)
+    for rk, r in enumerate(two):
+        ref2, osd2 = _joint_oracle(r, True, rank=rk)
+        _check_joint(r, ref2, osd2)
+    for k, v in two[0]["final"].items():
+        if v.is_floating_point():
+            assert torch.equal(v, two[1]["final"][k]), k                      # replicas stay identical
+    assert abs(two[0]["loss_ct"] - one["loss_ct"]) > 1e-3                  # 2B keys: a different denominator than one rank
+
+
+def test_moco_trainer_two_ranks_vs_oracle(cuda):
+    """MocoPretrainer on two ranks with the same batch: keys gathered (2B rows enqueued, pointer += 2B), gradient mean, fused
+    SGD-momentum, one-launch EMA of the key encoder -- against the oracle step with the gather emulated."""
+    from oracle import moco as OM
+    two = run_ranks("moco", 2)
+    r = two[0]
+    sd = r["init"]
+    osd = {k: (v.clone().requires_grad_(True) if k.startswith("encoder_q.") and v.is_floating_point() and "running" not in k else v.clone())
+           for k, v in sd.items()}
+    queue, ptr = sd["queue"].clone(), sd["queue_ptr"].clone()
+    ref, _, _ = OM.training_step(r["xq"], r["xk"], osd, queue, ptr, 0.2, 0.99, gather=lambda t: torch.cat([t, t], 0))
+    ref.backward()
+    assert abs(r["loss"] - float(ref)) <= 1e-3 * max(1.0, abs(float(ref)))
+    fin = r["final"]
+    assert int(fin["queue_ptr"]) == int(ptr) == 8 and rel(fin["queue"], queue) <= 1e-4
+    lr, wd = 0.05, 1e-4
+    for k in ("encoder_q.down_conv1.double_conv.double_conv.0.weight", "encoder_q.double_conv.double_conv.3.weight",
+              "encoder_q.down_conv2.double_conv.double_conv.4.bias"):
+        exp = sd[k] - lr * (osd[k].grad + wd * sd[k])                      # first SGD-momentum step: buf = g + wd*p
+        assert rel(fin[k] - sd[k], exp - sd[k]) <= 5e-3, k
+    kk = "encoder_k.double_conv.double_conv.0.weight"
+    assert rel(fin[kk], osd[kk]) <= 1e-6                                    # EMA before the forward (A-8), one launch
+    for k, v in fin.items():
+        if v.is_floating_point():
+            assert torch.equal(v, two[1]["final"][k]), k
+
+
+def test_spark_trainer_two_ranks_equals_one_rank(cuda):
+    """SparKPretrainer (LAMB) with grad-less ``densify_projs`` parameters in the arena (SURVEY A-10): two ranks fed the same
+    batches match one rank; a static loss scale inside the fused step leaves the update unchanged."""
+    one = run_ranks("spark", 1)[0]
+    two = run_ranks("spark", 2)
+    scaled = run_ranks("spark", 1, loss_scale=256)[0]
+    assert any(n.startswith("densify_projs") for n in one["names"])
+    for r in two:
+        assert np.allclose(r["losses"], one["losses"], rtol=1e-6)
+        assert rel(r["arena"], one["arena"]) <= 1e-6
+    assert np.allclose(scaled["losses"], one["losses"], rtol=1e-6) and rel(scaled["arena"], one["arena"]) <= 1e-5

@@ -1,5 +1,9 @@
-"""Full-size checks (BASELINE configs[1]: bs 32, 512 x 512, bf16) through size-independent properties -- the oracle cannot
-run these shapes in seconds, the properties can:
+"""Full-size checks (BASELINE configs[1]: bs 32, 512 x 512; f16 = the bench's default arithmetic, bf16 as well).
+(1) Sampled windows against fp64: for every 3x3 layer shape of the bench step, output windows scattered over the
+(32, S, S, C) tensor -- image corners and edges, the last image (offsets past 2^31 bytes), tile seams -- are recomputed on
+the CPU in float64 from the input window + halo and the quantised weights, for the forward / data-gradient kernel; weight
+gradients against a float64 reference on a 2-image sub-batch.  A dropped tap, a wrong halo or a mis-addressed tile shows here.
+(2) Size-independent properties -- the oracle cannot run these shapes in seconds, the properties can:
   * exact homogeneity: scaling an operand by 2 scales conv / data-gradient / weight-gradient outputs by exactly 2 (a power
     of two commutes with every fp32 accumulation and bf16 rounding in the kernels);
   * batch equivariance: permuting the images permutes the outputs bit for bit (tiles never mix images);
@@ -9,8 +13,15 @@ run these shapes in seconds, the properties can:
 """
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+
+# same per-dtype bar as the op-level tests (tests/test_gpu_fwd_ops.py:11): relative to the max of the reference window
+TOL = {"f16": 2e-3, "bf16": 1.6e-2}
+# every 3x3 conv of the reference UNet at 512 x 512 (Cin, Cout, S) -- SURVEY Appendix B (down1.conv1 has Cin = 1: direct kernel)
+LAYERS = [(64, 64, 512), (128, 64, 512), (64, 128, 256), (128, 128, 256), (256, 128, 256), (128, 256, 128), (256, 256, 128),
+          (512, 256, 128), (256, 512, 64), (512, 512, 64), (1024, 512, 64), (512, 1024, 32), (1024, 1024, 32)]
 
 B, H, W = 32, 512, 512
 
@@ -27,17 +38,97 @@ def _act(ops, t):
     return ops.Act(t, 0, t.shape[3])
 
 
+def _windows(S, n, gen, win=8):
+    """(b, y0, x0) origins of win x win output windows: the four corners of the first and the last image, windows straddling
+    16-row / 32-column tile seams, and random ones."""
+    out = [(b, y, x) for b in (0, B - 1) for y in (0, S - win) for x in (0, S - win)]
+    while len(out) < n:
+        b = int(torch.randint(0, B, (1,), generator=gen))
+        if len(out) % 2 == 0 and S >= 64:
+            y = 16 * int(torch.randint(1, S // 16, (1,), generator=gen)) - win // 2
+            x = 32 * int(torch.randint(1, S // 32, (1,), generator=gen)) - win // 2
+        else:
+            y, x = int(torch.randint(0, S - win + 1, (1,), generator=gen)), int(torch.randint(0, S - win + 1, (1,), generator=gen))
+        out.append((b, y, x))
+    return out[:n]
+
+
+def _halo(t_bhwc, b, y0, x0, win, S):
+    """(1, C, win+2, win+2) float64 window of image b with one pixel of halo, zero outside the image (padding = 1)."""
+    C = t_bhwc.shape[3]
+    out = torch.zeros(win + 2, win + 2, C, dtype=torch.float64)
+    ys, xs = max(y0 - 1, 0), max(x0 - 1, 0)
+    ye, xe = min(y0 + win + 1, S), min(x0 + win + 1, S)
+    out[ys - (y0 - 1):ye - (y0 - 1), xs - (x0 - 1):xe - (x0 - 1)] = t_bhwc[b, ys:ye, xs:xe].double().cpu()
+    return out.permute(2, 0, 1).unsqueeze(0)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("layer", LAYERS)
+def test_conv3x3_fwd_and_dgrad_sampled_windows_fp64(ops, layer, dt):
+    Cin, Cout, S = layer
+    tdt = ops.TORCH_DT[ops.dt_code(dt)]
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(B, S, S, Cin, generator=g, device="cuda").to(tdt)
+    dy = torch.randn(B, S, S, Cout, generator=g, device="cuda").to(tdt)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g, device="cuda") / (3 * Cin ** 0.5)
+    wq = w.to(tdt).double().cpu()                                  # what the packed copies hold
+    y = ops.new_act(B, S, S, Cout, dt, "cuda")
+    ops.conv3x3_fwd(_act(ops, x), ops.pack_conv3x3(w, dt), y, ops.new_stats(B, S, S, Cout, "cuda"))
+    dx = ops.new_act(B, S, S, Cin, dt, "cuda")
+    ops.conv3x3_fwd(_act(ops, dy), ops.pack_conv3x3(w, dt, transpose_flip=True), dx, None)
+    win = 8
+    n = int(max(6, min(64, 6e9 / (2.0 * win * win * 9 * Cin * Cout * 2))))       # ~6 GFLOP of float64 per case
+    wq_t = wq.permute(1, 0, 2, 3).flip(2, 3).contiguous()                          # data gradient = conv with the flipped, transposed taps
+    worst_f = worst_d = 0.0
+    for (b, y0, x0) in _windows(S, n, torch.Generator().manual_seed(7), win):
+        ref = F.conv2d(_halo(x, b, y0, x0, win, S), wq)[0].permute(1, 2, 0)
+        got = y.buf[b, y0:y0 + win, x0:x0 + win].double().cpu()
+        e = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+        assert e <= TOL[dt], f"forward {layer} {dt}: window (b={b}, y={y0}, x={x0}) err {e:.3e}"
+        worst_f = max(worst_f, e)
+        refd = F.conv2d(_halo(dy, b, y0, x0, win, S), wq_t)[0].permute(1, 2, 0)
+        gotd = dx.buf[b, y0:y0 + win, x0:x0 + win].double().cpu()
+        e = (gotd - refd).abs().max().item() / max(refd.abs().max().item(), 1e-6)
+        assert e <= TOL[dt], f"dgrad {layer} {dt}: window (b={b}, y={y0}, x={x0}) err {e:.3e}"
+        worst_d = max(worst_d, e)
+    print(f"[fullsize {dt} {Cin}->{Cout}@{S}] {n} windows: fwd err {worst_f:.2e}, dgrad err {worst_d:.2e} (tol {TOL[dt]})")
+
+
+@pytest.mark.parametrize("case", [(64, 64, 512, "f16"), (128, 64, 512, "f16"), (128, 128, 256, "f16"), (64, 64, 512, "bf16"),
+                                  (1024, 1024, 32, "f16")])
+def test_conv3x3_wgrad_fp64_two_image_subbatch(ops, case):
+    """Weight gradient at the full image size on two images against float64 (the split-K schedule depends on the pixel count,
+    so the full-size tiling is what runs; 32 images would only lengthen the K loop -- covered by the homogeneity test below)."""
+    from cmunet_amd import _lib
+    Cin, Cout, S, dt = case
+    tdt = ops.TORCH_DT[ops.dt_code(dt)]
+    nb = 2
+    g = torch.Generator(device="cuda").manual_seed(13)
+    x = torch.randn(nb, S, S, Cin, generator=g, device="cuda").to(tdt)
+    dy = torch.randn(nb, S, S, Cout, generator=g, device="cuda").to(tdt)
+    ws = torch.empty(_lib.lib().cmu_conv3x3_wgrad_ws_bytes(nb, S, S, Cin, Cout, ops.dt_code(dt)), dtype=torch.uint8, device="cuda")
+    dW = torch.empty(Cout, Cin, 3, 3, device="cuda")
+    ops.conv3x3_wgrad(_act(ops, x), _act(ops, dy), dW, ws)
+    xs, ds = x.double().cpu().permute(0, 3, 1, 2), dy.double().cpu().permute(0, 3, 1, 2)
+    ref = torch.nn.grad.conv2d_weight(xs, (Cout, Cin, 3, 3), ds, padding=1)
+    e = (dW.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    print(f"[fullsize wgrad {dt} {Cin}->{Cout}@{S}] err {e:.2e}")
+    assert e <= 2e-4, e          # fp32 accumulation of exactly representable 16-bit products: only the summation order differs
+
+
 # (Cin, Cout, H): first kernel (64->64), 64-channel wide variant (128->64), wide kernel (128->128 at the second level)
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("shape", [(64, 64, 512), (128, 64, 512), (128, 128, 256)])
-def test_conv3x3_homogeneity_permutation_checksum(ops, shape):
+def test_conv3x3_homogeneity_permutation_checksum(ops, shape, dt):
     Cin, Cout, S = shape
     g = torch.Generator(device="cuda").manual_seed(1)
-    x = torch.randn(B, S, S, Cin, generator=g, device="cuda").to(torch.bfloat16)
+    x = torch.randn(B, S, S, Cin, generator=g, device="cuda").to(ops.TORCH_DT[ops.dt_code(dt)])
     w = torch.randn(Cout, Cin, 3, 3, generator=g, device="cuda") / (3 * Cin ** 0.5)
-    wp = ops.pack_conv3x3(w, "bf16")
+    wp = ops.pack_conv3x3(w, dt)
 
     def conv(inp):
-        y = ops.new_act(B, S, S, Cout, "bf16", "cuda")
+        y = ops.new_act(B, S, S, Cout, dt, "cuda")
         st = ops.new_stats(B, S, S, Cout, "cuda")
         ops.conv3x3_fwd(_act(ops, inp), wp, y, st)
         return y.buf, st
@@ -49,7 +140,7 @@ def test_conv3x3_homogeneity_permutation_checksum(ops, shape):
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(2)).cuda()
     y3, _ = conv(x[perm].contiguous())
     assert torch.equal(y3, y1[perm]), "outputs depend on the position of an image in the batch"
-    # checksum: slab sums (fp32 accumulators before rounding) against the stored bf16 tensor
+    # checksum: slab sums (fp32 accumulators before rounding) against the stored 16-bit tensor
     s = st1.double().sum(0)
     yd = y1.double()
     ref1, ref2 = yd.sum((0, 1, 2)), (yd * yd).sum((0, 1, 2))
@@ -57,19 +148,21 @@ def test_conv3x3_homogeneity_permutation_checksum(ops, shape):
     assert ((s[1] - ref2).abs() <= 4e-3 * ref2).all()
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("shape", [(64, 64, 512), (64, 128, 256), (128, 64, 512)])
-def test_conv3x3_backward_homogeneity(ops, shape):
+def test_conv3x3_backward_homogeneity(ops, shape, dt):
     from cmunet_amd import _lib
     Cin, Cout, S = shape
+    tdt = ops.TORCH_DT[ops.dt_code(dt)]
     g = torch.Generator(device="cuda").manual_seed(3)
-    x = torch.randn(B, S, S, Cin, generator=g, device="cuda").to(torch.bfloat16)
-    dy = torch.randn(B, S, S, Cout, generator=g, device="cuda").to(torch.bfloat16)
+    x = torch.randn(B, S, S, Cin, generator=g, device="cuda").to(tdt)
+    dy = torch.randn(B, S, S, Cout, generator=g, device="cuda").to(tdt)
     w = torch.randn(Cout, Cin, 3, 3, generator=g, device="cuda") / (3 * Cin ** 0.5)
-    wpf = ops.pack_conv3x3(w, "bf16", transpose_flip=True)
-    ws = torch.empty(_lib.lib().cmu_conv3x3_wgrad_ws_bytes(B, S, S, Cin, Cout, ops.dt_code("bf16")), dtype=torch.uint8, device="cuda")
+    wpf = ops.pack_conv3x3(w, dt, transpose_flip=True)
+    ws = torch.empty(_lib.lib().cmu_conv3x3_wgrad_ws_bytes(B, S, S, Cin, Cout, ops.dt_code(dt)), dtype=torch.uint8, device="cuda")
 
     def bwd(d):
-        dx = ops.new_act(B, S, S, Cin, "bf16", "cuda")
+        dx = ops.new_act(B, S, S, Cin, dt, "cuda")
         ops.conv3x3_fwd(_act(ops, d), wpf, dx, None)
         dW = torch.empty(Cout, Cin, 3, 3, device="cuda")
         ops.conv3x3_wgrad(_act(ops, x), _act(ops, d), dW, ws)
@@ -83,7 +176,9 @@ def test_conv3x3_backward_homogeneity(ops, shape):
     assert torch.equal(dx3, dx1) and torch.equal(dW3, dW1), "backward kernels are not bitwise reproducible"
 
 
-def test_training_step_reproducible_and_consistent():
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_training_step_reproducible_and_consistent(dt):
+    """``f16``: with the dynamic loss scaler, as bench.py runs it."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from cmunet_amd import model as M
@@ -95,8 +190,8 @@ def test_training_step_reproducible_and_consistent():
 
     def run(steps):
         torch.manual_seed(0)
-        net = M.UNet(out_classes=2, dtype="bf16").to(dev)
-        tr = MaskedReconPretrainer(net, lr=1.5e-4 * B / 256.0, betas=(0.9, 0.95), weight_decay=0.05)
+        net = M.UNet(out_classes=2, dtype=dt).to(dev)
+        tr = MaskedReconPretrainer(net, lr=1.5e-4 * B / 256.0, betas=(0.9, 0.95), weight_decay=0.05, amp=(dt == "f16"))
         losses = [float(tr.step(img, mask)) for _ in range(steps)]
         return losses, tr.flat.grad.clone(), tr.flat.arena.clone(), tr
 
@@ -116,3 +211,39 @@ def test_training_step_reproducible_and_consistent():
     # (the forward above moved the BatchNorm running statistics, not the batch-statistics output: same logits)
     assert abs(loss_again - ref) <= 2e-4 * max(1.0, abs(ref)), (loss_again, ref)
     assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+    if dt == "f16":
+        sc, _, _, good, skipped = tr.amp.read()
+        assert (good, skipped) == (3, 0) and sc == 65536.0, (sc, good, skipped)
+
+
+def test_spark_full_size_step_f16_mask075():
+    """BASELINE config 5 as stated: SparK sparse UNet at 512 x 512, mask ratio 0.75 (256 of 1,024 patches kept), fp16.  One
+    step at bs 8 with a static loss scale: finite, bitwise reproducible, a loss of the order of 1 (targets are patch-normalised)
+    and gradients of a sane size.  (Parity of the same configuration against the reference: the 128-pixel fixture
+    ``spark_unet_m75`` in tests/test_gpu_pretrain.py.)"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cmunet_amd import spark as S
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    enc = S.build_sparse_encoder("unet_sparse", input_size=512, dtype="f16")
+    model = S.SparK(enc, S.UnetDecoder(dtype="f16"), mask_ratio=0.75, densify_norm="", dtype="f16").to(dev).train()
+    assert model.fmap_h == 32 and model.len_keep == 256
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(8, 1, 512, 512, generator=g).to(dev)
+    active = model.mask(8, dev, g)
+    assert active.view(8, -1).sum(1).tolist() == [256] * 8
+
+    def run():
+        model.zero_grad()
+        model.grad_scale = 4096.0
+        loss = model(x, active_b1ff=active)
+        loss.backward()
+        return float(loss), torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None])
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    l1, g1 = run()
+    model.load_state_dict(sd0)
+    l2, g2 = run()
+    assert l1 == l2 and torch.equal(g1, g2) and torch.isfinite(g1).all() and 0.3 < l1 < 3.0, (l1, l2)
+    gn = float(g1.norm()) / 4096.0
+    assert 1e-3 < gn < 1e3, gn

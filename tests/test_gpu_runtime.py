@@ -1,0 +1,136 @@
+"""Host-side runtime behaviour of the HIP path on the GPU: device binding of the C-ABI launches, the shared loss / metric
+pass and its cache, the dynamic loss scaler (AmpOptimWrapper of cmunet_config.py:76-78 = torch GradScaler's protocol)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cuda():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda")
+
+
+def test_seg_stats_cache_is_keyed_on_tensor_identity(cuda):
+    """Two successive no-grad evaluations whose tensors are freed in between: the caching allocator hands the second batch the
+    first batch's addresses (version 0 again) -- the loss / Dice / IoU must be those of the second batch."""
+    from cmunet_amd import metrics as M
+    from oracle import losses as OL
+    crit = M.DiceLoss(activation="softmax", threshold=0.5, ignore_channels=[0]) + M.CrossEntropyLoss()
+    iou = M.IoU(threshold=0.5, activation="softmax", ignore_channels=[0])
+    g = torch.Generator().manual_seed(0)
+    seen_ptrs, vals = [], []
+    for it in range(3):
+        lo = torch.randn(2, 2, 32, 32, generator=g)
+        y1 = (torch.rand(2, 32, 32, generator=g) > 0.7).double()
+        y = torch.stack([1 - y1, y1], 1)
+        with torch.no_grad():
+            p, t = lo.to(cuda), y.to(cuda)
+            seen_ptrs.append((p.data_ptr(), t.data_ptr()))
+            got = (float(crit(p, t)), float(iou(p, t)))
+        del p, t
+        ref = (float(OL.dice_ce_loss(lo, y)), float(OL.iou_loss(lo, y)))
+        vals.append(got)
+        assert abs(got[0] - ref[0]) <= 1e-5 and abs(got[1] - ref[1]) <= 1e-6, (it, got, ref)
+    assert len(set(seen_ptrs)) < 3, "the allocator did not reuse the addresses: the scenario was not exercised"
+    assert len({v[0] for v in vals}) == 3
+    # one pair evaluated by several objects -> one fused pass (same output tensor)
+    p, t = torch.randn(1, 2, 16, 16).to(cuda), torch.zeros(1, 2, 16, 16, dtype=torch.float64).to(cuda)
+    assert M.seg_stats(p, t) is M.seg_stats(p, t)
+    p.add_(1.0)                                                      # in-place change: new pass
+    a = M.seg_stats(p, t)
+    p.add_(1.0)
+    assert M.seg_stats(p, t) is not a
+
+
+def test_amp_scaler_protocol(cuda):
+    """cmu_amp_*: scale on the device; clean steps unscale exactly (power of two) and count towards growth, an inf / nan skips
+    the update, halves the scale and resets the tracker; Adam's bias corrections use the number of updates actually taken."""
+    from cmunet_amd import ops
+    n = 1000
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) for _ in range(5)]
+    amp = ops.AmpScaler(cuda, init_scale=1024.0, growth_interval=2)
+    p, m, v = p0.clone().to(cuda), torch.zeros(n, device=cuda), torch.zeros(n, device=cuda)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref], lr=1e-2, betas=(0.9, 0.95), weight_decay=0.05)
+    sched = [False, True, False, False, False]                       # step 1 carries an inf
+    scale, clean = 1024.0, 0
+    for it, (gr, bad) in enumerate(zip(grads, sched)):
+        gs = (gr * scale).to(cuda)
+        if bad:
+            gs[17] = float("inf")
+        amp.check(gs)
+        ops.adam_step(p, gs, m, v, None, 1e-2, 0.9, 0.95, 1e-8, 0.05, True, 10 ** 6, 1.0, amp)    # host step number is ignored
+        amp.update()
+        if not bad:
+            opt.zero_grad()
+            ref.grad = gr.clone()
+            opt.step()
+        assert (p.cpu() - ref.detach()).abs().max().item() <= 2e-6, it
+        if bad:
+            scale, clean = scale * 0.5, 0
+        else:
+            clean += 1
+            if clean == 2:
+                scale, clean = scale * 2.0, 0
+    sc, found, tracker, good, skipped = amp.read()
+    # clean, skip (x0.5, tracker 0), clean, clean (growth x2, tracker 0), clean
+    assert (sc, found, tracker, good, skipped) == (1024.0, 0.0, 1, 4, 1)
+    gn = torch.full((n,), float("nan"), device=cuda)
+    amp.check(gn)
+    assert amp.read()[1] == 1.0
+
+
+def test_masked_recon_trainer_f16_amp_tracks_f32(cuda):
+    """The bench's default arithmetic on a small model: f16 storage + dynamic loss scale follows the f32 trainer (loss within
+    2 %), never skips a step from an overflow at the initial scale, and without the scale the f16 gradients of a large batch of
+    pixels underflow (which is why the reference's AMP wrapper scales)."""
+    from cmunet_amd import model as M
+    from cmunet_amd.pretrain import MaskedReconPretrainer, random_patch_mask_device
+    from oracle import unet as OU
+    sd = OU.make_state_dict(base_ch=16, depth=3, seed=9)
+    nets = {}
+    for key, dt, amp in (("f32", "f32", False), ("f16amp", "f16", True)):
+        n = M.UNet(base_ch=16, depth=3, dtype=dt)
+        n.load_state_dict(sd)
+        nets[key] = MaskedReconPretrainer(n.to(cuda).train(), lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05, amp=amp)
+    g = torch.Generator(device=cuda).manual_seed(0)
+    for it in range(4):
+        x = torch.randn(4, 64, 64, generator=g, device=cuda)
+        mask = random_patch_mask_device(4, 64, 64, 16, 0.5, g, cuda)
+        la, lb = float(nets["f32"].step(x, mask)), float(nets["f16amp"].step(x, mask))
+        assert math.isfinite(lb) and abs(la - lb) <= 2e-2 * max(1.0, abs(la)), (it, la, lb)
+    sc, _, tracker, good, skipped = nets["f16amp"].amp.read()
+    assert (good, skipped, tracker) == (4, 0, 4) and sc == 65536.0
+    a, b = nets["f32"].flat.arena, nets["f16amp"].flat.arena
+    assert (a - b).abs().max().item() <= 4.5e-3                       # 4 Adam steps of 1e-3: at most a few sign disagreements
+
+
+def test_launches_follow_the_tensors_device(cuda):
+    """every C-ABI launch is bound to the device that owns its tensors (the reference's driver uses cuda:1,
+    Finetuning/train.py:246,451).  With two GPUs: a model on cuda:1 runs there while the current device stays 0."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (tests/test_cpu_abi.py covers the mixed-device check without a GPU)")
+    from cmunet_amd import model as M
+    from oracle import unet as OU
+    sd = OU.make_state_dict(base_ch=16, depth=3, seed=1)
+    x = torch.randn(2, 32, 32, generator=torch.Generator().manual_seed(0))
+    outs = []
+    for d in (0, 1):
+        net = M.UNet(base_ch=16, depth=3, dtype="f32")
+        net.load_state_dict(sd)
+        net = net.to(f"cuda:{d}").eval()
+        torch.cuda.set_device(0)
+        with torch.no_grad():
+            outs.append(net(x.to(f"cuda:{d}")).cpu())
+        assert torch.cuda.current_device() == 0
+    assert torch.equal(outs[0], outs[1])
+    ref = OU.unet_forward(x, sd, training=False)
+    assert (outs[1] - ref).abs().max().item() <= 1e-3
