@@ -92,12 +92,25 @@ _SIGS = {
     "cmu_mask_select": (_I, [_P, _L, _P, _P, _I, _P, _I, _I, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "cmu_bn_bwd_reduce_masked": (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P, _P]),
     "cmu_bn_bwd_apply_masked": (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "cmu_sparse_tile_list": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "cmu_conv3x3_tiles_supported": (_I, [_I, _I, _I, _I, _I, _I]),
+    "cmu_conv3x3_fwd_tiles": (_I, [_P, _L, _P, _P, _I, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "cmu_conv3x3_wgrad_tiles": (_I, [_P, _L, _P, _P, _I, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "cmu_spark_loss_ws_bytes": (_L, [_I, _I]),
     "cmu_spark_loss_fwd_bwd": (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P]),
     "cmu_gap_fwd": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cmu_gap_bwd": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "cmu_ema_update": (_I, [_P, _P, _L, _F, _P]),
     "cmu_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _L, _F, _P, _P]),
+    "cmu_skinny16_gemm_ws_bytes": (_L, [_I, _I, _L]),
+    "cmu_skinny16_gemm_fwd": (_I, [_P, _P, _P, _P, _I, _I, _L, _I, _P, _P]),
+    "cmu_skinny16_gemm_dgrad": (_I, [_P, _P, _P, _I, _I, _L, _I, _P]),
+    "cmu_skinny16_gemm_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _L, _I, _P]),
+    "cmu_bn1d_colsums": (_I, [_P, _P, _I, _I, _P]),
+    "cmu_bn1d_relu_fwd": (_I, [_P, _P, _L, _P, _P, _P, _P, _F, _F, _I, _I, _P, _P, _P, _I, _I, _P]),
+    "cmu_bn1d_bwd_colsums": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I, _P]),
+    "cmu_bn1d_relu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _P, _P, _P, _I, _I, _P]),
+    "cmu_conv1x1_nchw_fwd": (_I, [_P, _L, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "cmu_amp_state_bytes": (_I, []),
     "cmu_amp_init": (_I, [_P, _F, _P]),
     "cmu_amp_check_finite": (_I, [_P, _L, _P, _P]),

@@ -8,9 +8,10 @@
   MomentumUpdateHook.momentum(cur_iter, max_iter)                              core/hooks/momentum_update_hook.py:29-40
 
 The mmengine registry / Runner are not rebuilt (out of scope); the classes take the same config
-dicts (``cmunet_config.py:5-42``) and build their children directly.  Conv blocks, losses, EMA and the
-optimiser run on the HIP kernels; the two MLP necks (fc -> BN1d -> ReLU -> fc, M = batch rows) are plain
-library GEMMs (rocBLAS through torch.nn.functional.linear), which the design rules allow for un-fused GEMMs.
+dicts (``cmunet_config.py:5-42``) and build their children directly.  Conv blocks, losses, EMA, the optimiser, the MLP
+necks (fc -> BN1d -> ReLU -> fc on <= 32 rows per GPU: weight-streaming skinny GEMMs + BatchNorm1d kernels, csrc/skinny.hip,
+necks.hip) and the target latent's 1x1 reduction all run on the HIP kernels; only a Linear on more than 32 rows would be a
+plain library GEMM.
 
 Reference quirks are replicated behind ``ref_compat=True``: the mask of sample 0 masks
 the whole batch (A-1); a fresh randomly initialised Conv2d(1024,256,1) reduces the target latent at every
@@ -23,7 +24,6 @@ import numpy as np
 import torch
 import torch.distributed as dist
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import _lib, ops
 from .model import DoubleConv, DownBlock, UpBlock, _EngineOwner, _named_state, _param_args, _require_cuda
@@ -223,32 +223,74 @@ class MUNetPretrainDecoder(_EngineOwner, nn.Module):
 
 
 class _SkinnyLinearFn(torch.autograd.Function):
-    """nn.Linear on <= 32 rows through the weight-streaming kernels (csrc/skinny.hip): one pass over the weights for the
-    forward, one for the input gradient, one write of the weight gradient."""
+    """nn.Linear on <= 32 rows through the weight-streaming kernels (csrc/skinny.hip, necks.hip): one pass over the weights
+    for the forward, one for the input gradient, one write of the weight gradient.  ``compute_dt`` None: exact fp32 products;
+    'f16' / 'bf16': the AMP arithmetic (operands rounded in registers, fp32 accumulation)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, compute_dt):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return ops.skinny_gemm_fwd(x.detach(), weight.detach(), None if bias is None else bias.detach())
+        ctx.compute_dt = compute_dt
+        return ops.skinny_gemm_fwd(x.detach(), weight.detach(), None if bias is None else bias.detach(), compute_dt)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = ops.skinny_gemm_dgrad(dy, weight.detach()) if ctx.needs_input_grad[0] else None
-        dw, db = (ops.skinny_gemm_wgrad(dy, x.detach(), ctx.has_bias) if ctx.needs_input_grad[1] else (None, None))
+        dx = ops.skinny_gemm_dgrad(dy, weight.detach(), ctx.compute_dt) if ctx.needs_input_grad[0] else None
+        dw, db = (ops.skinny_gemm_wgrad(dy, x.detach(), ctx.has_bias, ctx.compute_dt) if ctx.needs_input_grad[1] else (None, None))
         if ctx.has_bias and db is None and ctx.needs_input_grad[2]:
             db = dy.sum(0)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def neck_linear(fc, x):
+def neck_linear(fc, x, compute_dt=None):
     """``fc(x)`` for the necks' Linear layers (nonlinear_neck.py:63-66, 95-101): skinny kernels for <= 32 fp32 rows, else the
     library GEMM (rocBLAS through torch) that a plain tall product is."""
     if ops.skinny_eligible(x, fc.weight):
-        return _SkinnyLinearFn.apply(x, fc.weight, fc.bias)
+        return _SkinnyLinearFn.apply(x, fc.weight, fc.bias, compute_dt)
     return fc(x)
+
+
+class _BN1dFn(torch.autograd.Function):
+    """(Sync)BatchNorm1d (+ the ReLU that follows it) of the necks on the kernels of csrc/necks.hip.  More than one rank and
+    ``sync``: the column sums are exchanged (one all-reduce forward, one backward), as nn.SyncBatchNorm does."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn, relu, sync):
+        x = x.detach().float().contiguous()
+        training = bn.training or bn.running_mean is None
+        world = dist.get_world_size() if (sync and training and dist.is_available() and dist.is_initialized()) else 1
+        sums, count = None, x.shape[0]
+        if world > 1:
+            sums = ops.bn1d_colsums(x)
+            dist.all_reduce(sums)
+            count = x.shape[0] * world
+        y, mean, invstd = ops.bn1d_relu_fwd(x, None if weight is None else weight.detach(), None if bias is None else bias.detach(),
+                                            bn.running_mean, bn.running_var, bn.momentum if bn.momentum is not None else 0.1, bn.eps,
+                                            training, relu, sums, count)
+        if training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+        ctx.save_for_backward(x, y, mean, invstd, weight)
+        ctx.relu, ctx.world, ctx.count, ctx.training = relu, world, count, training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, invstd, weight = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        if not ctx.training:                    # eval mode: a fixed affine map
+            k = invstd if weight is None else invstd * weight
+            dz = dy * (y > 0) if ctx.relu else dy
+            return dz * k, None, None, None, None, None
+        sums = None
+        if ctx.world > 1:
+            sums = ops.bn1d_bwd_colsums(dy, x, y, mean, invstd, ctx.relu)
+            dist.all_reduce(sums)
+        dx, dg, db = ops.bn1d_relu_bwd(dy, x, y, mean, invstd, None if weight is None else weight.detach(), ctx.relu, sums, ctx.count,
+                                       affine=weight is not None)
+        return dx, dg, db, None, None, None
 
 
 class NonLinearNeck(nn.Module):
@@ -289,22 +331,11 @@ class NonLinearNeck(nn.Module):
             if isinstance(m, nn.BatchNorm1d) and m.affine:
                 nn.init.constant_(m.weight, 1)
 
-    def _bn(self, bn, x):
-        if self._sync and self.training and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            # statistics over all ranks (SyncBN, C5 in SURVEY 2.5): one all-reduce of (sum, sumsq)
-            n = torch.tensor([x.shape[0]], dtype=x.dtype, device=x.device)
-            s = torch.cat([x.sum(0), (x * x).sum(0), n])
-            s = _AllReduceSum.apply(s)
-            cnt = s[-1]
-            mean = s[:x.shape[1]] / cnt
-            var = s[x.shape[1]:-1] / cnt - mean * mean
-            with torch.no_grad():
-                bn.running_mean.mul_(1 - bn.momentum).add_(bn.momentum * mean.detach())
-                bn.running_var.mul_(1 - bn.momentum).add_(bn.momentum * var.detach() * cnt / (cnt - 1))
-                bn.num_batches_tracked += 1
-            y = (x - mean) / torch.sqrt(var + bn.eps)
-            return y * bn.weight + bn.bias if bn.affine else y
-        return bn(x)
+    def _bn(self, bn, x, relu):
+        """BatchNorm1d over the rows (+ the ReLU that follows when ``relu``); eval mode uses the running statistics."""
+        if not x.is_cuda:
+            raise RuntimeError("NonLinearNeck: the HIP path needs CUDA/ROCm tensors (no CPU fallback)")
+        return _BN1dFn.apply(x, bn.weight if bn.affine else None, bn.bias if bn.affine else None, bn, relu, self._sync)
 
     def forward(self, x):
         if self.with_avg_pool:
@@ -312,28 +343,16 @@ class NonLinearNeck(nn.Module):
         else:
             x = x[:, 0, :]
         x = x.reshape(x.size(0), -1)
-        x = neck_linear(self.fc0, x)
-        x = self._bn(self.bn0, x)
-        for fc_name, bn_name in zip(self.fc_names, self.bn_names):
-            x = self.relu(x)
-            x = neck_linear(getattr(self, fc_name), x)
+        cdt = getattr(self, "compute_dtype", None)
+        layers = [("fc0", "bn0")] + list(zip(self.fc_names, self.bn_names))
+        for i, (fc_name, bn_name) in enumerate(layers):
+            x = neck_linear(getattr(self, fc_name), x, cdt)
+            last = i == len(layers) - 1
             if bn_name is not None:
-                x = self._bn(getattr(self, bn_name), x)
+                x = self._bn(getattr(self, bn_name), x, relu=not last)       # ReLU precedes every later fc (nonlinear_neck.py:96)
+            elif not last:
+                x = self.relu(x)
         return x.unsqueeze(dim=1)
-
-
-class _AllReduceSum(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, t):
-        t = t.clone()
-        dist.all_reduce(t)
-        return t
-
-    @staticmethod
-    def backward(ctx, g):
-        g = g.clone()
-        dist.all_reduce(g)
-        return g
 
 
 class CMUNetPretrainHead(nn.Module):
@@ -374,7 +393,7 @@ class _CMUNetFn(torch.autograd.Function):
     target latent."""
 
     @staticmethod
-    def forward(ctx, module, img, img_t, mask, names, *params):
+    def forward(ctx, module, img, img_t, mask, reduce_w, reduce_b, names, *params):
         eng = module._engine(img.device)
         sd = _named_state(module)
         tr = module.training
@@ -383,7 +402,9 @@ class _CMUNetFn(torch.autograd.Function):
         tctx = eng.encoder_forward(sd, img_t.detach().float().contiguous(), tr, "target_backbone.", None)
         pctx = eng.decoder_forward(sd, ectx["latent"], ectx["skips"], tr, "pixel_decoder.", None, True)
         fctx = eng.decoder_forward(sd, ectx["latent"], ectx["skips"], tr, "feature_decoder.", None, True)
-        latent_t = ops.apply_to_nchw(tctx["latent"])
+        # cmunet.py:128-129: the per-call Conv2d(C, C/4, 1) on the target latent, straight from the raw NHWC latent and its
+        # pending BatchNorm+ReLU into the NCHW fp32 tensor the reference re-views as an image (no gradient: target branch)
+        latent_t = ops.conv1x1_nchw_fwd(tctx["latent"], reduce_w.detach().float(), None if reduce_b is None else reduce_b.detach().float())
         ctx.module, ctx.names, ctx.eng = module, names, eng
         ctx.saved = (ectx, pctx, fctx)
         return pctx["logits"], fctx["logits"], latent_t
@@ -403,7 +424,7 @@ class _CMUNetFn(torch.autograd.Function):
         d_skips = [Act((view(a) + view(b)).contiguous()) for a, b in zip(ds_p, ds_f)]
         eng.encoder_backward(sd, ectx, d_latent, d_skips, grads)
         ctx.saved = None
-        return (None, None, None, None, None, *[grads.get(n) for n in ctx.names])
+        return (None, None, None, None, None, None, None, *[grads.get(n) for n in ctx.names])
 
 
 class CM_UNet(_EngineOwner, nn.Module):
@@ -432,8 +453,14 @@ class CM_UNet(_EngineOwner, nn.Module):
         self.feature_decoder = _build(with_dt(neck['feature']))
         self.projector = _build(neck['projector'])
         self.target_projector = _build(neck['projector'])
+        # necks under the AMP configuration (cmunet_config.py:76-78): nn.Linear multiplies 16-bit operands into fp32; with fp32
+        # storage (parity tests) the products are exact fp32
+        self._neck_dtype = None if ops.dt_code(dtype) == ops.F32 else dtype
         self.target_cls = target_cls
         self.head = _build(head)
+        for m in (self.projector, self.target_projector, getattr(self.head, "predictor", None)):
+            if isinstance(m, NonLinearNeck):
+                m.compute_dtype = self._neck_dtype
         self.base_momentum = base_momentum
         self.momentum = base_momentum
         for p in self.target_backbone.parameters():
@@ -463,14 +490,14 @@ class CM_UNet(_EngineOwner, nn.Module):
     def extract_feat(self, img):
         return self.backbone(img)
 
-    def _reduce_channels(self, latent_t, reduce_w=None, reduce_b=None):
-        """cmunet.py:128-129: nn.Conv2d(C,256,1) constructed (default init) at every call, never trained (A-2)."""
-        C = latent_t.shape[1]
+    def _reduce_weights(self, C, device, reduce_w=None, reduce_b=None):
+        """cmunet.py:128-129: nn.Conv2d(C,256,1) constructed (default init) at every call, never trained (A-2); the weights
+        are injectable for tests."""
         if reduce_w is None:
             # 256 for the reference geometry (1024 channels at /16): whatever makes Cr*(H/2^d)*(W/2^d) == H*W
-            conv = nn.Conv2d(C, self.reduced_channels(), kernel_size=1).to(latent_t.device, latent_t.dtype)
+            conv = nn.Conv2d(C, self.reduced_channels(), kernel_size=1).to(device)
             reduce_w, reduce_b = conv.weight, conv.bias
-        return F.conv2d(latent_t, reduce_w, reduce_b)
+        return reduce_w, reduce_b
 
     def reduced_channels(self):
         n_down = sum(1 for n, _ in self.backbone.named_children() if n.startswith("down_conv"))
@@ -482,10 +509,11 @@ class CM_UNet(_EngineOwner, nn.Module):
         if mask is None:
             mask = self.backbone.make_mask(img)
         names, params = _param_args(self)
-        pred_pixel, pred_feature, latent_t = _CMUNetFn.apply(self, img, img_t, mask, names, *params)
+        C_lat = self.target_backbone.double_conv.double_conv[3].weight.shape[0]
+        reduce_w, reduce_b = self._reduce_weights(C_lat, img.device, reduce_w, reduce_b)
+        pred_pixel, pred_feature, lt = _CMUNetFn.apply(self, img, img_t, mask, reduce_w, reduce_b, names, *params)
         proj_s = self.projector(torch.mean(pred_feature, dim=1, keepdim=True))
         with torch.no_grad():
-            lt = self._reduce_channels(latent_t, reduce_w, reduce_b)
             lt = lt.reshape(B, -1).reshape(B, 1, H, W)          # 256*(H/16)*(W/16) == H*W (cmunet.py:130)
             proj_t = self.target_projector(torch.mean(lt, dim=1, keepdim=True))
         return self.head(img, pred_pixel, mask, proj_s, proj_t)

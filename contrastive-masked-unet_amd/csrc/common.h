@@ -112,11 +112,13 @@ struct F16Traits {
 #pragma unroll
         for (int i = 0; i < 8; ++i) f[i] = (float)h[i];
     }
+    // (pairs: the vector conversion compiles to gfx950's v_cvt_pk_f16_f32 -- one instruction per two elements, round to
+    // nearest even like the scalar cast)
     __device__ static inline u32x4 pack(const float* f) {
-        f16x8 h;
+        u32x4 c;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) h[i] = (_Float16)f[i];
-        return __builtin_bit_cast(u32x4, h);
+        for (int i = 0; i < 4; ++i) c[i] = pack2(f[2 * i], f[2 * i + 1]);
+        return c;
     }
     __device__ static inline void mma16(const u32x4& a, const u32x4& b, f32x16& acc) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
@@ -124,7 +126,9 @@ struct F16Traits {
     __device__ static inline float to_float(_Float16 v) { return (float)v; }
     __device__ static inline _Float16 from_float(float v) { return (_Float16)v; }
     __device__ static inline uint32_t pack2(float a, float b) {   // a in the low half, b in the high half
-        return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)a) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)b) << 16);
+        typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+        typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){a, b}, f16x2_t));
     }
 };
 

@@ -59,6 +59,10 @@ struct IGParams {
     int buf_ok;           // first kernel, 3x3 mode: one image and the weight pack fit buffer descriptors
     // persistent wide kernel: division by nblk / tilesX / tilesY as (mulhi(n, M) + n) >> s (n < 2^31)
     unsigned fd_nblk[2], fd_tx[2], fd_ty[2];
+    // sparse (SparK) form of the persistent kernel: only the spatial tiles tile_list[0 .. *tile_count) are computed (device
+    // arrays written by cmu_sparse_tile_list; dense tile numbering (b * tilesY + ty) * tilesX + tx); the rest of y is untouched
+    const int* tile_list;
+    const int* tile_count;
 };
 // round-up magic for unsigned division by d >= 1: s = ceil(log2 d), M = floor(2^32 * (2^s - d) / d) + 1
 static inline void cmu_fastdiv_init(unsigned d, unsigned* out) {
@@ -664,6 +668,94 @@ extern "C" int cmu_convT2x2_dgrad(const void* dOut, int64_t ldd, const void* wpa
     p.B = B; p.H = H; p.W = W; p.K = Cout; p.N = Cin; p.Cq = Cout;
     fill_tiles(p);
     CMU_DISPATCH_DT(dt, convT_dgrad_t, p, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Sparse (SparK) form: the persistent kernel over a device-side list of spatial tiles
+// ---------------------------------------------------------------------------------------------------
+template <class TR>
+static int conv3x3_tiles_ok_t(IGParams p) {
+    return igemm3_eligible<TR>(p) && cmu_conv_persist_enabled() && p.H % 16 == 0 && p.W % 32 == 0 ? 1 : 0;
+}
+extern "C" int cmu_conv3x3_tiles_supported(int B, int H, int W, int Cin, int Cout, int dt) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || cmu_dtype_size(dt) <= 0) return 0;
+    IGParams p = {};
+    p.B = B; p.H = H; p.W = W; p.K = Cin; p.N = Cout; p.ldx = Cin; p.ldy = Cout;
+    CMU_DISPATCH_DT(dt, conv3x3_tiles_ok_t, p);
+}
+extern "C" int cmu_conv3x3_fwd_tiles(const void* x, int64_t ldx, const float* in_scale, const float* in_shift, int relu_from,
+                                     const void* wpacked, void* y, int64_t ldy, const int* tile_list, const int* tile_count, int B, int H,
+                                     int W, int Cin, int Cout, int dt, void* stream) {
+    CMU_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && tile_list && tile_count, "cmu_conv3x3_fwd_tiles: bad dims / null list");
+    CMU_CHECK_ARG(cmu_dtype_size(dt) > 0, "cmu_conv3x3_fwd_tiles: bad dtype %d", dt);
+    int rc;
+    if ((rc = check_act("cmu_conv3x3_fwd_tiles(x)", x, ldx, Cin, dt))) return rc;
+    if ((rc = check_act("cmu_conv3x3_fwd_tiles(y)", y, ldy, Cout, dt))) return rc;
+    CMU_CHECK_ARG(wpacked && cmu_aligned16(wpacked), "cmu_conv3x3_fwd_tiles: packed weights null/unaligned");
+    CMU_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "cmu_conv3x3_fwd_tiles: scale/shift must both be set");
+    CMU_CHECK_ARG(relu_from >= 0 && relu_from % (16 / cmu_dtype_size(dt)) == 0, "cmu_conv3x3_fwd_tiles: relu_from=%d must be a multiple of the 16-byte chunk", relu_from);
+    IGParams p = {};
+    p.x = x; p.ldx = ldx; p.in_scale = in_scale; p.in_shift = in_shift; p.relu_from = relu_from;
+    p.w = wpacked; p.y = y; p.ldy = ldy; p.stats = nullptr; p.bias = nullptr;
+    p.B = B; p.H = H; p.W = W; p.K = Cin; p.N = Cout; p.Cq = Cout;
+    p.tile_list = tile_list; p.tile_count = tile_count;
+    fill_tiles(p);
+    if (!cmu_conv3x3_tiles_supported(B, H, W, Cin, Cout, dt)) {
+        cmu_set_error("cmu_conv3x3_fwd_tiles: shape (H=%d W=%d Cin=%d Cout=%d) is not served by the persistent kernel "
+                      "(whole 16 x 32 tiles, whole channel blocks): call cmu_conv3x3_fwd", H, W, Cin, Cout);
+        return CMU_ERR_UNSUPPORTED;
+    }
+    CMU_DISPATCH_DT(dt, launch_igemm3_any, p, (hipStream_t)stream);
+}
+
+// Active-tile list of a (B, H, W) level for the patch map `active` (B, f, f): tile (b, ty, tx) of th x tw pixels is listed
+// iff one of the patches it overlaps is active.  One workgroup, ascending tile order (deterministic), count in count[0].
+__global__ __launch_bounds__(1024) void sparse_tile_list_kernel(const uint8_t* __restrict__ active, int f, int sbits, int B, int tilesY,
+                                                               int tilesX, int th, int tw, int* __restrict__ list, int* __restrict__ count) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int total = B * tilesY * tilesX;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < total; t0 += 1024) {
+        const int t = t0 + (int)threadIdx.x;
+        bool on = false;
+        if (t < total) {
+            const int tx = t % tilesX, ty = (t / tilesX) % tilesY, b = t / (tilesX * tilesY);
+            const int py0 = (ty * th) >> sbits, py1 = (ty * th + th - 1) >> sbits;
+            const int px0 = (tx * tw) >> sbits, px1 = (tx * tw + tw - 1) >> sbits;
+            for (int py = py0; py <= py1 && py < f; ++py)
+                for (int px = px0; px <= px1 && px < f; ++px) on |= active[((int64_t)b * f + py) * f + px] != 0;
+        }
+        const unsigned long long m = __ballot(on);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (on) list[off + before] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int s = 0;
+            for (int w = 0; w < 16; ++w) s += wsum[w];
+            base += s;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) count[0] = base;
+}
+extern "C" int cmu_sparse_tile_list(const uint8_t* active, int f, int B, int H, int W, int tile_h, int tile_w, int* list, int* count,
+                                    void* stream) {
+    CMU_CHECK_ARG(active && list && count && f > 0 && B > 0 && H > 0 && W > 0 && tile_h > 0 && tile_w > 0, "cmu_sparse_tile_list: bad args");
+    const int sbits = sp_shift_bits(H, f);
+    CMU_CHECK_ARG(sbits >= 0 && W == H, "cmu_sparse_tile_list: H must be f << s and the level square (H=%d, W=%d, f=%d)", H, W, f);
+    const int tilesY = cmu_div_up(H, tile_h), tilesX = cmu_div_up(W, tile_w);
+    CMU_CHECK_ARG((int64_t)B * tilesY * tilesX < (1ll << 30), "cmu_sparse_tile_list: too many tiles");
+    hipLaunchKernelGGL(sparse_tile_list_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, active, f, sbits, B, tilesY, tilesX, tile_h, tile_w,
+                       list, count);
+    CMU_CHECK_LAUNCH("cmu_sparse_tile_list");
+    return CMU_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------

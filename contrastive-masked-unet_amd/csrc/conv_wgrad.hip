@@ -38,6 +38,10 @@ struct WGParams {
     int CA, CB;   // channels of A (output channels) and B (input channels)
     int CApad, CBpad;
     int nAB, nBB, splitk, ntiles, tilesX, tilesY;
+    // sparse (SparK) form of the first kernel: the K loop runs over the 16 x 16 pixel tiles tile_list[0 .. *tile_count) only
+    // (device arrays from cmu_sparse_tile_list; elsewhere dY is zero by construction, so the sum is unchanged)
+    const int* tile_list;
+    const int* tile_count;
 };
 
 template <class TR, int MODE>
@@ -146,7 +150,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WGParams p) {
     u32x4 breg[C::B_ITERS];
     unsigned b_ok = 0;  // bit it: B chunk is inside the image (so the transform applies)
 
+    const int ntiles = (MODE == MODE_W3 && p.tile_list != nullptr) ? __builtin_amdgcn_readfirstlane(*p.tile_count) : p.ntiles;
     auto load_tile = [&](int tile) {
+        if (MODE == MODE_W3 && p.tile_list != nullptr) tile = __builtin_amdgcn_readfirstlane(p.tile_list[tile]);
         const int tx = tile % p.tilesX, ty = (tile / p.tilesX) % p.tilesY, b = tile / (p.tilesX * p.tilesY);
         const int ty0 = ty * 16, tx0 = tx * 16;
 #pragma unroll
@@ -225,17 +231,17 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WGParams p) {
     // store_tile from registers loaded one iteration earlier); registers are then refilled with tile t+2.
     // One barrier per tile; a wave's LDS writes overlap the other waves' MFMAs.
     int tile = split;
-    if (tile < p.ntiles) {
+    if (tile < ntiles) {
         load_tile(tile);
         store_tile();
-        if (tile + p.splitk < p.ntiles) load_tile(tile + p.splitk);
+        if (tile + p.splitk < ntiles) load_tile(tile + p.splitk);
     }
     __syncthreads();
 #ifdef CMU_IG_STAMPS
     const int stamp_slot = (blockIdx.x % 7 == 0 && blockIdx.x / 7 < 64) ? (int)(blockIdx.x / 7) : -1;
     int stamp_i = -1;
 #endif
-    for (; tile < p.ntiles; tile += p.splitk) {
+    for (; tile < ntiles; tile += p.splitk) {
 #ifdef CMU_IG_STAMPS
         ++stamp_i;
 #endif
@@ -275,11 +281,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WGParams p) {
             }
         }
         WG_STAMP(1);
-        if (tile + p.splitk < p.ntiles) store_tile();                       // tile t+1: registers -> the other buffer
+        if (tile + p.splitk < ntiles) store_tile();                       // tile t+1: registers -> the other buffer
         WG_STAMP(2);
         __syncthreads();
         WG_STAMP(3);
-        if (tile + 2 * p.splitk < p.ntiles) load_tile(tile + 2 * p.splitk);  // tile t+2: in flight during the next compute
+        if (tile + 2 * p.splitk < ntiles) load_tile(tile + 2 * p.splitk);  // tile t+2: in flight during the next compute
         WG_STAMP(4);
         smA = stA;
         smB = stB;
@@ -624,6 +630,25 @@ extern "C" int cmu_conv3x3_wgrad(const void* x, int64_t ldx, const float* in_sca
         if (dt == CMU_F16) return wgrad3_wide_t<F16Traits>(p, dW, (hipStream_t)stream);
         return wgrad3_wide_t<BF16Traits>(p, dW, (hipStream_t)stream);
     }
+    wg_geometry(B, H, W, Cout, Cin, dt, 1, p);
+    CMU_DISPATCH_DT(dt, wgrad3_t, p, dW, (hipStream_t)stream);
+}
+
+// Sparse (SparK) weight gradient: the first kernel over a device-side list of 16 x 16 pixel tiles (cmu_sparse_tile_list with
+// tile_h = tile_w = 16).  ws: cmu_conv3x3_wgrad_ws_bytes.
+extern "C" int cmu_conv3x3_wgrad_tiles(const void* x, int64_t ldx, const float* in_scale, const float* in_shift, int relu_from,
+                                       const void* dY, int64_t ldd, float* dW, const int* tile_list, const int* tile_count, int B, int H,
+                                       int W, int Cin, int Cout, int dt, void* ws, void* stream) {
+    int rc;
+    if ((rc = wg_check("cmu_conv3x3_wgrad_tiles(x)", x, ldx, Cin, dt))) return rc;
+    if ((rc = wg_check("cmu_conv3x3_wgrad_tiles(dY)", dY, ldd, Cout, dt))) return rc;
+    CMU_CHECK_ARG(dW && ws && tile_list && tile_count && B > 0 && H > 0 && W > 0, "cmu_conv3x3_wgrad_tiles: null argument / bad dims");
+    CMU_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "cmu_conv3x3_wgrad_tiles: scale/shift must both be set");
+    CMU_CHECK_ARG(relu_from >= 0 && relu_from % (16 / cmu_dtype_size(dt)) == 0, "cmu_conv3x3_wgrad_tiles: relu_from=%d must be a multiple of the 16-byte chunk", relu_from);
+    WGParams p = {};
+    p.a = dY; p.lda = ldd; p.b = x; p.ldb = ldx; p.b_scale = in_scale; p.b_shift = in_shift; p.relu_from = relu_from;
+    p.ws = (float*)ws; p.B = B; p.H = H; p.W = W; p.CA = Cout; p.CB = Cin;
+    p.tile_list = tile_list; p.tile_count = tile_count;
     wg_geometry(B, H, W, Cout, Cin, dt, 1, p);
     CMU_DISPATCH_DT(dt, wgrad3_t, p, dW, (hipStream_t)stream);
 }

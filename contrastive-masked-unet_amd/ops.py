@@ -361,6 +361,40 @@ def bn_bwd_apply_masked(dA, y, save_mean, save_invstd, coef, dY, active):
          _p(coef), dY.ptr(), dY.ld, _p(active), active.shape[-1], y.B, y.H, y.W, y.C, y.dt, _stream())
 
 
+class TileList:
+    """Device-side list of the spatial tiles of one level that overlap an active patch (cmu_sparse_tile_list): ``list`` int32,
+    ``count`` int32 (1,) -- both stay on the device.  ``n_dense`` is the dense tile count (the list's capacity)."""
+
+    def __init__(self, active, H, W, tile_h, tile_w):
+        B, f = active.shape[0], active.shape[-1]
+        self.tile_h, self.tile_w = tile_h, tile_w
+        self.n_dense = B * ((H + tile_h - 1) // tile_h) * ((W + tile_w - 1) // tile_w)
+        self.list = torch.empty(self.n_dense, dtype=torch.int32, device=active.device)
+        self.count = torch.empty(1, dtype=torch.int32, device=active.device)
+        call("cmu_sparse_tile_list", _p(active), f, B, H, W, tile_h, tile_w, _p(self.list), _p(self.count), _stream())
+
+
+def conv3x3_tiles_supported(B, H, W, Cin, Cout, dt):
+    return bool(_lib.lib().cmu_conv3x3_tiles_supported(B, H, W, Cin, Cout, dt_code(dt)))
+
+
+def conv3x3_fwd_tiles(x, wpacked, out, tiles, active_fraction=1.0):
+    """conv3x3_fwd over the listed 16 x 32 tiles only (``out`` elsewhere untouched).  ``active_fraction``: share of listed
+    tiles, for the profiler's algorithmic FLOP count only."""
+    assert x.dt == out.dt and (x.B, x.H, x.W) == (out.B, out.H, out.W) and (tiles.tile_h, tiles.tile_w) == (16, 32)
+    call("cmu_conv3x3_fwd_tiles", x.ptr(), x.ld, _p(x.scale), _p(x.shift), x.relu_from, _p(wpacked), out.ptr(), out.ld,
+         _p(tiles.list), _p(tiles.count), x.B, x.H, x.W, x.C, out.C, x.dt, _stream(),
+         work=2.0 * 9 * x.C * out.C * x.B * x.H * x.W * active_fraction)
+
+
+def conv3x3_wgrad_tiles(x, dY, dW, ws, tiles, active_fraction=1.0):
+    Cout, Cin = dW.shape[0], dW.shape[1]
+    assert x.C == Cin and dY.C == Cout and (tiles.tile_h, tiles.tile_w) == (16, 16)
+    call("cmu_conv3x3_wgrad_tiles", x.ptr(), x.ld, _p(x.scale), _p(x.shift), x.relu_from, dY.ptr(), dY.ld, _p(_f32c(dW)),
+         _p(tiles.list), _p(tiles.count), x.B, x.H, x.W, Cin, Cout, x.dt, _p(ws), _stream(),
+         work=2.0 * 9 * Cin * Cout * x.B * x.H * x.W * active_fraction)
+
+
 def spark_loss_fwd_bwd(rec, img, active, loss, drec, loss_scale, p, ws):
     B, f = active.shape[0], active.shape[-1]
     call("cmu_spark_loss_fwd_bwd", _p(_f32c(rec)), _p(_f32c(img)), _p(active), _p(loss), _p(drec), float(loss_scale), B, f, p, _p(ws),
@@ -486,34 +520,105 @@ def skinny_eligible(x, weight):
             and x.shape[1] % 8 == 0 and x.shape[1] >= 8)
 
 
-def skinny_gemm_fwd(x, weight, bias=None):
+def _mm16(compute_dt, K, need):
+    """16-bit-operand kernels apply for compute_dt f16 / bf16 when K allows; None / f32 -> the exact fp32 kernels."""
+    if compute_dt is None:
+        return None
+    dt = dt_code(compute_dt)
+    return dt if (dt in (F16, BF16) and K % need == 0) else None
+
+
+def skinny_gemm_fwd(x, weight, bias=None, compute_dt=None):
+    """``compute_dt`` 'f16' / 'bf16': operands rounded to that type in registers (the AMP arithmetic), fp32 accumulation."""
     x, weight = _f32c(x), _f32c(weight)
     M, K = x.shape
     N = weight.shape[0]
     y = torch.empty(M, N, dtype=torch.float32, device=x.device)
-    ws = torch.empty(_lib.lib().cmu_skinny_gemm_ws_bytes(M, N, K), dtype=torch.uint8, device=x.device)
-    call("cmu_skinny_gemm_fwd", _p(x), _p(weight), _p(None if bias is None else _f32c(bias)), _p(y), M, N, K, _p(ws), _stream())
+    dt16 = _mm16(compute_dt, K, 16)
+    b = _p(None if bias is None else _f32c(bias))
+    if dt16 is not None:
+        ws = torch.empty(_lib.lib().cmu_skinny16_gemm_ws_bytes(M, N, K), dtype=torch.uint8, device=x.device)
+        call("cmu_skinny16_gemm_fwd", _p(x), _p(weight), b, _p(y), M, N, K, dt16, _p(ws), _stream(), work=2.0 * M * N * K)
+    else:
+        ws = torch.empty(_lib.lib().cmu_skinny_gemm_ws_bytes(M, N, K), dtype=torch.uint8, device=x.device)
+        call("cmu_skinny_gemm_fwd", _p(x), _p(weight), b, _p(y), M, N, K, _p(ws), _stream(), work=2.0 * M * N * K)
     return y
 
 
-def skinny_gemm_dgrad(dy, weight):
+def skinny_gemm_dgrad(dy, weight, compute_dt=None):
     dy, weight = _f32c(dy), _f32c(weight)
     M, N = dy.shape
     K = weight.shape[1]
     dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
-    ws = torch.empty(_lib.lib().cmu_skinny_gemm_bwd_ws_bytes(M, N), dtype=torch.uint8, device=dy.device)
-    call("cmu_skinny_gemm_dgrad", _p(dy), _p(weight), _p(dx), M, N, K, _p(ws), _stream())
+    dt16 = _mm16(compute_dt, K, 4)
+    if dt16 is not None:
+        call("cmu_skinny16_gemm_dgrad", _p(dy), _p(weight), _p(dx), M, N, K, dt16, _stream(), work=2.0 * M * N * K)
+    else:
+        ws = torch.empty(_lib.lib().cmu_skinny_gemm_bwd_ws_bytes(M, N), dtype=torch.uint8, device=dy.device)
+        call("cmu_skinny_gemm_dgrad", _p(dy), _p(weight), _p(dx), M, N, K, _p(ws), _stream(), work=2.0 * M * N * K)
     return dx
 
 
-def skinny_gemm_wgrad(dy, x, with_bias=False):
+def skinny_gemm_wgrad(dy, x, with_bias=False, compute_dt=None, out=None):
+    """``out``: optional preallocated (N, K) fp32 tensor (a view of a trainer's gradient arena)."""
     dy, x = _f32c(dy), _f32c(x)
     M, N = dy.shape
     K = x.shape[1]
-    dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+    dw = out if out is not None else torch.empty(N, K, dtype=torch.float32, device=dy.device)
+    assert dw.shape == (N, K) and dw.dtype == torch.float32 and dw.is_contiguous()
     db = torch.empty(N, dtype=torch.float32, device=dy.device) if with_bias else None
-    call("cmu_skinny_gemm_wgrad", _p(dy), _p(x), _p(dw), _p(db), M, N, K, _stream())
+    dt16 = _mm16(compute_dt, K, 4)
+    if dt16 is not None:
+        call("cmu_skinny16_gemm_wgrad", _p(dy), _p(x), _p(dw), _p(db), M, N, K, dt16, _stream(), work=2.0 * M * N * K)
+    else:
+        call("cmu_skinny_gemm_wgrad", _p(dy), _p(x), _p(dw), _p(db), M, N, K, _stream(), work=2.0 * M * N * K)
     return dw, db
+
+
+# ---- BatchNorm1d (+ ReLU) of the necks and the target latent's 1x1 reduction (csrc/necks.hip) ---------------------------------
+def bn1d_colsums(x):
+    M, N = x.shape
+    sums = torch.empty(2, N, dtype=torch.float32, device=x.device)
+    call("cmu_bn1d_colsums", _p(_f32c(x)), _p(sums), M, N, _stream())
+    return sums
+
+
+def bn1d_relu_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, sums=None, count=0):
+    M, N = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(N, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(N, dtype=torch.float32, device=x.device)
+    call("cmu_bn1d_relu_fwd", _p(_f32c(x)), _p(sums), int(count), _p(gamma), _p(beta), _p(running_mean), _p(running_var), float(momentum),
+         float(eps), int(training), int(relu), _p(y), _p(mean), _p(invstd), M, N, _stream())
+    return y, mean, invstd
+
+
+def bn1d_bwd_colsums(dy, x, y, mean, invstd, relu):
+    M, N = x.shape
+    sums = torch.empty(2, N, dtype=torch.float32, device=x.device)
+    call("cmu_bn1d_bwd_colsums", _p(_f32c(dy)), _p(x), _p(y), _p(mean), _p(invstd), int(relu), _p(sums), M, N, _stream())
+    return sums
+
+
+def bn1d_relu_bwd(dy, x, y, mean, invstd, gamma, relu, sums=None, count=0, affine=True):
+    M, N = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.empty(N, dtype=torch.float32, device=x.device) if affine else None
+    db = torch.empty(N, dtype=torch.float32, device=x.device) if affine else None
+    call("cmu_bn1d_relu_bwd", _p(_f32c(dy)), _p(x), _p(y), _p(mean), _p(invstd), _p(gamma), int(relu), _p(sums), int(count), _p(dx), _p(dg),
+         _p(db), M, N, _stream())
+    return dx, dg, db
+
+
+def conv1x1_nchw_fwd(x, weight, bias=None):
+    """x: Act (NHWC + pending transform); weight (N, K) or (N, K, 1, 1) fp32 -> (B, N, H, W) fp32."""
+    w = _f32c(weight.reshape(weight.shape[0], -1))
+    N, K = w.shape
+    assert K == x.C
+    out = torch.empty(x.B, N, x.H, x.W, dtype=torch.float32, device=x.buf.device)
+    call("cmu_conv1x1_nchw_fwd", x.ptr(), x.ld, _p(x.scale), _p(x.shift), x.relu_from, _p(w), _p(None if bias is None else _f32c(bias)),
+         _p(out), x.B, x.H, x.W, K, N, x.dt, _stream(), work=2.0 * K * N * x.B * x.H * x.W)
+    return out
 
 
 def random_patch_mask(B, H, W, patch_size=16, mask_ratio=0.65, seed=0, offset=0, device="cuda"):

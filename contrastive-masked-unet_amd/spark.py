@@ -10,12 +10,21 @@ models/__init__.py:40-49}).
       state_dict keys: sparse_encoder.sp_cnn.*, dense_decoder.*, mask_tokens.{i}, densify_projs.{i}.* (built but
       unused for the full UNet, kept for key parity: SURVEY A-10)
 
-The module-global ``_cur_active`` of the reference (encoder.py:12) is an explicit argument here.  Round-1
-execution model (csrc/sparse.hip): the dense implicit-GEMM kernels compute every conv; sparse-BatchNorm
-statistics over the active positions, the masked BN+ReLU apply, the densify step and the loss are HBM-bound
-kernels with the patch mask looked up per pixel.  ``sbn=True``: the bottleneck's two BatchNorms exchange their statistics
+The module-global ``_cur_active`` of the reference (encoder.py:12) is an explicit argument here.  Execution model
+(csrc/sparse.hip): sparse-BatchNorm statistics over the active positions, the masked BN+ReLU apply, the densify step
+and the loss are HBM-bound kernels with the patch mask looked up per pixel.  The encoder's convolutions run on the
+MFMA implicit-GEMM kernels; where whole kernel tiles fall on masked patches they are SKIPPED (K17): per level a
+device-side list of the 16 x 32 pixel tiles (forward / data gradient, persistent kernel) and 16 x 16 pixel tiles
+(weight gradient) that overlap an active patch is built once per step (``ops.TileList``) -- the reference computes
+the dense op and multiplies by the mask (encoder.py:20-23).  What a dense tile can skip depends on the patch side at
+the level: 16 px (level 1): 1 - 0.75^2 = 44 % of the 16 x 32 tiles and 25 % of the 16 x 16 tiles remain at mask ratio
+0.75; 8 px (level 2): 90 % remain; deeper levels have patches of 4 / 2 / 1 px, every tile holds an active pixel and the
+convolutions stay dense (their outputs at masked positions are discarded by the masked consumers).
+``CMU_SPARK_TILES=0`` keeps every level dense (A/B switch).  ``sbn=True``: the bottleneck's two BatchNorms exchange their statistics
 (forward sums and counts, backward sums) over the default process group, as nn.SyncBatchNorm does for SparseSyncBatchNorm2d.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -152,12 +161,32 @@ class SparK(_EngineOwner, nn.Module):
         import torch.distributed as dist
         return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
-    def _sp_convbn_fwd(self, eng, sd, pconv, pbn, x, x_img, inv_pix, active, count, B, H, W, training, sync=False):
+    def _level_tiles(self, eng, active, B, H, W):
+        """Tile lists of one level: (conv list 16 x 32, wgrad list 16 x 16, fraction of conv tiles, fraction of wgrad tiles)
+        or None where tile skipping cannot pay (patch side < 8 px: every tile holds an active pixel)."""
+        if os.environ.get("CMU_SPARK_TILES", "1") == "0":
+            return None
+        f = active.shape[-1]
+        ps = H // f
+        if ps < 8 or H % 16 != 0 or W % 32 != 0:
+            return None
+        keep = 1.0 - self.mask_ratio
+        conv = ops.TileList(active, H, W, 16, 32)
+        cf = 1.0 - (1.0 - keep) ** max(1, (16 // ps) * (32 // ps))          # expected share of listed tiles (profiler only)
+        wg, wf = None, 1.0
+        if ps >= 16:
+            wg = ops.TileList(active, H, W, 16, 16)
+            wf = 1.0 - (1.0 - keep) ** max(1, (16 // ps) ** 2)
+        return {"conv": conv, "wgrad": wg, "cf": cf, "wf": wf}
+
+    def _sp_convbn_fwd(self, eng, sd, pconv, pbn, x, x_img, inv_pix, active, count, B, H, W, training, sync=False, tiles=None):
         w = sd[pconv + "weight"]
         C = w.shape[0]
         y = eng._new(B, H, W, C)
         if x_img is not None:
             ops.conv3x3_c1_fwd(x_img, w.detach(), y, None, inv_pix, True)
+        elif tiles is not None and ops.conv3x3_tiles_supported(B, H, W, x.C, C, eng.dt):
+            ops.conv3x3_fwd_tiles(x, eng._wp(pconv, w, False), y, tiles["conv"], tiles["cf"])    # masked tiles never computed
         else:
             ops.conv3x3_fwd(x, eng._wp(pconv, w, False), y, None)
         scale, shift, mean, invstd = eng._f32(C), eng._f32(C), eng._f32(C), eng._f32(C)
@@ -178,7 +207,7 @@ class SparK(_EngineOwner, nn.Module):
         a = eng._new(B, H, W, C)
         ops.mask_select(yt, active, a, relu=True)                                  # BN + ReLU, zeros at masked positions
         return {"pconv": pconv, "pbn": pbn, "x": x, "x_img": x_img, "mask": inv_pix, "mps": True, "y": yt, "a": a,
-                "mean": mean, "invstd": invstd, "sync": sync, "count_all": count}
+                "mean": mean, "invstd": invstd, "sync": sync, "count_all": count, "tiles": tiles}
 
     def _sp_convbn_bwd(self, eng, sd, s, dA, active, count, grads, need_dx):
         y = s["y"]
@@ -198,15 +227,24 @@ class SparK(_EngineOwner, nn.Module):
         grads[s["pbn"] + "weight"], grads[s["pbn"] + "bias"] = dgamma, dbeta
         grads[s["pconv"] + "bias"] = torch.zeros(C, dtype=torch.float32, device=eng.device)
         dW = torch.empty_like(w, dtype=torch.float32)
+        tiles = s.get("tiles")
         if s["x_img"] is not None:
             ops.conv3x3_c1_wgrad(s["x_img"], dY, dW, eng.scratch.get("wg", eng.lib.cmu_conv3x3_c1_wgrad_ws_bytes(B, H, W, C)), s["mask"], True)
         else:
-            ops.conv3x3_wgrad(s["x"], dY, dW, eng.scratch.get("wg", eng.lib.cmu_conv3x3_wgrad_ws_bytes(B, H, W, w.shape[1], C, eng.dt)))
+            wsb = eng.scratch.get("wg", eng.lib.cmu_conv3x3_wgrad_ws_bytes(B, H, W, w.shape[1], C, eng.dt))
+            if tiles is not None and tiles["wgrad"] is not None:
+                ops.conv3x3_wgrad_tiles(s["x"], dY, dW, wsb, tiles["wgrad"], tiles["wf"])      # dY is zero outside the listed tiles
+            else:
+                ops.conv3x3_wgrad(s["x"], dY, dW, wsb)
         grads[s["pconv"] + "weight"] = dW
         if not need_dx or s["x_img"] is not None:
             return None
-        dX = eng._new(B, H, W, w.shape[1])
-        ops.conv3x3_fwd(dY, eng._wp(s["pconv"], w, True), dX, None)
+        Cin = w.shape[1]
+        dX = eng._new(B, H, W, Cin)
+        if tiles is not None and ops.conv3x3_tiles_supported(B, H, W, C, Cin, eng.dt):
+            ops.conv3x3_fwd_tiles(dY, eng._wp(s["pconv"], w, True), dX, tiles["conv"], tiles["cf"])   # dX is only needed where active
+        else:
+            ops.conv3x3_fwd(dY, eng._wp(s["pconv"], w, True), dX, None)
         return dX
 
     def _step(self, inp_bchw, active_b1ff, need_grads):
@@ -229,8 +267,10 @@ class SparK(_EngineOwner, nn.Module):
         for i in range(1, nd + 1):
             p = f"{ep}down_conv{i}.double_conv.double_conv."
             cnt = n_cells * (h // f) * (w_ // f)
-            s1 = self._sp_convbn_fwd(eng, sd, p + "0.", p + "1.", x, ximg, inv_pix if ximg is not None else None, active, cnt, B, h, w_, training)
-            s2 = self._sp_convbn_fwd(eng, sd, p + "3.", p + "4.", s1["a"], None, None, active, cnt, B, h, w_, training)
+            tl = self._level_tiles(eng, active, B, h, w_)
+            s1 = self._sp_convbn_fwd(eng, sd, p + "0.", p + "1.", x, ximg, inv_pix if ximg is not None else None, active, cnt, B, h, w_, training,
+                                     tiles=tl)
+            s2 = self._sp_convbn_fwd(eng, sd, p + "3.", p + "4.", s1["a"], None, None, active, cnt, B, h, w_, training, tiles=tl)
             C = s2["a"].C
             one, zero = self._ident(eng, C)
             pooled = eng._new(B, h // 2, w_ // 2, C)

@@ -259,6 +259,24 @@ int cmu_bn_bwd_reduce_masked(const void* dA, int64_t ldd, const void* y, int64_t
 int cmu_bn_bwd_apply_masked(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift,
                             const float* save_mean, const float* save_invstd, const float* coef, void* dY, int64_t ldo,
                             const uint8_t* active, int f, int B, int H, int W, int C, int dt, void* stream);
+/* Tile skipping for the sparse encoder (K17; Spark/encoder.py:20-23 computes the dense op and multiplies by the mask --
+ * here the masked tiles are never computed).  cmu_sparse_tile_list writes, in ascending order, the indices (dense numbering
+ * (b * tilesY + ty) * tilesX + tx) of the tile_h x tile_w pixel tiles of a (B, H, W) level that overlap an active patch,
+ * and their number to count[0] -- both on the device: the consumers read the count there, nothing synchronises with the host.
+ * list: B * ceil(H / tile_h) * ceil(W / tile_w) ints.
+ *   cmu_conv3x3_fwd_tiles   cmu_conv3x3_fwd (forward and, with the flipped pack, data gradient) over a 16 x 32 tile list;
+ *                           y outside the listed tiles is left untouched (its consumers select by the mask).  Shapes the
+ *                           persistent kernel serves (cmu_conv3x3_tiles_supported != 0): whole tiles, whole channel blocks.
+ *   cmu_conv3x3_wgrad_tiles cmu_conv3x3_wgrad with the contraction restricted to a 16 x 16 tile list (dY is zero elsewhere). */
+int cmu_sparse_tile_list(const uint8_t* active, int f, int B, int H, int W, int tile_h, int tile_w, int* list, int* count, void* stream);
+int cmu_conv3x3_tiles_supported(int B, int H, int W, int Cin, int Cout, int dt);
+int cmu_conv3x3_fwd_tiles(const void* x, int64_t ldx, const float* in_scale, const float* in_shift, int relu_from,
+                          const void* wpacked, void* y, int64_t ldy, const int* tile_list, const int* tile_count,
+                          int B, int H, int W, int Cin, int Cout, int dt, void* stream);
+int cmu_conv3x3_wgrad_tiles(const void* x, int64_t ldx, const float* in_scale, const float* in_shift, int relu_from,
+                            const void* dY, int64_t ldd, float* dW, const int* tile_list, const int* tile_count,
+                            int B, int H, int W, int Cin, int Cout, int dt, void* ws, void* stream);
+
 /* SparK loss (spark.py:112-123): p x p patches, target patch normalised with its own mean / unbiased variance
  * (eps 1e-6), l2 = patch mean of (rec-target)^2, loss = sum over NON-active patches / (count + 1e-8).
  * rec, img (B,f*p,f*p) fp32; drec nullable.  ws: cmu_spark_loss_ws_bytes(B,f).                              */
@@ -359,6 +377,44 @@ int cmu_skinny_gemm_fwd(const float* x, const float* w, const float* bias, float
 int64_t cmu_skinny_gemm_bwd_ws_bytes(int M, int N);
 int cmu_skinny_gemm_dgrad(const float* dy, const float* w, float* dx, int M, int N, int64_t K, void* ws, void* stream);
 int cmu_skinny_gemm_wgrad(const float* dy, const float* x, float* dw, float* dbias, int M, int N, int64_t K, void* stream);
+
+/* 16-bit-operand variants for the AMP configuration (cmunet_config.py:76-78: nn.Linear under autocast multiplies fp16
+ * operands into fp32): x, w, dy, dx, dw stay fp32 in memory (the master weights of the optimiser), operands are rounded to
+ * dt (CMU_F16 / CMU_BF16) in registers, accumulation fp32 -- v_mfma_f32_32x32x16.  Same contracts as above; fwd needs
+ * K % 16 == 0; dgrad reads dy in place (no workspace).                                                                  */
+int64_t cmu_skinny16_gemm_ws_bytes(int M, int N, int64_t K);
+int cmu_skinny16_gemm_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int64_t K, int dt, void* ws,
+                          void* stream);
+int cmu_skinny16_gemm_dgrad(const float* dy, const float* w, float* dx, int M, int N, int64_t K, int dt, void* stream);
+int cmu_skinny16_gemm_wgrad(const float* dy, const float* x, float* dw, float* dbias, int M, int N, int64_t K, int dt, void* stream);
+
+/* ---- BatchNorm1d (+ ReLU) of the necks' hidden layer (nonlinear_neck.py:58-60, 95-98: (Sync)BN eps 1e-6 then ReLU), rows M x
+ * columns N fp32.  Statistics per column over the rows; on more than one rank the caller exchanges the column sums
+ * (SyncBN):
+ *   cmu_bn1d_colsums      sums[2][N] = (sum x, sum x^2)                       -> all-reduce -> cmu_bn1d_relu_fwd(sums, count)
+ *   cmu_bn1d_relu_fwd     y = [relu](gamma * (x - mean) * invstd + beta); sums == NULL: statistics of the M rows (two-pass
+ *                         variance, as F.batch_norm), else mean = sums[0]/count, var = sums[1]/count - mean^2; training:
+ *                         save_mean / save_invstd written, running statistics updated (unbiased variance, momentum);
+ *                         training == 0: running statistics used.  gamma / beta nullable (affine=False).
+ *   cmu_bn1d_bwd_colsums  sums[2][N] = (sum dz, sum dz * xhat), dz = dy * [y > 0] when relu   -> all-reduce
+ *   cmu_bn1d_relu_bwd     dx = gamma * invstd * (dz - S0/count - xhat * S1/count) with (S0, S1) = sums or, if NULL, the local
+ *                         sums (count = M); dgamma / dbeta (nullable) = LOCAL sums (the gradient exchange averages them).   */
+int cmu_bn1d_colsums(const float* x, float* sums, int M, int N, void* stream);
+int cmu_bn1d_relu_fwd(const float* x, const float* sums, int64_t count, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, float momentum, float eps, int training, int relu, float* y, float* save_mean,
+                      float* save_invstd, int M, int N, void* stream);
+int cmu_bn1d_bwd_colsums(const float* dy, const float* x, const float* y, const float* save_mean, const float* save_invstd, int relu,
+                         float* sums, int M, int N, void* stream);
+int cmu_bn1d_relu_bwd(const float* dy, const float* x, const float* y, const float* save_mean, const float* save_invstd,
+                      const float* gamma, int relu, const float* sums, int64_t count, float* dx, float* dgamma, float* dbeta, int M,
+                      int N, void* stream);
+
+/* Conv2d(K, N, 1) from an NHWC dt tensor with its pending transform to an NCHW fp32 tensor: the per-call `reduce_channels`
+ * of the target latent (Pretraining/CM-UNet/cmae/models/algorithms/cmunet.py:128-131; the reference then re-views the NCHW
+ * memory as a (B,1,H,W) image).  w (N,K) fp32 (rounded to dt in registers), bias (N) or NULL.  K a whole number of 32-byte
+ * slices, H*W % 4 == 0.                                                                                                   */
+int cmu_conv1x1_nchw_fwd(const void* x, int64_t ldx, const float* in_scale, const float* in_shift, int relu_from, const float* w,
+                         const float* bias, float* out, int B, int H, int W, int K, int N, int dt, void* stream);
 
 #ifdef __cplusplus
 }

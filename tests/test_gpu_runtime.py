@@ -25,9 +25,9 @@ def test_seg_stats_cache_is_keyed_on_tensor_identity(cuda):
     iou = M.IoU(threshold=0.5, activation="softmax", ignore_channels=[0])
     g = torch.Generator().manual_seed(0)
     seen_ptrs, vals = [], []
-    for it in range(3):
-        lo = torch.randn(2, 2, 32, 32, generator=g)
-        y1 = (torch.rand(2, 32, 32, generator=g) > 0.7).double()
+    for it in range(6):            # (tensors of 2 / 4 MB: the freed blocks are the only ones of their size in the allocator's pools)
+        lo = torch.randn(2, 2, 256, 256, generator=g)
+        y1 = (torch.rand(2, 256, 256, generator=g) > 0.7).double()
         y = torch.stack([1 - y1, y1], 1)
         with torch.no_grad():
             p, t = lo.to(cuda), y.to(cuda)
@@ -37,8 +37,8 @@ def test_seg_stats_cache_is_keyed_on_tensor_identity(cuda):
         ref = (float(OL.dice_ce_loss(lo, y)), float(OL.iou_loss(lo, y)))
         vals.append(got)
         assert abs(got[0] - ref[0]) <= 1e-5 and abs(got[1] - ref[1]) <= 1e-6, (it, got, ref)
-    assert len(set(seen_ptrs)) < 3, "the allocator did not reuse the addresses: the scenario was not exercised"
-    assert len({v[0] for v in vals}) == 3
+    assert len(set(seen_ptrs)) < 6, "the allocator did not reuse the addresses: the scenario was not exercised"
+    assert len({v[0] for v in vals}) == 6
     # one pair evaluated by several objects -> one fused pass (same output tensor)
     p, t = torch.randn(1, 2, 16, 16).to(cuda), torch.zeros(1, 2, 16, 16, dtype=torch.float64).to(cuda)
     assert M.seg_stats(p, t) is M.seg_stats(p, t)

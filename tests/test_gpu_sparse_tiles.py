@@ -1,0 +1,141 @@
+"""Tile skipping of the SparK sparse encoder (reference semantics Spark/encoder.py:20-36: dense op, then
+`*= active`): the device-side tile list, the persistent conv kernel and the weight-gradient kernel over listed tiles against
+their dense forms, and the whole SparK step with and without skipping."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cmunet_amd import ops as o
+    return o
+
+
+def _active(B, f, keep, seed):
+    g = torch.Generator().manual_seed(seed)
+    a = torch.zeros(B, f * f, dtype=torch.uint8)
+    for b in range(B):
+        a[b, torch.randperm(f * f, generator=g)[:keep]] = 1
+    return a.view(B, f, f)
+
+
+@pytest.mark.parametrize("case", [(3, 4, 64, 16, 32, 4), (2, 8, 128, 16, 32, 16), (2, 8, 128, 16, 16, 16), (2, 8, 64, 16, 32, 16),
+                                  (1, 32, 512, 16, 32, 256), (4, 4, 64, 16, 16, 0), (2, 4, 64, 16, 32, 16), (5, 8, 256, 16, 32, 3)])
+def test_tile_list_matches_numpy(ops, case):
+    B, f, H, th, tw, keep = case
+    act = _active(B, f, keep, seed=sum(case))
+    tl = ops.TileList(act.cuda(), H, H, th, tw)
+    n = int(tl.count.item())
+    got = tl.list[:n].cpu().numpy()
+    px = np.repeat(np.repeat(act.numpy(), H // f, 1), H // f, 2)            # (B, H, H) pixel map
+    ty, tx = H // th, H // tw
+    on = px.reshape(B, ty, th, tx, tw).max(axis=(2, 4)).reshape(-1)
+    ref = np.nonzero(on)[0]
+    assert n == len(ref) and np.array_equal(got, ref), (n, len(ref))
+    assert tl.n_dense == B * ty * tx
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
+@pytest.mark.parametrize("shape", [(2, 128, 64, 64, 8), (2, 64, 64, 128, 4), (1, 128, 128, 128, 8), (3, 64, 256, 128, 4)])
+def test_conv_tiles_bit_identical_on_listed_tiles_and_untouched_elsewhere(ops, dt, shape):
+    """The persistent kernel over a tile list: on the listed 16 x 32 tiles the output equals the dense launch bit for bit
+    (same kernel, same per-tile arithmetic); the other tiles keep what was there before (a sentinel)."""
+    B, S, Cin, Cout, f = shape
+    if not ops.conv3x3_tiles_supported(B, S, S, Cin, Cout, dt):
+        pytest.skip("shape not served by the persistent kernel for this dtype")
+    tdt = ops.TORCH_DT[ops.dt_code(dt)]
+    g = torch.Generator(device="cuda").manual_seed(1)
+    act = _active(B, f, max(1, f * f // 4), seed=S + Cin).cuda()
+    x = torch.randn(B, S, S, Cin, generator=g, device="cuda").to(tdt)
+    sc = (1 + 0.2 * torch.randn(Cin, generator=g, device="cuda")).contiguous()
+    sh = (0.1 * torch.randn(Cin, generator=g, device="cuda")).contiguous()
+    w = torch.randn(Cout, Cin, 3, 3, generator=g, device="cuda") / (3 * Cin ** 0.5)
+    wp = ops.pack_conv3x3(w, dt)
+    xa = ops.Act(x, 0, Cin, sc, sh, 0)
+    dense = ops.new_act(B, S, S, Cout, dt, "cuda")
+    ops.conv3x3_fwd(xa, wp, dense, None)
+    tl = ops.TileList(act, S, S, 16, 32)
+    out = ops.Act(torch.full((B, S, S, Cout), 7.0, dtype=tdt, device="cuda"))
+    ops.conv3x3_fwd_tiles(xa, wp, out, tl)
+    n = int(tl.count.item())
+    listed = torch.zeros(tl.n_dense, dtype=torch.bool, device="cuda")
+    listed[tl.list[:n].long()] = True
+    m = listed.view(B, S // 16, S // 32).repeat_interleave(16, 1).repeat_interleave(32, 2)     # (B, S, S) pixels of listed tiles
+    assert 0 < n < tl.n_dense
+    assert torch.equal(out.buf[m], dense.buf[m]), "listed tiles differ from the dense launch"
+    assert bool((out.buf[~m] == 7.0).all()), "a skipped tile was written"
+    # every active pixel lies in a listed tile
+    pix = act.bool().repeat_interleave(S // f, 1).repeat_interleave(S // f, 2)
+    assert bool((m | ~pix).all())
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
+@pytest.mark.parametrize("shape", [(2, 128, 64, 64, 8), (2, 64, 32, 64, 4), (1, 128, 128, 64, 8)])
+def test_wgrad_tiles_equals_dense_when_dy_is_masked(ops, dt, shape):
+    """Weight gradient over the listed 16 x 16 tiles == the dense weight gradient when dY vanishes outside the active patches
+    (the sparse BatchNorm backward writes zeros there); only the split-K summation order differs."""
+    from cmunet_amd import _lib
+    B, S, Cin, Cout, f = shape
+    tdt = ops.TORCH_DT[ops.dt_code(dt)]
+    g = torch.Generator(device="cuda").manual_seed(2)
+    act = _active(B, f, max(1, f * f // 4), seed=S + Cout).cuda()
+    pix = act.bool().repeat_interleave(S // f, 1).repeat_interleave(S // f, 2).unsqueeze(-1)
+    x = torch.randn(B, S, S, Cin, generator=g, device="cuda").to(tdt)
+    dy = (torch.randn(B, S, S, Cout, generator=g, device="cuda") * pix).to(tdt)
+    ws = torch.empty(_lib.lib().cmu_conv3x3_wgrad_ws_bytes(B, S, S, Cin, Cout, ops.dt_code(dt)), dtype=torch.uint8, device="cuda")
+    dW = torch.empty(Cout, Cin, 3, 3, device="cuda")
+    ops.conv3x3_wgrad(ops.Act(x), ops.Act(dy), dW, ws)
+    tl = ops.TileList(act, S, S, 16, 16)
+    dWt = torch.empty_like(dW)
+    ops.conv3x3_wgrad_tiles(ops.Act(x), ops.Act(dy), dWt, ws, tl)
+    assert 0 < int(tl.count.item()) < tl.n_dense
+    e = (dW - dWt).abs().max().item() / dW.abs().max().item()
+    assert e <= (1e-5 if dt != "f32" else 2e-5), e
+    # against float64 as well
+    ref = torch.nn.grad.conv2d_weight(x.double().cpu().permute(0, 3, 1, 2), (Cout, Cin, 3, 3), dy.double().cpu().permute(0, 3, 1, 2), padding=1)
+    assert (dWt.double().cpu() - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
+
+
+_STEP = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from cmunet_amd import spark as S
+torch.manual_seed(5)
+dt = sys.argv[1]
+enc = S.build_sparse_encoder("unet_sparse", input_size=128, base_ch=64, depth=5, dtype=dt)
+model = S.SparK(enc, S.UnetDecoder(base_ch=64, depth=5, dtype=dt), mask_ratio=0.75, densify_norm="", dtype=dt).cuda().train()
+g = torch.Generator().manual_seed(11)
+x = torch.randn(2, 1, 128, 128, generator=g).cuda()
+active = model.mask(2, "cuda", g)
+loss = model(x, active_b1ff=active)
+loss.backward()
+torch.save({"loss": loss.detach().cpu(), "grads": {k: p.grad.cpu() for k, p in model.named_parameters() if p.grad is not None}}, sys.argv[2])
+'''
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16"])
+def test_spark_step_with_and_without_tile_skipping(ops, dt, tmp_path):
+    """The whole SparK step (reference geometry, 128 px, mask ratio 0.75) with CMU_SPARK_TILES=1 (default) and =0: identical
+    loss (the forward is the same arithmetic on every active pixel) and equal gradients up to the weight gradients' summation
+    order at the levels that skip."""
+    outs = {}
+    for flag in ("1", "0"):
+        o = str(tmp_path / f"r{flag}.pt")
+        env = dict(os.environ, CMU_SPARK_TILES=flag)
+        subprocess.run([sys.executable, "-c", _STEP % ROOT, dt, o], env=env, check=True, timeout=420)
+        outs[flag] = torch.load(o)
+    assert float(outs["1"]["loss"]) == float(outs["0"]["loss"])
+    for k, g0 in outs["0"]["grads"].items():
+        g1 = outs["1"]["grads"][k]
+        e = (g1 - g0).abs().max().item() / max(g0.abs().max().item(), 1e-12)
+        assert e <= (2e-5 if dt == "f32" else 2e-3), (k, e)
