@@ -9,7 +9,9 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+dtype = sys.argv[2] if len(sys.argv) > 2 else "f16"          # storage dtype of the profiled bench run
+trait = {"f16": "<F16Traits", "bf16": "<BF16Traits", "f32": "<F32Traits"}[dtype]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go = os.path.join(root, "gpurun_out")
 
@@ -43,7 +45,7 @@ with open(os.path.join(root, "profiles", f"{tag}_hbm_traffic_per_step.csv"), "w"
 tj = {}
 for k in rows:
     base = k.split("<")[0]
-    if base in ("conv_igemm3p_kernel", "conv_igemm3_kernel", "conv_igemm_kernel", "conv_wgrad2_kernel", "conv_wgrad_kernel", "conv_wgradT2_kernel") and "BF16" in k:
+    if base in ("conv_igemm3p_kernel", "conv_igemm3_kernel", "conv_igemm_kernel", "conv_wgrad2_kernel", "conv_wgrad_kernel", "conv_wgradT2_kernel", "conv_gemm_kernel") and trait in k:
         d = tj.setdefault(base, {"launches_per_step": 0, "fetch": 0.0, "write": 0.0, "instances": []})
         d["launches_per_step"] += launches[k]
         d["fetch"] += fetch[k]
@@ -56,8 +58,10 @@ for base, d in tj.items():
                  "fetch_bytes_per_launch": d["fetch"] / n, "write_bytes_per_launch": d["write"] / n,
                  "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `bench.py --steps 1 --warmup 1`, KB*1024, FETCH_SIZE "
                            f"doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); {tag}"}
+out["_command"] = {"dtype": dtype, "workload": "recon", "tag": tag,
+                   "command": "python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events (rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE)"}
 json.dump(out, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
 st = glob.glob(os.path.join(go, f"prof_{tag}", "*", "*_kernel_stats.csv"))
 if st:
     shutil.copy(max(st, key=os.path.getmtime), os.path.join(root, "profiles", f"{tag}_kernel_stats.csv"))
-print("wrote profiles/ for", tag, "-", ", ".join(f"{k}: {v['hbm_bytes_per_launch'] / 1e9:.2f} GB/launch x {v['launches_per_step']}" for k, v in out.items()))
+print("wrote profiles/ for", tag, "-", ", ".join(f"{k}: {v['hbm_bytes_per_launch'] / 1e9:.2f} GB/launch x {v['launches_per_step']}" for k, v in out.items() if k != "_command"))
