@@ -84,7 +84,7 @@ _SIGS = {
     "cmu_softmax_ce_dice_ws_bytes": (_L, [_I, _I, _I]),
     "cmu_softmax_ce_dice_fwd_bwd": (_I, [_P, _P, _P, _P, _F, _I, _I, _I, _P, _P]),
     "cmu_infonce_inbatch_fwd_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
-    "cmu_moco_ws_bytes": (_L, [_I, _I]),
+    "cmu_moco_ws_bytes": (_L, [_I, _I, _I]),
     "cmu_moco_infonce_enqueue": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P]),
     "cmu_l2_normalize_rows": (_I, [_P, _P, _I, _I, _P]),
     "cmu_masked_stats_rows": (_I, []),

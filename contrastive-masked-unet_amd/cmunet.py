@@ -396,6 +396,7 @@ class _CMUNetFn(torch.autograd.Function):
     def forward(ctx, module, img, img_t, mask, reduce_w, reduce_b, names, *params):
         eng = module._engine(img.device)
         sd = _named_state(module)
+        eng.prepack(sd)                # every conv / conv-transpose weight pack of the four networks in one launch
         tr = module.training
         x = img.detach().float().contiguous()
         ectx = eng.encoder_forward(sd, x, tr, "backbone.", mask, not module.ref_compat)

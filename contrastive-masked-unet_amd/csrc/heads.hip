@@ -292,133 +292,7 @@ extern "C" int cmu_infonce_inbatch_fwd_bwd(const float* pred, const float* keys,
     return CMU_OK;
 }
 
-// ---------------------------------------------------------------------------------------------
-// MoCo: InfoNCE against the queue + ring-buffer enqueue in ONE launch.
-//   grid = B blocks (one query row each).  Every block streams the (D,K) queue twice (logits, gradient);
-//   the block that draws the last ticket sums the per-row losses in row order, writes the gathered keys
-//   into queue[:, ptr:ptr+Nk] and advances the pointer -- after all readers of the old queue are done.
-// ws: [0] ticket (u32, zeroed by a memset node before the launch), [4..4+B) per-row losses (float).
-// ---------------------------------------------------------------------------------------------
-constexpr int MOCO_MAX_K_LDS = 16384;
-__global__ __launch_bounds__(256) void moco_kernel(const float* __restrict__ q_raw, const float* __restrict__ k_raw,
-                                                  const float* __restrict__ keys_all, int Nk, float* queue, int64_t* queue_ptr,
-                                                  float* loss, float* __restrict__ dq, float* __restrict__ k_norm_out, int B, int D,
-                                                  int K, float temp, unsigned* ticket, float* row_loss) {
-    extern __shared__ float sm[];  // [D] qn, [D] kn, [K] logits (if K fits)
-    __shared__ float red[4];
-    __shared__ unsigned last_flag;
-    float* qn = sm;
-    float* kn = sm + D;
-    float* lg = sm + 2 * D;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* q = q_raw + (int64_t)b * D;
-    const float* kk = k_raw + (int64_t)b * D;
-    float s = 0.f, s2 = 0.f;
-    for (int d = tid; d < D; d += 256) {
-        s = fmaf(q[d], q[d], s);
-        s2 = fmaf(kk[d], kk[d], s2);
-    }
-    const float qnorm = fmaxf(sqrtf(block_sum(s, red)), 1e-12f);
-    const float knorm = fmaxf(sqrtf(block_sum(s2, red)), 1e-12f);
-    float pos = 0.f;
-    for (int d = tid; d < D; d += 256) {
-        qn[d] = q[d] / qnorm;
-        kn[d] = kk[d] / knorm;
-        pos = fmaf(qn[d], kn[d], pos);
-        if (k_norm_out) k_norm_out[(int64_t)b * D + d] = kn[d];
-    }
-    pos = block_sum(pos, red) / temp;  // also the barrier that publishes qn/kn
-    // pass 1: negatives l_j = qn . queue[:, j] / temp ; thread per column (coalesced over j)
-    const int ptr0 = (int)queue_ptr[0];
-    float m = pos;
-    for (int j = tid; j < K; j += 256) {
-        float a = 0.f;
-        for (int d = 0; d < D; ++d) a = fmaf(qn[d], queue[(int64_t)d * K + j], a);
-        a /= temp;
-        lg[j] = a;
-        m = fmaxf(m, a);
-    }
-    m = block_max(m, red);
-    float se = 0.f;
-    for (int j = tid; j < K; j += 256) se += expf(lg[j] - m);
-    se = block_sum(se, red) + expf(pos - m);
-    const float lse = m + logf(se);
-    if (tid == 0) row_loss[b] = (lse - pos) / (float)B;   // CE with label 0, mean over the batch
-    if (dq) {
-        // d loss / d logit_j = (softmax_j - [j==0]) / B ; d logit / d qn = key / temp
-        const float gpos = (expf(pos - m) / se - 1.f) / ((float)B * temp);
-        __syncthreads();
-        for (int j = tid; j < K; j += 256) lg[j] = expf(lg[j] - m) / se / ((float)B * temp);
-        __syncthreads();
-        // pass 2: dqn[d] = gpos*kn[d] + sum_j g_j queue[d][j]; one wave per d (rows of the queue are contiguous)
-        for (int d = wave; d < D; d += 4) {
-            const float* row = queue + (int64_t)d * K;
-            float a = 0.f;
-            for (int j = lane; j < K; j += 64) a = fmaf(lg[j], row[j], a);
-            a = wave_sum(a);
-            if (lane == 0) kn[d] = fmaf(gpos, kn[d], a);   // kn now holds dqn
-        }
-        __syncthreads();
-        float dot = 0.f;
-        for (int d = tid; d < D; d += 256) dot = fmaf(kn[d], qn[d], dot);
-        dot = block_sum(dot, red);
-        for (int d = tid; d < D; d += 256) dq[(int64_t)b * D + d] = (kn[d] - qn[d] * dot) / qnorm;
-    }
-    // ---- ticket: the last block to finish reading the old queue performs the enqueue -----------------
-    __syncthreads();
-    if (tid == 0) {
-        __threadfence();
-        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        last_flag = (t == (unsigned)(gridDim.x - 1)) ? 1u : 0u;
-        if (last_flag) __threadfence();
-    }
-    __syncthreads();
-    if (!last_flag) return;
-    if (tid == 0) {
-        double tot = 0.0;
-        for (int r = 0; r < B; ++r) tot += (double)__hip_atomic_load(&row_loss[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        loss[0] = (float)tot;
-    }
-    // queue[:, ptr + i] = key_i  (moco2_module.py:172); keys_all == NULL: this rank's normalised keys
-    for (int64_t o = tid; o < (int64_t)Nk * D; o += 256) {
-        const int d = (int)(o / Nk), i = (int)(o % Nk);   // consecutive threads -> consecutive columns (coalesced store)
-        float v;
-        if (keys_all) v = __hip_atomic_load(&keys_all[(int64_t)i * D + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else {
-            // recompute the normalised key of row i (k_norm_out may be NULL)
-            const float* kr = k_raw + (int64_t)i * D;
-            float ss = 0.f;
-            for (int e = 0; e < D; ++e) ss = fmaf(kr[e], kr[e], ss);
-            v = kr[d] / fmaxf(sqrtf(ss), 1e-12f);
-        }
-        queue[(int64_t)d * K + ptr0 + i] = v;
-    }
-    if (tid == 0) queue_ptr[0] = (int64_t)((ptr0 + Nk) % K);
-}
-extern "C" int64_t cmu_moco_ws_bytes(int B, int K) { return 16 + (int64_t)B * (int64_t)sizeof(float); }
-extern "C" int cmu_moco_infonce_enqueue(const float* q_raw, const float* k_raw, const float* keys_all, int Nk, float* queue,
-                                        int64_t* queue_ptr, float* loss, float* dq, float* k_norm_out, int B, int D, int K,
-                                        float temperature, void* ws, void* stream) {
-    CMU_CHECK_ARG(q_raw && k_raw && queue && queue_ptr && loss && ws && B > 0 && D > 0 && K > 0 && temperature > 0.f,
-                  "cmu_moco_infonce_enqueue: bad args");
-    if (!keys_all) Nk = B;
-    CMU_CHECK_ARG(Nk > 0 && K % Nk == 0, "cmu_moco_infonce_enqueue: K=%d must be a multiple of the gathered batch %d (moco2_module.py:169)", K, Nk);
-    CMU_CHECK_ARG(K <= MOCO_MAX_K_LDS && (size_t)(2 * D + K) * 4 <= 160 * 1024 - 64, "cmu_moco_infonce_enqueue: K=%d, D=%d exceed the LDS-resident logits budget", K, D);
-    hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(ws, 0, 16, st);
-    if (e != hipSuccess) { cmu_set_error("cmu_moco_infonce_enqueue: memset: %s", hipGetErrorString(e)); return CMU_ERR_LAUNCH; }
-    const size_t lds = (size_t)(2 * D + K) * sizeof(float);
-    static CmuPerDevice attr_set;   // hipFuncSetAttribute is per device
-    if (!attr_set.done()) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&moco_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-        if (e != hipSuccess) { cmu_set_error("cmu_moco_infonce_enqueue: LDS attribute: %s", hipGetErrorString(e)); return CMU_ERR_LAUNCH; }
-        attr_set.mark();
-    }
-    hipLaunchKernelGGL(moco_kernel, dim3(B), dim3(256), lds, st, q_raw, k_raw, keys_all, Nk, queue, queue_ptr, loss, dq, k_norm_out, B, D, K,
-                       temperature, (unsigned*)ws, (float*)((char*)ws + 16));
-    CMU_CHECK_LAUNCH("cmu_moco_infonce_enqueue");
-    return CMU_OK;
-}
+// (MoCo's InfoNCE + queue update: moco.hip)
 
 // ---------------------------------------------------------------------------------------------
 // EMA and Adam over flat fp32 arenas (float4 per lane)

@@ -122,6 +122,10 @@ class UNetEngine:
             plan = (sig, keys, ops.PackPlan(items, self.dt), [sd[k[0] + "weight"] for k in keys])
             self._pack_plan = plan
         _, keys, pp, params = plan
+        stamp = (ops.PARAM_GENERATION, tuple(prm._version for prm in params))
+        if getattr(self, "_pack_stamp", None) == stamp and all(k in self.packs.items for k in keys):
+            return                                  # nothing was updated since the last pack (evaluation loops, frozen encoders)
+        self._pack_stamp = stamp
         pp.run()
         for key, out, prm in zip(keys, pp.outs, params):
             self.packs.items[key] = ((prm._version, ops.PARAM_GENERATION), prm.data_ptr(), out)

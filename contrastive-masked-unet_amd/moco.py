@@ -30,6 +30,7 @@ class _EncoderGapFn(torch.autograd.Function):
     def forward(ctx, module, x, names, *params):
         eng = module._engine(x.device)
         sd = _named_state(module)
+        eng.prepack(sd)
         B = x.shape[0]
         ectx = eng.encoder_forward(sd, x.detach().float().contiguous().view(B, x.shape[-2], x.shape[-1]), module.training, "")
         lat = ectx["latent"]
@@ -141,7 +142,7 @@ class _MocoLossFn(torch.autograd.Function):
             keys_all = concat_all_gather(kn)                       # moco2_module.py:163-164
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         dq = torch.empty_like(q_raw)
-        ws = torch.empty(_lib.lib().cmu_moco_ws_bytes(B, K), dtype=torch.uint8, device=dev)
+        ws = torch.empty(_lib.lib().cmu_moco_ws_bytes(B, D, K), dtype=torch.uint8, device=dev)
         ops.moco_infonce_enqueue(q_raw.detach().contiguous(), k_raw.detach().contiguous(), keys_all, queue, queue_ptr, loss, dq,
                                  None, temperature, ws)
         ctx.save_for_backward(dq)

@@ -59,6 +59,7 @@ class _UNetFn(torch.autograd.Function):
     def forward(ctx, module, x, mask, mask_per_sample, names, *params):
         eng = module._engine(x.device)
         sd = _named_state(module)
+        eng.prepack(sd)
         training = module.training
         logits, saved = eng.unet_forward(sd, x.detach().float().contiguous(), training, mask, mask_per_sample)
         ctx.module, ctx.saved, ctx.names, ctx.eng = module, saved, names, eng

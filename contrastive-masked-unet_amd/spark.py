@@ -250,6 +250,7 @@ class SparK(_EngineOwner, nn.Module):
     def _step(self, inp_bchw, active_b1ff, need_grads):
         eng = self._engine(inp_bchw.device)
         sd = _named_state(self)
+        eng.prepack(sd)
         training = self.training
         B, _, H, W = inp_bchw.shape
         f, r = active_b1ff.shape[-1], self.downsample_raito

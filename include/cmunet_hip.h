@@ -226,8 +226,10 @@ int cmu_infonce_inbatch_fwd_bwd(const float* pred, const float* keys, float* los
  * CE with label 0 on the PRE-enqueue queue; then queue[:, ptr:ptr+Nk] = keys_all^T (keys_all (Nk,D),
  * the all-gathered normalised keys; may be NULL on one rank = normalised k_raw) and *ptr=(ptr+Nk)%K.
  * dq (nullable) = d loss / d q_raw.  k_norm_out (nullable, (B,D)) receives normalised keys.
- * ws: cmu_moco_ws_bytes(B,K).                                                                     */
-int64_t cmu_moco_ws_bytes(int B, int K);
+ * One persistent launch of five phases with grid-wide barriers (row norms; logits = q . queue as a skinny MFMA GEMM; row
+ * softmax + loss; gradient = p . queue^T as a second skinny GEMM split over K; dq, enqueue, pointer), every phase spread over
+ * all workgroups, fixed-order sums.  K % 4 == 0.  ws: cmu_moco_ws_bytes(B, D, K) bytes, 16-byte aligned.                  */
+int64_t cmu_moco_ws_bytes(int B, int D, int K);
 int cmu_moco_infonce_enqueue(const float* q_raw, const float* k_raw, const float* keys_all, int Nk,
                              float* queue, int64_t* queue_ptr, float* loss, float* dq, float* k_norm_out,
                              int B, int D, int K, float temperature, void* ws, void* stream);

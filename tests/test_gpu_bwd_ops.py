@@ -349,15 +349,22 @@ def test_infonce_inbatch(ops, rank, world, B):
     check(dp.cpu(), p.grad, 1e-4, "infonce dpred")
 
 
+@pytest.mark.parametrize("shape", [(8, 128, 512), (32, 1024, 4096), (5, 72, 260), (40, 64, 1024)])
 @pytest.mark.parametrize("gathered", [False, True])
-def test_moco_infonce_enqueue(ops, gathered):
+def test_moco_infonce_enqueue(ops, gathered, shape):
+    """(32, 1024, 4096) = BASELINE config 3 per GPU; (5, 72, 260): ragged tiles; (40, 64, 1024): more than one 32-row tile."""
     from cmunet_amd import _lib
     from oracle import moco as OM
-    B, D, K, T = 8, 128, 512, 0.2
+    B, D, K = shape
+    T = 0.2
+    if K % (2 * B if gathered else B) != 0:
+        K = (K // (2 * B)) * 2 * B                          # moco2_module.py:169: K % gathered batch == 0
+    if K % 4 != 0:
+        pytest.skip("K % 4")
     g = torch.Generator().manual_seed(17)
     q_raw, k_raw = torch.randn(B, D, generator=g), torch.randn(B, D, generator=g)
     queue = OM.init_queue(D, K, seed=3)
-    ptr = torch.tensor([K - (16 if gathered else 8)], dtype=torch.long)       # wraps to 0 after the enqueue
+    ptr = torch.tensor([K - (2 * B if gathered else B)], dtype=torch.long)    # wraps to 0 after the enqueue
     qr = q_raw.clone().requires_grad_(True)
     logits, labels, k, _ = OM.logits_from_embeddings(qr, k_raw, queue, T)
     keys_all = torch.cat([k, F.normalize(torch.randn(B, D, generator=g), dim=1)]) if gathered else k
@@ -367,13 +374,20 @@ def test_moco_infonce_enqueue(ops, gathered):
     ref.backward()
     qd, pd = queue.clone().cuda(), ptr.clone().cuda()
     loss, dq, kn = torch.empty(1, device="cuda"), torch.empty(B, D, device="cuda"), torch.empty(B, D, device="cuda")
-    ws = ws_bytes(_lib.lib().cmu_moco_ws_bytes(B, K))
+    ws = ws_bytes(_lib.lib().cmu_moco_ws_bytes(B, D, K))
     ops.moco_infonce_enqueue(q_raw.cuda(), k_raw.cuda(), keys_all.cuda() if gathered else None, qd, pd, loss, dq, kn, T, ws)
     check(loss.cpu(), ref.detach().view(1), 2e-5, "moco loss")
     check(dq.cpu(), qr.grad, 1e-4, "moco dq")
     check(kn.cpu(), k, 1e-6, "normalised keys")
     check(qd.cpu(), ref_queue, 1e-6, "queue after enqueue")
     assert int(pd.item()) == int(ref_ptr.item()) == 0
+    # bitwise reproducible (fixed-order sums across workgroups), and a second call works on the moved pointer
+    qd2, pd2 = queue.clone().cuda(), ptr.clone().cuda()
+    loss2, dq2 = torch.empty(1, device="cuda"), torch.empty(B, D, device="cuda")
+    ops.moco_infonce_enqueue(q_raw.cuda(), k_raw.cuda(), keys_all.cuda() if gathered else None, qd2, pd2, loss2, dq2, None, T, ws)
+    assert torch.equal(loss2, loss) and torch.equal(dq2, dq) and torch.equal(qd2, qd)
+    ops.moco_infonce_enqueue(q_raw.cuda(), k_raw.cuda(), keys_all.cuda() if gathered else None, qd2, pd2, loss2, None, None, T, ws)
+    assert int(pd2.item()) == (2 * B if gathered else B) % K and bool(torch.isfinite(loss2).all())
 
 
 def test_l2norm_ema_adam(ops):
