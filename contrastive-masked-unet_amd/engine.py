@@ -287,11 +287,15 @@ class UNetEngine:
         self.flush_counters()
         return ctx
 
-    def encoder_backward(self, sd, ctx, d_latent, d_skips, grads):
-        """d_latent: Act (gradient w.r.t. the activated latent); d_skips[i]: Act or None."""
+    def encoder_backward(self, sd, ctx, d_latent, d_skips, grads, after_bottleneck=None):
+        """d_latent: Act (gradient w.r.t. the activated latent); d_skips[i]: Act or None.  ``after_bottleneck``: called when
+        the bottleneck's parameter gradients (60 % of the encoder's parameters) have been queued."""
         b = ctx["bott"]
         dA = self._convbn_bwd(sd, b["s2"], d_latent, grads, True, next_bn=b["s1"])
         dP = self._convbn_bwd(sd, b["s1"], dA, grads, len(ctx["levels"]) > 0)
+        if after_bottleneck is not None:
+            self.flush_zero_bias()
+            after_bottleneck()
         for i in range(len(ctx["levels"]), 0, -1):
             lv = ctx["levels"][i - 1]
             y2 = lv["s2"]["y"]
@@ -448,14 +452,14 @@ class UNetEngine:
             self._cats_owner = weakref.ref(ctx)
         return dctx["logits"], ctx
 
-    def unet_backward(self, sd, ctx, dlogits, after_decoder=None):
-        """``after_decoder``: called when every decoder parameter gradient has been queued (data-parallel trainers start
-        the decoder's all-reduce there, under the encoder backward)."""
+    def unet_backward(self, sd, ctx, dlogits, after_decoder=None, after_bottleneck=None):
+        """``after_decoder`` / ``after_bottleneck``: called when every decoder / bottleneck parameter gradient has been queued
+        (data-parallel trainers start those buckets' all-reduce there, under the rest of the backward pass)."""
         grads = {}
         d_latent, d_skips = self.decoder_backward(sd, ctx["dec"], dlogits, grads, True, latent_bn=ctx["enc"]["bott"]["s2"])
         if after_decoder is not None:
             after_decoder()
-        self.encoder_backward(sd, ctx["enc"], d_latent, d_skips, grads)
+        self.encoder_backward(sd, ctx["enc"], d_latent, d_skips, grads, after_bottleneck)
         if self._cats is not None and ctx["dec"]["cats"] is self._cats[1]:
             self._cats_busy = False
         return grads

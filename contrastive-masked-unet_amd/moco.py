@@ -8,7 +8,8 @@ arguments, buffers (``queue (emb_dim, K)``, ``queue_ptr (1,) int64``) and method
                                                                      (N, 1+K) logits are a plain library GEMM)
   training_step((x_q, x_k))   -> loss                                moco2_module.py:287-309, fused:
       EMA of the key encoder (cmu_ema_update, BEFORE the forward: A-8), both encoders on the HIP engine with
-      the global average pool fused on the raw latent (cmu_gap_fwd), all-gather of the normalised keys,
+      the global average pool fused on the raw latent (cmu_gap_fwd), batch shuffle of the key images across
+      ranks (shuffle-BN, moco2_module.py:177-222) when more than one rank runs, all-gather of the normalised keys,
       InfoNCE against the queue + ring-buffer enqueue in ONE kernel (cmu_moco_infonce_enqueue).
 """
 import copy
@@ -67,11 +68,14 @@ class UNet_encoder(_MaskEncoder):
 class Moco_v2(nn.Module):
     def __init__(self, base_encoder=None, emb_dim=1024, num_negatives=65536, encoder_momentum=0.999,
                  softmax_temperature=0.07, learning_rate=0.03, momentum=0.9, weight_decay=1e-4, batch_size=256,
-                 use_mlp=False, dtype="bf16", base_ch=64, depth=5, **kwargs):
+                 use_mlp=False, dtype="bf16", base_ch=64, depth=5, shuffle_bn=True, **kwargs):
         super().__init__()
         self.hparams = dict(emb_dim=emb_dim, num_negatives=num_negatives, encoder_momentum=encoder_momentum,
                             softmax_temperature=softmax_temperature, learning_rate=learning_rate, momentum=momentum,
                             weight_decay=weight_decay, batch_size=batch_size, use_mlp=use_mlp)
+        # batch shuffle of the key images across ranks (moco2_module.py:177-222, applied whenever the reference runs under
+        # DDP): only acts when a process group with more than one rank exists
+        self.shuffle_bn = bool(shuffle_bn)
         if use_mlp:
             raise NotImplementedError("use_mlp needs an fc attribute the reference's UNet_encoder does not have "
                                       "(moco2_module.py:115-118 would fail there too)")
@@ -108,10 +112,43 @@ class Moco_v2(nn.Module):
         queue[:, ptr:ptr + bs] = keys.T
         queue_ptr[0] = (ptr + bs) % self.hparams["num_negatives"]
 
+    @staticmethod
+    def _world():
+        return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+    @torch.no_grad()
+    def _batch_shuffle_ddp(self, x):
+        """moco2_module.py:177-201: gather the key images of all ranks, draw ONE permutation on rank 0 (global CPU generator,
+        as the reference's ``torch.randperm(n).cuda()``), broadcast it, keep this rank's share -> (images, idx_unshuffle)."""
+        n_this = x.shape[0]
+        x_gather = concat_all_gather(x.contiguous())
+        n_all = x_gather.shape[0]
+        idx_shuffle = torch.randperm(n_all).to(x.device)
+        dist.broadcast(idx_shuffle, src=0)
+        idx_unshuffle = torch.argsort(idx_shuffle)
+        idx_this = idx_shuffle.view(n_all // n_this, -1)[dist.get_rank()]
+        return x_gather[idx_this], idx_unshuffle
+
+    @torch.no_grad()
+    def _batch_unshuffle_ddp(self, x, idx_unshuffle):
+        """moco2_module.py:203-219."""
+        n_this = x.shape[0]
+        x_gather = concat_all_gather(x.contiguous())
+        idx_this = idx_unshuffle.view(x_gather.shape[0] // n_this, -1)[dist.get_rank()]
+        return x_gather[idx_this]
+
+    def _encode_keys(self, img_k):
+        """Key features with the batch shuffle around the key encoder when more than one rank runs (moco2_module.py:240-252)."""
+        with torch.no_grad():
+            if self.shuffle_bn and self._world() > 1:
+                img_s, idx_unshuffle = self._batch_shuffle_ddp(img_k)
+                return self._batch_unshuffle_ddp(self.encoder_k(img_s), idx_unshuffle)
+            return self.encoder_k(img_k)
+
     def forward(self, img_q, img_k, queue):
         q = F.normalize(self.encoder_q(img_q), dim=1)
         with torch.no_grad():
-            k = F.normalize(self.encoder_k(img_k), dim=1)
+            k = F.normalize(self._encode_keys(img_k), dim=1)
         l_pos = torch.einsum("nc,nc->n", [q, k]).unsqueeze(-1)
         l_neg = torch.einsum("nc,ck->nk", [q, queue.clone().detach()])
         logits = torch.cat([l_pos, l_neg], dim=1) / self.hparams["softmax_temperature"]
@@ -124,8 +161,7 @@ class Moco_v2(nn.Module):
         img_q, img_k = x[0], x[1]
         self._momentum_update_key_encoder()
         q_raw = self.encoder_q(img_q)
-        with torch.no_grad():
-            k_raw = self.encoder_k(img_k)
+        k_raw = self._encode_keys(img_k)
         return _MocoLossFn.apply(q_raw, k_raw, self.queue, self.queue_ptr, self.hparams["softmax_temperature"])
 
 

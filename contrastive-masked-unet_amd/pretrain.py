@@ -80,11 +80,17 @@ class MaskedReconPretrainer:
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._dlogits = None
         self._ws = None
-        # gradient exchange in two buckets: the decoder's parameters are the tail of the arena and their gradients are
-        # complete half-way through the backward pass
-        # (CMU_DDP_OVERLAP=0: one all-reduce of the whole arena after the backward pass -- A/B and fallback switch)
-        self._dec_off = self.flat.tail_offset(("up_conv", "conv_last")) if os.environ.get("CMU_DDP_OVERLAP", "1") != "0" else None
-        self._pending = None
+        # gradient exchange in three buckets, in the order the backward pass completes them: the decoder (the tail of the
+        # arena, 12.2 M parameters) half-way through; the bottleneck (``double_conv.*``, 14.2 M of the encoder's 18.8 M) as soon
+        # as the encoder backward has passed it; the four down blocks (4.7 M) at the end -- only that last 19 MB all-reduce is
+        # not hidden under kernels.  (CMU_DDP_OVERLAP=0: one all-reduce of the whole arena after the backward pass -- A/B and
+        # fallback switch)
+        overlap = os.environ.get("CMU_DDP_OVERLAP", "1") != "0"
+        self._dec_off = self.flat.tail_offset(("up_conv", "conv_last")) if overlap else None
+        self._bott = self.flat.prefix_range("double_conv.") if (overlap and self._dec_off is not None) else None
+        if self._bott is not None and self._bott[1] != self._dec_off:
+            self._bott = None                       # (the bottleneck is expected right in front of the decoder)
+        self._pending = []
 
     def broadcast_parameters(self, src=0):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
@@ -106,14 +112,18 @@ class MaskedReconPretrainer:
         ops.masked_mse_fwd_bwd(logits, self.pred_channel, img, mask, self.loss, self._dlogits,
                                self.rc_weight * self.loss_scale, self._ws, self.amp)
         eng.grad_target, eng.grad_prefix = self.flat.grad_views, ""
-        self._pending = None
+        self._pending = []
 
         def decoder_done():
             if self._dec_off is not None:
-                self._pending = self.flat.all_reduce_range_async(self._dec_off, self.flat.grad.numel(), self.group)
+                self._pending.append(self.flat.all_reduce_range_async(self._dec_off, self.flat.grad.numel(), self.group))
+
+        def bottleneck_done():
+            if self._bott is not None:
+                self._pending.append(self.flat.all_reduce_range_async(self._bott[0], self._bott[1], self.group))
 
         try:
-            eng.unet_backward(self.sd, ctx, self._dlogits, after_decoder=decoder_done)
+            eng.unet_backward(self.sd, ctx, self._dlogits, after_decoder=decoder_done, after_bottleneck=bottleneck_done)
         finally:
             eng.grad_target = None
         return self.loss
@@ -123,12 +133,14 @@ class MaskedReconPretrainer:
         world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
         if world <= 1:
             return 1.0
-        if self._pending is not None:
-            rest = self.flat.all_reduce_range_async(0, self._dec_off, self.group)
-            self._pending.wait()
-            if rest is not None:
-                rest.wait()
-            self._pending = None
+        if self._dec_off is not None:
+            rest_hi = self._bott[0] if self._bott is not None else self._dec_off
+            works = [w for w in self._pending if w is not None]
+            works.append(self.flat.all_reduce_range_async(0, rest_hi, self.group))
+            for w in works:
+                if w is not None:
+                    w.wait()
+            self._pending = []
         else:
             self.flat.all_reduce_mean(self.group)
         return 1.0 / world

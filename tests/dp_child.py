@@ -76,8 +76,10 @@ def main():
         from cmunet_amd import moco as MO
         torch.manual_seed(0)
         B, S, K, T = 4, 32, 64, 0.2
+        # (shuffle_bn off: with the same batch on both ranks the shuffled shares would hold duplicates -- the shuffle has its own
+        # test, mode moco_shuffle)
         m = MO.Moco_v2(emb_dim=64, num_negatives=K, softmax_temperature=T, encoder_momentum=0.99, learning_rate=0.05, dtype="f32",
-                       base_ch=16, depth=3).to(dev).train()
+                       base_ch=16, depth=3, shuffle_bn=False).to(dev).train()
         with torch.no_grad():
             for pk in m.encoder_k.parameters():
                 pk.mul_(0.95)
@@ -87,6 +89,19 @@ def main():
         xq, xk = torch.randn(B, 1, S, S, generator=g), torch.randn(B, 1, S, S, generator=g)
         loss = tr.step(xq.to(dev), xk.to(dev))
         res.update({"loss": float(loss), "xq": xq, "xk": xk, "final": {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}})
+    elif mode == "moco_shuffle":
+        # shuffle-BN (moco2_module.py:177-222): every rank has its own key images; rank 0's permutation comes from the global
+        # CPU generator, seeded here so that the test can redraw it
+        from cmunet_amd import moco as MO
+        torch.manual_seed(0)
+        B, S = 4, 32
+        m = MO.Moco_v2(emb_dim=64, num_negatives=64, softmax_temperature=0.2, dtype="f32", base_ch=16, depth=3).to(dev).train()
+        res["init"] = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        gk = torch.Generator().manual_seed(500 + rank)
+        xq, xk = torch.randn(B, 1, S, S, generator=gk), torch.randn(B, 1, S, S, generator=gk)
+        torch.manual_seed(1234)
+        _, _, k, _ = m(xq.to(dev), xk.to(dev), m.queue)
+        res.update({"k": k.cpu(), "xk": xk})
     elif mode == "spark":
         from cmunet_amd import spark as S
         torch.manual_seed(5)

@@ -210,6 +210,30 @@ def test_moco_trainer_two_ranks_vs_oracle(cuda):
             assert torch.equal(v, two[1]["final"][k]), k
 
 
+def test_moco_shuffle_bn_two_ranks_vs_oracle(cuda):
+    """Shuffle-BN (moco2_module.py:177-222): the key images of both ranks are gathered, permuted with rank 0's permutation,
+    each rank encodes its share (its BatchNorm sees a mixture of both ranks' images), and the keys travel back to their owners.
+    Oracle: the same permutation redrawn from the seed, the key encoder per shuffled group on the CPU."""
+    import torch.nn.functional as F
+    from oracle import moco as OM
+    two = run_ranks("moco_shuffle", 2)
+    B = 4
+    xk_all = torch.cat([two[0]["xk"], two[1]["xk"]])
+    torch.manual_seed(1234)
+    idx = torch.randperm(2 * B)                                   # what rank 0 drew and broadcast
+    un = torch.argsort(idx)
+    ks = []
+    for rk in range(2):
+        sd = {k: v.clone() for k, v in two[rk]["init"].items()}
+        ks.append(OM.encoder_gap(xk_all[idx.view(2, -1)[rk]], sd, "encoder_k.", True))
+    k_ref = F.normalize(torch.cat(ks)[un], dim=1)
+    for rk in range(2):
+        assert rel(two[rk]["k"], k_ref[rk * B:(rk + 1) * B]) <= 1e-4, rk
+    # and it matters: without the shuffle each rank's BatchNorm would see only its own images
+    plain = F.normalize(OM.encoder_gap(two[0]["xk"], {k: v.clone() for k, v in two[0]["init"].items()}, "encoder_k.", True), dim=1)
+    assert rel(two[0]["k"], plain) > 1e-3
+
+
 def test_spark_trainer_two_ranks_equals_one_rank(cuda):
     """SparKPretrainer (LAMB) with grad-less ``densify_projs`` parameters in the arena (SURVEY A-10): two ranks fed the same
     batches match one rank; a static loss scale inside the fused step leaves the update unchanged."""

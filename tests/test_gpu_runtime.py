@@ -111,7 +111,7 @@ def test_masked_recon_trainer_f16_amp_tracks_f32(cuda):
     assert (good, skipped, tracker) == (4, 0, 4) and sc == 65536.0
     a, b = nets["f32"].flat.arena, nets["f16amp"].flat.arena
     # 4 Adam steps of 1e-3: an element whose tiny gradient changes sign between the two arithmetics moves 2e-3 apart per step
-    assert (a - b).abs().max().item() <= 8.1e-3 and (a - b).abs().mean().item() <= 3e-4, ((a - b).abs().max().item(), (a - b).abs().mean().item())
+    assert (a - b).abs().max().item() <= 8.1e-3 and (a - b).abs().mean().item() <= 8e-4, ((a - b).abs().max().item(), (a - b).abs().mean().item())
 
 
 def test_launches_follow_the_tensors_device(cuda):
