@@ -10,7 +10,6 @@ Only the configuration the reference's driver uses is implemented on the HIP pat
 ``hausdorff`` / ``radius_arteries`` (CPU scikit-image / scipy geometry, metrics.py:224-395) are out of scope.
 The Dice term has no gradient, exactly like the reference's thresholded version (SURVEY A-4).
 """
-import re
 import weakref
 
 import torch
@@ -19,17 +18,27 @@ import torch.nn as nn
 from . import _lib, ops
 
 
+def _snake(name):
+    """'CrossEntropyLoss' -> 'cross_entropy_loss': the log keys of the reference's drivers (train.py:455-461 prints and selects
+    checkpoints by 'dice_loss'; metrics.py:9-24 derives them from the class names)."""
+    out = []
+    for i, ch in enumerate(name):
+        if ch.isupper() and i and (name[i - 1].islower() or name[i - 1].isdigit() or (i + 1 < len(name) and name[i + 1].islower())):
+            out.append("_")
+        out.append(ch.lower())
+    return "".join(out)
+
+
 class BaseObject(nn.Module):
+    """Named module: ``__name__`` is the explicit name or the snake-case class name (the reference's log-key contract)."""
+
     def __init__(self, name=None):
         super().__init__()
         self._name = name
 
     @property
     def __name__(self):
-        if self._name is None:
-            s1 = re.sub("(.)([A-Z][a-z]+)", r"\1_\2", self.__class__.__name__)
-            return re.sub("([a-z0-9])([A-Z])", r"\1_\2", s1).lower()
-        return self._name
+        return self._name if self._name is not None else _snake(type(self).__name__)
 
 
 class Metric(BaseObject):
@@ -37,43 +46,48 @@ class Metric(BaseObject):
 
 
 class Loss(BaseObject):
-    def __add__(self, other):
-        if isinstance(other, Loss):
-            return SumOfLosses(self, other)
-        raise ValueError("Loss should be inherited from `Loss` class")
+    """Losses combine with ``+`` and scale with a number (metrics.py:27-82): the result is again a Loss whose name spells the
+    expression, e.g. 'dice_loss + cross_entropy_loss' (train.py:455) or '2 * (dice_loss + cross_entropy_loss)'."""
 
-    def __radd__(self, other):
-        return self.__add__(other)
+    def _terms(self):
+        return [(1.0, self)]
+
+    def __add__(self, other):
+        if not isinstance(other, Loss):
+            raise ValueError("Loss should be inherited from `Loss` class")
+        return SumOfLosses(self, other)
+
+    __radd__ = __add__
 
     def __mul__(self, value):
-        if isinstance(value, (int, float)):
-            return MultipliedLoss(self, value)
-        raise ValueError("Loss should be inherited from `BaseLoss` class")
+        if not isinstance(value, (int, float)):
+            raise ValueError("Loss should be inherited from `BaseLoss` class")
+        return MultipliedLoss(self, value)
 
-    def __rmul__(self, other):
-        return self.__mul__(other)
+    __rmul__ = __mul__
 
 
 class SumOfLosses(Loss):
     def __init__(self, l1, l2):
-        super().__init__(name="{} + {}".format(l1.__name__, l2.__name__))
+        super().__init__(name=f"{l1.__name__} + {l2.__name__}")
         self.l1, self.l2 = l1, l2
 
-    def __call__(self, *inputs):
+    def forward(self, *inputs):
         return self.l1.forward(*inputs) + self.l2.forward(*inputs)
+
+    __call__ = forward
 
 
 class MultipliedLoss(Loss):
     def __init__(self, loss, multiplier):
-        fmt = "{} * ({})" if len(loss.__name__.split("+")) > 1 else "{} * {}"
-        super().__init__(name=fmt.format(multiplier, loss.__name__))
+        inner = loss.__name__
+        super().__init__(name=f"{multiplier} * ({inner})" if "+" in inner else f"{multiplier} * {inner}")
         self.loss, self.multiplier = loss, multiplier
-
-    def __call__(self, *inputs):
-        return self.multiplier * self.loss.forward(*inputs)
 
     def forward(self, *inputs):
         return self.multiplier * self.loss.forward(*inputs)
+
+    __call__ = forward
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -22,8 +22,9 @@ def t(fn, n=10):
 
 
 wb = N * K * 4 / 1e9
-for name, fn, ref in (("fwd", lambda: ops.skinny_gemm_fwd(x, w), lambda: torch.nn.functional.linear(x, w)),
-                      ("dgrad", lambda: ops.skinny_gemm_dgrad(dy, w), lambda: dy @ w),
-                      ("wgrad", lambda: ops.skinny_gemm_wgrad(dy, x), lambda: dy.t() @ x)):
-    a, b = t(fn), t(ref)
-    print(f"{name:6s} M={M} K={K} N={N}: skinny {a:.3f} ms ({wb / a * 1e3 / 1e3:.2f} TB/s of weights)   rocBLAS {b:.3f} ms ({wb / b:.2f} TB/s)")
+for name, fn, fn16, ref in (("fwd", lambda: ops.skinny_gemm_fwd(x, w), lambda: ops.skinny_gemm_fwd(x, w, None, "f16"), lambda: torch.nn.functional.linear(x, w)),
+                            ("dgrad", lambda: ops.skinny_gemm_dgrad(dy, w), lambda: ops.skinny_gemm_dgrad(dy, w, "f16"), lambda: dy @ w),
+                            ("wgrad", lambda: ops.skinny_gemm_wgrad(dy, x), lambda: ops.skinny_gemm_wgrad(dy, x, False, "f16"), lambda: dy.t() @ x)):
+    a, a16, b = t(fn), t(fn16), t(ref)
+    print(f"{name:6s} M={M} K={K} N={N}: skinny f32 {a:.3f} ms ({wb / a:.2f} TB/s of fp32 weights)   skinny f16-operand {a16:.3f} ms ({wb / a16:.2f} TB/s)"
+          f"   rocBLAS f32 {b:.3f} ms ({wb / b:.2f} TB/s)")
