@@ -94,6 +94,10 @@ _SIGS = {
     "cmu_bn_bwd_apply_masked": (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P]),
     "cmu_sparse_tile_list": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "cmu_conv3x3_tiles_supported": (_I, [_I, _I, _I, _I, _I, _I]),
+    "cmu_sparse_pixel_list_ws_bytes": (_L, [_I, _I]),
+    "cmu_sparse_pixel_list": (_I, [_P, _I, _I, _I, _I, _P, _L, _P, _P, _P]),
+    "cmu_conv3x3_rows_supported": (_I, [_I, _I, _I, _I, _I, _I]),
+    "cmu_conv3x3_fwd_rows": (_I, [_P, _L, _P, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
     "cmu_conv3x3_fwd_tiles": (_I, [_P, _L, _P, _P, _I, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "cmu_conv3x3_wgrad_tiles": (_I, [_P, _L, _P, _P, _I, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "cmu_spark_loss_ws_bytes": (_L, [_I, _I]),

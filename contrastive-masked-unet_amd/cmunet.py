@@ -224,21 +224,24 @@ class MUNetPretrainDecoder(_EngineOwner, nn.Module):
 
 class _SkinnyLinearFn(torch.autograd.Function):
     """nn.Linear on <= 32 rows through the weight-streaming kernels (csrc/skinny.hip, necks.hip): one pass over the weights
-    for the forward, one for the input gradient, one write of the weight gradient.  ``compute_dt`` None: exact fp32 products;
-    'f16' / 'bf16': the AMP arithmetic (operands rounded in registers, fp32 accumulation)."""
+    for the forward, one for the input gradient, one write of the weight gradient.  ``compute_dt`` None: exact fp32 products
+    everywhere; 'f16' / 'bf16' (the AMP configuration): the 16-bit-operand kernel where it is the faster one -- measured at
+    K = 262,144, N = 1,536 (tools/skinny_bench.py, profiles/r02_workloads.txt): weight gradient 0.37 ms against 0.55 ms exact;
+    the forward is bound by its 32-rows-per-wave load pattern in both forms (0.72 ms) and the input gradient is faster exact
+    (0.38 against 0.48 ms), so those two stay on the exact fp32 kernels (at least the precision autocast would give)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, compute_dt):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.compute_dt = compute_dt
-        return ops.skinny_gemm_fwd(x.detach(), weight.detach(), None if bias is None else bias.detach(), compute_dt)
+        return ops.skinny_gemm_fwd(x.detach(), weight.detach(), None if bias is None else bias.detach())
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = ops.skinny_gemm_dgrad(dy, weight.detach(), ctx.compute_dt) if ctx.needs_input_grad[0] else None
+        dx = ops.skinny_gemm_dgrad(dy, weight.detach()) if ctx.needs_input_grad[0] else None
         dw, db = (ops.skinny_gemm_wgrad(dy, x.detach(), ctx.has_bias, ctx.compute_dt) if ctx.needs_input_grad[1] else (None, None))
         if ctx.has_bias and db is None and ctx.needs_input_grad[2]:
             db = dy.sum(0)

@@ -539,6 +539,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IGParams p) {
 #include "conv_igemm3.inc"
 #include "conv_igemm3p.inc"
 #include "conv_gemm.inc"
+#include "conv_gather.inc"
 
 // ---------------------------------------------------------------------------------------------------
 // host launchers
@@ -706,6 +707,84 @@ extern "C" int cmu_conv3x3_fwd_tiles(const void* x, int64_t ldx, const float* in
         return CMU_ERR_UNSUPPORTED;
     }
     CMU_DISPATCH_DT(dt, launch_igemm3_any, p, (hipStream_t)stream);
+}
+
+__global__ void sparse_tile_list_kernel(const uint8_t* __restrict__ active, int f, int sbits, int B, int tilesY, int tilesX, int th, int tw,
+                                        int* __restrict__ list, int* __restrict__ count);
+
+// ---- gather form: the convolution over a list of active pixels (conv_gather.inc) ---------------------------------------------------
+template <class TR>
+static int conv3x3_rows_ok_t(IGParams p) {
+    constexpr int KSC = 128 / (int)sizeof(typename TR::elem_t);
+    static const bool on = []() { const char* e = getenv("CMU_SPARK_GATHER"); return !(e && e[0] == '0'); }();
+    if (!on || p.N % 256 != 0 || p.K % KSC != 0) return 0;
+    const int64_t px = (int64_t)p.B * p.H * p.W;
+    if ((px * p.ldx + p.K) * (int64_t)sizeof(typename TR::elem_t) >= 0x7fff0000ll) return 0;          // 32-bit buffer offsets over the whole tensor
+    if ((int64_t)(p.K / (32 / (int)sizeof(typename TR::elem_t))) * 9 * cmu_conv3x3_npad(p.N) * 32 >= 0x7fff0000ll) return 0;
+    return 1;
+}
+extern "C" int cmu_conv3x3_rows_supported(int B, int H, int W, int Cin, int Cout, int dt) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || cmu_dtype_size(dt) <= 0) return 0;
+    IGParams p = {};
+    p.B = B; p.H = H; p.W = W; p.K = Cin; p.N = Cout; p.ldx = Cin; p.ldy = Cout;
+    CMU_DISPATCH_DT(dt, conv3x3_rows_ok_t, p);
+}
+extern "C" int cmu_conv3x3_fwd_rows(const void* x, int64_t ldx, const void* wpacked, void* y, int64_t ldy, const int* rows, const int* n_rows,
+                                    int64_t max_rows, int B, int H, int W, int Cin, int Cout, int dt, void* stream) {
+    CMU_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && rows && n_rows && max_rows > 0, "cmu_conv3x3_fwd_rows: bad dims / null list");
+    CMU_CHECK_ARG(cmu_dtype_size(dt) > 0, "cmu_conv3x3_fwd_rows: bad dtype %d", dt);
+    int rc;
+    if ((rc = check_act("cmu_conv3x3_fwd_rows(x)", x, ldx, Cin, dt))) return rc;
+    if ((rc = check_act("cmu_conv3x3_fwd_rows(y)", y, ldy, Cout, dt))) return rc;
+    CMU_CHECK_ARG(wpacked && cmu_aligned16(wpacked), "cmu_conv3x3_fwd_rows: packed weights null/unaligned");
+    IGParams p = {};
+    p.x = x; p.ldx = ldx; p.w = wpacked; p.y = y; p.ldy = ldy;
+    p.B = B; p.H = H; p.W = W; p.K = Cin; p.N = Cout; p.Cq = Cout;
+    p.tile_list = rows; p.tile_count = n_rows;
+    const int64_t px = (int64_t)B * H * W;
+    if (!cmu_conv3x3_rows_supported(B, H, W, Cin, Cout, dt) || (px * ldx + Cin) * cmu_dtype_size(dt) >= 0x7fff0000ll ||
+        (px * ldy + Cout) * cmu_dtype_size(dt) >= (1ll << 40)) {
+        cmu_set_error("cmu_conv3x3_fwd_rows: needs Cout %% 256 == 0, Cin a whole number of 128-byte steps and an input tensor below 2 GiB "
+                      "(Cin=%d Cout=%d): call cmu_conv3x3_fwd / cmu_conv3x3_fwd_tiles", Cin, Cout);
+        return CMU_ERR_UNSUPPORTED;
+    }
+    CMU_CHECK_ARG(cmu_div_up64(max_rows, 256) * (Cout / 256) < (1ll << 31), "cmu_conv3x3_fwd_rows: grid too large");
+    CMU_DISPATCH_DT(dt, launch_conv_gather, p, max_rows, (hipStream_t)stream);
+}
+
+// rows[r] = dense pixel index (b*H + y)*W + x of the r-th active pixel, patch-major (patch order = cmu_sparse_tile_list with tiles
+// of one patch; pixels row-major inside a patch); entries past the end up to `capacity` are -1; count[0] = number of rows
+__global__ void sparse_pixel_rows_kernel(const int* __restrict__ plist, const int* __restrict__ pcount, int f, int s, int H, int W,
+                                         int* __restrict__ rows, int64_t capacity, int* __restrict__ count) {
+    const int np = pcount[0];
+    const int64_t n = (int64_t)np * s * s;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < capacity; r += (int64_t)gridDim.x * blockDim.x) {
+        int v = -1;
+        if (r < n) {
+            const int pi = (int)(r / (s * s)), in = (int)(r % (s * s));
+            const int t = plist[pi];                                   // (b*f + fy)*f + fx
+            const int fx = t % f, fy = (t / f) % f, b = t / (f * f);
+            v = (b * H + fy * s + in / s) * W + fx * s + in % s;
+        }
+        rows[r] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) count[0] = (int)n;
+}
+extern "C" int64_t cmu_sparse_pixel_list_ws_bytes(int B, int f) { return ((int64_t)B * f * f + 16) * (int64_t)sizeof(int); }
+extern "C" int cmu_sparse_pixel_list(const uint8_t* active, int f, int B, int H, int W, int* rows, int64_t capacity, int* count, void* ws,
+                                     void* stream) {
+    CMU_CHECK_ARG(active && rows && count && ws && f > 0 && B > 0 && H > 0 && W == H && capacity > 0, "cmu_sparse_pixel_list: bad args");
+    const int sbits = sp_shift_bits(H, f);
+    CMU_CHECK_ARG(sbits >= 0 && (int64_t)B * H * W < (1ll << 31), "cmu_sparse_pixel_list: H must be f << s (H=%d, f=%d)", H, f);
+    const int s = 1 << sbits;
+    int* plist = (int*)ws + 16;
+    int* pcount = (int*)ws;
+    hipLaunchKernelGGL(sparse_tile_list_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, active, f, sbits, B, f, f, s, s, plist, pcount);
+    CMU_CHECK_LAUNCH("cmu_sparse_pixel_list(patches)");
+    const int grid = (int)(cmu_div_up64(capacity, 256) < 4096 ? cmu_div_up64(capacity, 256) : 4096);
+    hipLaunchKernelGGL(sparse_pixel_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, plist, pcount, f, s, H, W, rows, capacity, count);
+    CMU_CHECK_LAUNCH("cmu_sparse_pixel_list(rows)");
+    return CMU_OK;
 }
 
 // Active-tile list of a (B, H, W) level for the patch map `active` (B, f, f): tile (b, ty, tx) of th x tw pixels is listed

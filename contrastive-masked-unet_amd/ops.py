@@ -374,6 +374,34 @@ class TileList:
         call("cmu_sparse_tile_list", _p(active), f, B, H, W, tile_h, tile_w, _p(self.list), _p(self.count), _stream())
 
 
+class PixelList:
+    """Device-side list of the active pixels of one level (cmu_sparse_pixel_list): ``rows`` int32 dense pixel indices, patch-
+    major, padded with -1 to ``capacity``; ``count`` int32 (1,).  ``max_rows``: host-side upper bound of the count (the number
+    of active patches x patch area when the caller knows it, else the dense pixel count)."""
+
+    def __init__(self, active, H, W, max_rows=None):
+        B, f = active.shape[0], active.shape[-1]
+        dense = B * H * W
+        self.max_rows = dense if max_rows is None else min(int(max_rows), dense)
+        self.capacity = max(256, (self.max_rows + 255) // 256 * 256)
+        self.rows = torch.empty(self.capacity, dtype=torch.int32, device=active.device)
+        self.count = torch.empty(1, dtype=torch.int32, device=active.device)
+        ws = torch.empty(_lib.lib().cmu_sparse_pixel_list_ws_bytes(B, f), dtype=torch.uint8, device=active.device)
+        call("cmu_sparse_pixel_list", _p(active), f, B, H, W, _p(self.rows), self.capacity, _p(self.count), _p(ws), _stream())
+
+
+def conv3x3_rows_supported(B, H, W, Cin, Cout, dt):
+    return bool(_lib.lib().cmu_conv3x3_rows_supported(B, H, W, Cin, Cout, dt_code(dt)))
+
+
+def conv3x3_fwd_rows(x, wpacked, out, pixels):
+    """3x3 convolution at the listed pixels only (gather-GEMM, csrc/conv_gather.inc); ``out`` elsewhere untouched.  ``x`` carries no
+    pending transform (the sparse encoder's inputs are already activated and masked)."""
+    assert x.dt == out.dt and (x.B, x.H, x.W) == (out.B, out.H, out.W) and x.scale is None
+    call("cmu_conv3x3_fwd_rows", x.ptr(), x.ld, _p(wpacked), out.ptr(), out.ld, _p(pixels.rows), _p(pixels.count), pixels.capacity,
+         x.B, x.H, x.W, x.C, out.C, x.dt, _stream(), work=2.0 * 9 * x.C * out.C * pixels.max_rows)
+
+
 def conv3x3_tiles_supported(B, H, W, Cin, Cout, dt):
     return bool(_lib.lib().cmu_conv3x3_tiles_supported(B, H, W, Cin, Cout, dt_code(dt)))
 

@@ -19,8 +19,11 @@ device-side list of the 16 x 32 pixel tiles (forward / data gradient, persistent
 the dense op and multiplies by the mask (encoder.py:20-23).  What a dense tile can skip depends on the patch side at
 the level: 16 px (level 1): 1 - 0.75^2 = 44 % of the 16 x 32 tiles and 25 % of the 16 x 16 tiles remain at mask ratio
 0.75; 8 px (level 2): 90 % remain; deeper levels have patches of 4 / 2 / 1 px, every tile holds an active pixel and the
-convolutions stay dense (their outputs at masked positions are discarded by the masked consumers).
-``CMU_SPARK_TILES=0`` keeps every level dense (A/B switch).  ``sbn=True``: the bottleneck's two BatchNorms exchange their statistics
+dense tile list cannot skip anything -- there the forward and data-gradient convolutions with at least 256 output channels
+run as a GATHER-GEMM over the list of active pixels (``ops.PixelList`` / ``ops.conv3x3_fwd_rows``, csrc/conv_gather.inc):
+GEMM rows = active pixels, the halo gathered per tap from the dense input, outputs scattered to the active positions --
+exactly the active fraction of the dense FLOPs.  ``CMU_SPARK_TILES=0`` keeps every level dense, ``CMU_SPARK_GATHER=0`` only
+the gather levels (A/B switches).  ``sbn=True``: the bottleneck's two BatchNorms exchange their statistics
 (forward sums and counts, backward sums) over the default process group, as nn.SyncBatchNorm does for SparseSyncBatchNorm2d.
 """
 import os
@@ -161,14 +164,19 @@ class SparK(_EngineOwner, nn.Module):
         import torch.distributed as dist
         return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
-    def _level_tiles(self, eng, active, B, H, W):
-        """Tile lists of one level: (conv list 16 x 32, wgrad list 16 x 16, fraction of conv tiles, fraction of wgrad tiles)
-        or None where tile skipping cannot pay (patch side < 8 px: every tile holds an active pixel)."""
+    def _level_tiles(self, eng, active, B, H, W, n_cells):
+        """What one level can skip: {'conv': 16 x 32 tile list, 'wgrad': 16 x 16 tile list, 'cf' / 'wf': expected shares of
+        listed tiles (profiler only), 'pix': list of active pixels for the gather kernel} -- or None.  Patch side >= 8 px: tile
+        lists; smaller patches (every dense tile holds an active pixel): the pixel list."""
         if os.environ.get("CMU_SPARK_TILES", "1") == "0":
             return None
         f = active.shape[-1]
         ps = H // f
-        if ps < 8 or H % 16 != 0 or W % 32 != 0:
+        if ps < 8:
+            if os.environ.get("CMU_SPARK_GATHER", "1") == "0" or H != W:
+                return None
+            return {"conv": None, "wgrad": None, "cf": 1.0, "wf": 1.0, "pix": ops.PixelList(active, H, W, n_cells * ps * ps)}
+        if H % 16 != 0 or W % 32 != 0:
             return None
         keep = 1.0 - self.mask_ratio
         conv = ops.TileList(active, H, W, 16, 32)
@@ -177,7 +185,7 @@ class SparK(_EngineOwner, nn.Module):
         if ps >= 16:
             wg = ops.TileList(active, H, W, 16, 16)
             wf = 1.0 - (1.0 - keep) ** max(1, (16 // ps) ** 2)
-        return {"conv": conv, "wgrad": wg, "cf": cf, "wf": wf}
+        return {"conv": conv, "wgrad": wg, "cf": cf, "wf": wf, "pix": None}
 
     def _sp_convbn_fwd(self, eng, sd, pconv, pbn, x, x_img, inv_pix, active, count, B, H, W, training, sync=False, tiles=None):
         w = sd[pconv + "weight"]
@@ -185,7 +193,9 @@ class SparK(_EngineOwner, nn.Module):
         y = eng._new(B, H, W, C)
         if x_img is not None:
             ops.conv3x3_c1_fwd(x_img, w.detach(), y, None, inv_pix, True)
-        elif tiles is not None and ops.conv3x3_tiles_supported(B, H, W, x.C, C, eng.dt):
+        elif tiles is not None and tiles["pix"] is not None and ops.conv3x3_rows_supported(B, H, W, x.C, C, eng.dt):
+            ops.conv3x3_fwd_rows(x, eng._wp(pconv, w, False), y, tiles["pix"])                   # GEMM rows = active pixels only
+        elif tiles is not None and tiles["conv"] is not None and ops.conv3x3_tiles_supported(B, H, W, x.C, C, eng.dt):
             ops.conv3x3_fwd_tiles(x, eng._wp(pconv, w, False), y, tiles["conv"], tiles["cf"])    # masked tiles never computed
         else:
             ops.conv3x3_fwd(x, eng._wp(pconv, w, False), y, None)
@@ -241,8 +251,10 @@ class SparK(_EngineOwner, nn.Module):
             return None
         Cin = w.shape[1]
         dX = eng._new(B, H, W, Cin)
-        if tiles is not None and ops.conv3x3_tiles_supported(B, H, W, C, Cin, eng.dt):
-            ops.conv3x3_fwd_tiles(dY, eng._wp(s["pconv"], w, True), dX, tiles["conv"], tiles["cf"])   # dX is only needed where active
+        if tiles is not None and tiles["pix"] is not None and ops.conv3x3_rows_supported(B, H, W, C, Cin, eng.dt):
+            ops.conv3x3_fwd_rows(dY, eng._wp(s["pconv"], w, True), dX, tiles["pix"])                  # dX is only needed where active
+        elif tiles is not None and tiles["conv"] is not None and ops.conv3x3_tiles_supported(B, H, W, C, Cin, eng.dt):
+            ops.conv3x3_fwd_tiles(dY, eng._wp(s["pconv"], w, True), dX, tiles["conv"], tiles["cf"])
         else:
             ops.conv3x3_fwd(dY, eng._wp(s["pconv"], w, True), dX, None)
         return dX
@@ -268,7 +280,7 @@ class SparK(_EngineOwner, nn.Module):
         for i in range(1, nd + 1):
             p = f"{ep}down_conv{i}.double_conv.double_conv."
             cnt = n_cells * (h // f) * (w_ // f)
-            tl = self._level_tiles(eng, active, B, h, w_)
+            tl = self._level_tiles(eng, active, B, h, w_, n_cells)
             s1 = self._sp_convbn_fwd(eng, sd, p + "0.", p + "1.", x, ximg, inv_pix if ximg is not None else None, active, cnt, B, h, w_, training,
                                      tiles=tl)
             s2 = self._sp_convbn_fwd(eng, sd, p + "3.", p + "4.", s1["a"], None, None, active, cnt, B, h, w_, training, tiles=tl)
@@ -281,8 +293,9 @@ class SparK(_EngineOwner, nn.Module):
         p = f"{ep}double_conv.double_conv."
         cnt_b = n_cells * (h // f) * (w_ // f)
         sbn = bool(getattr(self.sparse_encoder, "sbn", False))     # (SparK's own ``sbn`` only concerns the densify norms)
-        b1 = self._sp_convbn_fwd(eng, sd, p + "0.", p + "1.", x, ximg, None, active, cnt_b, B, h, w_, training, sync=sbn)
-        b2 = self._sp_convbn_fwd(eng, sd, p + "3.", p + "4.", b1["a"], None, None, active, cnt_b, B, h, w_, training, sync=sbn)
+        tlb = self._level_tiles(eng, active, B, h, w_, n_cells) if nd > 0 else None
+        b1 = self._sp_convbn_fwd(eng, sd, p + "0.", p + "1.", x, ximg, None, active, cnt_b, B, h, w_, training, sync=sbn, tiles=tlb)
+        b2 = self._sp_convbn_fwd(eng, sd, p + "3.", p + "4.", b1["a"], None, None, active, cnt_b, B, h, w_, training, sync=sbn, tiles=tlb)
 
         # ---- densify (spark.py:98-111): feature maps from the smallest to the largest, mask_tokens[i] likewise ----
         feats = [b2["a"]] + [lv["s2"]["a"] for lv in reversed(levels)]

@@ -269,8 +269,22 @@ int cmu_bn_bwd_apply_masked(const void* dA, int64_t ldd, const void* y, int64_t 
  *   cmu_conv3x3_fwd_tiles   cmu_conv3x3_fwd (forward and, with the flipped pack, data gradient) over a 16 x 32 tile list;
  *                           y outside the listed tiles is left untouched (its consumers select by the mask).  Shapes the
  *                           persistent kernel serves (cmu_conv3x3_tiles_supported != 0): whole tiles, whole channel blocks.
- *   cmu_conv3x3_wgrad_tiles cmu_conv3x3_wgrad with the contraction restricted to a 16 x 16 tile list (dY is zero elsewhere). */
+ *   cmu_conv3x3_wgrad_tiles cmu_conv3x3_wgrad with the contraction restricted to a 16 x 16 tile list (dY is zero elsewhere).
+ *
+ * Gather form for the levels whose patches are smaller than a tile (every dense tile holds an active pixel there): the
+ * convolution over the LIST of active pixels -- GEMM rows = active pixels (rows[r] = dense pixel index (b*H + y)*W + x, patch-
+ * major, written with its count by cmu_sparse_pixel_list), K = 9 taps x Cin gathered per tap from the dense NHWC input (masked
+ * neighbours hold zeros there), outputs scattered to y at the listed pixels, the rest of y untouched.  FLOPs = active fraction
+ * of the dense launch.  Same packed weights as cmu_conv3x3_fwd (flipped pack: data gradient).
+ *   cmu_conv3x3_rows_supported  Cout % 256 == 0, Cin a whole number of 128-byte steps, input tensor below 2 GiB
+ *   cmu_sparse_pixel_list       rows[0 .. capacity) (entries past the end = -1), count[0]; ws: cmu_sparse_pixel_list_ws_bytes(B, f)
+ *   cmu_conv3x3_fwd_rows        max_rows: upper bound of *n_rows known to the host (sizes the grid; surplus workgroups exit)   */
 int cmu_sparse_tile_list(const uint8_t* active, int f, int B, int H, int W, int tile_h, int tile_w, int* list, int* count, void* stream);
+int64_t cmu_sparse_pixel_list_ws_bytes(int B, int f);
+int cmu_sparse_pixel_list(const uint8_t* active, int f, int B, int H, int W, int* rows, int64_t capacity, int* count, void* ws, void* stream);
+int cmu_conv3x3_rows_supported(int B, int H, int W, int Cin, int Cout, int dt);
+int cmu_conv3x3_fwd_rows(const void* x, int64_t ldx, const void* wpacked, void* y, int64_t ldy, const int* rows, const int* n_rows,
+                         int64_t max_rows, int B, int H, int W, int Cin, int Cout, int dt, void* stream);
 int cmu_conv3x3_tiles_supported(int B, int H, int W, int Cin, int Cout, int dt);
 int cmu_conv3x3_fwd_tiles(const void* x, int64_t ldx, const float* in_scale, const float* in_shift, int relu_from,
                           const void* wpacked, void* y, int64_t ldy, const int* tile_list, const int* tile_count,

@@ -106,6 +106,60 @@ def test_wgrad_tiles_equals_dense_when_dy_is_masked(ops, dt, shape):
     assert (dWt.double().cpu() - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("case", [(2, 4, 32, 4), (3, 8, 32, 16), (2, 8, 8, 64), (1, 4, 64, 5), (2, 16, 16, 0)])
+def test_pixel_list_matches_numpy(ops, case):
+    """cmu_sparse_pixel_list: active pixels in patch-major order (patches ascending, pixels row-major inside a patch), -1 padding."""
+    B, f, H, keep = case
+    act = _active(B, f, keep, seed=sum(case))
+    pl = ops.PixelList(act.cuda(), H, H, max_rows=B * keep * (H // f) ** 2 if keep else None)
+    n = int(pl.count.item())
+    s = H // f
+    ref = []
+    for b in range(B):
+        for fy in range(f):
+            for fx in range(f):
+                if act[b, fy, fx]:
+                    for py in range(s):
+                        for px in range(s):
+                            ref.append((b * H + fy * s + py) * H + fx * s + px)
+    got = pl.rows.cpu().numpy()
+    assert n == len(ref) and np.array_equal(got[:n], np.array(ref, dtype=np.int32)) and (got[n:] == -1).all()
+    assert pl.capacity % 256 == 0 and pl.capacity >= n
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
+@pytest.mark.parametrize("shape", [(2, 32, 128, 256, 8), (2, 16, 256, 256, 8), (3, 8, 512, 512, 4), (1, 32, 64, 256, 16), (2, 4, 1024, 1024, 4)])
+def test_conv_rows_gather_vs_dense_at_active_pixels(ops, dt, shape):
+    """The gather-GEMM over the list of active pixels against the dense launch on the same (masked) input: equal at every
+    active pixel up to the summation order (tap-major K here, slice-major there), untouched elsewhere; with the flipped pack
+    (data gradient) as well."""
+    B, S, Cin, Cout, f = shape
+    if not ops.conv3x3_rows_supported(B, S, S, Cin, Cout, dt):
+        pytest.skip("shape not served by the gather kernel for this dtype")
+    tdt = ops.TORCH_DT[ops.dt_code(dt)]
+    g = torch.Generator(device="cuda").manual_seed(3)
+    act = _active(B, f, max(1, f * f // 4), seed=S + Cin).cuda()
+    pix = act.bool().repeat_interleave(S // f, 1).repeat_interleave(S // f, 2)
+    x = (torch.randn(B, S, S, Cin, generator=g, device="cuda") * pix.unsqueeze(-1)).to(tdt)           # masked input, as in SparK
+    w = torch.randn(Cout, Cin, 3, 3, generator=g, device="cuda") / (3 * Cin ** 0.5)
+    pl = ops.PixelList(act, S, S, max_rows=int(act.sum()) * (S // f) ** 2)
+    tol = {"f32": 2e-5, "f16": 2e-3, "bf16": 1.6e-2}[dt]
+    for flip in (False, True):
+        if flip and not ops.conv3x3_rows_supported(B, S, S, Cout, Cin, dt):
+            continue
+        ci, co = (Cout, Cin) if flip else (Cin, Cout)
+        xin = x if not flip else (torch.randn(B, S, S, ci, generator=g, device="cuda") * pix.unsqueeze(-1)).to(tdt)
+        wp = ops.pack_conv3x3(w, dt, transpose_flip=flip)
+        dense = ops.new_act(B, S, S, co, dt, "cuda")
+        ops.conv3x3_fwd(ops.Act(xin), wp, dense, None)
+        out = ops.Act(torch.full((B, S, S, co), 7.0, dtype=tdt, device="cuda"))
+        ops.conv3x3_fwd_rows(ops.Act(xin), wp, out, pl)
+        a, b = out.buf[pix].float(), dense.buf[pix].float()
+        err = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-6)
+        assert err <= tol, (flip, err)
+        assert bool((out.buf[~pix] == 7.0).all()), "a masked pixel was written"
+
+
 _STEP = r'''
 import sys, torch
 sys.path.insert(0, %r)
@@ -125,17 +179,22 @@ torch.save({"loss": loss.detach().cpu(), "grads": {k: p.grad.cpu() for k, p in m
 
 @pytest.mark.parametrize("dt", ["f32", "f16"])
 def test_spark_step_with_and_without_tile_skipping(ops, dt, tmp_path):
-    """The whole SparK step (reference geometry, 128 px, mask ratio 0.75) with CMU_SPARK_TILES=1 (default) and =0: identical
-    loss (the forward is the same arithmetic on every active pixel) and equal gradients up to the weight gradients' summation
-    order at the levels that skip."""
+    """The whole SparK step (reference geometry, 128 px, mask ratio 0.75) with tile lists + gather levels (default), tile lists
+    only (CMU_SPARK_GATHER=0) and fully dense (CMU_SPARK_TILES=0): tile lists give the identical loss and equal gradients up to
+    the weight gradients' summation order; the gather levels agree to rounding."""
     outs = {}
-    for flag in ("1", "0"):
-        o = str(tmp_path / f"r{flag}.pt")
-        env = dict(os.environ, CMU_SPARK_TILES=flag)
+    for flag, gather in (("1", "1"), ("1", "0"), ("0", "0")):
+        o = str(tmp_path / f"r{flag}{gather}.pt")
+        env = dict(os.environ, CMU_SPARK_TILES=flag, CMU_SPARK_GATHER=gather)
         subprocess.run([sys.executable, "-c", _STEP % ROOT, dt, o], env=env, check=True, timeout=420)
-        outs[flag] = torch.load(o)
-    assert float(outs["1"]["loss"]) == float(outs["0"]["loss"])
-    for k, g0 in outs["0"]["grads"].items():
-        g1 = outs["1"]["grads"][k]
-        e = (g1 - g0).abs().max().item() / max(g0.abs().max().item(), 1e-12)
-        assert e <= (2e-5 if dt == "f32" else 2e-3), (k, e)
+        outs[flag + gather] = torch.load(o)
+    # tile lists alone: the forward is the same arithmetic on every active pixel
+    assert float(outs["10"]["loss"]) == float(outs["00"]["loss"])
+    ltol, gtol = (1e-5, 5e-3) if dt == "f32" else (5e-3, 3e-2)       # (the gather kernel sums K tap-major: rounding-level differences,
+    # amplified by sparse BatchNorm over few positions -- the reference's own f32 run sits ~3e-3 from its f64 run, test_gpu_pretrain)
+    assert abs(float(outs["11"]["loss"]) - float(outs["00"]["loss"])) <= ltol * abs(float(outs["00"]["loss"]))   # through 10 BatchNorms)
+    for key, tol in (("10", 2e-5 if dt == "f32" else 2e-3), ("11", gtol)):
+        for k, g0 in outs["00"]["grads"].items():
+            g1 = outs[key]["grads"][k]
+            e = (g1 - g0).abs().max().item() / max(g0.abs().max().item(), 1e-12)
+            assert e <= tol, (key, k, e)
