@@ -94,6 +94,8 @@ _SIGS = {
     "cmu_bn_bwd_apply_masked": (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P]),
     "cmu_sparse_tile_list": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "cmu_conv3x3_tiles_supported": (_I, [_I, _I, _I, _I, _I, _I]),
+    "cmu_rows_channel_stats": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "cmu_bn_bwd_reduce_rows": (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _P, _P]),
     "cmu_sparse_pixel_list_ws_bytes": (_L, [_I, _I]),
     "cmu_sparse_pixel_list": (_I, [_P, _I, _I, _I, _I, _P, _L, _P, _P, _P]),
     "cmu_conv3x3_rows_supported": (_I, [_I, _I, _I, _I, _I, _I]),

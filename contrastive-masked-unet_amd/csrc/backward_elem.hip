@@ -36,11 +36,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const unsigned char*
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            float* __restrict__ ws, int64_t npix, int C, int cpb, int ppb,
-                                                           const uint8_t* __restrict__ amask, int f, int sbits, int H, int W) {
+                                                           const uint8_t* __restrict__ amask, int f, int sbits, int H, int W,
+                                                           const int* __restrict__ rows, const int* __restrict__ n_rows) {
     constexpr int EPC = TR::EPC;
     constexpr int ES = (int)sizeof(typename TR::elem_t);
     __shared__ float red[256];
     const int tid = threadIdx.x;
+    if (rows != nullptr) npix = *n_rows;      // sparse form: the loop runs over the list of active pixels only
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *reinterpret_cast<int*>(ws) = (int)gridDim.x;
     ws += BNWS_HDR / 4;
     const int nchunk = C / EPC;
@@ -55,8 +57,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const unsigned char*
         s1[e] = s2[e] = 0.f;
     }
     if (active)
-        for (int64_t p = (int64_t)blockIdx.x * ppb + prow; p < npix; p += (int64_t)gridDim.x * ppb) {
-            if (amask && !sp_active(amask, f, sbits, (int)(p / ((int64_t)W * H)), (int)((p / W) % H), (int)(p % W), 0)) continue;
+        for (int64_t pp = (int64_t)blockIdx.x * ppb + prow; pp < npix; pp += (int64_t)gridDim.x * ppb) {
+            int64_t p = pp;
+            if (rows != nullptr) {
+                p = rows[pp];
+                if (p < 0) continue;
+            } else if (amask && !sp_active(amask, f, sbits, (int)(p / ((int64_t)W * H)), (int)((p / W) % H), (int)(p % W), 0)) {
+                continue;
+            }
             float g[EPC], v[EPC];
             TR::unpack(ld_global16(dA + (p * ldd + ch * EPC) * ES), g);
             TR::unpack(ld_global16(y + (p * ldy + ch * EPC) * ES), v);
@@ -131,17 +139,20 @@ static void chunk_geometry(int nchunk, int* cpb, int* ppb, int* gy) {
 template <class TR>
 static int bn_bwd_reduce_t(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift,
                            const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef, int B, int H, int W,
-                           int C, void* ws, const uint8_t* active, int f, int64_t count, hipStream_t st) {
+                           int C, void* ws, const uint8_t* active, int f, int64_t count, hipStream_t st, const int* rows = nullptr,
+                           const int* n_rows = nullptr, int64_t max_rows = 0) {
     int cpb, ppb, gy;
     chunk_geometry(C / TR::EPC, &cpb, &ppb, &gy);
     const int64_t npix = (int64_t)B * H * W;
     const int sbits = active ? sp_shift_bits(H, f) : 0;
-    int gx = (int)(cmu_div_up64(npix, ppb * 4) < RED_MAX_BLOCKS ? cmu_div_up64(npix, ppb * 4) : RED_MAX_BLOCKS);
+    const int64_t nloop = rows ? max_rows : npix;
+    int gx = (int)(cmu_div_up64(nloop, ppb * 4) < RED_MAX_BLOCKS ? cmu_div_up64(nloop, ppb * 4) : RED_MAX_BLOCKS);
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<TR>), dim3(gx, gy), dim3(256), 0, st, (const unsigned char*)dA, ldd,
-                       (const unsigned char*)y, ldy, scale, shift, mean, invstd, (float*)ws, npix, C, cpb, ppb, active, f, sbits, H, W);
+                       (const unsigned char*)y, ldy, scale, shift, mean, invstd, (float*)ws, npix, C, cpb, ppb, active, f, sbits, H, W, rows,
+                       n_rows);
     CMU_CHECK_LAUNCH("cmu_bn_bwd_reduce");
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cmu_div_up(C, 16)), dim3(256), 0, st, (const float*)ws, (double)(active ? count : npix), dgamma,
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cmu_div_up(C, 16)), dim3(256), 0, st, (const float*)ws, (double)((active || rows) ? count : npix), dgamma,
                        dbeta, coef, C);
     CMU_CHECK_LAUNCH("cmu_bn_bwd_reduce(final)");
     return CMU_OK;
@@ -185,6 +196,18 @@ extern "C" int cmu_bn_bwd_reduce_masked(const void* dA, int64_t ldd, const void*
     CMU_CHECK_ARG(sp_shift_bits(H, f) >= 0 && (f << sp_shift_bits(H, f)) == W, "cmu_bn_bwd_reduce_masked: H,W must be f times a power of two");
     CMU_DISPATCH_DT(dt, bn_bwd_reduce_t, dA, ldd, y, ldy, scale, shift, save_mean, save_invstd, dgamma, dbeta, coef, B, H, W, C, ws, active, f,
                     count, (hipStream_t)stream);
+}
+// the same over a list of active pixels (cmu_sparse_pixel_list): visits the listed pixels only
+extern "C" int cmu_bn_bwd_reduce_rows(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift,
+                                      const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* coef,
+                                      const int* rows, const int* n_rows, int64_t max_rows, int64_t count, int B, int H, int W, int C, int dt,
+                                      void* ws, void* stream) {
+    int rc;
+    if ((rc = check_pair("cmu_bn_bwd_reduce_rows", dA, ldd, y, ldy, C, dt))) return rc;
+    CMU_CHECK_ARG(scale && shift && save_mean && save_invstd && coef && ws && rows && n_rows && max_rows > 0 && count > 0 && B > 0,
+                  "cmu_bn_bwd_reduce_rows: null argument");
+    CMU_DISPATCH_DT(dt, bn_bwd_reduce_t, dA, ldd, y, ldy, scale, shift, save_mean, save_invstd, dgamma, dbeta, coef, B, H, W, C, ws,
+                    (const uint8_t*)nullptr, 0, count, (hipStream_t)stream, rows, n_rows, max_rows);
 }
 
 template <class TR>

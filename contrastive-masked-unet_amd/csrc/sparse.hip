@@ -18,7 +18,8 @@ constexpr int SP_ROWS = 1024;  // slab rows written by cmu_masked_channel_stats 
 template <class TR>
 __global__ __launch_bounds__(256) void masked_stats_kernel(const unsigned char* __restrict__ x, int64_t ldx,
                                                           const uint8_t* __restrict__ active, int f, int sbits, int invert,
-                                                          float* __restrict__ slab, int B, int H, int W, int C, int cpb, int ppb) {
+                                                          float* __restrict__ slab, int B, int H, int W, int C, int cpb, int ppb,
+                                                          const int* __restrict__ rows, const int* __restrict__ n_rows) {
     constexpr int EPC = TR::EPC;
     constexpr int ES = (int)sizeof(typename TR::elem_t);
     __shared__ float red[256];
@@ -27,14 +28,20 @@ __global__ __launch_bounds__(256) void masked_stats_kernel(const unsigned char* 
     const int ch = blockIdx.y * cpb + tid % cpb;
     const int prow = tid / cpb;
     const bool on = prow < ppb && ch < nchunk;
-    const int64_t npix = (int64_t)B * H * W;
+    const int64_t npix = rows != nullptr ? (int64_t)*n_rows : (int64_t)B * H * W;     // sparse form: the list of active pixels
     float s1[EPC], s2[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
     if (on)
-        for (int64_t p = (int64_t)blockIdx.x * ppb + prow; p < npix; p += (int64_t)gridDim.x * ppb) {
-            const int xx = (int)(p % W), yy = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
-            if (!sp_active(active, f, sbits, b, yy, xx, invert)) continue;
+        for (int64_t pp = (int64_t)blockIdx.x * ppb + prow; pp < npix; pp += (int64_t)gridDim.x * ppb) {
+            int64_t p = pp;
+            if (rows != nullptr) {
+                p = rows[pp];
+                if (p < 0) continue;
+            } else {
+                const int xx = (int)(p % W), yy = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
+                if (!sp_active(active, f, sbits, b, yy, xx, invert)) continue;
+            }
             float v[EPC];
             TR::unpack(ld_global16(x + (p * ldx + ch * EPC) * ES), v);
 #pragma unroll
@@ -72,11 +79,11 @@ static void sp_geometry(int nchunk, int* cpb, int* ppb, int* gy) {
 
 template <class TR>
 static int masked_stats_t(const void* x, int64_t ldx, const uint8_t* active, int f, int sbits, int invert, float* slab, int B, int H, int W,
-                          int C, hipStream_t st) {
+                          int C, hipStream_t st, const int* rows = nullptr, const int* n_rows = nullptr) {
     int cpb, ppb, gy;
     sp_geometry(C / TR::EPC, &cpb, &ppb, &gy);
     hipLaunchKernelGGL((masked_stats_kernel<TR>), dim3(SP_ROWS, gy), dim3(256), 0, st, (const unsigned char*)x, ldx, active, f, sbits, invert,
-                       slab, B, H, W, C, cpb, ppb);
+                       slab, B, H, W, C, cpb, ppb, rows, n_rows);
     CMU_CHECK_LAUNCH("cmu_masked_channel_stats");
     return CMU_OK;
 }
@@ -90,6 +97,16 @@ extern "C" int cmu_masked_channel_stats(const void* x, int64_t ldx, const uint8_
     const int sbits = sp_shift_bits(H, f);
     CMU_CHECK_ARG(sbits >= 0 && (f << sbits) == W, "cmu_masked_channel_stats: H=%d, W=%d must be f=%d times a power of two", H, W, f);
     CMU_DISPATCH_DT(dt, masked_stats_t, x, ldx, active, f, sbits, invert, slab, B, H, W, C, (hipStream_t)stream);
+}
+
+// the same statistics over a list of active pixels (cmu_sparse_pixel_list): only the listed pixels are visited
+extern "C" int cmu_rows_channel_stats(const void* x, int64_t ldx, const int* rows, const int* n_rows, float* slab, int B, int H, int W, int C,
+                                      int dt, void* stream) {
+    const int es = cmu_dtype_size(dt);
+    CMU_CHECK_ARG(es > 0 && x && rows && n_rows && slab && B > 0 && H > 0 && W > 0, "cmu_rows_channel_stats: bad args");
+    const int epc = 16 / es;
+    CMU_CHECK_ARG(C > 0 && C % epc == 0 && ldx % epc == 0 && ldx >= C && cmu_aligned16(x), "cmu_rows_channel_stats: C / ld alignment");
+    CMU_DISPATCH_DT(dt, masked_stats_t, x, ldx, (const uint8_t*)nullptr, 1, 0, 0, slab, B, H, W, C, (hipStream_t)stream, rows, n_rows);
 }
 
 template <class TR>

@@ -344,6 +344,19 @@ def masked_channel_stats(x, active, invert=False):
     return slab
 
 
+def rows_channel_stats(x, pixels):
+    """masked_channel_stats over a PixelList: the listed pixels only."""
+    rows = _lib.lib().cmu_masked_stats_rows()
+    slab = torch.empty((rows, 2, x.C), dtype=torch.float32, device=x.buf.device)
+    call("cmu_rows_channel_stats", x.ptr(), x.ld, _p(pixels.rows), _p(pixels.count), _p(slab), x.B, x.H, x.W, x.C, x.dt, _stream())
+    return slab
+
+
+def bn_bwd_reduce_rows(dA, y, save_mean, save_invstd, dgamma, dbeta, coef, pixels, count, ws):
+    call("cmu_bn_bwd_reduce_rows", dA.ptr(), dA.ld, y.ptr(), y.ld, _p(y.scale), _p(y.shift), _p(save_mean), _p(save_invstd), _p(dgamma),
+         _p(dbeta), _p(coef), _p(pixels.rows), _p(pixels.count), pixels.capacity, int(count), y.B, y.H, y.W, y.C, y.dt, _p(ws), _stream())
+
+
 def mask_select(x, active, out, relu=False, invert=False, fill=None, use_transform=True):
     sc = x.scale if use_transform else None
     sh = x.shift if use_transform else None

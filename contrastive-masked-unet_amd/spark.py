@@ -172,12 +172,13 @@ class SparK(_EngineOwner, nn.Module):
             return None
         f = active.shape[-1]
         ps = H // f
+        gather = os.environ.get("CMU_SPARK_GATHER", "1") != "0" and H == W
+        # the list of active pixels drives the gather convolutions (small patches) and, at every level, the statistics passes
+        pix = ops.PixelList(active, H, W, n_cells * ps * ps) if gather else None
         if ps < 8:
-            if os.environ.get("CMU_SPARK_GATHER", "1") == "0" or H != W:
-                return None
-            return {"conv": None, "wgrad": None, "cf": 1.0, "wf": 1.0, "pix": ops.PixelList(active, H, W, n_cells * ps * ps)}
+            return {"conv": None, "wgrad": None, "cf": 1.0, "wf": 1.0, "pix": pix, "gather": True} if gather else None
         if H % 16 != 0 or W % 32 != 0:
-            return None
+            return {"conv": None, "wgrad": None, "cf": 1.0, "wf": 1.0, "pix": pix, "gather": False} if gather else None
         keep = 1.0 - self.mask_ratio
         conv = ops.TileList(active, H, W, 16, 32)
         cf = 1.0 - (1.0 - keep) ** max(1, (16 // ps) * (32 // ps))          # expected share of listed tiles (profiler only)
@@ -185,7 +186,7 @@ class SparK(_EngineOwner, nn.Module):
         if ps >= 16:
             wg = ops.TileList(active, H, W, 16, 16)
             wf = 1.0 - (1.0 - keep) ** max(1, (16 // ps) ** 2)
-        return {"conv": conv, "wgrad": wg, "cf": cf, "wf": wf, "pix": None}
+        return {"conv": conv, "wgrad": wg, "cf": cf, "wf": wf, "pix": pix, "gather": False}
 
     def _sp_convbn_fwd(self, eng, sd, pconv, pbn, x, x_img, inv_pix, active, count, B, H, W, training, sync=False, tiles=None):
         w = sd[pconv + "weight"]
@@ -193,14 +194,19 @@ class SparK(_EngineOwner, nn.Module):
         y = eng._new(B, H, W, C)
         if x_img is not None:
             ops.conv3x3_c1_fwd(x_img, w.detach(), y, None, inv_pix, True)
-        elif tiles is not None and tiles["pix"] is not None and ops.conv3x3_rows_supported(B, H, W, x.C, C, eng.dt):
+        elif tiles is not None and tiles["gather"] and ops.conv3x3_rows_supported(B, H, W, x.C, C, eng.dt):
             ops.conv3x3_fwd_rows(x, eng._wp(pconv, w, False), y, tiles["pix"])                   # GEMM rows = active pixels only
         elif tiles is not None and tiles["conv"] is not None and ops.conv3x3_tiles_supported(B, H, W, x.C, C, eng.dt):
             ops.conv3x3_fwd_tiles(x, eng._wp(pconv, w, False), y, tiles["conv"], tiles["cf"])    # masked tiles never computed
         else:
             ops.conv3x3_fwd(x, eng._wp(pconv, w, False), y, None)
         scale, shift, mean, invstd = eng._f32(C), eng._f32(C), eng._f32(C), eng._f32(C)
-        slab = ops.masked_channel_stats(y, active) if training else None          # statistics over ACTIVE pixels only
+        if not training:
+            slab = None
+        elif tiles is not None and tiles["pix"] is not None:
+            slab = ops.rows_channel_stats(y, tiles["pix"])                         # statistics over the list of active pixels
+        else:
+            slab = ops.masked_channel_stats(y, active)                             # ... or over all pixels with the mask looked up
         if sync and training and self._sync_world() > 1:
             # SparseSyncBatchNorm2d (encoder.py:54-55 on nn.SyncBatchNorm): sums, sums of squares and counts of all ranks
             import torch.distributed as dist
@@ -224,7 +230,11 @@ class SparK(_EngineOwner, nn.Module):
         B, H, W, C = y.B, y.H, y.W, y.C
         w = sd[s["pconv"] + "weight"]
         dgamma, dbeta, coef = eng._f32(C), eng._f32(C), eng._f32(2, C)
-        ops.bn_bwd_reduce_masked(dA, y, s["mean"], s["invstd"], dgamma, dbeta, coef, active, count, eng._bn_ws(C))
+        tiles = s.get("tiles")
+        if tiles is not None and tiles["pix"] is not None:
+            ops.bn_bwd_reduce_rows(dA, y, s["mean"], s["invstd"], dgamma, dbeta, coef, tiles["pix"], count, eng._bn_ws(C))
+        else:
+            ops.bn_bwd_reduce_masked(dA, y, s["mean"], s["invstd"], dgamma, dbeta, coef, active, count, eng._bn_ws(C))
         if s.get("sync") and self._sync_world() > 1:
             # SyncBatchNorm backward: the input gradient uses the sums over ALL ranks; dgamma / dbeta stay local (the gradient
             # exchange averages them like every other parameter gradient)
@@ -237,7 +247,6 @@ class SparK(_EngineOwner, nn.Module):
         grads[s["pbn"] + "weight"], grads[s["pbn"] + "bias"] = dgamma, dbeta
         grads[s["pconv"] + "bias"] = torch.zeros(C, dtype=torch.float32, device=eng.device)
         dW = torch.empty_like(w, dtype=torch.float32)
-        tiles = s.get("tiles")
         if s["x_img"] is not None:
             ops.conv3x3_c1_wgrad(s["x_img"], dY, dW, eng.scratch.get("wg", eng.lib.cmu_conv3x3_c1_wgrad_ws_bytes(B, H, W, C)), s["mask"], True)
         else:
@@ -251,7 +260,7 @@ class SparK(_EngineOwner, nn.Module):
             return None
         Cin = w.shape[1]
         dX = eng._new(B, H, W, Cin)
-        if tiles is not None and tiles["pix"] is not None and ops.conv3x3_rows_supported(B, H, W, C, Cin, eng.dt):
+        if tiles is not None and tiles["gather"] and ops.conv3x3_rows_supported(B, H, W, C, Cin, eng.dt):
             ops.conv3x3_fwd_rows(dY, eng._wp(s["pconv"], w, True), dX, tiles["pix"])                  # dX is only needed where active
         elif tiles is not None and tiles["conv"] is not None and ops.conv3x3_tiles_supported(B, H, W, C, Cin, eng.dt):
             ops.conv3x3_fwd_tiles(dY, eng._wp(s["pconv"], w, True), dX, tiles["conv"], tiles["cf"])

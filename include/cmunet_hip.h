@@ -280,6 +280,12 @@ int cmu_bn_bwd_apply_masked(const void* dA, int64_t ldd, const void* y, int64_t 
  *   cmu_sparse_pixel_list       rows[0 .. capacity) (entries past the end = -1), count[0]; ws: cmu_sparse_pixel_list_ws_bytes(B, f)
  *   cmu_conv3x3_fwd_rows        max_rows: upper bound of *n_rows known to the host (sizes the grid; surplus workgroups exit)   */
 int cmu_sparse_tile_list(const uint8_t* active, int f, int B, int H, int W, int tile_h, int tile_w, int* list, int* count, void* stream);
+/* cmu_masked_channel_stats / cmu_bn_bwd_reduce_masked over the list of active pixels: only the listed pixels are visited. */
+int cmu_rows_channel_stats(const void* x, int64_t ldx, const int* rows, const int* n_rows, float* slab, int B, int H, int W, int C, int dt,
+                           void* stream);
+int cmu_bn_bwd_reduce_rows(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift,
+                           const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* coef, const int* rows,
+                           const int* n_rows, int64_t max_rows, int64_t count, int B, int H, int W, int C, int dt, void* ws, void* stream);
 int64_t cmu_sparse_pixel_list_ws_bytes(int B, int f);
 int cmu_sparse_pixel_list(const uint8_t* active, int f, int B, int H, int W, int* rows, int64_t capacity, int* count, void* ws, void* stream);
 int cmu_conv3x3_rows_supported(int B, int H, int W, int Cin, int Cout, int dt);

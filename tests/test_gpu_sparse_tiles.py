@@ -160,6 +160,38 @@ def test_conv_rows_gather_vs_dense_at_active_pixels(ops, dt, shape):
         assert bool((out.buf[~pix] == 7.0).all()), "a masked pixel was written"
 
 
+@pytest.mark.parametrize("dt", ["f16", "f32"])
+def test_rows_statistics_equal_masked_statistics(ops, dt):
+    """The sparse-BatchNorm statistics (forward sums, backward sums) driven by the list of active pixels == the masked passes
+    over all pixels (same pixels, different visiting order: fp32 summation-order tolerance)."""
+    from cmunet_amd import _lib
+    B, S, C, f = 3, 64, 128, 8
+    tdt = ops.TORCH_DT[ops.dt_code(dt)]
+    g = torch.Generator(device="cuda").manual_seed(4)
+    act = _active(B, f, 17, seed=9).cuda()
+    y = ops.Act(torch.randn(B, S, S, C, generator=g, device="cuda").to(tdt))
+    pl = ops.PixelList(act, S, S)
+    a = ops.masked_channel_stats(y, act).double().sum(0)
+    b = ops.rows_channel_stats(y, pl).double().sum(0)
+    assert (a - b).abs().max().item() <= 1e-5 * a.abs().max().item()
+    sc, sh = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.1
+    mean, invstd = torch.randn(C, device="cuda") * 0.1, torch.rand(C, device="cuda") + 0.5
+    yt = y.with_transform(sc, sh, 0)
+    dA = ops.Act(torch.randn(B, S, S, C, generator=g, device="cuda").to(tdt))
+    count = int(act.sum()) * (S // f) ** 2
+    outs = []
+    for use_rows in (False, True):
+        dg, db, coef = torch.empty(C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(2, C, device="cuda")
+        ws = torch.empty(_lib.lib().cmu_bn_bwd_ws_bytes(C), dtype=torch.uint8, device="cuda")
+        if use_rows:
+            ops.bn_bwd_reduce_rows(dA, yt, mean, invstd, dg, db, coef, pl, count, ws)
+        else:
+            ops.bn_bwd_reduce_masked(dA, yt, mean, invstd, dg, db, coef, act, count, ws)
+        outs.append((dg.clone(), db.clone(), coef.clone()))
+    for u, v in zip(*outs):
+        assert (u - v).abs().max().item() <= 2e-5 * max(v.abs().max().item(), 1e-6)
+
+
 _STEP = r'''
 import sys, torch
 sys.path.insert(0, %r)
@@ -190,7 +222,7 @@ def test_spark_step_with_and_without_tile_skipping(ops, dt, tmp_path):
         outs[flag + gather] = torch.load(o)
     # tile lists alone: the forward is the same arithmetic on every active pixel
     assert float(outs["10"]["loss"]) == float(outs["00"]["loss"])
-    ltol, gtol = (1e-5, 5e-3) if dt == "f32" else (5e-3, 0.15)       # (the gather kernel sums K tap-major: rounding-level differences,
+    ltol, gtol = (1e-5, 2e-2) if dt == "f32" else (5e-3, 0.15)       # (the gather kernel sums K tap-major: rounding-level differences,
     # amplified by sparse BatchNorm over few positions -- the reference's own f32 run sits ~3e-3 from its f64 run, and f16 storage
     # is held to 10-15 % on gradient norms against the reference fixture: test_gpu_pretrain)
     assert abs(float(outs["11"]["loss"]) - float(outs["00"]["loss"])) <= ltol * abs(float(outs["00"]["loss"]))   # through 10 BatchNorms)
