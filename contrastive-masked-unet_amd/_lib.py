@@ -174,8 +174,9 @@ class EventProfiler:
     """Optional per-entry-point timing with HIP events on the launch stream (bench.py's roofline leg).
     ``work`` is the algorithmic FLOP (or byte) count the caller attributes to the launch."""
 
-    def __init__(self):
+    def __init__(self, gemm_only=False):
         self.records = []      # (name, start_event, end_event, work, kernel tag)
+        self.gemm_only = gemm_only   # time only the GEMM-shaped entries (work > 0): a quarter of the events of a step
 
     def summary(self):
         import torch
@@ -257,7 +258,7 @@ def call(name, *args, work=0.0):
 
 
 def _call_bound(l, fn, name, args, work):
-    if PROFILER is not None:
+    if PROFILER is not None and (work > 0 or not PROFILER.gemm_only):
         import torch
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
