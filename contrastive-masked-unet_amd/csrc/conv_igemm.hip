@@ -717,7 +717,7 @@ template <class TR>
 static int conv3x3_rows_ok_t(IGParams p) {
     constexpr int KSC = 128 / (int)sizeof(typename TR::elem_t);
     static const bool on = []() { const char* e = getenv("CMU_SPARK_GATHER"); return !(e && e[0] == '0'); }();
-    if (!on || p.N % 256 != 0 || p.K % KSC != 0) return 0;
+    if (!on || p.N % 128 != 0 || p.K % KSC != 0) return 0;
     const int64_t px = (int64_t)p.B * p.H * p.W;
     if ((px * p.ldx + p.K) * (int64_t)sizeof(typename TR::elem_t) >= 0x7fff0000ll) return 0;          // 32-bit buffer offsets over the whole tensor
     if ((int64_t)(p.K / (32 / (int)sizeof(typename TR::elem_t))) * 9 * cmu_conv3x3_npad(p.N) * 32 >= 0x7fff0000ll) return 0;
@@ -744,11 +744,11 @@ extern "C" int cmu_conv3x3_fwd_rows(const void* x, int64_t ldx, const void* wpac
     const int64_t px = (int64_t)B * H * W;
     if (!cmu_conv3x3_rows_supported(B, H, W, Cin, Cout, dt) || (px * ldx + Cin) * cmu_dtype_size(dt) >= 0x7fff0000ll ||
         (px * ldy + Cout) * cmu_dtype_size(dt) >= (1ll << 40)) {
-        cmu_set_error("cmu_conv3x3_fwd_rows: needs Cout %% 256 == 0, Cin a whole number of 128-byte steps and an input tensor below 2 GiB "
+        cmu_set_error("cmu_conv3x3_fwd_rows: needs Cout %% 128 == 0, Cin a whole number of 128-byte steps and an input tensor below 2 GiB "
                       "(Cin=%d Cout=%d): call cmu_conv3x3_fwd / cmu_conv3x3_fwd_tiles", Cin, Cout);
         return CMU_ERR_UNSUPPORTED;
     }
-    CMU_CHECK_ARG(cmu_div_up64(max_rows, 256) * (Cout / 256) < (1ll << 31), "cmu_conv3x3_fwd_rows: grid too large");
+    CMU_CHECK_ARG(cmu_div_up64(max_rows, 256) * (Cout / 128) < (1ll << 31), "cmu_conv3x3_fwd_rows: grid too large");
     CMU_DISPATCH_DT(dt, launch_conv_gather, p, max_rows, (hipStream_t)stream);
 }
 

@@ -178,7 +178,7 @@ class SparK(_EngineOwner, nn.Module):
         if ps < 8:
             return {"conv": None, "wgrad": None, "cf": 1.0, "wf": 1.0, "pix": pix, "gather": True} if gather else None
         if H % 16 != 0 or W % 32 != 0:
-            return {"conv": None, "wgrad": None, "cf": 1.0, "wf": 1.0, "pix": pix, "gather": False} if gather else None
+            return {"conv": None, "wgrad": None, "cf": 1.0, "wf": 1.0, "pix": pix, "gather": True} if gather else None
         keep = 1.0 - self.mask_ratio
         conv = ops.TileList(active, H, W, 16, 32)
         cf = 1.0 - (1.0 - keep) ** max(1, (16 // ps) * (32 // ps))          # expected share of listed tiles (profiler only)
@@ -186,7 +186,8 @@ class SparK(_EngineOwner, nn.Module):
         if ps >= 16:
             wg = ops.TileList(active, H, W, 16, 16)
             wf = 1.0 - (1.0 - keep) ** max(1, (16 // ps) ** 2)
-        return {"conv": conv, "wgrad": wg, "cf": cf, "wf": wf, "pix": pix, "gather": False}
+        # (where both apply -- level 2: 90 % of the tiles against 25 % of the rows -- the gather kernel is taken first)
+        return {"conv": conv, "wgrad": wg, "cf": cf, "wf": wf, "pix": pix, "gather": pix is not None}
 
     def _sp_convbn_fwd(self, eng, sd, pconv, pbn, x, x_img, inv_pix, active, count, B, H, W, training, sync=False, tiles=None):
         w = sd[pconv + "weight"]

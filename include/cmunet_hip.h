@@ -276,7 +276,7 @@ int cmu_bn_bwd_apply_masked(const void* dA, int64_t ldd, const void* y, int64_t 
  * major, written with its count by cmu_sparse_pixel_list), K = 9 taps x Cin gathered per tap from the dense NHWC input (masked
  * neighbours hold zeros there), outputs scattered to y at the listed pixels, the rest of y untouched.  FLOPs = active fraction
  * of the dense launch.  Same packed weights as cmu_conv3x3_fwd (flipped pack: data gradient).
- *   cmu_conv3x3_rows_supported  Cout % 256 == 0, Cin a whole number of 128-byte steps, input tensor below 2 GiB
+ *   cmu_conv3x3_rows_supported  Cout % 128 == 0, Cin a whole number of 128-byte steps, input tensor below 2 GiB
  *   cmu_sparse_pixel_list       rows[0 .. capacity) (entries past the end = -1), count[0]; ws: cmu_sparse_pixel_list_ws_bytes(B, f)
  *   cmu_conv3x3_fwd_rows        max_rows: upper bound of *n_rows known to the host (sizes the grid; surplus workgroups exit)   */
 int cmu_sparse_tile_list(const uint8_t* active, int f, int B, int H, int W, int tile_h, int tile_w, int* list, int* count, void* stream);

@@ -128,7 +128,8 @@ def test_pixel_list_matches_numpy(ops, case):
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
-@pytest.mark.parametrize("shape", [(2, 32, 128, 256, 8), (2, 16, 256, 256, 8), (3, 8, 512, 512, 4), (1, 32, 64, 256, 16), (2, 4, 1024, 1024, 4)])
+@pytest.mark.parametrize("shape", [(2, 32, 128, 256, 8), (2, 16, 256, 256, 8), (3, 8, 512, 512, 4), (1, 32, 64, 256, 16), (2, 4, 1024, 1024, 4),
+                                   (2, 64, 64, 128, 8), (2, 32, 128, 128, 8), (1, 16, 128, 384, 4)])
 def test_conv_rows_gather_vs_dense_at_active_pixels(ops, dt, shape):
     """The gather-GEMM over the list of active pixels against the dense launch on the same (masked) input: equal at every
     active pixel up to the summation order (tap-major K here, slice-major there), untouched elsewhere; with the flipped pack
