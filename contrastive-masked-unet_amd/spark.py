@@ -19,10 +19,11 @@ device-side list of the 16 x 32 pixel tiles (forward / data gradient, persistent
 the dense op and multiplies by the mask (encoder.py:20-23).  What a dense tile can skip depends on the patch side at
 the level: 16 px (level 1): 1 - 0.75^2 = 44 % of the 16 x 32 tiles and 25 % of the 16 x 16 tiles remain at mask ratio
 0.75; 8 px (level 2): 90 % remain; deeper levels have patches of 4 / 2 / 1 px, every tile holds an active pixel and the
-dense tile list cannot skip anything -- there the forward and data-gradient convolutions with at least 256 output channels
-run as a GATHER-GEMM over the list of active pixels (``ops.PixelList`` / ``ops.conv3x3_fwd_rows``, csrc/conv_gather.inc):
-GEMM rows = active pixels, the halo gathered per tap from the dense input, outputs scattered to the active positions --
-exactly the active fraction of the dense FLOPs.  ``CMU_SPARK_TILES=0`` keeps every level dense, ``CMU_SPARK_GATHER=0`` only
+dense tile list cannot skip anything.  From level 2 down the forward and data-gradient convolutions (output channels a
+multiple of 128) therefore run as a GATHER-GEMM over the list of active pixels (``ops.PixelList`` /
+``ops.conv3x3_fwd_rows``, csrc/conv_gather.inc): GEMM rows = active pixels, the halo gathered per tap from the dense input,
+outputs scattered to the active positions -- exactly the active fraction of the dense FLOPs; the same list drives the
+sparse-BatchNorm statistics passes at every level.  ``CMU_SPARK_TILES=0`` keeps every level dense, ``CMU_SPARK_GATHER=0`` only
 the gather levels (A/B switches).  ``sbn=True``: the bottleneck's two BatchNorms exchange their statistics
 (forward sums and counts, backward sums) over the default process group, as nn.SyncBatchNorm does for SparseSyncBatchNorm2d.
 """
