@@ -245,3 +245,61 @@ def test_unet_smallest_inputs_vs_oracle(M, shape):
         assert e <= 2e-2, f"d{k}: {e:.3e}"
     with pytest.raises(AssertionError):
         m(torch.randn(1, 24, 16).cuda())                     # not a multiple of 2^4
+
+
+_REF_SIZES = {}
+
+
+def _reference_size_case(size):
+    """CPU oracle of the full-depth base-64 UNet on one size x size image, in float32 (what the reference computes) and in float64
+    (the truth both float32 runs scatter around); computed once per size."""
+    if size not in _REF_SIZES:
+        from oracle import unet as OU
+        sd = OU.make_state_dict(base_ch=64, depth=5, seed=21)
+        g = torch.Generator().manual_seed(size)
+        x = torch.randn(1, size, size, generator=g)
+        go = torch.randn(1, 2, size, size, generator=g)
+        osd = OU.clone_sd(sd, requires_grad=True)
+        ref = OU.unet_forward(x, osd, training=True)
+        (ref * go).sum().backward()
+        osd64 = {k: (v.double().requires_grad_(True) if v.is_floating_point() and "running" not in k else (v.double() if v.is_floating_point() else v.clone()))
+                 for k, v in sd.items()}
+        ref64 = OU.unet_forward(x.double(), osd64, training=True)
+        (ref64 * go.double()).sum().backward()
+        _REF_SIZES[size] = (sd, x, go, ref.detach(), {k: v.grad for k, v in osd.items() if v.requires_grad}, ref64.detach(),
+                            {k: v.grad for k, v in osd64.items() if torch.is_tensor(v) and v.requires_grad})
+    return _REF_SIZES[size]
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16"])
+@pytest.mark.parametrize("size", [224, 256])
+def test_unet_reference_image_sizes_vs_oracle(M, size, dt):
+    """The sizes the reference actually trains at: 224 x 224 (CM-UNet / MoCo crops, cmunet_dataset.py:60-88) and
+    256 x 256 (finetuning, dataset.py:46-47) through the reference UNet (base 64, depth 5): at 224 the levels are 224 / 112 / 56 /
+    28 / 14 pixels wide -- partial 16 x 32 tiles at every level but the first, the one-tile kernels instead of the persistent one.
+    With random weights and a random output gradient the float32 gradients of the oracle itself sit 3e-3 ... 2e-2 (max norm) from
+    its float64 run, so the bar is stated against the float64 truth: logits within the dtype's tolerance, argmax equal where the
+    margin allows, and for f32 storage every checked gradient within 8x the oracle's own float32 error in relative L2 (floor 2e-3)."""
+    sd, x, go, ref32, g32, ref64, g64 = _reference_size_case(size)
+    m = M.UNet(dtype=dt)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    logits = m(x.cuda())
+    (logits * go.cuda()).sum().backward()
+    tol = TOLS[dt]
+    e, e_cpu = rel_err(logits, ref64), rel_err(ref32, ref64)
+    assert e <= max(tol * 2, 5 * e_cpu), f"logits {e:.3e} (oracle f32: {e_cpu:.3e})"
+    margin = (ref64[:, 1] - ref64[:, 0]).abs()
+    sure = margin > 4 * tol * ref64.abs().max()
+    assert torch.equal(logits.detach().cpu().argmax(1)[sure], ref64.argmax(1)[sure])
+    worst = 0.0
+    for k in ("conv_last.weight", "down_conv1.double_conv.double_conv.0.weight", "down_conv3.double_conv.double_conv.3.weight",
+              "double_conv.double_conv.3.weight", "up_conv4.up_sample.weight", "up_conv4.double_conv.double_conv.3.weight",
+              "up_conv1.double_conv.double_conv.0.weight"):
+        # relative L2 error of the whole tensor (the max norm of a 2-million-element gradient picks its single worst outlier)
+        l2 = lambda a, b: (a.detach().double().cpu() - b).norm().item() / max(b.norm().item(), 1e-12)
+        e2, e2_cpu = l2(m.get_parameter(k).grad, g64[k]), l2(g32[k].double(), g64[k])
+        worst = max(worst, e2 / max(e2_cpu, 1e-9))
+        bar = max(8 * e2_cpu, 2e-3) if dt == "f32" else tol * 20
+        assert e2 <= bar, f"d{k}: {e2:.3e} (oracle f32: {e2_cpu:.3e})"
+    print(f"[unet {size}x{size} {dt}] logits err vs f64 {e:.2e} (oracle f32 {e_cpu:.2e}); worst gradient error ratio to the oracle's f32 {worst:.1f}")

@@ -328,3 +328,42 @@ if world > 1:
         assert torch.equal(a, b)                                  # synchronised statistics: the same numbers on both ranks
     assert not torch.equal(diff[0]["down"][0], diff[1]["down"][0])   # the down blocks' SparseBatchNorm2d stay per-rank
     assert not torch.equal(diff[0]["bott"][0], nosync[0]["bott"][0])
+
+
+def test_cmunet_joint_step_reference_geometry(cuda):
+    """The joint step at the reference's own geometry (224 x 224 crops, depth 5, projector in_channels = 224*224 =
+    50,176 -> 1,536 -> 256, cmunet_config.py:18-26; mask ratio 0.65 -> 127 of 196 patches) with base 32 channels, f32 storage,
+    against the oracle: both losses and gradients at every stage of the chain (head, projector, decoders, encoder)."""
+    from cmunet_amd import cmunet as C
+    from cmunet_amd.pretrain import create_random_patch_mask
+    from oracle import cmunet as OC
+    torch.manual_seed(0)
+    B, S = 4, 224
+    model = C.build_model(C.cmunet_config(img_size=S, dtype="f32", base_ch=32, depth=5)).to(cuda).train()
+    model.init_weights()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() == 1 and ("bn" in n or ".1." in n or ".4." in n):
+                p.add_(0.2 * torch.randn_like(p))
+    assert model.projector.fc0.weight.shape == (1536, 50176) and model.reduced_channels() == 256
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(1)
+    img, img_t = torch.randn(B, S, S, generator=g), torch.randn(B, S, S, generator=g)
+    mask = torch.from_numpy(create_random_patch_mask(B, S, 16, 0.65, np.random.RandomState(2)))
+    assert int(mask[0].sum()) == 127 * 256
+    rw, rb = torch.randn(256, 512, 1, 1, generator=g) * 0.05, torch.randn(256, generator=g) * 0.1
+    losses = model(img.to(cuda), mode='loss', img_t=img_t.to(cuda), mask=mask.to(cuda), reduce_w=rw.to(cuda), reduce_b=rb.to(cuda))
+    (losses['loss_ct'] + losses['loss_rc']).backward()
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and not k.startswith("target_") else v.clone())
+           for k, v in sd.items()}
+    ref = OC.forward_train(img, img_t, mask.numpy(), rw, rb, osd, temperature=0.07, ct_weight=1.0, rc_weight=1.0)
+    (ref['loss_ct'] + ref['loss_rc']).backward()
+    assert abs(float(losses['loss_rc']) - float(ref['loss_rc'])) <= 2e-4 * max(1, abs(float(ref['loss_rc'])))
+    assert abs(float(losses['loss_ct']) - float(ref['loss_ct'])) <= 2e-3 * max(1, abs(float(ref['loss_ct'])))
+    params = dict(model.named_parameters())
+    for k in ("head.predictor.fc1.weight", "head.predictor.bn0.weight", "projector.fc1.weight", "projector.fc0.weight", "projector.bn0.bias",
+              "feature_decoder.conv_last.weight", "pixel_decoder.conv_last.weight", "pixel_decoder.up_conv4.up_sample.weight",
+              "feature_decoder.up_conv1.double_conv.double_conv.3.weight", "backbone.double_conv.double_conv.3.weight",
+              "backbone.down_conv1.double_conv.double_conv.0.weight", "backbone.down_conv3.double_conv.double_conv.1.weight"):
+        e = (params[k].grad.detach().double().cpu() - osd[k].grad.double()).norm().item() / max(osd[k].grad.double().norm().item(), 1e-12)
+        assert e <= 5e-3, f"d{k}: relative L2 error {e:.2e}"          # (f32 oracle against f32 kernels: rounding on both sides)
