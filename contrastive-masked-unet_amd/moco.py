@@ -65,6 +65,29 @@ class UNet_encoder(_MaskEncoder):
         return _EncoderGapFn.apply(self, x, names, *params)
 
 
+class _QueueLogitsFn(torch.autograd.Function):
+    """l_neg = q @ queue (moco2_module.py:262, ``einsum("nc,ck->nk")``) for <= 32 query rows on the weight-streaming skinny
+    kernels: the queue (D, K) is the matrix whose rows are contiguous in k -- the "input gradient" shape forward, the "forward"
+    shape backward (dq = dl @ queue^T); exact fp32 products."""
+
+    @staticmethod
+    def forward(ctx, q, queue):
+        ctx.save_for_backward(queue)
+        return ops.skinny_gemm_dgrad(q.detach().contiguous(), queue.detach())
+
+    @staticmethod
+    def backward(ctx, dl):
+        (queue,) = ctx.saved_tensors
+        return ops.skinny_gemm_fwd(dl.contiguous(), queue.detach()), None
+
+
+def queue_logits(q, queue):
+    if q.is_cuda and q.dtype == torch.float32 and queue.dtype == torch.float32 and 1 <= q.shape[0] <= 32 and queue.is_contiguous() \
+            and queue.shape[1] % 8 == 0:
+        return _QueueLogitsFn.apply(q, queue)
+    return torch.einsum("nc,ck->nk", [q, queue])          # more than 32 rows: a plain library GEMM
+
+
 class Moco_v2(nn.Module):
     def __init__(self, base_encoder=None, emb_dim=1024, num_negatives=65536, encoder_momentum=0.999,
                  softmax_temperature=0.07, learning_rate=0.03, momentum=0.9, weight_decay=1e-4, batch_size=256,
@@ -149,8 +172,8 @@ class Moco_v2(nn.Module):
         q = F.normalize(self.encoder_q(img_q), dim=1)
         with torch.no_grad():
             k = F.normalize(self._encode_keys(img_k), dim=1)
-        l_pos = torch.einsum("nc,nc->n", [q, k]).unsqueeze(-1)
-        l_neg = torch.einsum("nc,ck->nk", [q, queue.clone().detach()])
+        l_pos = (q * k).sum(dim=1, keepdim=True)                     # einsum("nc,nc->n")
+        l_neg = queue_logits(q, queue.detach())                     # (the reference's queue.clone() is dropped: A-8)
         logits = torch.cat([l_pos, l_neg], dim=1) / self.hparams["softmax_temperature"]
         labels = torch.zeros(logits.shape[0], dtype=torch.long, device=logits.device)
         return logits, labels, k, q

@@ -133,8 +133,25 @@ def test_moco_step_vs_oracle(cuda):
     # key encoder after the EMA (before the forward, A-8)
     assert rel(m.encoder_k.double_conv.double_conv[0].weight, osd["encoder_k.double_conv.double_conv.0.weight"]) <= 1e-6
     # API-faithful forward(): logits (N, 1+K), labels 0
+    m.zero_grad()
     lg, lb, kk, qq = m(xq.to(cuda), xk.to(cuda), m.queue)
     assert lg.shape == (B, 1 + K) and int(lb.sum()) == 0 and kk.shape == (B, 64)
+    # ... and its logits / gradient (through the skinny-kernel q @ queue) equal the oracle's on the same, already updated state
+    F.cross_entropy(lg, lb).backward()
+    sd2 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    osd2 = {k: (v.clone().requires_grad_(True) if k.startswith("encoder_q.") and v.is_floating_point() and "running" not in k else v.clone())
+            for k, v in sd2.items()}
+    for k in list(osd2):                       # the forward above already advanced the BatchNorm buffers: rewind them for the oracle
+        if "running" in k or "num_batches" in k:
+            osd2[k] = osd[k].clone() if k in osd else osd2[k]
+    q2 = OM.encoder_gap(xq, osd2, "encoder_q.", True)
+    with torch.no_grad():
+        k2 = OM.encoder_gap(xk, osd2, "encoder_k.", True)
+    lg2, lb2, _, _ = OM.logits_from_embeddings(q2, k2, sd2["queue"], T)
+    assert rel(lg, lg2) <= 1e-3
+    F.cross_entropy(lg2, lb2).backward()
+    kname = "encoder_q.double_conv.double_conv.3.weight"
+    assert rel(pq[kname].grad, osd2[kname].grad) <= 5e-3
 
 
 def test_masked_recon_trainer_matches_autograd_path(cuda):
