@@ -7,7 +7,8 @@ import sys
 import numpy as np
 import torch
 
-LIB = "tools/_diag/libcmunet_stamps.so"
+import os
+LIB = os.environ.get("CMU_STAMPS_LIB", "tools/_diag/libcmunet_stamps.so")
 B, H, Cin, Cout = 32, 256, 128, 128
 if len(sys.argv) > 3:
     H, Cin, Cout = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
@@ -46,4 +47,5 @@ for grp in range(2):
         d = (rows[:, 1:7] - rows[:, 0:6]).mean(0)
         rel = it - 2
         print(f"  it {rel:+3d}{' (last slice)' if rel % nsl == 0 else '             '}: " + "  ".join(f"{n} {v:6.0f}" for n, v in zip(names, d))
-              + f"   total {(rows[:, 6] - rows[:, 0]).mean():6.0f}")
+              + f"   total {(rows[:, 6] - rows[:, 0]).mean():6.0f}"
+              + (f"   [st7 - st3 {(rows[:, 7] - rows[:, 3]).mean():6.0f}]" if (rows[:, 7] > rows[:, 3]).all() else ""))
