@@ -588,6 +588,8 @@ static int conv3x3_fwd_t(IGParams p, hipStream_t st) {
 template <class TR>
 static int convT_fwd_t(IGParams p, hipStream_t st) {
     typedef IGCfg<TR, MODE_CONVT_FWD> C;
+    if (conv_gemm_s_eligible<TR>(p, false))
+        return p.in_scale ? launch_conv_gemm_s<TR, false, true>(p, st, "cmu_convT2x2_fwd") : launch_conv_gemm_s<TR, false, false>(p, st, "cmu_convT2x2_fwd");
     if (conv_gemm_eligible<TR>(p, false))
         return p.in_scale ? launch_conv_gemm<TR, false, true>(p, st, "cmu_convT2x2_fwd") : launch_conv_gemm<TR, false, false>(p, st, "cmu_convT2x2_fwd");
     p.nslices = cmu_div_up(p.K, C::KC);
@@ -599,6 +601,7 @@ static int convT_dgrad_t(IGParams p, hipStream_t st) {
     {
         IGParams q = p;
         q.K = 4 * p.K;   // the GEMM's contraction runs over (sub-pixel position, output channel)
+        if (conv_gemm_s_eligible<TR>(q, true)) return launch_conv_gemm_s<TR, true, false>(q, st, "cmu_convT2x2_dgrad");
         if (conv_gemm_eligible<TR>(q, true)) return launch_conv_gemm<TR, true, false>(q, st, "cmu_convT2x2_dgrad");
     }
     p.nslices = 4 * cmu_div_up(p.K, C::KC);
