@@ -227,10 +227,16 @@ def test_spark_step_with_and_without_tile_skipping(ops, dt, tmp_path):
     # sparse BatchNorm over a few dozen positions amplifies by a condition number of ~5e4 (the reference's own f32 run sits ~3e-3
     # from its f64 run, tests/test_gpu_pretrain.py).  So this whole-step A/B is a sanity bound on relative L2 errors per tensor;
     # the strict comparisons are the op-level tests above and the reference fixtures.
-    ltol, gtol = (1e-4, 5e-2) if dt == "f32" else (1e-2, 0.3)
+    # (per tensor: a loose bound -- a 64-element bias can move by a third in f16; over all gradients together: a tighter one)
+    ltol, gtol, atol = (1e-4, 5e-2, 2e-2) if dt == "f32" else (1e-2, 0.5, 0.15)
     assert abs(float(outs["11"]["loss"]) - float(outs["00"]["loss"])) <= ltol * abs(float(outs["00"]["loss"]))
-    for key, tol in (("10", 1e-3 if dt == "f32" else 5e-2), ("11", gtol)):
+    for key, tol, all_tol in (("10", 1e-3 if dt == "f32" else 5e-2, 1e-3 if dt == "f32" else 5e-2), ("11", gtol, atol)):
+        num = den = 0.0
         for k, g0 in outs["00"]["grads"].items():
             g1 = outs[key]["grads"][k]
-            e = (g1 - g0).norm().item() / max(g0.norm().item(), 1e-12)
-            assert e <= tol, (key, k, e)
+            d2, n2 = (g1 - g0).double().pow(2).sum().item(), g0.double().pow(2).sum().item()
+            # each tensor relative to its own norm, and all of them relative to the norm of the whole gradient
+            assert d2 ** 0.5 <= tol * max(n2 ** 0.5, 1e-12), (key, k, (d2 / max(n2, 1e-24)) ** 0.5)
+            num, den = num + d2, den + n2
+        print(f"{dt} {key}: all gradients rel L2 {(num / den) ** 0.5:.3e}")
+        assert (num / den) ** 0.5 <= all_tol, (key, (num / den) ** 0.5)

@@ -1,10 +1,11 @@
 """Per-level time of the ConvTranspose2d 2x2 entries on the bench shapes (bs 32, UNet 64x5 at 512^2), against the
 HBM floor (algorithmic bytes / 6.3 TB/s) and the MFMA rate: python tools/convt_sweep.py [f16|bf16]."""
+import os
 import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from cmunet_amd import ops  # noqa: E402
 
 dt = sys.argv[1] if len(sys.argv) > 1 else "f16"
