@@ -20,6 +20,12 @@
 //     pixels a transposed read touches land on the four 64-byte quarters of the 256-byte bank row.
 //   * accumulators of the k-parts are combined through LDS, partial slabs [split][tap][n][c] go to a
 //     workspace and a second kernel sums them in split order (deterministic) into the reference layout.
+// (Its eight waves multiply, then stage, in lockstep.  Running waves 4-7 one stage phase ahead -- the two-phase ping-pong of
+// conv_wgrad2.inc -- on THIS loop measured 11.9 against 10.2 ms of weight-gradient time per bench step: alone on its SIMD a
+// wave waits for every transposed fragment read, which two waves multiplying side by side hide for each other; the
+// ping-pong needs the register double buffer of fragments that conv_wgrad2.inc has and the 144 accumulator registers
+// here leave no room for.  The Cout = 64 layers that still run here are 64 x 64 blocks: 7.2 MFMAs per staged chunk
+// whatever the schedule, against 10.3 for the 128 x 64 blocks of conv_wgrad2.inc.)
 #include "common.h"
 #include <stdlib.h>
 
