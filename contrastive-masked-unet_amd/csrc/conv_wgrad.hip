@@ -461,12 +461,19 @@ static bool wg2_shape_ok(int CA, int CB, int dt) {
     static const bool on = []() { const char* e = getenv("CMU_WGRAD_WIDE"); return !(e && e[0] == '0'); }();
     return on && cmu_dtype_size(dt) == 2 && CA % 128 == 0 && CB % 64 == 0;
 }
-static void wg2_geometry(int B, int H, int W, int CA, int CB, WGParams& p) {
+// swapped roles (conv_wgrad2.inc, SWAP): Cout = 64 with Cin in whole 128-blocks.  CMU_WGRAD_SWAP=0 keeps those layers on the
+// first kernel (A/B switch)
+static bool wg2_swap_ok(int CA, int CB, int dt) {
+    static const bool on = []() { const char* e = getenv("CMU_WGRAD_SWAP"); return !(e && e[0] == '0'); }();
+    static const bool wide = []() { const char* e = getenv("CMU_WGRAD_WIDE"); return !(e && e[0] == '0'); }();
+    return on && wide && cmu_dtype_size(dt) == 2 && CA == 64 && CB % 128 == 0;
+}
+static void wg2_geometry(int B, int H, int W, int CA, int CB, WGParams& p, bool swap = false) {
     p.tilesX = cmu_div_up(W, 16);
     p.tilesY = cmu_div_up(H, 8);
     p.ntiles = B * p.tilesX * p.tilesY;
-    p.nAB = CA / 128;
-    p.nBB = CB / 64;
+    p.nAB = (swap ? CB : CA) / 128;   // blocks of the plain 128-channel operand
+    p.nBB = (swap ? CA : CB) / 64;    // blocks of the haloed 64-channel operand
     p.CApad = CA;
     p.CBpad = CB;
     p.splitk = wg_splitk(p.nAB * p.nBB, p.ntiles, 1, cmu_wg_wide_target());
@@ -515,12 +522,12 @@ static int wgradT_wide_t(WGParams p, float* dW, float* dbias, hipStream_t st) {
     CMU_CHECK_LAUNCH("cmu_convT2x2_wgrad(bias final)");
     return CMU_OK;
 }
-template <class TR>
+template <class TR, bool SWAP>
 static int wgrad3_wide_t(WGParams p, float* dW, hipStream_t st) {
     typedef WG2Cfg<TR> C;
     static CmuPerDevice attr_set;   // hipFuncSetAttribute is per device
     if (!attr_set.done()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad2_kernel<TR>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad2_kernel<TR, SWAP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            C::LDS_BYTES);
         if (e != hipSuccess) {
             cmu_set_error("cmu_conv3x3_wgrad(wide): hipFuncSetAttribute(%d B LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
@@ -533,12 +540,13 @@ static int wgrad3_wide_t(WGParams p, float* dW, hipStream_t st) {
     pp.dtx = p.splitk % p.tilesX;
     pp.dty = (p.splitk / p.tilesX) % p.tilesY;
     pp.dtb = p.splitk / (p.tilesX * p.tilesY);
-    hipLaunchKernelGGL((conv_wgrad2_kernel<TR>), dim3(p.nAB * p.nBB * p.splitk), dim3(512), C::LDS_BYTES, st, pp);
+    hipLaunchKernelGGL((conv_wgrad2_kernel<TR, SWAP>), dim3(p.nAB * p.nBB * p.splitk), dim3(512), C::LDS_BYTES, st, pp);
     cmu_set_kernel_tag("conv_wgrad2_kernel");
     CMU_CHECK_LAUNCH("cmu_conv3x3_wgrad(wide)");
     const int64_t total = (int64_t)9 * p.CA * p.CB;
     const int grid = (int)(cmu_div_up64(total, 64) < CMU_WGR_CAP ? cmu_div_up64(total, 64) : CMU_WGR_CAP);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)p.ws, p.splitk, 9, p.CApad, p.CBpad, p.CA, p.CB, dW,
+    // (the slab is [split][tap][Cout][Cin] in both forms: p.CA = Cout rows of p.CB = Cin)
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)p.ws, p.splitk, 9, p.CA, p.CB, p.CA, p.CB, dW,
                        (int)MODE_W3);
     CMU_CHECK_LAUNCH("cmu_conv3x3_wgrad(reduce)");
     return CMU_OK;
@@ -610,9 +618,9 @@ extern "C" int64_t cmu_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int 
     WGParams p = {};
     wg_geometry(B, H, W, Cout, Cin, dt, 1, p);
     int64_t need = (int64_t)p.splitk * 9 * p.CApad * p.CBpad * (int64_t)sizeof(float);
-    if (wg2_shape_ok(Cout, Cin, dt)) {   // either kernel may run (the wide one needs 4 GiB-addressable tensors)
+    if (wg2_shape_ok(Cout, Cin, dt) || wg2_swap_ok(Cout, Cin, dt)) {   // either kernel may run (the wide one needs 4 GiB-addressable tensors)
         WGParams q = {};
-        wg2_geometry(B, H, W, Cout, Cin, q);
+        wg2_geometry(B, H, W, Cout, Cin, q, !wg2_shape_ok(Cout, Cin, dt));
         const int64_t w = (int64_t)q.splitk * 9 * q.CApad * q.CBpad * (int64_t)sizeof(float);
         if (w > need) need = w;
     }
@@ -633,8 +641,15 @@ extern "C" int cmu_conv3x3_wgrad(const void* x, int64_t ldx, const float* in_sca
     if (wg2_shape_ok(Cout, Cin, dt) && (px * ldd + Cout) * 2 < 0x7fff0000ll && ((px + W + 1) * ldx + Cin) * 2 < 0x7fff0000ll &&
         (in_scale == nullptr || ((reinterpret_cast<uintptr_t>(in_scale) | reinterpret_cast<uintptr_t>(in_shift)) & 3) == 0)) {
         wg2_geometry(B, H, W, Cout, Cin, p);
-        if (dt == CMU_F16) return wgrad3_wide_t<F16Traits>(p, dW, (hipStream_t)stream);
-        return wgrad3_wide_t<BF16Traits>(p, dW, (hipStream_t)stream);
+        if (dt == CMU_F16) return wgrad3_wide_t<F16Traits, false>(p, dW, (hipStream_t)stream);
+        return wgrad3_wide_t<BF16Traits, false>(p, dW, (hipStream_t)stream);
+    }
+    // swapped roles: the halo is on dY here, the plain images are X
+    if (wg2_swap_ok(Cout, Cin, dt) && ((px + W + 1) * ldd + Cout) * 2 < 0x7fff0000ll && (px * ldx + Cin) * 2 < 0x7fff0000ll &&
+        (in_scale == nullptr || ((reinterpret_cast<uintptr_t>(in_scale) | reinterpret_cast<uintptr_t>(in_shift)) & 15) == 0)) {
+        wg2_geometry(B, H, W, Cout, Cin, p, true);
+        if (dt == CMU_F16) return wgrad3_wide_t<F16Traits, true>(p, dW, (hipStream_t)stream);
+        return wgrad3_wide_t<BF16Traits, true>(p, dW, (hipStream_t)stream);
     }
     wg_geometry(B, H, W, Cout, Cin, dt, 1, p);
     CMU_DISPATCH_DT(dt, wgrad3_t, p, dW, (hipStream_t)stream);

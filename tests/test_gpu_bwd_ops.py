@@ -64,7 +64,10 @@ WG_CASES = [(2, 20, 24, 32, 64, True), (1, 16, 16, 16, 16, False), (2, 7, 9, 8, 
             # Cout % 128 == 0 and Cin % 64 == 0 -> wide-tile kernel (conv_wgrad2.inc) for the 16-bit dtypes: partial tiles in
             # both directions, several blocks per operand, a single tile per split, more splits than tiles
             (2, 20, 24, 64, 128, True), (1, 7, 37, 128, 256, False), (3, 33, 16, 192, 128, True), (1, 8, 16, 64, 128, True),
-            (1, 5, 3, 64, 128, True)]
+            (1, 5, 3, 64, 128, True),
+            # Cout == 64 and Cin % 128 == 0 -> the same kernel with the operands' roles swapped (halo on dY, transform on the
+            # plain images, taps flipped at the store); (3, 16, 32, 128, 64) above is one more
+            (2, 20, 24, 128, 64, True), (1, 7, 37, 256, 64, True), (1, 5, 3, 128, 64, False), (2, 33, 16, 128, 64, True)]
 
 
 @pytest.mark.parametrize("dt", DTS)
