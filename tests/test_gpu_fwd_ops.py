@@ -192,7 +192,9 @@ def test_bnrelu_maxpool(ops, dt):
 @pytest.mark.parametrize("case", [(2, 8, 8, 32, 16, True), (1, 5, 9, 64, 32, False), (2, 16, 16, 16, 8, True),
                                   # 4*Cout % 256 == 0 and Cin a whole number of 128-byte steps -> GEMM kernel (conv_gemm.inc):
                                   # partial tiles, several channel blocks, with / without pending transform
-                                  (1, 5, 9, 64, 64, True), (2, 20, 17, 128, 128, False), (1, 16, 16, 192, 64, True)])
+                                  (1, 5, 9, 64, 64, True), (2, 20, 17, 128, 128, False), (1, 16, 16, 192, 64, True),
+                                  # (up to four 128-byte K steps: the two-workgroups-per-CU form; more: the ping-pong form)
+                                  (1, 9, 7, 320, 64, True), (2, 20, 17, 384, 128, False)])
 def test_convT2x2_fwd(ops, dt, case):
     B, H, W, Cin, Cout, tf = case
     if dt != "f32" and Cout % 8:
