@@ -33,6 +33,11 @@ for _ in range(5):
 torch.cuda.synchronize()
 buf = np.zeros(64 * 16 * 8, dtype=np.uint64)
 assert lib.cmu_debug_ig_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+clk = buf.reshape(32, 256)[:4, 200:203].astype(np.int64)
+clk = clk[clk[:, 1] > 0]
+if len(clk):
+    print(f"shader clock over the workgroup's stream: {(clk[:, 0] / clk[:, 1]).mean() * 100:.0f} MHz "
+          f"({clk[:, 0].mean() / clk[:, 2].mean():.0f} cycles per position, {clk[:, 2].mean():.0f} positions)")
 NIT = 12
 st = buf.reshape(32, 256)[:4, :2 * NIT * 8].reshape(4, 2, NIT, 8).astype(np.int64)
 nsl = Cin // 16
