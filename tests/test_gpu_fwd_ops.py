@@ -310,13 +310,12 @@ torch.save({"y": y.buf.float().cpu(), "s": st.sum(0).cpu()}, sys.argv[1])
 
 
 @pytest.mark.parametrize("chans,hw", [((64, 128), (48, 96)), ((128, 64), (48, 96)), ((64, 64), (48, 96)),
-                                      ((128, 64), (64, 96)), ((64, 64), (96, 64))])      # H % 32 == 0: the 32 x 32-pixel tiles
+                                      ((128, 64), (64, 96)), ((64, 64), (96, 64))])
 def test_conv3x3_persistent_kernel_is_bit_identical(chans, hw):
     """The persistent wide kernel (conv_igemm3p.inc: one workgroup walks a list of tiles) against the one-tile-per-workgroup
     kernel (CMU_CONV_PERSIST=0) on a whole-tile shape, with 13 workgroups forced so that every workgroup streams several
     tiles and the per-XCD item ranges are uneven: same MFMA order per accumulator, same statistics folding order ->
-    identical bits (with the 32 x 32-pixel tiles of the 64-channel layers the stored outputs are still identical; the
-    statistics are the same sums folded over 8 rows per wave instead of 4: compared to 2e-5), for the forward (pending transform + BN statistics), the plain data gradient and the data gradient
+    identical bits, for the forward (pending transform + BN statistics), the plain data gradient and the data gradient
     with fused BN-backward sums."""
     import os
     import subprocess
@@ -357,18 +356,12 @@ torch.save({k: v.cpu() for k, v in out.items()}, sys.argv[1])
     for env in ({"CMU_CONV_PERSIST": "0"}, {"CMU_CONV_PERSIST": "1", "CMU_CONV_PERSIST_GRID": "13"}):
         with tempfile.NamedTemporaryFile(suffix=".pt", delete=False) as f:
             path = f.name
-        subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, CMU_CONV_WIDE="2", CMU_CONV_TALL="1", **env),
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, CMU_CONV_WIDE="2", **env),
                        timeout=300)
         outs.append(torch.load(path))
         os.unlink(path)
-    tall = hw[0] % 32 == 0 and chans[1] == 64      # 32 x 32-pixel tiles: a wave sums 8 rows instead of 4 before the slab
     for k in outs[0]:
-        if tall and k in ("s", "slab"):
-            a, b = outs[0][k].double().sum(0), outs[1][k].double().sum(0)
-            assert (a - b).abs().max().item() <= 1e-5 * max(b.abs().max().item(), 1.0), k
-            assert (outs[0][k].double() - outs[1][k].double()).abs().max().item() <= 2e-5 * max(outs[0][k].abs().max().item(), 1.0), k
-        else:
-            assert torch.equal(outs[0][k].view(torch.uint8), outs[1][k].view(torch.uint8)), k
+        assert torch.equal(outs[0][k].view(torch.uint8), outs[1][k].view(torch.uint8)), k
 
 
 @pytest.mark.parametrize("dt", DTS)
