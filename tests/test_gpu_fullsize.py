@@ -104,6 +104,50 @@ def test_conv3x3_fwd_and_dgrad_sampled_windows_fp64(ops, layer, dt):
     print(f"[fullsize {dt} {Cin}->{Cout}@{S}] {n} windows: fwd err {worst_f:.2e}, dgrad err {worst_d:.2e} (tol {TOL[dt]})")
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("level", [(128, 256), (256, 128), (1024, 32)])     # (Cin, low-res size): two-workgroup form x2, ping-pong form
+def test_convT_fwd_and_dgrad_sampled_pixels_fp64(ops, level, dt):
+    """ConvTranspose2d 2x2 forward (pending BatchNorm+ReLU on the input, output into the left half of a concat buffer) and data
+    gradient (+ BatchNorm-backward sums) at the bench sizes, bs 32, on sampled low-res pixels against float64 dot products."""
+    Cin, S = level
+    Cout = Cin // 2
+    tdt = ops.TORCH_DT[ops.dt_code(dt)]
+    g = torch.Generator(device="cuda").manual_seed(21)
+    x = torch.randn(B, S, S, Cin, generator=g, device="cuda").to(tdt)
+    sc, sh = torch.rand(Cin, generator=g, device="cuda") + 0.5, torch.randn(Cin, generator=g, device="cuda") * 0.2
+    w = torch.randn(Cin, Cout, 2, 2, generator=g, device="cuda") / Cin ** 0.5
+    bias = torch.randn(Cout, generator=g, device="cuda")
+    wq = w.to(tdt).double().cpu()
+    cat = torch.zeros(B, 2 * S, 2 * S, 2 * Cout, dtype=tdt, device="cuda")
+    ops.convT2x2_fwd(ops.Act(x, 0, Cin, sc, sh, 0), ops.pack_convT2x2(w, dt, 0), bias, ops.Act(cat, 0, Cout))
+    dcat = torch.randn(B, 2 * S, 2 * S, 2 * Cout, generator=g, device="cuda").to(tdt)
+    dx = ops.new_act(B, S, S, Cin, dt, "cuda")
+    mean, invstd = torch.zeros(Cin, device="cuda"), torch.ones(Cin, device="cuda")
+    slab = ops.new_stats(B, S, S, Cin, "cuda")
+    ops.convT2x2_dgrad_bn(ops.Act(dcat, 0, Cout), ops.pack_convT2x2(w, dt, 1), dx, ops.Act(x, 0, Cin, sc, sh, 0), mean, invstd, slab)
+    assert (cat[..., Cout:] == 0).all()                                              # the skip half of the concat buffer is untouched
+    gen = torch.Generator().manual_seed(5)
+    pts = [(0, 0, 0), (B - 1, S - 1, S - 1), (B - 1, 0, S - 1), (7, S - 1, 0), (3, 15, 16), (3, 16, 15)]
+    pts += [tuple(int(torch.randint(0, n, (1,), generator=gen)) for n in (B, S, S)) for _ in range(58)]
+    worst_f = worst_d = 0.0
+    for (b, yy, xx) in pts:
+        a = torch.relu(x[b, yy, xx].double().cpu() * sc.double().cpu() + sh.double().cpu()).to(torch.float32).to(tdt).double()   # as staged
+        ref = torch.einsum("c,cnij->ijn", a, wq) + bias.double().cpu()
+        got = cat[b, 2 * yy:2 * yy + 2, 2 * xx:2 * xx + 2, :Cout].double().cpu()
+        worst_f = max(worst_f, (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6))
+        d = dcat[b, 2 * yy:2 * yy + 2, 2 * xx:2 * xx + 2, :Cout].double().cpu()
+        refd = torch.einsum("ijn,cnij->c", d, wq)
+        worst_d = max(worst_d, (dx.buf[b, yy, xx].double().cpu() - refd).abs().max().item() / max(refd.abs().max().item(), 1e-6))
+    print(f"[fullsize convT {dt} {Cin}->{Cout}@{S}] {len(pts)} pixels: fwd err {worst_f:.2e}, dgrad err {worst_d:.2e} (tol {2 * TOL[dt]} / {TOL[dt]})")
+    assert worst_f <= 2 * TOL[dt] and worst_d <= TOL[dt], (worst_f, worst_d)
+    # BatchNorm-backward sums of the data gradient against the stored dX (whole tensor, float64 on the device)
+    gate = (x.double() * sc.double() + sh.double()) > 0
+    dz = dx.buf.double() * gate
+    s1 = slab.double().sum(0)[0].cpu()
+    ref1 = dz.sum((0, 1, 2)).cpu()
+    assert (s1 - ref1).abs().max().item() <= 1e-4 * max(ref1.abs().max().item(), dz.abs().sum((0, 1, 2)).max().item() * 1e-3), "sum(gate * dX)"
+
+
 @pytest.mark.parametrize("case", [(64, 64, 512, "f16"), (128, 64, 512, "f16"), (128, 128, 256, "f16"), (64, 64, 512, "bf16"),
                                   (1024, 1024, 32, "f16")])
 def test_conv3x3_wgrad_fp64_two_image_subbatch(ops, case):
