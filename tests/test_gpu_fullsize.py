@@ -170,6 +170,30 @@ def test_conv3x3_wgrad_fp64_two_image_subbatch(ops, case):
     assert e <= 2e-4, e          # fp32 accumulation of exactly representable 16-bit products: only the summation order differs
 
 
+@pytest.mark.parametrize("case", [(128, 256, "f16"), (512, 64, "f16"), (128, 256, "bf16")])
+def test_convT_wgrad_fp64_two_image_subbatch(ops, case):
+    """ConvTranspose2d 2x2 weight and bias gradient at the bench image sizes on two images against float64 (pending
+    BatchNorm+ReLU on the input, dOut in the left half of a concat buffer)."""
+    from cmunet_amd import _lib
+    Cin, S, dt = case
+    Cout, nb = Cin // 2, 2
+    tdt = ops.TORCH_DT[ops.dt_code(dt)]
+    g = torch.Generator(device="cuda").manual_seed(17)
+    x = torch.randn(nb, S, S, Cin, generator=g, device="cuda").to(tdt)
+    sc, sh = torch.rand(Cin, generator=g, device="cuda") + 0.5, torch.randn(Cin, generator=g, device="cuda") * 0.2
+    dcat = torch.randn(nb, 2 * S, 2 * S, 2 * Cout, generator=g, device="cuda").to(tdt)
+    dW, db = torch.empty(Cin, Cout, 2, 2, device="cuda"), torch.empty(Cout, device="cuda")
+    ws = torch.empty(_lib.lib().cmu_convT2x2_wgrad_ws_bytes(nb, S, S, Cin, Cout, ops.dt_code(dt)), dtype=torch.uint8, device="cuda")
+    ops.convT2x2_wgrad(ops.Act(x, 0, Cin, sc, sh, 0), ops.Act(dcat, 0, Cout), dW, db, ws)
+    a = torch.relu(x.double() * sc.double() + sh.double()).float().to(tdt).double()            # the operand as staged
+    d = dcat[..., :Cout].double().view(nb, S, 2, S, 2, Cout)                                    # [b, y, i, x, j, n]
+    ref = torch.einsum("byxc,byixjn->cnij", a, d)
+    e = (dW.double() - ref).abs().max().item() / ref.abs().max().item()
+    eb = (db.double() - dcat[..., :Cout].double().sum((0, 1, 2))).abs().max().item() / dcat[..., :Cout].double().sum((0, 1, 2)).abs().max().item()
+    print(f"[fullsize convT wgrad {dt} {Cin}->{Cout}@{S}] dW err {e:.2e}, dbias err {eb:.2e}")
+    assert e <= 2e-4 and eb <= 2e-4, (e, eb)
+
+
 # (Cin, Cout, H): first kernel (64->64), 64-channel wide variant (128->64), wide kernel (128->128 at the second level)
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("shape", [(64, 64, 512), (128, 64, 512), (128, 128, 256)])
