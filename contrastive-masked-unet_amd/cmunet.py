@@ -227,8 +227,9 @@ class _SkinnyLinearFn(torch.autograd.Function):
     for the forward, one for the input gradient, one write of the weight gradient.  ``compute_dt`` None: exact fp32 products
     everywhere; 'f16' / 'bf16' (the AMP configuration): the 16-bit-operand kernel where it is the faster one -- measured at
     K = 262,144, N = 1,536 (tools/skinny_bench.py, profiles/r02_workloads.txt): weight gradient 0.37 ms against 0.55 ms exact;
-    the forward is bound by its 32-rows-per-wave load pattern in both forms (0.72 ms) and the input gradient is faster exact
-    (0.38 against 0.48 ms), so those two stay on the exact fp32 kernels (at least the precision autocast would give)."""
+    the exact forward stages its operands through LDS as contiguous runs (0.41 ms; the 16-bit-operand form still reads 32 rows
+    per wave a megabyte apart: 0.72 ms) and the input gradient is faster exact (0.38 against 0.48 ms), so those two stay on the
+    exact fp32 kernels (at least the precision autocast would give)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, compute_dt):

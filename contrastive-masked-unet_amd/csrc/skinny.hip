@@ -13,6 +13,7 @@
 // 32 weight rows (fwd) or 128 weight columns (dgrad, wgrad); the other operand (x, dy: <= 32 rows) comes from L2.
 // Split-K partial sums (fwd) go through a slab and a fixed-order second kernel: no atomics, bitwise reproducible.
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x4s __attribute__((ext_vector_type(4)));
 
@@ -27,30 +28,69 @@ __device__ static inline f32x16 sk_zero() {
 }
 
 // ---- forward: block = 4 waves = 4 x 32 rows of w over one K range; grid (ceil(N/128), splits) -------------------------------------
-constexpr int SKF_STEP = 8;      // k per load pair (two halves x four floats)
-constexpr int SKF_UNROLL = 4;    // load pairs in flight per wave
+// The MFMA wants lane = weight row (four consecutive k per lane), but read that way a wave touches 32 rows a megabyte apart with
+// 32 bytes each per load -- 2.2 TB/s of weights at K = 262,144 whatever the number of streams per workgroup (measured both
+// ways).  So the operands go through LDS: per 64-k chunk the workgroup loads its 128 weight rows and the 32 rows of x as 128-byte
+// runs (lane = 16-byte piece of a run, 8 rows per wave instruction), stores them row-major with a 144-byte pitch and the waves
+// read their operands from there (conflict-free 16-byte reads: bank = 4 * row mod 64 inside a lane group); two buffers, one
+// barrier per chunk, the next chunk's loads in flight across the MFMAs.
+constexpr int SKF_KC = 32;                 // k per staged chunk (46 KB of LDS per workgroup: three per CU keep ~60 KB of loads in flight)
+constexpr int SKF_PITCH = SKF_KC + 4;      // floats per LDS row
+constexpr int SKF_ROWS = 128 + 32;         // weight rows + x rows per buffer
+constexpr int SKF_LDS_BYTES = 2 * SKF_ROWS * SKF_PITCH * 4;   // 46,080
 __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ slab,
                                                         int M, int N, int64_t K, int64_t kchunk) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    extern __shared__ __attribute__((aligned(16))) float sk_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
-    const int n = (blockIdx.x * 4 + wave) * 32 + c;           // w row of this lane (B operand column)
+    const int n0 = blockIdx.x * 128;
+    const int n = n0 + wave * 32 + c;                         // w row of this lane (B operand column)
     const int64_t k0 = (int64_t)blockIdx.y * kchunk, k1 = k0 + kchunk < K ? k0 + kchunk : K;
-    const bool nok = n < N, mok = c < M;
-    const float* wp = w + (int64_t)(nok ? n : 0) * K + 4 * h;
-    const float* xp = x + (int64_t)(mok ? c : 0) * K + 4 * h;
-    f32x16 acc = sk_zero();
-    for (int64_t kb = k0; kb < k1; kb += SKF_STEP * SKF_UNROLL) {
-        f32x4s wv[SKF_UNROLL], xv[SKF_UNROLL];
+    const bool nok = n < N;
+    // staging role: piece = 16 bytes of a row's run; with P = SKF_KC / 4 pieces per row a pass of the 256 threads covers 256 / P rows
+    constexpr int P = SKF_KC / 4, RPP = 256 / P, WIT = 128 / RPP, XIT = 32 / RPP;
+    const int piece = tid % P, srow = tid / P;
+    f32x4s wreg[WIT], xreg[XIT];
+    auto load_chunk = [&](int64_t kb) {
+        const int64_t k = kb + 4 * piece;
+        const bool kok = k < k1;
 #pragma unroll
-        for (int u = 0; u < SKF_UNROLL; ++u) {
-            const int64_t k = kb + u * SKF_STEP;
-            wv[u] = sk_ld4(wp + k, nok && k < k1);
-            xv[u] = sk_ld4(xp + k, mok && k < k1);
+        for (int it = 0; it < WIT; ++it) {
+            const int row = n0 + srow + RPP * it;
+            wreg[it] = sk_ld4(w + (int64_t)(row < N ? row : 0) * K + k, kok && row < N);
         }
 #pragma unroll
-        for (int u = 0; u < SKF_UNROLL; ++u)
+        for (int it = 0; it < XIT; ++it) {
+            const int row = srow + RPP * it;
+            xreg[it] = sk_ld4(x + (int64_t)(row < M ? row : 0) * K + k, kok && row < M);
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        float* base = sk_lds + buf * (SKF_ROWS * SKF_PITCH) + 4 * piece;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[u][j], wv[u][j], acc, 0, 0, 0);
+        for (int it = 0; it < WIT; ++it) *reinterpret_cast<f32x4s*>(base + (srow + RPP * it) * SKF_PITCH) = wreg[it];
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) *reinterpret_cast<f32x4s*>(base + (128 + srow + RPP * it) * SKF_PITCH) = xreg[it];
+    };
+    f32x16 acc = sk_zero();
+    const int nch = (int)((k1 - k0 + SKF_KC - 1) / SKF_KC);
+    if (nch > 0) {
+        load_chunk(k0);
+        store_chunk(0);
+    }
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+        if (ch + 1 < nch) load_chunk(k0 + (int64_t)(ch + 1) * SKF_KC);
+        const float* wl = sk_lds + (ch & 1) * (SKF_ROWS * SKF_PITCH) + (wave * 32 + c) * SKF_PITCH + 4 * h;
+        const float* xl = sk_lds + (ch & 1) * (SKF_ROWS * SKF_PITCH) + (128 + c) * SKF_PITCH + 4 * h;
+#pragma unroll
+        for (int u = 0; u < SKF_KC / 8; ++u) {
+            const f32x4s wv = *reinterpret_cast<const f32x4s*>(wl + 8 * u), xv = *reinterpret_cast<const f32x4s*>(xl + 8 * u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[j], wv[j], acc, 0, 0, 0);
+        }
+        if (ch + 1 < nch) store_chunk((ch + 1) & 1);
+        __syncthreads();
     }
     // D[m][n]: lane holds column n (its w row), rows m = (e & 3) + 8 (e >> 2) + 4 h
     float* out = slab + (int64_t)blockIdx.y * M * N;
@@ -72,10 +112,13 @@ __global__ void skinny_fwd_reduce_kernel(const float* __restrict__ slab, const f
 }
 static int skf_splits(int N, int64_t K, int64_t* kchunk) {
     const int nblk = cmu_div_up(N, 128);
-    int splits = (int)cmu_div_up64(1024, nblk);                       // ~4 workgroups per CU
+    // three workgroups fit a CU (LDS): one round of 768 measured best at both projector shapes (512: 0.49 / 0.083 ms, 768: 0.413 /
+    // 0.081, 1,024: 0.436 / 0.095, 1,536: 0.434 / 0.098 at K = 262,144 / 50,176); CMU_SKF_WGS overrides (A/B)
+    static const int target = []() { const char* e = getenv("CMU_SKF_WGS"); return e ? atoi(e) : 768; }();
+    int splits = (int)cmu_div_up64(target, nblk);
     int64_t kc = cmu_div_up64(K, splits);
-    kc = cmu_div_up64(kc, SKF_STEP * SKF_UNROLL) * (SKF_STEP * SKF_UNROLL);
-    if (kc < SKF_STEP * SKF_UNROLL) kc = SKF_STEP * SKF_UNROLL;
+    kc = cmu_div_up64(kc, SKF_KC) * SKF_KC;
+    if (kc < SKF_KC) kc = SKF_KC;
     *kchunk = kc;
     return (int)cmu_div_up64(K, kc);
 }
@@ -89,7 +132,16 @@ extern "C" int cmu_skinny_gemm_fwd(const float* x, const float* w, const float* 
     CMU_CHECK_ARG(cmu_aligned16(x) && cmu_aligned16(w), "cmu_skinny_gemm_fwd: x / w must be 16-byte aligned");
     int64_t kc;
     const int splits = skf_splits(N, K, &kc);
-    hipLaunchKernelGGL(skinny_fwd_kernel, dim3(cmu_div_up(N, 128), splits), dim3(256), 0, (hipStream_t)stream, x, w, (float*)ws, M, N, K, kc);
+    static CmuPerDevice attr_set;   // hipFuncSetAttribute is per device
+    if (!attr_set.done()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SKF_LDS_BYTES);
+        if (e != hipSuccess) {
+            cmu_set_error("cmu_skinny_gemm_fwd: hipFuncSetAttribute(%d B LDS): %s", SKF_LDS_BYTES, hipGetErrorString(e));
+            return CMU_ERR_LAUNCH;
+        }
+        attr_set.mark();
+    }
+    hipLaunchKernelGGL(skinny_fwd_kernel, dim3(cmu_div_up(N, 128), splits), dim3(256), SKF_LDS_BYTES, (hipStream_t)stream, x, w, (float*)ws, M, N, K, kc);
     CMU_CHECK_LAUNCH("cmu_skinny_gemm_fwd");
     hipLaunchKernelGGL(skinny_fwd_reduce_kernel, dim3((unsigned)cmu_div_up64((int64_t)M * N, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)ws, bias, y, M, N, splits);
