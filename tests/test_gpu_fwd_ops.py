@@ -149,6 +149,34 @@ def test_conv3x3_c1_fwd(ops, dt, shape, masked):
     check(s[1], (ref * ref).sum((0, 2, 3)), 1e-4, "c1 stats sumsq")
 
 
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", [(2, 5, 7, 40, True), (3, 16, 16, 128, True), (2, 9, 4, 64, False), (3, 4, 4, 20, True), (1, 70, 3, 8, False)])
+def test_gap_fwd(ops, dt, case):
+    """Global average pool of relu(bn(y)) (MoCo encoder head, moco_data_module.py:62-64): 16-byte-chunk kernel where C allows, the
+    element kernel otherwise; with and without a pending transform; more pixels than one pass of the pixel parts."""
+    B, H, W, C, tf = case
+    g = torch.Generator().manual_seed(sum(case[:4]))
+    y = q(torch.randn(B, C, H, W, generator=g), dt, ops)
+    ya = to_act(y, dt, ops, ld=C + 16, coff=8 if dt != "f32" else 4)
+    ref = y.double()
+    if tf:
+        sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+        ya = ya.with_transform(sc.cuda(), sh.cuda(), 0)
+        ref = F.relu(ref * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+    out = torch.full((B, C), 3.0, device="cuda")
+    ops.gap_fwd(ya, out)
+    check(out.cpu(), ref.mean((2, 3)), 1e-5, "gap")
+    # backward: every pixel of a channel gets dout / (H W), written into a channel slice of a wider buffer
+    dout = torch.randn(B, C, generator=g)
+    dbuf = torch.full((B, H, W, C + 16), 5.0, dtype=ops.TORCH_DT[ops.dt_code(dt)], device="cuda")
+    dA = ops.Act(dbuf, 8 if dt != "f32" else 4, C)
+    ops.gap_bwd(dout.cuda(), dA)
+    want = q((dout / (H * W)).float(), dt, ops).view(B, 1, 1, C).expand(B, H, W, C)
+    got = dbuf[..., dA.coff:dA.coff + C].float().cpu()
+    assert (got - want).abs().max().item() <= TOL[dt] * max(want.abs().max().item(), 1e-6)
+    assert (dbuf[..., :dA.coff] == 5.0).all() and (dbuf[..., dA.coff + C:] == 5.0).all()
+
+
 @pytest.mark.parametrize("training", [True, False])
 def test_bn_finalize(ops, training):
     B, H, W, C = 3, 20, 24, 48
