@@ -379,6 +379,61 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// the same reduction four channels per lane (16-byte loads: four times the bytes in flight; every output element still sums its
+// slabs in the scalar kernel's order, so the two kernels agree bit for bit).  Needs the fast slab axis in whole 4-element groups.
+__device__ static inline f32x4 sum_split4(const float* __restrict__ p, int64_t stride, int part, int splitk) {
+    constexpr int U = 8;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int k = part;
+    for (; k + 4 * (U - 1) < splitk; k += 4 * U) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (int64_t)(k + 4 * u) * stride);
+#pragma unroll
+        for (int u = 0; u < U; ++u) s += v[u];
+    }
+    for (; k < splitk; k += 4) s += *reinterpret_cast<const f32x4*>(p + (int64_t)k * stride);
+    return s;
+}
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restrict__ ws, int splitk, int T, int CApad, int CBpad, int CA,
+                                                           int CB, float* __restrict__ dW, int mode) {
+    __shared__ f32x4 red[4][64];
+    const int F = (mode == 2 ? CA : CB) / 4;                       // 4-element groups along the slab's fast axis
+    const int S = mode == 2 ? CB : CA;                             // the slower channel axis
+    const int64_t total = (int64_t)T * S * F;
+    const int ol = threadIdx.x & 63, part = threadIdx.x >> 6;
+    for (int64_t o0 = (int64_t)blockIdx.x * 64; o0 < total; o0 += (int64_t)gridDim.x * 64) {
+        const int64_t o = o0 + ol;
+        const int f4 = (int)(o % F), sl = (int)((o / F) % S), t = (int)(o / ((int64_t)F * S));
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (o < total) {
+            if (mode == 2) s = sum_split4(ws + ((int64_t)t * CB + sl) * CA + 4 * f4, (int64_t)T * CB * CA, part, splitk);
+            else s = sum_split4(ws + ((int64_t)t * CApad + sl) * CBpad + 4 * f4, (int64_t)T * CApad * CBpad, part, splitk);
+        }
+        __syncthreads();
+        red[part][ol] = s;
+        __syncthreads();
+        if (part == 0 && o < total) {
+            s = (red[0][ol] + red[1][ol]) + (red[2][ol] + red[3][ol]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (mode == 2) dW[((int64_t)sl * CA + 4 * f4 + j) * 4 + t] = s[j];             // slab [ij][c][n]: sl = c, fast = n
+                else if (mode == MODE_W3) dW[((int64_t)sl * CB + 4 * f4 + j) * 9 + t] = s[j];  // (Cout,Cin,3,3): sl = n, fast = c
+                else dW[((int64_t)(4 * f4 + j) * CA + sl) * 4 + t] = s[j];                     // (Cin,Cout,2,2): sl = n, fast = c
+            }
+        }
+    }
+}
+// CMU_WGR_VEC=0 keeps the scalar reduction (A/B switch)
+static void launch_wgrad_reduce(const float* ws, int splitk, int T, int CApad, int CBpad, int CA, int CB, float* dW, int mode, hipStream_t st) {
+    static const bool vec_on = []() { const char* e = getenv("CMU_WGR_VEC"); return !(e && e[0] == '0'); }();
+    const bool vec = vec_on && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && (mode == 2 ? CA % 4 == 0 : (CB % 4 == 0 && CBpad % 4 == 0));
+    const int64_t total = (int64_t)T * CA * CB / (vec ? 4 : 1);
+    const int grid = (int)(cmu_div_up64(total, 64) < CMU_WGR_CAP ? cmu_div_up64(total, 64) : CMU_WGR_CAP);
+    if (vec) hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(grid), dim3(256), 0, st, ws, splitk, T, CApad, CBpad, CA, CB, dW, mode);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, ws, splitk, T, CApad, CBpad, CA, CB, dW, mode);
+}
+
 // per-channel sum over all pixels (ConvTranspose2d bias gradient)
 template <class TR>
 __global__ __launch_bounds__(256) void channel_sum_kernel(const unsigned char* __restrict__ x, int64_t ldx, float* __restrict__ ws,
@@ -513,9 +568,7 @@ static int wgradT_wide_t(WGParams p, float* dW, float* dbias, hipStream_t st) {
     hipLaunchKernelGGL((conv_wgradT2_kernel<TR>), dim3(p.nAB * p.nBB * p.splitk), dim3(512), C::LDS_BYTES, st, pp);
     cmu_set_kernel_tag("conv_wgradT2_kernel");
     CMU_CHECK_LAUNCH("cmu_convT2x2_wgrad(wide)");
-    const int64_t total = (int64_t)4 * p.CA * p.CB;
-    const int grid = (int)(cmu_div_up64(total, 64) < CMU_WGR_CAP ? cmu_div_up64(total, 64) : CMU_WGR_CAP);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)p.ws, p.splitk, 4, p.CApad, p.CBpad, p.CA, p.CB, dW, 2);
+    launch_wgrad_reduce((const float*)p.ws, p.splitk, 4, p.CApad, p.CBpad, p.CA, p.CB, dW, 2, st);
     CMU_CHECK_LAUNCH("cmu_convT2x2_wgrad(reduce)");
     const float* ws_sum = p.ws + (int64_t)p.splitk * 4 * p.CB * p.CA;
     hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cmu_div_up(p.CA, 128)), dim3(128), 0, st, ws_sum, p.splitk, p.CA, dbias);
@@ -543,11 +596,8 @@ static int wgrad3_wide_t(WGParams p, float* dW, hipStream_t st) {
     hipLaunchKernelGGL((conv_wgrad2_kernel<TR, SWAP>), dim3(p.nAB * p.nBB * p.splitk), dim3(512), C::LDS_BYTES, st, pp);
     cmu_set_kernel_tag("conv_wgrad2_kernel");
     CMU_CHECK_LAUNCH("cmu_conv3x3_wgrad(wide)");
-    const int64_t total = (int64_t)9 * p.CA * p.CB;
-    const int grid = (int)(cmu_div_up64(total, 64) < CMU_WGR_CAP ? cmu_div_up64(total, 64) : CMU_WGR_CAP);
     // (the slab is [split][tap][Cout][Cin] in both forms: p.CA = Cout rows of p.CB = Cin)
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)p.ws, p.splitk, 9, p.CA, p.CB, p.CA, p.CB, dW,
-                       (int)MODE_W3);
+    launch_wgrad_reduce((const float*)p.ws, p.splitk, 9, p.CA, p.CB, p.CA, p.CB, dW, (int)MODE_W3, st);
     CMU_CHECK_LAUNCH("cmu_conv3x3_wgrad(reduce)");
     return CMU_OK;
 }
@@ -575,10 +625,7 @@ template <class TR>
 static int wgrad3_t(WGParams p, float* dW, hipStream_t st) {
     int rc = launch_wgrad<TR, MODE_W3>(p, st, "cmu_conv3x3_wgrad");
     if (rc) return rc;
-    const int64_t total = (int64_t)9 * p.CA * p.CB;
-    const int grid = (int)(cmu_div_up64(total, 64) < CMU_WGR_CAP ? cmu_div_up64(total, 64) : CMU_WGR_CAP);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)p.ws, p.splitk, 9, p.CApad, p.CBpad, p.CA, p.CB, dW,
-                       (int)MODE_W3);
+    launch_wgrad_reduce((const float*)p.ws, p.splitk, 9, p.CApad, p.CBpad, p.CA, p.CB, dW, (int)MODE_W3, st);
     CMU_CHECK_LAUNCH("cmu_conv3x3_wgrad(reduce)");
     return CMU_OK;
 }
@@ -586,10 +633,7 @@ template <class TR>
 static int wgradT_t(WGParams p, float* dW, float* dbias, float* ws_sum, hipStream_t st) {
     int rc = launch_wgrad<TR, MODE_WT>(p, st, "cmu_convT2x2_wgrad");
     if (rc) return rc;
-    const int64_t total = (int64_t)4 * p.CA * p.CB;
-    const int grid = (int)(cmu_div_up64(total, 64) < CMU_WGR_CAP ? cmu_div_up64(total, 64) : CMU_WGR_CAP);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)p.ws, p.splitk, 4, p.CApad, p.CBpad, p.CA, p.CB, dW,
-                       (int)MODE_WT);
+    launch_wgrad_reduce((const float*)p.ws, p.splitk, 4, p.CApad, p.CBpad, p.CA, p.CB, dW, (int)MODE_WT, st);
     CMU_CHECK_LAUNCH("cmu_convT2x2_wgrad(reduce)");
     // bias gradient: sum of dOut over all (B,2H,2W) pixels
     const int nchunk = p.CA / TR::EPC;
