@@ -468,12 +468,33 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const unsigned char* _
         }
     }
 }
-__global__ void channel_sum_final_kernel(const float* __restrict__ ws, int nblocks, int C, float* out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// 16 channels x 16 row parts per 256-thread block, eight rows in flight per thread, fixed-order combine (one thread per channel
+// walking up to 256 rows was a chain of dependent round trips: 23 us per launch)
+__global__ __launch_bounds__(256) void channel_sum_final_kernel(const float* __restrict__ ws, int nblocks, int C, float* out) {
+    __shared__ double red[16][16];
+    const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += (double)ws[(int64_t)b * C + c];
-    out[c] = (float)s;
+    if (c < C) {
+        constexpr int U = 8;
+        int b = part;
+        for (; b + 16 * (U - 1) < nblocks; b += 16 * U) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = ws[(int64_t)(b + 16 * u) * C + c];
+#pragma unroll
+            for (int u = 0; u < U; ++u) s += (double)v[u];
+        }
+        for (; b < nblocks; b += 16) s += (double)ws[(int64_t)b * C + c];
+    }
+    red[part][cl] = s;
+    __syncthreads();
+    if (part == 0 && c < C) {
+        s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += red[q][cl];
+        out[c] = (float)s;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -571,7 +592,7 @@ static int wgradT_wide_t(WGParams p, float* dW, float* dbias, hipStream_t st) {
     launch_wgrad_reduce((const float*)p.ws, p.splitk, 4, p.CApad, p.CBpad, p.CA, p.CB, dW, 2, st);
     CMU_CHECK_LAUNCH("cmu_convT2x2_wgrad(reduce)");
     const float* ws_sum = p.ws + (int64_t)p.splitk * 4 * p.CB * p.CA;
-    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cmu_div_up(p.CA, 128)), dim3(128), 0, st, ws_sum, p.splitk, p.CA, dbias);
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cmu_div_up(p.CA, 16)), dim3(256), 0, st, ws_sum, p.splitk, p.CA, dbias);
     CMU_CHECK_LAUNCH("cmu_convT2x2_wgrad(bias final)");
     return CMU_OK;
 }
@@ -643,7 +664,7 @@ static int wgradT_t(WGParams p, float* dW, float* dbias, float* ws_sum, hipStrea
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL((channel_sum_kernel<TR>), dim3(gx, gy), dim3(256), 0, st, (const unsigned char*)p.a, p.lda, ws_sum, npix, p.CA, cpb, ppb);
     CMU_CHECK_LAUNCH("cmu_convT2x2_wgrad(bias)");
-    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cmu_div_up(p.CA, 128)), dim3(128), 0, st, (const float*)ws_sum, gx, p.CA, dbias);
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cmu_div_up(p.CA, 16)), dim3(256), 0, st, (const float*)ws_sum, gx, p.CA, dbias);
     CMU_CHECK_LAUNCH("cmu_convT2x2_wgrad(bias final)");
     return CMU_OK;
 }
