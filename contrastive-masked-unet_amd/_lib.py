@@ -44,6 +44,7 @@ _SIGS = {
     "cmu_skinny_gemm_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _L, _P]),
     "cmu_lamb_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _F, _F, _F, _F, _I, _I, _F, _I, _I, _L, _F, _P, _P]),
     "cmu_pack_desc_bytes": (_I, []),
+    "cmu_pack_desc_blocks": (_L, [_I, _I, _I, _I, _I]),
     "cmu_pack_batch": (_I, [_P, _I, _L, _I, _P]),
     "cmu_version": (_I, []),
     "cmu_dtype_size": (_I, [_I]),

@@ -134,7 +134,7 @@ class PackPlan:
             out = torch.empty(n, dtype=TORCH_DT[dt], device=dev)
             self.outs.append(out)
             recs.append(struct.pack("<QQiiiiqq", w.data_ptr(), out.data_ptr(), Cin, Cout, int(mode), kind, n, block))
-            block += (n + 4095) // 4096
+            block += l.cmu_pack_desc_blocks(kind, Cin, Cout, dt, int(mode))
         self.ptrs = [w.data_ptr() for w, _, _ in items]
         self.items = items
         self.total_blocks = block

@@ -59,9 +59,10 @@ int64_t cmu_pack_convT2x2_elems(int Cin, int Cout, int dt, int mode);
 int cmu_pack_convT2x2(const float* w, void* out, int Cin, int Cout, int dt, int mode, void* stream);
 /* Every pack of a training step in one launch.  descs_dev: device array of ndesc records of cmu_pack_desc_bytes() bytes
  * { const float* w; void* out; int32 Cin, Cout, mode, kind (0 conv3x3: mode = transpose_flip, 1 convT2x2); int64 total
- * (elements of the packed array); int64 block0 (first of its ceil(total/4096) workgroups) }, block0 ascending from 0;
+ * (elements of the packed array); int64 block0 (first of its cmu_pack_desc_blocks(...) workgroups) }, block0 ascending from 0;
  * total_blocks = sum of the workgroup counts.  Same layouts as cmu_pack_conv3x3 / cmu_pack_convT2x2.               */
 int cmu_pack_desc_bytes(void);
+int64_t cmu_pack_desc_blocks(int kind, int Cin, int Cout, int dt, int mode);
 int cmu_pack_batch(const void* descs_dev, int ndesc, int64_t total_blocks, int dt, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
