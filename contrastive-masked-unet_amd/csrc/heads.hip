@@ -72,6 +72,63 @@ __global__ __launch_bounds__(256) void mmse_rows_kernel(const float* __restrict_
         ws[row * 4 + 3] = den;
     }
 }
+// the same per-row quantities with one WAVE per image row (rows of whole 16-byte groups, at most 1,024 pixels): the row is read
+// once into registers (the block form walks it three times between four block-wide sums with two barriers each: 56 us for the
+// 16,384 rows of a bench batch)
+__global__ __launch_bounds__(256) void mmse_rows_wave_kernel(const float* __restrict__ logits, int K, int channel,
+                                                            const float* __restrict__ img, const uint8_t* __restrict__ mask,
+                                                            float* __restrict__ ws, int B, int H, int W, int rows) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int b = row / H, yy = row % H;
+    const float* im = img + (int64_t)row * W;
+    const float* pr = logits + (((int64_t)b * K + channel) * H + yy) * W;
+    const uint8_t* mk = mask + (int64_t)row * W;
+    f32x4 iv[4], pv[4];
+    uint32_t mv[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int x = (i * 64 + lane) * 4;
+        const bool ok = x < W;
+        iv[i] = ok ? *reinterpret_cast<const f32x4*>(im + x) : f32x4{0.f, 0.f, 0.f, 0.f};
+        pv[i] = ok ? *reinterpret_cast<const f32x4*>(pr + x) : f32x4{0.f, 0.f, 0.f, 0.f};
+        mv[i] = ok ? *reinterpret_cast<const uint32_t*>(mk + x) : 0u;
+        s += (iv[i][0] + iv[i][1]) + (iv[i][2] + iv[i][3]);
+    }
+    const float mean = wave_sum(s) / (float)W;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if ((i * 64 + lane) * 4 < W)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = iv[i][j] - mean;
+                v = fmaf(d, d, v);
+            }
+    const float var = wave_sum(v) / (float)(W > 1 ? W - 1 : 1);  // unbiased (torch.var default)
+    const float rstd = 1.f / sqrtf(var + 1.e-6f);
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if ((i * 64 + lane) * 4 < W)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t = (iv[i][j] - mean) * rstd;
+                const float d = pv[i][j] - t;
+                const float m = (float)((mv[i] >> (8 * j)) & 0xffu);
+                num = fmaf(d * d, m, num);
+                den += m;
+            }
+    num = wave_sum(num);
+    den = wave_sum(den);
+    if (lane == 0) {
+        ws[row * 4 + 0] = mean;
+        ws[row * 4 + 1] = rstd;
+        ws[row * 4 + 2] = num;
+        ws[row * 4 + 3] = den;
+    }
+}
 __global__ __launch_bounds__(256) void mmse_final_kernel(float* __restrict__ ws, int rows, float* loss) {
     __shared__ double red[4];
     double num = 0.0, den = 0.0;
@@ -104,6 +161,31 @@ __global__ void mmse_grad_kernel(const float* __restrict__ logits, int K, int ch
         dlogits[o] = g;
     }
 }
+// four pixels per thread (W a multiple of 4: a 16-byte group never leaves its row)
+__global__ void mmse_grad4_kernel(const float* __restrict__ logits, int K, int channel, const float* __restrict__ img,
+                                  const uint8_t* __restrict__ mask, const float* __restrict__ ws, float* __restrict__ dlogits,
+                                  float loss_scale, const CmuAmpState* __restrict__ amp, int B, int H, int W, int64_t total4) {
+    const int rows = B * H, W4 = W / 4;
+    if (amp != nullptr) loss_scale *= amp->scale;      // dynamic loss scale (power of two: exact)
+    const float k = 2.f * loss_scale / ws[rows * 4 + 1];
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total4; o += (int64_t)gridDim.x * blockDim.x) {
+        const int x4 = (int)(o % W4), yy = (int)((o / W4) % H), c = (int)((o / ((int64_t)W4 * H)) % K), b = (int)(o / ((int64_t)W4 * H * K));
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        if (c == channel) {
+            const int row = b * H + yy;
+            const f32x4 iv = *reinterpret_cast<const f32x4*>(img + (int64_t)row * W + 4 * x4);
+            const f32x4 lv = *reinterpret_cast<const f32x4*>(logits + 4 * o);
+            const uint32_t mv = *reinterpret_cast<const uint32_t*>(mask + (int64_t)row * W + 4 * x4);
+            const float mean = ws[row * 4 + 0], rstd = ws[row * 4 + 1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t = (iv[j] - mean) * rstd;
+                g[j] = k * (lv[j] - t) * (float)((mv >> (8 * j)) & 0xffu);
+            }
+        }
+        *reinterpret_cast<f32x4*>(dlogits + 4 * o) = g;
+    }
+}
 extern "C" int64_t cmu_masked_mse_ws_bytes(int B, int H) { return ((int64_t)B * H * 4 + 4) * (int64_t)sizeof(float); }
 extern "C" int cmu_masked_mse_fwd_bwd(const float* logits, int K, int channel, const float* img, const uint8_t* mask, float* loss,
                                       float* dlogits, float loss_scale, const void* amp_state, int B, int H, int W, void* ws,
@@ -111,12 +193,25 @@ extern "C" int cmu_masked_mse_fwd_bwd(const float* logits, int K, int channel, c
     CMU_CHECK_ARG(logits && img && mask && loss && ws && B > 0 && H > 0 && W > 0 && K > 0 && channel >= 0 && channel < K,
                   "cmu_masked_mse_fwd_bwd: bad args");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(mmse_rows_kernel, dim3(B * H), dim3(256), 0, st, logits, K, channel, img, mask, (float*)ws, B, H, W);
+    if (W % 4 == 0 && W <= 1024 && ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(img)) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(mask) & 3) == 0)
+        hipLaunchKernelGGL(mmse_rows_wave_kernel, dim3(cmu_div_up(B * H, 4)), dim3(256), 0, st, logits, K, channel, img, mask, (float*)ws, B, H, W,
+                           B * H);
+    else
+        hipLaunchKernelGGL(mmse_rows_kernel, dim3(B * H), dim3(256), 0, st, logits, K, channel, img, mask, (float*)ws, B, H, W);
     CMU_CHECK_LAUNCH("cmu_masked_mse(rows)");
     hipLaunchKernelGGL(mmse_final_kernel, dim3(1), dim3(256), 0, st, (float*)ws, B * H, loss);
     CMU_CHECK_LAUNCH("cmu_masked_mse(final)");
     if (dlogits) {
         const int64_t total = (int64_t)B * K * H * W;
+        if (W % 4 == 0 && ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(img) | reinterpret_cast<uintptr_t>(dlogits)) & 15) == 0 &&
+            (reinterpret_cast<uintptr_t>(mask) & 3) == 0) {
+            const int grid = (int)(cmu_div_up64(total / 4, 256) < 8192 ? cmu_div_up64(total / 4, 256) : 8192);
+            hipLaunchKernelGGL(mmse_grad4_kernel, dim3(grid), dim3(256), 0, st, logits, K, channel, img, mask, (const float*)ws, dlogits,
+                               loss_scale, (const CmuAmpState*)amp_state, B, H, W, total / 4);
+            CMU_CHECK_LAUNCH("cmu_masked_mse(grad)");
+            return CMU_OK;
+        }
         const int grid = (int)(cmu_div_up64(total, 256) < 8192 ? cmu_div_up64(total, 256) : 8192);
         hipLaunchKernelGGL(mmse_grad_kernel, dim3(grid), dim3(256), 0, st, logits, K, channel, img, mask, (const float*)ws, dlogits,
                            loss_scale, (const CmuAmpState*)amp_state, B, H, W, total);
