@@ -457,6 +457,23 @@ def main():
                            "launches_per_step": d["calls"] // args.steps,
                            "avg_launch_ms": round(d["ms"] / d["calls"], 4),
                            "share_of_timed_entries": round(d["ms"] / tot_ms, 3)}
+        if args.dtype in ("f16", "bf16"):
+            # what the matrix pipes of THIS chip sustain: back-to-back MFMAs from registers on every SIMD (csrc/probe.hip).  The
+            # power management lowers the shader clock under that load by an amount that depends on the operand data, so the
+            # nominal 2.5 PFLOP/s (2.4 GHz) is out of reach of any kernel fed with dense data; measured here, after the timed region
+            try:
+                from cmunet_amd import ops as _ops
+                sus = {}
+                for pat, label in ((0, "dense_normal_operands"), (1, "relu_operands_half_zero"), (2, "zero_operands")):
+                    tf, clk = _ops.mfma_sustained_rate(args.dtype, pat, device=dev)
+                    sus[label] = {"tflops": round(tf, 1), "clock_mhz": round(clk)}
+                ref = sus["dense_normal_operands"]["tflops"]
+                out["roofline"]["sustained"] = {
+                    "measured": sus, "frac_of_sustained_dense": round(ach / ref, 4),
+                    "note": "pure 32x32x16 MFMA loop from registers, all SIMDs, no LDS / memory (cmu_mfma_sustained_rate); `peak` stays the "
+                            "nominal dense figure at 2.4 GHz, `frac` = achieved / peak"}
+            except Exception as e:      # a diagnostic: never takes the line down
+                out["roofline"]["sustained"] = {"error": repr(e)}
         out["mfma_kernels"] = {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "launches_per_step": v["calls"] // args.steps,
                                    "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in mf.items()}
         out["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}

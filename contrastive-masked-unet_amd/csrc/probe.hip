@@ -1,0 +1,120 @@
+// probe.hip -- what MFMA rate does THIS chip sustain?  (measurement support for bench.py's roofline block)
+//
+// The conv kernels of this library are priced against the 2.5 PFLOP/s dense 16-bit peak (2.4 GHz).  Under a matrix-pipe
+// load the MI355X does not hold 2.4 GHz: its power management lowers the shader clock, and by how much depends on the
+// OPERAND DATA (bit toggling in the multipliers).  Measured with this probe (tools/mfma_clock.hip is the stand-alone
+// form; profiles/r02_mfma_clock.txt): back-to-back 32x32x16 f16 MFMAs from registers -- no LDS, no memory, every SIMD
+// busy -- run at 2.45 PFLOP/s / 2.38 GHz on all-zero operands, 2.0 PFLOP/s / 1.97 GHz on ReLU'd N(0,1) operands (half
+// zeros) and 1.63 PFLOP/s / 1.61 GHz on dense N(0,1) operands.  That last figure is the ceiling a kernel fed with dense
+// random data can reach on this chip whatever its schedule; bench.py reports it beside the nominal peak.
+//
+// cmu_mfma_sustained_rate runs that loop for about `iters` x 8 MFMAs per wave on the given stream and returns the rate
+// and the shader clock (s_memtime / s_memrealtime of one wave).  Operands are generated in the kernel (a hash of the lane
+// id; sum-of-uniforms ~ N(0,1)), so the probe needs no memory but a 64-byte scratch for its two counters.
+#include "common.h"
+
+typedef _Float16 pr_f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 pr_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float pr_f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ static inline unsigned pr_hash(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+// ~N(0,1): sum of four uniform bytes, centred and scaled (variance 4 * (256^2 - 1) / 12 -> / 147.8)
+__device__ static inline float pr_normal(unsigned h) {
+    const float s = (float)(h & 255u) + (float)((h >> 8) & 255u) + (float)((h >> 16) & 255u) + (float)(h >> 24);
+    return (s - 510.f) * (1.f / 147.8f);
+}
+
+// PATTERN 0: dense ~N(0,1) operands; 1: ReLU'd (half zeros); 2: all zeros.   BF = bf16 instead of f16
+template <bool BF, int PATTERN>
+__global__ __launch_bounds__(512) void mfma_probe_kernel(int iters, unsigned long long* out) {
+    const unsigned tid = threadIdx.x + blockIdx.x * 512u;
+    u32x4 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        unsigned w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float f0 = pr_normal(pr_hash(tid * 64u + i * 8u + q * 2u)), f1 = pr_normal(pr_hash(tid * 64u + i * 8u + q * 2u + 1u));
+            if (PATTERN == 1) { f0 = fmaxf(f0, 0.f); f1 = fmaxf(f1, 0.f); }
+            if (PATTERN == 2) { f0 = 0.f; f1 = 0.f; }
+            if (BF) {
+                w[q] = (__float_as_uint(f0) >> 16) | (__float_as_uint(f1) & 0xffff0000u);
+            } else {
+                const _Float16 h0 = (_Float16)f0, h1 = (_Float16)f1;
+                w[q] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+            }
+        }
+        (i < 4 ? a[i & 3] : b[i & 3]) = u32x4{w[0], w[1], w[2], w[3]};
+    }
+    pr_f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (BF)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pr_bf16x8, a[i & 3]), __builtin_bit_cast(pr_bf16x8, b[(i >> 1) & 3]), acc[i], 0, 0, 0);
+            else
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pr_f16x8, a[i & 3]), __builtin_bit_cast(pr_f16x8, b[(i >> 1) & 3]), acc[i], 0, 0, 0);
+        }
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc[i][e];
+    if (s == 123.456f) out[7] = 1ull;            // keeps the accumulators alive
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = r1 - r0;
+    }
+}
+
+extern "C" int cmu_mfma_sustained_rate(int dt, int pattern, int iters, void* scratch64, double* tflops, double* clock_mhz, void* stream) {
+    CMU_CHECK_ARG(dt == CMU_F16 || dt == CMU_BF16, "cmu_mfma_sustained_rate: dt must be f16 or bf16");
+    CMU_CHECK_ARG(pattern >= 0 && pattern <= 2 && iters > 0 && iters <= (1 << 24) && scratch64 && tflops && clock_mhz,
+                  "cmu_mfma_sustained_rate: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cmu_current_device()) != hipSuccess || cus <= 0) cus = 256;
+    unsigned long long* out = reinterpret_cast<unsigned long long*>(scratch64);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        cmu_set_error("cmu_mfma_sustained_rate: hipEventCreate failed");
+        return CMU_ERR_LAUNCH;
+    }
+    auto launch = [&](int n) {
+        const bool bf = dt == CMU_BF16;
+#define PR_GO(BF_, P_) hipLaunchKernelGGL((mfma_probe_kernel<BF_, P_>), dim3((unsigned)cus), dim3(512), 0, st, n, out)
+        if (pattern == 0) { if (bf) PR_GO(true, 0); else PR_GO(false, 0); }
+        else if (pattern == 1) { if (bf) PR_GO(true, 1); else PR_GO(false, 1); }
+        else { if (bf) PR_GO(true, 2); else PR_GO(false, 2); }
+#undef PR_GO
+    };
+    launch(iters / 16 + 1);                      // the clock settles under the load before the timed launch
+    hipError_t e = hipEventRecord(e0, st);
+    launch(iters);
+    if (e == hipSuccess) e = hipEventRecord(e1, st);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long h[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (e != hipSuccess || ms <= 0.f) {
+        cmu_set_error("cmu_mfma_sustained_rate: %s", hipGetErrorString(e));
+        return CMU_ERR_LAUNCH;
+    }
+    *tflops = (double)cus * 8.0 * (double)iters * 8.0 * 32768.0 / ((double)ms * 1e-3) * 1e-12;
+    *clock_mhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
+    return CMU_OK;
+}

@@ -135,3 +135,17 @@ def test_launches_follow_the_tensors_device(cuda):
     assert torch.equal(outs[0], outs[1])
     ref = OU.unet_forward(x, sd, training=False)
     assert (outs[1] - ref).abs().max().item() <= 1e-3
+
+
+def test_mfma_sustained_rate_probe(cuda):
+    """bench.py's measured ceiling (cmu_mfma_sustained_rate): the pure MFMA loop reports a plausible rate and clock, and
+    all-zero operands run at least as fast as dense random ones (the data-dependent power limit)."""
+    from cmunet_amd import ops
+    dense, clk_d = ops.mfma_sustained_rate("f16", 0, iters=20000, device=cuda)
+    zero, clk_z = ops.mfma_sustained_rate("f16", 2, iters=20000, device=cuda)
+    print(f"sustained f16 MFMA: dense operands {dense:.0f} TFLOP/s @ {clk_d:.0f} MHz, zero operands {zero:.0f} TFLOP/s @ {clk_z:.0f} MHz")
+    assert 500.0 < dense < 2600.0 and 500.0 < zero < 2600.0
+    assert 800.0 < clk_d < 2600.0 and 800.0 < clk_z < 2600.0
+    assert zero > 0.97 * dense
+    with pytest.raises(Exception, match="dt must be f16 or bf16"):
+        ops.mfma_sustained_rate("f32", 0, iters=10, device=cuda)

@@ -1,0 +1,151 @@
+// tools/mfma_clock.hip -- diagnostic: what shader clock and MFMA rate does the chip SUSTAIN under a pure matrix-pipe load?
+// The conv kernels run at 1.2-1.45 PFLOP/s with the clock at 1.2-1.45 GHz (tools/igemm3p_stamps.py): this program separates
+// the power limit from the kernels' own stalls.  Every wave issues back-to-back independent MFMAs from registers (no LDS, no
+// memory) for ~0.3 s per variant; wave 0 of a few workgroups reads s_memtime / s_memrealtime around its loop.
+//   build: hipcc -O3 --offload-arch=gfx950 -o tools/_diag/mfma_clock tools/mfma_clock.hip
+//   run:   tools/_diag/mfma_clock
+// Variants: instruction shape (32x32x16 / 16x16x32), dtype (f16 / bf16), operand data (random / zeros / small-range),
+// waves per SIMD (1 / 2), optional LDS fragment reads beside the MFMAs (6 x 1 KB per 8 MFMAs, the conv kernel's ratio).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+// MODE 0: 32x32x16 f16   1: 16x16x32 f16   2: 32x32x16 bf16
+template <int MODE, bool LDS>
+__global__ __launch_bounds__(512) void mfma_loop(const u32x4* __restrict__ src, int iters, unsigned long long* out, float* sink) {
+    __shared__ u32x4 lds[LDS ? 2048 : 1];
+    const int tid = threadIdx.x;
+    u32x4 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i] = src[(tid * 8 + i) & 4095];
+        b[i] = src[(tid * 8 + 4 + i) & 4095];
+    }
+    if (LDS) {
+        for (int i = tid; i < 2048; i += blockDim.x) lds[i] = src[i & 4095];
+        __syncthreads();
+    }
+    f32x16 acc[8];
+    f32x4 acc4[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc4[i][e] = 0.f;
+    }
+    unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+        if (LDS) {
+            // six 1 KB fragment reads per eight MFMAs (the persistent conv kernel's ratio); rotating addresses
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                a[i] = lds[(tid + 64 * i + 7 * it) & 2047];
+                b[i] = lds[(tid + 64 * (i + 3) + 5 * it) & 2047];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (MODE == 0)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i & 3]), __builtin_bit_cast(f16x8, b[(i >> 1) & 3]), acc[i], 0, 0, 0);
+            else if (MODE == 2)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i & 3]), __builtin_bit_cast(bf16x8, b[(i >> 1) & 3]), acc[i], 0, 0, 0);
+            else {
+                // two 16x16x32 = the FLOPs of one 32x32x16 ... no: 16*16*32*2 = 16,384 = half; issue two per slot
+                acc4[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[i & 3]), __builtin_bit_cast(f16x8, b[(i >> 1) & 3]), acc4[i], 0, 0, 0);
+                acc4[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[(i + 1) & 3]), __builtin_bit_cast(f16x8, b[(i >> 1) & 3]), acc4[i], 0, 0, 0);
+            }
+        }
+    }
+    unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc[i][e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += acc4[i][e];
+    }
+    if (s == 123.456f) sink[0] = s;
+    if (tid == 0 && blockIdx.x % 37 == 0 && blockIdx.x / 37 < 8) {
+        out[(blockIdx.x / 37) * 2 + 0] = c1 - c0;
+        out[(blockIdx.x / 37) * 2 + 1] = r1 - r0;
+    }
+}
+
+static unsigned short f2h(float f) { _Float16 h = (_Float16)f; unsigned short u; memcpy(&u, &h, 2); return u; }
+static unsigned short f2bf(float f) { unsigned u; memcpy(&u, &f, 4); return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); }
+
+template <int MODE, bool LDS>
+static void run(const char* name, const u32x4* src, int threads, int wg_per_cu, int cus, unsigned long long* d_out, float* d_sink) {
+    const int iters = 1200000 / (threads / 256);
+    const int grid = cus * wg_per_cu;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipMemset(d_out, 0, 16 * 8));
+    hipLaunchKernelGGL((mfma_loop<MODE, LDS>), dim3(grid), dim3(threads), 0, 0, src, iters / 20, d_out, d_sink);   // warm-up
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((mfma_loop<MODE, LDS>), dim3(grid), dim3(threads), 0, 0, src, iters, d_out, d_sink);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long h[16];
+    CK(hipMemcpy(h, d_out, sizeof(h), hipMemcpyDeviceToHost));
+    double clk = 0; int n = 0;
+    for (int i = 0; i < 8; ++i) if (h[2 * i + 1] > 0) { clk += (double)h[2 * i] / (double)h[2 * i + 1] * 100.0; ++n; }
+    const double flop = (double)grid * (threads / 64) * (double)iters * 8.0 * 32768.0;
+    const double cyc_per_mfma = n ? (double)h[0] / ((double)iters * 8.0) * (threads / 256 >= 2 ? 0.5 : 1.0) : 0;
+    printf("%-44s %4d thr x %d WG/CU: %8.2f ms  %7.1f TFLOP/s  clock %5.0f MHz  %.1f cycles per 32x32x16-equivalent per SIMD\n", name, threads, wg_per_cu, ms,
+           flop / ms * 1e-9, n ? clk / n : 0.0, cyc_per_mfma);
+    fflush(stdout);
+}
+
+int main() {
+    int cus = 256;
+    CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+    printf("CUs %d\n", cus);
+    std::vector<unsigned short> h_rand(4096 * 8), h_zero(4096 * 8, 0), h_small(4096 * 8), h_bf(4096 * 8), h_relu(4096 * 8);
+    srand(1);
+    for (size_t i = 0; i < h_rand.size(); ++i) {
+        // approx. normal(0, 1): sum of uniforms
+        float u = 0.f;
+        for (int k = 0; k < 12; ++k) u += (float)rand() / RAND_MAX;
+        u -= 6.f;
+        h_rand[i] = f2h(u);
+        h_bf[i] = f2bf(u);
+        h_small[i] = f2h(((i * 2654435761u) >> 28 & 1) ? 1.0f : 0.5f);   // two values: few toggling bits
+        h_relu[i] = f2h(u > 0.f ? u : 0.f);                               // post-ReLU activations: half zeros
+    }
+    u32x4 *d_rand, *d_zero, *d_small, *d_bf, *d_relu;
+    unsigned long long* d_out; float* d_sink;
+    CK(hipMalloc(&d_rand, 65536)); CK(hipMalloc(&d_zero, 65536)); CK(hipMalloc(&d_small, 65536)); CK(hipMalloc(&d_bf, 65536)); CK(hipMalloc(&d_relu, 65536));
+    CK(hipMalloc(&d_out, 16 * 8)); CK(hipMalloc(&d_sink, 4));
+    CK(hipMemcpy(d_rand, h_rand.data(), 65536, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_zero, h_zero.data(), 65536, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_small, h_small.data(), 65536, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_bf, h_bf.data(), 65536, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_relu, h_relu.data(), 65536, hipMemcpyHostToDevice));
+    run<0, false>("f16 32x32x16, N(0,1) operands", d_rand, 256, 1, cus, d_out, d_sink);
+    run<0, false>("f16 32x32x16, N(0,1) operands", d_rand, 512, 1, cus, d_out, d_sink);
+    run<0, false>("f16 32x32x16, zero operands", d_zero, 512, 1, cus, d_out, d_sink);
+    run<0, false>("f16 32x32x16, two-valued operands", d_small, 512, 1, cus, d_out, d_sink);
+    run<0, false>("f16 32x32x16, ReLU'd N(0,1) operands", d_relu, 512, 1, cus, d_out, d_sink);
+    run<1, false>("f16 16x16x32 (x2), N(0,1) operands", d_rand, 512, 1, cus, d_out, d_sink);
+    run<2, false>("bf16 32x32x16, N(0,1) operands", d_bf, 512, 1, cus, d_out, d_sink);
+    run<0, true>("f16 32x32x16 + 6 LDS frag reads / 8 MFMA", d_rand, 512, 1, cus, d_out, d_sink);
+    run<1, true>("f16 16x16x32 (x2) + 6 LDS frag reads / 8", d_rand, 512, 1, cus, d_out, d_sink);
+    run<0, false>("f16 32x32x16, N(0,1) operands (again)", d_rand, 512, 1, cus, d_out, d_sink);
+    return 0;
+}
