@@ -464,14 +464,16 @@ def main():
             try:
                 from cmunet_amd import ops as _ops
                 sus = {}
-                for pat, label in ((0, "dense_normal_operands"), (1, "relu_operands_half_zero"), (2, "zero_operands")):
-                    tf, clk = _ops.mfma_sustained_rate(args.dtype, pat, device=dev)
-                    sus[label] = {"tflops": round(tf, 1), "clock_mhz": round(clk)}
-                ref = sus["dense_normal_operands"]["tflops"]
+                for fed, fl in ((False, "registers"), (True, "lds_fed")):
+                    for pat, label in ((0, "dense_normal_operands"), (1, "relu_operands_half_zero"), (2, "zero_operands")):
+                        tf, clk = _ops.mfma_sustained_rate(args.dtype, pat, lds_fed=fed, device=dev)
+                        sus[f"{fl}.{label}"] = {"tflops": round(tf, 1), "clock_mhz": round(clk)}
+                ref = sus["lds_fed.dense_normal_operands"]["tflops"]
                 out["roofline"]["sustained"] = {
-                    "measured": sus, "frac_of_sustained_dense": round(ach / ref, 4),
-                    "note": "pure 32x32x16 MFMA loop from registers, all SIMDs, no LDS / memory (cmu_mfma_sustained_rate); `peak` stays the "
-                            "nominal dense figure at 2.4 GHz, `frac` = achieved / peak"}
+                    "measured": sus, "frac_of_sustained_lds_fed_dense": round(ach / ref, 4),
+                    "note": "32x32x16 MFMA loops on all SIMDs, operands held in registers or read from LDS at the conv kernel's fragment ratio "
+                            "(cmu_mfma_sustained_rate, csrc/probe.hip): the shader clock under a matrix load depends on the operand data; "
+                            "`peak` stays the nominal dense figure at 2.4 GHz and `frac` = achieved / peak"}
             except Exception as e:      # a diagnostic: never takes the line down
                 out["roofline"]["sustained"] = {"error": repr(e)}
         out["mfma_kernels"] = {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "launches_per_step": v["calls"] // args.steps,

@@ -47,7 +47,7 @@ _SIGS = {
     "cmu_pack_desc_blocks": (_L, [_I, _I, _I, _I, _I]),
     "cmu_pack_batch": (_I, [_P, _I, _L, _I, _P]),
     "cmu_version": (_I, []),
-    "cmu_mfma_sustained_rate": (_I, [_I, _I, _I, _P, _P, _P, _P]),
+    "cmu_mfma_sustained_rate": (_I, [_I, _I, _I, _I, _P, _P, _P, _P]),
     "cmu_dtype_size": (_I, [_I]),
     "cmu_pack_conv3x3_elems": (_L, [_I, _I, _I, _I]),
     "cmu_pack_conv3x3": (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -8,6 +8,10 @@
 // zeros) and 1.63 PFLOP/s / 1.61 GHz on dense N(0,1) operands.  That last figure is the ceiling a kernel fed with dense
 // random data can reach on this chip whatever its schedule; bench.py reports it beside the nominal peak.
 //
+// The same MFMAs fed from LDS at the persistent conv kernel's fragment ratio (lds_fed = 1) sustain 1.41 PFLOP/s at 1.44 GHz
+// on dense operands, 1.70 on ReLU'd ones: the ceiling of an LDS-tiled kernel on this chip.  (The 16x16x32 shape draws less:
+// 1.83 / 1.58 PFLOP/s from registers / LDS on the same dense data -- tools/mfma_clock.hip.)
+//
 // cmu_mfma_sustained_rate runs that loop for about `iters` x 8 MFMAs per wave on the given stream and returns the rate
 // and the shader clock (s_memtime / s_memrealtime of one wave).  Operands are generated in the kernel (a hash of the lane
 // id; sum-of-uniforms ~ N(0,1)), so the probe needs no memory but a 64-byte scratch for its two counters.
@@ -78,7 +82,76 @@ __global__ __launch_bounds__(512) void mfma_probe_kernel(int iters, unsigned lon
     }
 }
 
-extern "C" int cmu_mfma_sustained_rate(int dt, int pattern, int iters, void* scratch64, double* tflops, double* clock_mhz, void* stream) {
+// The same MFMAs FED FROM LDS at the persistent conv kernel's ratio (wave tile 128 x 64: per step 4 A + 2 B fragment reads of
+// 1 KB for 8 MFMAs), software-pipelined through a register double buffer: what a perfectly scheduled LDS-tiled kernel could
+// sustain.  64 KB of LDS filled with the pattern; `iters` steps of 8 MFMAs per wave.
+template <bool BF, int PATTERN>
+__global__ __launch_bounds__(512) void mfma_probe_lds_kernel(int iters, unsigned long long* out) {
+    __shared__ u32x4 lds[4096];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 4096; i += 512) {
+        unsigned w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float f0 = pr_normal(pr_hash((blockIdx.x * 4096u + i) * 8u + q * 2u)), f1 = pr_normal(pr_hash((blockIdx.x * 4096u + i) * 8u + q * 2u + 1u));
+            if (PATTERN == 1) { f0 = fmaxf(f0, 0.f); f1 = fmaxf(f1, 0.f); }
+            if (PATTERN == 2) { f0 = 0.f; f1 = 0.f; }
+            if (BF) {
+                w[q] = (__float_as_uint(f0) >> 16) | (__float_as_uint(f1) & 0xffff0000u);
+            } else {
+                const _Float16 h0 = (_Float16)f0, h1 = (_Float16)f1;
+                w[q] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+            }
+        }
+        lds[i] = u32x4{w[0], w[1], w[2], w[3]};
+    }
+    __syncthreads();
+    u32x4 fa[2][4], fb[2][2];
+    pr_f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    auto rd = [&](int set, int it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[set][i] = lds[(tid + 64 * i + 331 * it) & 4095];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fb[set][i] = lds[(tid + 64 * (i + 4) + 173 * it) & 4095];
+    };
+    auto mm = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (BF)
+                    acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pr_bf16x8, fa[set][i]), __builtin_bit_cast(pr_bf16x8, fb[set][j]), acc[i * 2 + j], 0, 0, 0);
+                else
+                    acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pr_f16x8, fa[set][i]), __builtin_bit_cast(pr_f16x8, fb[set][j]), acc[i * 2 + j], 0, 0, 0);
+            }
+    };
+    rd(0, 0);
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll 1
+    for (int it = 0; it < iters; it += 2) {
+        rd(1, it + 1);
+        mm(0);
+        rd(0, it + 2);
+        mm(1);
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc[i][e];
+    if (s == 123.456f) out[7] = 1ull;
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = r1 - r0;
+    }
+}
+
+extern "C" int cmu_mfma_sustained_rate(int dt, int pattern, int lds_fed, int iters, void* scratch64, double* tflops, double* clock_mhz, void* stream) {
     CMU_CHECK_ARG(dt == CMU_F16 || dt == CMU_BF16, "cmu_mfma_sustained_rate: dt must be f16 or bf16");
     CMU_CHECK_ARG(pattern >= 0 && pattern <= 2 && iters > 0 && iters <= (1 << 24) && scratch64 && tflops && clock_mhz,
                   "cmu_mfma_sustained_rate: bad arguments");
@@ -93,7 +166,11 @@ extern "C" int cmu_mfma_sustained_rate(int dt, int pattern, int iters, void* scr
     }
     auto launch = [&](int n) {
         const bool bf = dt == CMU_BF16;
-#define PR_GO(BF_, P_) hipLaunchKernelGGL((mfma_probe_kernel<BF_, P_>), dim3((unsigned)cus), dim3(512), 0, st, n, out)
+#define PR_GO(BF_, P_)                                                                                                       \
+    do {                                                                                                                    \
+        if (lds_fed) hipLaunchKernelGGL((mfma_probe_lds_kernel<BF_, P_>), dim3((unsigned)cus), dim3(512), 0, st, (n + 1) & ~1, out); \
+        else hipLaunchKernelGGL((mfma_probe_kernel<BF_, P_>), dim3((unsigned)cus), dim3(512), 0, st, n, out);               \
+    } while (0)
         if (pattern == 0) { if (bf) PR_GO(true, 0); else PR_GO(false, 0); }
         else if (pattern == 1) { if (bf) PR_GO(true, 1); else PR_GO(false, 1); }
         else { if (bf) PR_GO(true, 2); else PR_GO(false, 2); }
@@ -114,7 +191,8 @@ extern "C" int cmu_mfma_sustained_rate(int dt, int pattern, int iters, void* scr
         cmu_set_error("cmu_mfma_sustained_rate: %s", hipGetErrorString(e));
         return CMU_ERR_LAUNCH;
     }
-    *tflops = (double)cus * 8.0 * (double)iters * 8.0 * 32768.0 / ((double)ms * 1e-3) * 1e-12;
+    const double steps = lds_fed ? (double)((iters + 1) & ~1) : (double)iters;
+    *tflops = (double)cus * 8.0 * steps * 8.0 * 32768.0 / ((double)ms * 1e-3) * 1e-12;
     *clock_mhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
     return CMU_OK;
 }

@@ -40,14 +40,17 @@ def _p(t):
 
 
 
-def mfma_sustained_rate(dt="f16", pattern=0, iters=60000, device="cuda"):
+def mfma_sustained_rate(dt="f16", pattern=0, lds_fed=False, iters=60000, device="cuda"):
     """(TFLOP/s, shader clock in MHz) of back-to-back 16-bit MFMAs on every SIMD of the device (cmu_mfma_sustained_rate):
     the rate the chip's power management lets the matrix pipes hold on ``pattern`` 0 = dense ~N(0,1) operands, 1 = ReLU'd
-    operands (half zeros), 2 = zeros.  ~70 ms at the default ``iters``.  Measurement support for bench.py, not on the hot path."""
+    operands (half zeros), 2 = zeros; ``lds_fed``: operands read from LDS at the persistent conv kernel's fragment ratio instead
+    of held in registers.  ~70 ms at the default ``iters``.  Measurement support for bench.py, not on the hot path."""
     scratch = torch.zeros(8, dtype=torch.int64, device=device)
     tf, clk = ctypes.c_double(0.0), ctypes.c_double(0.0)
-    call("cmu_mfma_sustained_rate", dt_code(dt), int(pattern), int(iters), _p(scratch), ctypes.byref(tf), ctypes.byref(clk), _stream())
+    call("cmu_mfma_sustained_rate", dt_code(dt), int(pattern), int(bool(lds_fed)), int(iters), _p(scratch), ctypes.byref(tf),
+         ctypes.byref(clk), _stream())
     return tf.value, clk.value
+
 
 def _f32c(t):
     assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda

@@ -441,11 +441,14 @@ int cmu_conv1x1_nchw_fwd(const void* x, int64_t ldx, const float* in_scale, cons
 
 /* Measurement support (bench.py's roofline block; no reference counterpart): the 16-bit MFMA rate this chip SUSTAINS.
  * Every wave of a one-workgroup-per-CU grid issues iters x 8 back-to-back 32x32x16 MFMAs from registers (no LDS, no
- * memory); operands are generated in the kernel: pattern 0 = dense ~N(0,1), 1 = ReLU'd (half zeros), 2 = all zeros.
+ * memory) or -- lds_fed = 1 -- the same MFMAs fed from LDS at the persistent conv kernel's ratio (6 fragment reads of 1 KB
+ * per 8 MFMAs, register double buffer); operands are generated in the kernel: pattern 0 = dense ~N(0,1), 1 = ReLU'd
+ * (half zeros), 2 = all zeros.
  * The power management lowers the shader clock under this load by an amount that depends on the operand data
  * (csrc/probe.hip); *tflops and *clock_mhz (s_memtime / s_memrealtime of one wave) come back
  * after a synchronisation of the stream.  scratch64: 64 bytes of device memory.  Host-blocking; not for the hot path. */
-int cmu_mfma_sustained_rate(int dt, int pattern, int iters, void* scratch64, double* tflops, double* clock_mhz, void* stream);
+int cmu_mfma_sustained_rate(int dt, int pattern, int lds_fed, int iters, void* scratch64, double* tflops, double* clock_mhz,
+                            void* stream);
 
 #ifdef __cplusplus
 }

@@ -141,11 +141,13 @@ def test_mfma_sustained_rate_probe(cuda):
     """bench.py's measured ceiling (cmu_mfma_sustained_rate): the pure MFMA loop reports a plausible rate and clock, and
     all-zero operands run at least as fast as dense random ones (the data-dependent power limit)."""
     from cmunet_amd import ops
-    dense, clk_d = ops.mfma_sustained_rate("f16", 0, iters=20000, device=cuda)
-    zero, clk_z = ops.mfma_sustained_rate("f16", 2, iters=20000, device=cuda)
-    print(f"sustained f16 MFMA: dense operands {dense:.0f} TFLOP/s @ {clk_d:.0f} MHz, zero operands {zero:.0f} TFLOP/s @ {clk_z:.0f} MHz")
-    assert 500.0 < dense < 2600.0 and 500.0 < zero < 2600.0
-    assert 800.0 < clk_d < 2600.0 and 800.0 < clk_z < 2600.0
-    assert zero > 0.97 * dense
+    for fed in (False, True):
+        dense, clk_d = ops.mfma_sustained_rate("f16", 0, lds_fed=fed, iters=20000, device=cuda)
+        zero, clk_z = ops.mfma_sustained_rate("f16", 2, lds_fed=fed, iters=20000, device=cuda)
+        print(f"sustained f16 MFMA ({'LDS-fed' if fed else 'registers'}): dense operands {dense:.0f} TFLOP/s @ {clk_d:.0f} MHz, "
+              f"zero operands {zero:.0f} TFLOP/s @ {clk_z:.0f} MHz")
+        assert 500.0 < dense < 2600.0 and 500.0 < zero < 2600.0
+        assert 800.0 < clk_d < 2600.0 and 800.0 < clk_z < 2600.0
+        assert zero > 0.97 * dense
     with pytest.raises(Exception, match="dt must be f16 or bf16"):
         ops.mfma_sustained_rate("f32", 0, iters=10, device=cuda)

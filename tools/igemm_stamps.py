@@ -20,23 +20,34 @@ lib.cmu_last_error.restype = ctypes.c_char_p
 vp = ctypes.c_void_p
 i64 = ctypes.c_int64
 
+import os
+# CMU_SWEEP_DT=1: f16 (default 2: bf16).  CMU_SWEEP_DATA=zero_w | zero_x | zero_both: the same launch on operands that do not
+# toggle the multipliers -- the shader clock under an MFMA load depends on the data (csrc/probe.hip), so the time these take
+# against the normal run separates the power limit from the kernel's own stalls
+DT = int(os.environ.get("CMU_SWEEP_DT", "2"))
+TDT = torch.float16 if DT == 1 else torch.bfloat16
+DATA = os.environ.get("CMU_SWEEP_DATA", "normal")
 torch.manual_seed(0)
-x = torch.randn(B, H, W, Cin, device=dev).to(torch.bfloat16)
+x = torch.randn(B, H, W, Cin, device=dev).to(TDT)
 w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05
 sc = torch.rand(Cin, device=dev) + 0.5
 sh = torch.randn(Cin, device=dev) * 0.1
-n = lib.cmu_pack_conv3x3_elems(Cin, Cout, 2, 0)
-wp = torch.empty(n, dtype=torch.bfloat16, device=dev)
-rc = lib.cmu_pack_conv3x3(vp(w.data_ptr()), vp(wp.data_ptr()), Cin, Cout, 2, 0, vp(0))
+if DATA in ("zero_x", "zero_both"):
+    x.zero_(); sc.fill_(1.0); sh.zero_()
+if DATA in ("zero_w", "zero_both"):
+    w.zero_()
+n = lib.cmu_pack_conv3x3_elems(Cin, Cout, DT, 0)
+wp = torch.empty(n, dtype=TDT, device=dev)
+rc = lib.cmu_pack_conv3x3(vp(w.data_ptr()), vp(wp.data_ptr()), Cin, Cout, DT, 0, vp(0))
 assert rc == 0, lib.cmu_last_error()
-y = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=dev)
+y = torch.empty(B, H, W, Cout, dtype=TDT, device=dev)
 ntiles = lib.cmu_conv_ntiles(B, H, W)
 stats = torch.empty(ntiles * 2 * Cout, device=dev)
 
 
 def run():
     rc = lib.cmu_conv3x3_fwd(vp(x.data_ptr()), i64(Cin), vp(sc.data_ptr()), vp(sh.data_ptr()), 0, vp(wp.data_ptr()), vp(y.data_ptr()),
-                             i64(Cout), vp(stats.data_ptr()), B, H, W, Cin, Cout, 2, vp(0))
+                             i64(Cout), vp(stats.data_ptr()), B, H, W, Cin, Cout, DT, vp(0))
     assert rc == 0, lib.cmu_last_error()
 
 
@@ -51,7 +62,7 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 20
 fl = 2.0 * B * H * W * Cin * Cout * 9
-print(f"layer {Cin}->{Cout} @ {H}x{W} B={B}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TFLOP/s")
+print(f"layer {Cin}->{Cout} @ {H}x{W} B={B}{'' if DATA == 'normal' else ' [' + DATA + ']'}{' f16' if DT == 1 else ''}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TFLOP/s")
 
 if not hasattr(lib, "cmu_debug_ig_stamps"):
     sys.exit(0)

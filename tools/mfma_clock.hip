@@ -84,6 +84,97 @@ __global__ __launch_bounds__(512) void mfma_loop(const u32x4* __restrict__ src, 
     }
 }
 
+
+// MFMAs fed from LDS at the conv kernels' ratio, software-pipelined (register double buffer): wave tile 128 x 64 of fp32
+// accumulators (128 registers) in both shapes.  SHAPE 0: 32x32x16 -- per step 4 A + 2 B fragment reads (1 KB each), 8 MFMAs;
+// SHAPE 1: 16x16x32 -- per step 8 A + 4 B fragment reads, 32 MFMAs (twice the K: the same bytes per FLOP).
+template <int SHAPE>
+__global__ __launch_bounds__(512) void mfma_lds_loop(const u32x4* __restrict__ src, int iters, unsigned long long* out, float* sink) {
+    __shared__ u32x4 lds[4096];   // 64 KB
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 4096; i += blockDim.x) lds[i] = src[i & 4095];
+    __syncthreads();
+    constexpr int NA = SHAPE == 0 ? 4 : 8, NBF = SHAPE == 0 ? 2 : 4;
+    u32x4 fa[2][NA], fb[2][NBF];
+    f32x16 acc[8];
+    f32x4 acc4[32];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc4[i][e] = 0.f;
+    auto rd = [&](int set, int it) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) fa[set][i] = lds[(tid + 64 * i + 331 * it) & 4095];
+#pragma unroll
+        for (int i = 0; i < NBF; ++i) fb[set][i] = lds[(tid + 64 * (i + NA) + 173 * it) & 4095];
+    };
+    auto mm = [&](int set) {
+        if (SHAPE == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[set][i]), __builtin_bit_cast(f16x8, fb[set][j]), acc[i * 2 + j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc4[i * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa[set][i]), __builtin_bit_cast(f16x8, fb[set][j]), acc4[i * 4 + j], 0, 0, 0);
+        }
+    };
+    rd(0, 0);
+    unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll 1
+    for (int it = 0; it < iters; it += 2) {
+        rd(1, it + 1);
+        mm(0);
+        rd(0, it + 2);
+        mm(1);
+    }
+    unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc[i][e];
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += acc4[i][e];
+    if (s == 123.456f) sink[0] = s;
+    if (tid == 0 && blockIdx.x % 37 == 0 && blockIdx.x / 37 < 8) {
+        out[(blockIdx.x / 37) * 2 + 0] = c1 - c0;
+        out[(blockIdx.x / 37) * 2 + 1] = r1 - r0;
+    }
+}
+
+template <int SHAPE>
+static void run_lds(const char* name, const u32x4* src, int cus, unsigned long long* d_out, float* d_sink) {
+    const int iters = SHAPE == 0 ? 600000 : 150000;          // the same FLOPs per wave in both shapes
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipMemset(d_out, 0, 16 * 8));
+    hipLaunchKernelGGL((mfma_lds_loop<SHAPE>), dim3(cus), dim3(512), 0, 0, src, iters / 20, d_out, d_sink);
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((mfma_lds_loop<SHAPE>), dim3(cus), dim3(512), 0, 0, src, iters, d_out, d_sink);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long h[16];
+    CK(hipMemcpy(h, d_out, sizeof(h), hipMemcpyDeviceToHost));
+    double clk = 0; int n = 0;
+    for (int i = 0; i < 8; ++i) if (h[2 * i + 1] > 0) { clk += (double)h[2 * i] / (double)h[2 * i + 1] * 100.0; ++n; }
+    const double flop = (double)cus * 8.0 * (double)iters * (SHAPE == 0 ? 8.0 * 32768.0 : 32.0 * 16384.0);
+    printf("%-60s %8.2f ms  %7.1f TFLOP/s  clock %5.0f MHz\n", name, ms, flop / ms * 1e-9, n ? clk / n : 0.0);
+    fflush(stdout);
+}
+
 static unsigned short f2h(float f) { _Float16 h = (_Float16)f; unsigned short u; memcpy(&u, &h, 2); return u; }
 static unsigned short f2bf(float f) { unsigned u; memcpy(&u, &f, 4); return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); }
 
@@ -147,5 +238,10 @@ int main() {
     run<0, true>("f16 32x32x16 + 6 LDS frag reads / 8 MFMA", d_rand, 512, 1, cus, d_out, d_sink);
     run<1, true>("f16 16x16x32 (x2) + 6 LDS frag reads / 8", d_rand, 512, 1, cus, d_out, d_sink);
     run<0, false>("f16 32x32x16, N(0,1) operands (again)", d_rand, 512, 1, cus, d_out, d_sink);
+    run_lds<0>("f16 32x32x16 fed from LDS (6 frag reads / 8 MFMA), N(0,1)", d_rand, cus, d_out, d_sink);
+    run_lds<1>("f16 16x16x32 fed from LDS (12 frag reads / 32 MFMA), N(0,1)", d_rand, cus, d_out, d_sink);
+    run_lds<0>("f16 32x32x16 fed from LDS, ReLU'd N(0,1)", d_relu, cus, d_out, d_sink);
+    run_lds<1>("f16 16x16x32 fed from LDS, ReLU'd N(0,1)", d_relu, cus, d_out, d_sink);
+    run_lds<0>("f16 32x32x16 fed from LDS (again), N(0,1)", d_rand, cus, d_out, d_sink);
     return 0;
 }
