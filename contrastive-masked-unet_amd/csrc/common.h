@@ -123,10 +123,6 @@ struct F16Traits {
     __device__ static inline void mma16(const u32x4& a, const u32x4& b, f32x16& acc) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
     }
-    // 16x16x32: acc(16 x 16 f32, lane (r, g): rows 4g .. 4g+3 of column r) += A(16 x 32) * B(32 x 16), lane (r, g) holds k = 8g .. 8g+7
-    __device__ static inline void mma4(const u32x4& a, const u32x4& b, f32x4& acc) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
-    }
     __device__ static inline float to_float(_Float16 v) { return (float)v; }
     __device__ static inline _Float16 from_float(float v) { return (_Float16)v; }
     __device__ static inline uint32_t pack2(float a, float b) {   // a in the low half, b in the high half
@@ -155,9 +151,6 @@ struct BF16Traits {
     }
     __device__ static inline void mma16(const u32x4& a, const u32x4& b, f32x16& acc) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
-    }
-    __device__ static inline void mma4(const u32x4& a, const u32x4& b, f32x4& acc) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
     }
     __device__ static inline float to_float(__bf16 v) { return (float)v; }
     __device__ static inline __bf16 from_float(float v) { return (__bf16)v; }
