@@ -172,3 +172,33 @@ def make_neck_sd(prefix, in_ch, hid, out, seed, dtype=torch.float32):
     sd[prefix + "bn0.num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
     sd[prefix + "fc1.weight"] = (torch.randn(out, hid, generator=g, dtype=torch.float64) / hid ** 0.5).to(dtype)
     return sd
+
+
+def make_cmunet_sd(seed, img_size=224):
+    """Seeded state dict of the whole CM_UNet at the shipped configuration (cmunet_config.py: projector in = img_size^2 =
+    50,176), in the reference's key names.  tests/golden/cmunet_ref.npz was produced by loading exactly this into the
+    reference's own CM_UNet (oracle/gen_golden.py::gen_cmunet); the tests regenerate it from the seed (217.8 M parameters do
+    not fit a fixture)."""
+    sd = {}
+    for prefix, s, enc in (("backbone.", seed, True), ("target_backbone.", seed + 1, True), ("pixel_decoder.", seed + 2, False),
+                           ("feature_decoder.", seed + 3, False)):
+        part = U.make_state_dict(base_ch=64, depth=5, seed=s, encoder=enc, decoder=not enc)
+        sd.update({prefix + k: v for k, v in part.items()})
+    sd.update(make_neck_sd("projector.", img_size * img_size, 1536, 256, seed + 4))
+    sd.update(make_neck_sd("target_projector.", img_size * img_size, 1536, 256, seed + 5))
+    sd.update(make_neck_sd("head.predictor.", 256, 1536, 256, seed + 6))
+    return sd
+
+
+def cmunet_fixture_inputs(seed, B=4, S=224):
+    """The inputs of tests/golden/cmunet_ref.npz, regenerated: images from a seeded generator, the patch mask as the reference
+    draws it (numpy's global stream seeded with seed + 11: UNet_encoder.py:106-139), the per-call Conv2d(1024, 256, 1) of
+    cmunet.py:128 as torch creates it right after torch.manual_seed(seed + 12), and the head-only case's tensors."""
+    g = torch.Generator().manual_seed(seed + 10)
+    img, img_t = torch.randn(B, S, S, generator=g), torch.randn(B, S, S, generator=g)
+    mask = create_random_patch_mask(B, S, 16, 0.65, np.random.RandomState(seed + 11))
+    state = torch.get_rng_state()
+    torch.manual_seed(seed + 12)
+    rc = torch.nn.Conv2d(1024, 256, kernel_size=1)
+    torch.set_rng_state(state)
+    return img, img_t, mask, rc.weight.detach().clone(), rc.bias.detach().clone()

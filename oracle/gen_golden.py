@@ -178,6 +178,246 @@ def gen_spark(ref, S=64, ratio=0.6, name="spark_unet", seed=71):
          bott_running_var=rv)
 
 
+
+_CMAE = None
+
+
+def import_cmae():
+    """Pretraining/CM-UNet's own modules -- cmae/registry.py, models/backbones/UNet_encoder.py, models/necks/{munet_neck,
+    nonlinear_neck}.py, models/heads/cmunet_head.py, models/algorithms/{base,cmunet}.py, core/hooks/momentum_update_hook.py
+    -- executed unmodified behind plumbing stand-ins for the two libraries this image lacks (same policy as the timm stand-in
+    of import_spark; SURVEY section 8c lists mmengine 0.10.5 / mmcv 2.2.0 as absent):
+      mmengine.registry   Registry(name, ...) with register_module() / build(cfg) and the 20 root registry names cmae/registry.py
+                          imports as parents;
+      mmengine.model      BaseModule / BaseModel = nn.Module taking init_cfg (init_weights() is a no-op: the only init_cfg on
+                          this path sets BatchNorm weight 1 / bias 0, torch's default; weights are loaded explicitly anyway);
+      mmengine.dist       all_gather(t) -> [t]  (one rank);      mmengine.hooks.Hook = object; is_model_wrapper(m): true for the
+                          SimpleNamespace(module=...) the generator wraps the model in (the hook addresses runner.model.module)
+      mmcv.cnn            build_norm_layer(cfg, n): 'SyncBN' / 'BN1d' -> nn.BatchNorm1d(n, eps, affine) -- SyncBatchNorm over one
+                          rank IS BatchNorm1d on the (B, C) input of the necks, and torch's SyncBatchNorm refuses CPU tensors;
+    the package __init__ files (version checks against the absent libraries, dataset / runner imports) are not executed: the
+    package objects are empty modules whose __path__ points at the reference directories.  The reference hard-codes the device
+    (.cuda(), .to("cuda:0"): UNet_encoder.py:84,156, cmunet.py:128, cmunet_head.py:85); in THIS process Tensor.cuda /
+    Module.cuda / a 'cuda' target of Tensor.to are redirected to the CPU.  torch.distributed runs as one gloo rank
+    (cmunet_head.py:84 asks for the rank).  The arithmetic that runs is the reference's."""
+    global _CMAE
+    if _CMAE is not None:
+        return _CMAE
+    import importlib
+    import socket
+    import types
+    import torch.distributed as dist
+    import torch.nn as nn
+    root = os.path.join(REF, "Pretraining", "CM-UNet")
+
+    class Registry:
+        def __init__(self, name, *a, **k):
+            self.name, self._m = name, {}
+
+        def register_module(self, name=None, force=False, module=None):
+            def deco(cls):
+                self._m[name or cls.__name__] = cls
+                return cls
+            return deco(module) if module is not None else deco
+
+        def build(self, cfg):
+            cfg = dict(cfg)
+            return self._m[cfg.pop("type")](**cfg)
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    roots = ("DATA_SAMPLERS DATASETS EVALUATOR HOOKS LOG_PROCESSORS LOOPS METRICS MODEL_WRAPPERS MODELS OPTIM_WRAPPER_CONSTRUCTORS "
+             "OPTIM_WRAPPERS OPTIMIZERS PARAM_SCHEDULERS RUNNER_CONSTRUCTORS RUNNERS TASK_UTILS TRANSFORMS VISBACKENDS VISUALIZERS "
+             "WEIGHT_INITIALIZERS").split()
+    mod("mmengine", __version__="0.10.5")
+    mod("mmengine.registry", Registry=Registry, **{n: Registry(n) for n in roots})
+
+    class BaseModule(nn.Module):
+        def __init__(self, init_cfg=None):
+            super().__init__()
+            self.init_cfg = init_cfg
+
+        def init_weights(self):
+            pass
+
+    class BaseModel(BaseModule):
+        def __init__(self, data_preprocessor=None, init_cfg=None):
+            super().__init__(init_cfg)
+
+    mod("mmengine.model", BaseModule=BaseModule, BaseModel=BaseModel, is_model_wrapper=lambda m: isinstance(m, types.SimpleNamespace))
+    mod("mmengine.dist", all_gather=lambda t: [t])
+    mod("mmengine.hooks", Hook=object)
+
+    def build_norm_layer(cfg, num_features):
+        cfg = dict(cfg)
+        kind = cfg.pop("type")
+        assert kind in ("SyncBN", "BN1d", "BN"), kind
+        return kind.lower(), nn.BatchNorm1d(num_features, **cfg)
+
+    mod("mmcv", __version__="2.2.0")
+    mod("mmcv.cnn", build_norm_layer=build_norm_layer)
+    for pkg in ("cmae", "cmae.models", "cmae.models.backbones", "cmae.models.necks", "cmae.models.heads", "cmae.models.algorithms",
+                "cmae.core", "cmae.core.hooks"):
+        mod(pkg).__path__ = [os.path.join(root, *pkg.split("."))]
+    # device redirects (this process only)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    nn.Module.cuda = lambda self, *a, **k: self
+    _to = torch.Tensor.to
+
+    def to(self, *a, **k):
+        a = tuple("cpu" if (isinstance(x, str) and x.startswith("cuda")) or (isinstance(x, torch.device) and x.type == "cuda") else x for x in a)
+        if "device" in k and str(k["device"]).startswith("cuda"):
+            k["device"] = "cpu"
+        return _to(self, *a, **k)
+
+    torch.Tensor.to = to
+    if not dist.is_initialized():
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    reg = importlib.import_module("cmae.registry")
+    for name in ("cmae.models.backbones.UNet_encoder", "cmae.models.necks.munet_neck", "cmae.models.necks.nonlinear_neck",
+                 "cmae.models.heads.cmunet_head", "cmae.models.algorithms.base", "cmae.models.algorithms.cmunet"):
+        importlib.import_module(name)
+    try:
+        hook = importlib.import_module("cmae.core.hooks.momentum_update_hook")
+    except Exception as e:      # the hook pulls more of mmengine than the stand-in has: its formula is then pinned by value only
+        print("  (momentum_update_hook not importable behind the stand-in:", repr(e), ")")
+        hook = None
+    cfg = {}
+    exec(compile(open(os.path.join(root, "configs", "cmunet_config.py")).read(), "cmunet_config.py", "exec"), cfg)
+    _CMAE = (reg.MODELS, cfg["model"], hook)
+    return _CMAE
+
+
+def gen_cmunet(seed=4100):
+    """tests/golden/cmunet_ref.npz: the reference's own CM_UNet (cmunet_config.py, 224 x 224, bs 4) run here -- the patch mask of
+    UNet_encoder.create_random_patch_mask under a numpy seed, forward_train's two losses, the gradient norm of every trainable
+    parameter, a few gradients in full, the EMA of momentum_update -- and CMUNetPretrainHead.forward on its own (per-row target
+    normalisation, masked MSE, in-batch InfoNCE through the predictor neck).  The oracle restatement (oracle/cmunet.py) is
+    asserted equal on every number before the file is written."""
+    from oracle import cmunet as OC
+    MODELS, model_cfg, hook = import_cmae()
+    torch.manual_seed(0)
+    model = MODELS.build(model_cfg)
+    sd = OC.make_cmunet_sd(seed)
+    msd = model.state_dict()
+    assert set(msd) == set(sd), (sorted(set(msd) ^ set(sd))[:8])
+    assert all(tuple(msd[k].shape) == tuple(sd[k].shape) for k in sd)
+    model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    model.train()
+    B, S = 4, 224      # (bs 2 would do for the convolutions, but a two-sample BatchNorm1d in the necks passes gradients of order eps)
+    g = torch.Generator().manual_seed(seed + 10)
+    img, img_t = torch.randn(B, S, S, generator=g), torch.randn(B, S, S, generator=g)
+    # the reference draws its patch mask from numpy's global RNG and its reduce_channels conv from torch's (cmunet.py:128)
+    np.random.seed(seed + 11)
+    torch.manual_seed(seed + 12)
+    losses = model.forward_train(img, img_t=img_t)
+    (losses["loss_ct"] + losses["loss_rc"]).backward()
+    # the same draws again, on their own
+    np.random.seed(seed + 11)
+    mask = model.backbone.create_random_patch_mask(B, S)
+    torch.manual_seed(seed + 12)
+    rc = torch.nn.Conv2d(1024, 256, kernel_size=1)
+    rw, rb = rc.weight.detach().clone(), rc.bias.detach().clone()
+    assert mask.shape == (B, S, S) and int(mask[0].sum()) == (int(0.65 * S * S) // 256) * 256
+    fi = OC.cmunet_fixture_inputs(seed, B, S)     # what the tests regenerate
+    assert torch.equal(fi[0], img) and torch.equal(fi[1], img_t) and np.array_equal(fi[2], mask) and torch.equal(fi[3], rw) and torch.equal(fi[4], rb)
+    named = dict(model.named_parameters())
+    trainable = sorted(k for k, p in named.items() if p.requires_grad)
+    assert all(named[k].grad is not None for k in trainable) and not any(k.startswith("target_") for k in trainable)
+    # ---- oracle == reference ------------------------------------------------------------------------------------------
+    osd = {k: (v.clone().requires_grad_(True) if k in trainable else v.clone()) for k, v in sd.items()}
+    np.random.seed(seed + 11)
+    omask = OC.create_random_patch_mask(B, S, 16, 0.65)
+    assert np.array_equal(omask, mask), "oracle mask != reference mask under the same numpy seed"
+    ol = OC.forward_train(img, img_t, mask, rw, rb, osd, temperature=0.07, ct_weight=1.0, rc_weight=1.0)
+    (ol["loss_ct"] + ol["loss_rc"]).backward()
+    close(ol["loss_rc"].detach(), losses["loss_rc"].detach(), what="cmunet loss_rc")
+    close(ol["loss_ct"].detach(), losses["loss_ct"].detach(), tol=1e-4, what="cmunet loss_ct")
+    for k in trainable:
+        gr, go = named[k].grad, osd[k].grad
+        if gr.abs().max() < 1e-7:
+            assert go.abs().max() < 1e-5, k
+            continue
+        e = ((go - gr).norm() / gr.norm()).item()
+        assert e <= 2e-3, f"oracle != reference on d{k}: {e:.2e}"
+    for k, v in model.state_dict().items():
+        if "running_" in k or "num_batches" in k:
+            close(osd[k].double(), v.double(), tol=1e-4, what=k)
+    after_bn = {k: v.clone() for k, v in model.state_dict().items() if k.endswith(("bn0.running_var", "double_conv.double_conv.4.running_mean"))}
+    # ---- EMA (cmunet.py:78-92) ---------------------------------------------------------------------------------------------
+    model.momentum = 0.9
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.momentum_update()
+    OC.momentum_update(before, 0.9)
+    tkeys = sorted(k for k in named if k.startswith("target_"))
+    for k in tkeys:
+        close(before[k], named[k].detach(), tol=1e-6, what="ema " + k)
+    ema_norms = torch.stack([named[k].detach().double().norm() for k in tkeys])
+    ema_sample = named["target_backbone.down_conv1.double_conv.double_conv.0.weight"].detach().clone()
+    grad_norms = torch.stack([named[k].grad.double().norm() for k in trainable])
+    spot = ("backbone.down_conv1.double_conv.double_conv.0.weight", "backbone.double_conv.double_conv.4.weight",
+            "pixel_decoder.conv_last.weight", "feature_decoder.conv_last.weight", "projector.bn0.weight", "head.predictor.bn0.bias",
+            "pixel_decoder.up_conv1.up_sample.bias")
+    spot_grads = {"grad." + k: named[k].grad.detach().clone() for k in spot}
+    # ---- MomentumUpdateHook (momentum_update_hook.py:29-47) driven by a stand-in runner ------------------------------------------
+    hook_cases, hook_m = [], []
+    if hook is not None:
+        import types
+        for it, mx, base, end in ((0, 100, 0.99, 1.0), (37, 100, 0.99, 1.0), (100, 100, 0.99, 1.0), (5, 300, 0.996, 0.996), (250, 300, 0.9, 0.999)):
+            model.base_momentum = base
+            runner = types.SimpleNamespace(model=types.SimpleNamespace(module=model), iter=it, max_iters=mx)
+            hook.MomentumUpdateHook(end_momentum=end).before_train_iter(runner, 0)
+            assert abs(OC.momentum_schedule(it, mx, base, end) - model.momentum) < 1e-12
+            hook_cases.append((it, mx, base, end))
+            hook_m.append(model.momentum)
+        # after_train_iter -> momentum_update() through the wrapper branch
+        model.momentum = 0.5
+        b2 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        hook.MomentumUpdateHook().after_train_iter(types.SimpleNamespace(model=types.SimpleNamespace(module=model)), 0)
+        OC.momentum_update(b2, 0.5)
+        close(b2["target_projector.fc1.weight"], named["target_projector.fc1.weight"].detach(), tol=1e-6, what="hook ema")
+        model.base_momentum = 0.996
+    # ---- the head on its own (cmunet_head.py:47-91), small image ----------------------------------------------------------------
+    Hh, Wh, Bh = 32, 48, 4
+    x = torch.randn(Bh, Hh, Wh, generator=g) * 2 + 0.5
+    pred = torch.randn(Bh, Hh, Wh, generator=g).requires_grad_(True)
+    mk = (torch.rand(Bh, Hh, Wh, generator=g) > 0.4).to(torch.uint8)
+    ps = torch.randn(Bh, 1, 256, generator=g).requires_grad_(True)
+    pt = torch.randn(Bh, 1, 256, generator=g)
+    model.zero_grad()
+    hl = model.head(x, pred, mk, ps, pt)
+    (hl["loss_ct"] + hl["loss_rc"]).backward()
+    hsd = {k: (v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in k)) for k, v in model.state_dict().items()
+           if k.startswith("head.")}
+    # (the predictor's BatchNorm buffers advanced in the call above: the oracle starts from the state before it)
+    for k in list(hsd):
+        if "running_" in k or "num_batches" in k:
+            hsd[k] = osd[k].detach().clone()
+    po, pso = pred.detach().clone().requires_grad_(True), ps.detach().clone().requires_grad_(True)
+    oh = OC.head(x, po, mk, pso, pt, hsd, "head.", 0.07, 1.0, 1.0)
+    (oh["loss_ct"] + oh["loss_rc"]).backward()
+    close(oh["loss_rc"].detach(), hl["loss_rc"].detach(), what="head loss_rc")
+    close(oh["loss_ct"].detach(), hl["loss_ct"].detach(), tol=1e-4, what="head loss_ct")
+    close(po.grad, pred.grad, tol=1e-4, what="head dpred")
+    close(pso.grad, ps.grad, tol=2e-4, what="head dproj_s")
+    out = {"seed": np.array(seed), "B": np.array(B), "S": np.array(S), "mask_patches": mask[:, ::16, ::16].copy(),
+           "loss_ct": losses["loss_ct"].detach(), "loss_rc": losses["loss_rc"].detach(),
+           "trainable": np.array(trainable), "grad_norms": grad_norms,
+           "hook_cases": np.array(hook_cases, dtype=np.float64), "hook_momentum": np.array(hook_m, dtype=np.float64),
+           "target_keys": np.array(tkeys), "ema_norms": ema_norms, "ema_sample": ema_sample,
+           "head.x": x, "head.pred": pred.detach(), "head.mask": mk, "head.proj_s": ps.detach(), "head.proj_t": pt,
+           "head.loss_ct": hl["loss_ct"].detach(), "head.loss_rc": hl["loss_rc"].detach(), "head.dpred": pred.grad, "head.dproj_s": ps.grad}
+    out.update(spot_grads)
+    out.update({"after." + k: v for k, v in after_bn.items()})
+    save("cmunet_ref", **out)
+
 def gen_cldice(M):
     """soft_cldice of the reference (metrics.py:401-431, the driver's configuration train.py:464) on vessel-like masks."""
     from oracle import losses as OL
@@ -297,6 +537,9 @@ def main():
         return
     if "--only-cldice" in sys.argv:
         gen_cldice(M)
+        return
+    if "--only-cmunet" in sys.argv:     # tests/golden/cmunet_ref.npz alone (the reference's cmae modules behind the mmengine stand-in)
+        gen_cmunet()
         return
 
     def load(mod, sd):

@@ -260,3 +260,57 @@ def test_random_resized_crop_params_contract():
         x0, y0, cw, ch = random_resized_crop_params(256, 256, rng)
         assert 0 <= x0 and 0 <= y0 and cw >= 1 and ch >= 1 and x0 + cw <= 256 and y0 + ch <= 256
         assert 0.18 <= cw * ch / 65536 <= 1.0 and 0.70 <= cw / ch <= 1.40
+
+
+def test_cmunet_oracle_vs_reference_fixture(golden_dir):
+    """tests/golden/cmunet_ref.npz holds what the REFERENCE's own CM_UNet produced in the build container (cmae modules behind the
+    mmengine / mmcv plumbing stand-in of oracle/gen_golden.py::import_cmae; shipped cmunet_config.py, 224 x 224, bs 4): the patch
+    mask under a numpy seed, forward_train's two losses, the gradient norm of every trainable parameter, a few gradients in full, the
+    EMA of momentum_update, MomentumUpdateHook's schedule and CMUNetPretrainHead.forward alone.  The oracle restatement, fed with the
+    regenerated weights and inputs, must reproduce them: rows a7-a12 of SURVEY section 8 are pinned by the reference."""
+    f = fx(golden_dir, "cmunet_ref")
+    seed, B, S = int(f["seed"]), int(f["B"]), int(f["S"])
+    img, img_t, mask, rw, rb = OC.cmunet_fixture_inputs(seed, B, S)
+    assert np.array_equal(mask[:, ::16, ::16], f["mask_patches"].numpy())          # create_random_patch_mask (UNet_encoder.py:106-139)
+    assert np.array_equal(np.repeat(np.repeat(mask[:, ::16, ::16], 16, 1), 16, 2), mask)
+    sd = OC.make_cmunet_sd(seed, S)
+    trainable = [str(k) for k in f["trainable"]]
+    osd = {k: (v.clone().requires_grad_(True) if k in set(trainable) else v.clone()) for k, v in sd.items()}
+    assert sorted(k for k, v in osd.items() if v.is_floating_point() and "running" not in k and not k.startswith("target_")) == trainable
+    out = OC.forward_train(img, img_t, mask, rw, rb, osd, temperature=0.07, ct_weight=1.0, rc_weight=1.0)
+    (out["loss_ct"] + out["loss_rc"]).backward()
+    assert abs(float(out["loss_rc"]) - float(f["loss_rc"])) <= 2e-5 * max(1.0, abs(float(f["loss_rc"])))
+    assert abs(float(out["loss_ct"]) - float(f["loss_ct"])) <= 1e-4 * max(1.0, abs(float(f["loss_ct"])))
+    norms = torch.stack([osd[k].grad.double().norm() for k in trainable])
+    ref = f["grad_norms"].double()
+    # (a bias in front of a training-mode BatchNorm -- the conv biases, fc0.bias of the necks -- has an analytically zero gradient:
+    # what both sides hold there is rounding noise of the summation order, compared by magnitude only)
+    # (so has feature_decoder.conv_last.bias: a constant added to the projector's input shifts fc0's output by a constant)
+    noise = torch.tensor([k.endswith((".0.bias", ".3.bias", "fc0.bias")) or k == "feature_decoder.conv_last.bias" for k in trainable])
+    big = ~noise
+    assert ((norms[big] - ref[big]).abs() / ref[big]).max().item() <= 2e-3
+    assert norms[noise].max().item() <= 1e-2 and ref[noise].max().item() <= 1e-2
+    for k in f:
+        if k.startswith("grad."):
+            g, r = osd[k[5:]].grad, f[k]
+            assert (g - r).norm().item() <= 2e-3 * r.norm().item() + 1e-7, k
+        if k.startswith("after."):
+            assert close(osd[k[6:]].float(), f[k].float(), 1e-4), k
+    # EMA (cmunet.py:78-92) at momentum 0.9 from the post-step state
+    st = {k: v.detach().clone() for k, v in osd.items()}
+    OC.momentum_update(st, 0.9)
+    tk = [str(k) for k in f["target_keys"]]
+    en = torch.stack([st[k].double().norm() for k in tk])
+    assert ((en - f["ema_norms"].double()).abs() / f["ema_norms"].double().clamp_min(1e-12)).max().item() <= 1e-6
+    assert close(st["target_backbone.down_conv1.double_conv.double_conv.0.weight"], f["ema_sample"], 1e-6)
+    # MomentumUpdateHook's schedule (momentum_update_hook.py:29-40)
+    for (it, mx, base, end), m in zip(f["hook_cases"].numpy(), f["hook_momentum"].numpy()):
+        assert abs(OC.momentum_schedule(int(it), int(mx), float(base), float(end)) - float(m)) < 1e-12
+    # the head alone (cmunet_head.py:47-91)
+    hsd = {k: (v.clone().requires_grad_(v.is_floating_point() and "running" not in k)) for k, v in sd.items() if k.startswith("head.")}
+    pred, ps = f["head.pred"].clone().requires_grad_(True), f["head.proj_s"].clone().requires_grad_(True)
+    hl = OC.head(f["head.x"], pred, f["head.mask"], ps, f["head.proj_t"], hsd, "head.", 0.07, 1.0, 1.0)
+    (hl["loss_ct"] + hl["loss_rc"]).backward()
+    assert abs(float(hl["loss_rc"]) - float(f["head.loss_rc"])) <= 2e-5 * max(1.0, abs(float(f["head.loss_rc"])))
+    assert abs(float(hl["loss_ct"]) - float(f["head.loss_ct"])) <= 1e-4 * max(1.0, abs(float(f["head.loss_ct"])))
+    assert close(pred.grad, f["head.dpred"], 1e-4) and close(ps.grad, f["head.dproj_s"], 2e-4)

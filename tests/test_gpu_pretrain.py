@@ -82,6 +82,75 @@ def test_cmunet_joint_step_vs_oracle(cuda):
             assert rel(v, before[k]) <= 1e-6, k
 
 
+def test_cmunet_joint_step_vs_reference_fixture(cuda, golden_dir):
+    """The HIP path against what the REFERENCE's own CM_UNet produced (tests/golden/cmunet_ref.npz, written by
+    oracle/gen_golden.py::gen_cmunet from the reference's cmae modules; shipped cmunet_config.py at 224 x 224, bs 4): the same
+    seeded state loaded under the reference's key names (strict), the same images, the reference's patch mask and per-call
+    reduce_channels conv -> forward_train's two losses, the gradient norm of every trainable parameter, sampled gradients in
+    full, BatchNorm buffers, the EMA of momentum_update, the hook's schedule, and CMUNetPretrainHead.forward alone."""
+    from cmunet_amd import cmunet as C
+    from cmunet_amd.pretrain import create_random_patch_mask
+    from oracle import cmunet as OC
+    f = np.load(f"{golden_dir}/cmunet_ref.npz")
+    seed, B, S = int(f["seed"]), int(f["B"]), int(f["S"])
+    img, img_t, mask, rw, rb = OC.cmunet_fixture_inputs(seed, B, S)
+    # the product's own host-side mask generator draws the reference's mask from the same numpy stream (UNet_encoder.py:106-139)
+    pm = create_random_patch_mask(B, S, 16, 0.65, np.random.RandomState(seed + 11))
+    assert np.array_equal(pm, mask) and np.array_equal(pm[:, ::16, ::16], f["mask_patches"])
+    model = C.build_model(C.cmunet_config(img_size=S, dtype="f32")).to(cuda).train()
+    sd = OC.make_cmunet_sd(seed, S)
+    model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)        # the reference's state_dict key names
+    trainable = [str(k) for k in f["trainable"]]
+    named = dict(model.named_parameters())
+    assert sorted(k for k, p in named.items() if p.requires_grad) == trainable
+    losses = model(img.to(cuda), mode='loss', img_t=img_t.to(cuda), mask=torch.from_numpy(mask).to(cuda), reduce_w=rw.to(cuda), reduce_b=rb.to(cuda))
+    (losses['loss_ct'] + losses['loss_rc']).backward()
+    d_rc, d_ct = abs(float(losses['loss_rc']) - float(f["loss_rc"])), abs(float(losses['loss_ct']) - float(f["loss_ct"]))
+    print(f"CM_UNet vs reference: loss_rc {float(losses['loss_rc']):.6f} (ref {float(f['loss_rc']):.6f}), loss_ct {float(losses['loss_ct']):.6f} "
+          f"(ref {float(f['loss_ct']):.6f})")
+    assert d_rc <= 2e-4 * max(1.0, abs(float(f["loss_rc"]))) and d_ct <= 2e-3 * max(1.0, abs(float(f["loss_ct"])))
+    ref = torch.from_numpy(f["grad_norms"]).double()
+    got = torch.stack([named[k].grad.double().norm().cpu() for k in trainable])
+    noise = torch.tensor([k.endswith((".0.bias", ".3.bias", "fc0.bias")) or k == "feature_decoder.conv_last.bias" for k in trainable])
+    relerr = ((got - ref).abs() / ref.clamp_min(1e-30))[~noise]
+    worst = int(torch.argmax(relerr))
+    print(f"  gradient norms of {int((~noise).sum())} parameters: worst relative difference {float(relerr[worst]):.2e} "
+          f"({[k for k, n in zip(trainable, noise) if not n][worst]})")
+    assert float(relerr.max()) <= 5e-3
+    assert float(got[noise].max()) <= 1e-2                  # analytically zero (bias in front of a training-mode BatchNorm)
+    for k in f.files:
+        if k.startswith("grad."):
+            e = rel(named[k[5:]].grad, torch.from_numpy(f[k]))
+            assert e <= 5e-3, f"d{k[5:]}: {e:.2e}"
+        if k.startswith("after."):
+            assert rel(model.state_dict()[k[6:]].float(), torch.from_numpy(f[k]).float()) <= 1e-4, k
+    for k in named:
+        if k.startswith("target_"):
+            assert named[k].grad is None
+    # EMA (cmunet.py:78-92) at the fixture's momentum
+    model.momentum = 0.9
+    model.momentum_update()
+    tk = [str(k) for k in f["target_keys"]]
+    en = torch.stack([named[k].detach().double().norm().cpu() for k in tk])
+    assert float(((en - torch.from_numpy(f["ema_norms"])).abs() / torch.from_numpy(f["ema_norms"]).clamp_min(1e-12)).max()) <= 1e-6
+    assert rel(named["target_backbone.down_conv1.double_conv.double_conv.0.weight"].detach(), torch.from_numpy(f["ema_sample"])) <= 1e-6
+    for (it, mx, base, end), m in zip(f["hook_cases"], f["hook_momentum"]):
+        assert abs(C.momentum_schedule(int(it), int(mx), float(base), float(end)) - float(m)) < 1e-12
+    # the head alone (cmunet_head.py:47-91): the reference takes pred_pixel[:, 1]; channel 1 of a 2-channel map here
+    model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)        # (predictor BatchNorm buffers back to the fixture's start)
+    model.zero_grad()
+    x, mk = torch.from_numpy(f["head.x"]).to(cuda), torch.from_numpy(f["head.mask"]).to(cuda)
+    pred = torch.from_numpy(f["head.pred"]).to(cuda)
+    logits = torch.stack([torch.zeros_like(pred), pred], 1).contiguous().requires_grad_(True)
+    ps = torch.from_numpy(f["head.proj_s"]).to(cuda).requires_grad_(True)
+    hl = model.head(x, logits, mk, ps, torch.from_numpy(f["head.proj_t"]).to(cuda))
+    (hl["loss_ct"] + hl["loss_rc"]).backward()
+    assert abs(float(hl["loss_rc"]) - float(f["head.loss_rc"])) <= 2e-5 * max(1.0, abs(float(f["head.loss_rc"])))
+    assert abs(float(hl["loss_ct"]) - float(f["head.loss_ct"])) <= 1e-4 * max(1.0, abs(float(f["head.loss_ct"])))
+    assert rel(logits.grad[:, 1], torch.from_numpy(f["head.dpred"])) <= 1e-4 and float(logits.grad[:, 0].abs().max()) == 0.0
+    assert rel(ps.grad, torch.from_numpy(f["head.dproj_s"])) <= 1e-3
+
+
 def test_cmunet_modules_standalone(cuda):
     """UNet_encoder / MUNetPretrainDecoder used on their own keep the reference's tensor contract."""
     from cmunet_amd import cmunet as C
