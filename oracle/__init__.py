@@ -16,8 +16,13 @@ Pinning (see DESIGN.md "Oracle"):
   * dense UNet blocks and tensor losses are pinned against the reference
     itself, imported in the build container by ``oracle/gen_golden.py``
     (the reference has no tests / golden vectors of its own: SURVEY F2);
-  * the CM-UNet / MoCo parts of the reference cannot be imported
-    (mmengine / lightning absent, hard-coded CUDA): their restatement is
-    pinned only through the shared blocks and closed forms
-    -> "parity unpinned by the reference" for those rows.
+  * the CM-UNet (cmae.*) and MoCo (moco2_module.py) parts need mmengine / mmcv /
+    pytorch-lightning / torchvision, which this image lacks, and hard-code the
+    device: ``gen_golden.py`` runs the reference's own modules behind plumbing
+    stand-ins for those libraries (registry, base classes, one-rank all_gather,
+    SyncBN -> BatchNorm1d, a CPU redirect of .cuda(); the same policy as the timm
+    stand-in of the SparK fixtures) and writes ``tests/golden/cmunet_ref.npz`` /
+    ``moco_ref.npz`` after asserting oracle == reference on every number.  What
+    only exists on more than one rank (label offsets B*rank, gathered keys,
+    shuffle-BN) stays restated and is covered by the gloo tests.
 """

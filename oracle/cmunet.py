@@ -1,9 +1,9 @@
 """Oracle: CM-UNet pretraining step, restated on CPU.  TEST INFRASTRUCTURE ONLY.
 
-The reference's cmae.* package cannot be imported here (mmengine/mmcv absent, hard-coded
-.cuda(): SURVEY section 8c), so this file restates it; its conv blocks are the ones in
-oracle/unet.py (pinned against the imported Finetuning/model.py), the loss math is closed
-form.  PARITY UNPINNED BY THE REFERENCE for the rows in this file (no reference tests).
+PINNED BY THE REFERENCE: oracle/gen_golden.py::gen_cmunet runs the reference's own cmae modules (CM_UNet.forward_train /
+backward / momentum_update, CMUNetPretrainHead, NonLinearNeck, UNet_encoder incl. its numpy patch mask, MomentumUpdateHook)
+in the build container behind an mmengine / mmcv plumbing stand-in, asserts this file equal on every number and writes
+tests/golden/cmunet_ref.npz (shipped cmunet_config.py, 224 x 224, bs 4; one rank).
 
 Follows, under /root/reference/Pretraining/CM-UNet/:
   create_random_patch_mask  cmae/models/backbones/UNet_encoder.py:106-139

@@ -418,6 +418,149 @@ def gen_cmunet(seed=4100):
     out.update({"after." + k: v for k, v in after_bn.items()})
     save("cmunet_ref", **out)
 
+
+_MOCO = None
+
+
+def import_moco():
+    """Pretraining/MoCo's own moco2_module.py / moco_data_module.py (Moco_v2, UNet_encoder, concat_all_gather) executed
+    unmodified behind plumbing stand-ins for the libraries this image lacks (pytorch-lightning 1.6,
+    lightning-bolts 0.5 -- whose vendored copy is incomplete --, torchvision, wandb):
+      pytorch_lightning   LightningModule = nn.Module + save_hyperparameters() (the constructor's arguments as self.hparams),
+                          log / log_dict no-ops, a plain `trainer` attribute; Trainer, LightningDataModule, ModelCheckpoint,
+                          WandbLogger, DDPPlugin, DDP2Plugin as empty classes; rank_zero_only = identity;
+      torchvision         empty transforms / transforms.functional / datasets modules (data pipeline only; ImageFolder = object);
+      pl_bolts            utils flags (_TORCHVISION_AVAILABLE False, _PIL_AVAILABLE True), warn_missing_pkg no-op, the three
+                          normalisation names transforms.py imports; pl_bolts/metrics/aggregation.py is the reference's own file.
+    Only the model code runs: Moco_v2.__init__ / training_step / forward / _momentum_update_key_encoder /
+    _dequeue_and_enqueue / _compute_l_s with a stand-in trainer whose strategy is not DDP (one process)."""
+    global _MOCO
+    if _MOCO is not None:
+        return _MOCO
+    import importlib
+    import inspect
+    import types
+    import torch.nn as nn
+    root = os.path.join(REF, "Pretraining", "MoCo")
+    mdir = os.path.join(root, "pl_bolts", "models", "self_supervised", "moco")
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class LightningModule(nn.Module):
+        def save_hyperparameters(self, *a, logger=True, ignore=()):
+            fr = inspect.currentframe().f_back
+            av = inspect.getargvalues(fr)
+            self.hparams = types.SimpleNamespace(**{k: av.locals[k] for k in av.args if k != "self" and k not in ignore})
+
+        def log(self, *a, **k):
+            pass
+
+        def log_dict(self, *a, **k):
+            pass
+
+    empty = lambda n: type(n, (), {})       # noqa: E731
+    mod("pytorch_lightning", LightningModule=LightningModule, Trainer=empty("Trainer"), LightningDataModule=empty("LightningDataModule"))
+    mod("pytorch_lightning.callbacks", ModelCheckpoint=empty("ModelCheckpoint"))
+    mod("pytorch_lightning.loggers", WandbLogger=empty("WandbLogger"))
+    mod("pytorch_lightning.plugins", DDPPlugin=empty("DDPPlugin"), DDP2Plugin=empty("DDP2Plugin"))
+    mod("pytorch_lightning.utilities", rank_zero_only=lambda f: f, _module_available=lambda n: False)
+    tv = mod("torchvision")
+    tv.transforms = mod("torchvision.transforms")
+    tv.transforms.functional = mod("torchvision.transforms.functional")
+    tv.datasets = mod("torchvision.datasets", ImageFolder=object, DatasetFolder=object)
+    mod("pl_bolts").__path__ = [os.path.join(root, "pl_bolts")]
+    mod("pl_bolts.utils", _TORCHVISION_AVAILABLE=False, _PIL_AVAILABLE=True)
+    mod("pl_bolts.utils.warnings", warn_missing_pkg=lambda *a, **k: None)
+    mod("pl_bolts.transforms")
+    mod("pl_bolts.transforms.dataset_normalizations", imagenet_normalization=None, cifar10_normalization=None, stl10_normalization=None)
+    mod("pl_bolts.metrics").__path__ = [os.path.join(root, "pl_bolts", "metrics")]
+    agg = importlib.import_module("pl_bolts.metrics.aggregation")
+    for n in ("accuracy", "mean", "precision_at_k"):
+        setattr(sys.modules["pl_bolts.metrics"], n, getattr(agg, n))
+    for clash in ("transforms", "utils", "models", "encoder", "decoder"):      # plain module names other reference trees also use
+        sys.modules.pop(clash, None)
+    sys.path[:] = [q for q in sys.path if "/Pretraining/Spark" not in q and not q.rstrip("/").endswith("Finetuning")]
+    sys.path.insert(0, mdir)
+    m2 = importlib.import_module("moco2_module")
+    _MOCO = m2
+    return _MOCO
+
+
+def gen_moco(seed=5200):
+    """tests/golden/moco_ref.npz: the reference's own Moco_v2 (UNet_encoder of moco_data_module.py:47-66; emb 1024, K = 64 negatives,
+    tau 0.2, m 0.99) through one training_step at bs 4, 64 x 64: loss, logits, the enqueued keys and pointer, the gradient norm of
+    every query-encoder parameter, sampled gradients, the key encoder after its EMA; a second step (pointer 4 -> 8, the queue holding
+    the first step's keys); forward()'s (logits, labels, k, q) contract.  The oracle (oracle/moco.py) is asserted equal first."""
+    import types
+    from oracle import moco as OM, unet as OU
+    m2 = import_moco()
+    B, S, K, T, EM = 4, 64, 64, 0.2, 0.99
+    torch.manual_seed(0)
+    model = m2.Moco_v2(emb_dim=1024, num_negatives=K, encoder_momentum=EM, softmax_temperature=T)
+    model.trainer = types.SimpleNamespace(datamodule=types.SimpleNamespace(name="synthetic"), strategy=None)
+    sd = OM.make_moco_sd(seed, K)
+    msd = model.state_dict()
+    assert set(sd) <= set(msd) and all(tuple(msd[k].shape) == tuple(v.shape) for k, v in sd.items()), sorted(set(sd) - set(msd))[:5]
+    assert set(msd) - set(sd) == {"val_queue", "val_queue_ptr"}
+    model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=False)
+    model.train()
+    xq, xk, xq2, xk2 = OM.moco_fixture_inputs(seed, B, S)
+    named = dict(model.named_parameters())
+    qkeys = sorted(k for k, p in named.items() if p.requires_grad)
+    assert all(k.startswith("encoder_q.") for k in qkeys)
+    loss = model.training_step(((xq, xk), 0), 0)
+    loss.backward()
+    # oracle == reference
+    osd = {k: (v.clone().requires_grad_(True) if k in qkeys else v.clone()) for k, v in sd.items()}
+    queue, ptr = sd["queue"].clone(), sd["queue_ptr"].clone()
+    ol, ologits, ok = OM.training_step(xq, xk, osd, queue, ptr, T, EM)
+    ol.backward()
+    close(ol.detach(), loss.detach(), what="moco loss")
+    close(queue, model.queue, tol=1e-5, what="moco queue")
+    assert int(ptr) == int(model.queue_ptr) == B
+    for k in qkeys:
+        gr, go = named[k].grad, osd[k].grad
+        if k.endswith((".0.bias", ".3.bias")):
+            continue
+        e = ((go - gr).norm() / gr.norm()).item()
+        assert e <= 2e-3, f"oracle != reference on d{k}: {e:.2e}"
+    kkeys = sorted(k for k in named if k.startswith("encoder_k."))
+    for k in kkeys:
+        close(osd[k], named[k].detach(), tol=1e-6, what="ema " + k)
+    gn = torch.stack([named[k].grad.double().norm() for k in qkeys])
+    spot = ("encoder_q.down_conv1.double_conv.double_conv.0.weight", "encoder_q.double_conv.double_conv.3.weight",
+            "encoder_q.down_conv2.double_conv.double_conv.4.bias")
+    out = {"seed": np.array(seed), "B": np.array(B), "S": np.array(S), "K": np.array(K), "T": np.array(T), "EM": np.array(EM),
+           "loss": loss.detach(), "keys": model.queue[:, :B].t().clone(), "queue_ptr": model.queue_ptr.clone(),
+           "qkeys": np.array(qkeys), "grad_norms": gn, "kkeys": np.array(kkeys),
+           "ema_norms": torch.stack([named[k].detach().double().norm() for k in kkeys]),
+           "ema_sample": named["encoder_k.double_conv.double_conv.0.weight"].detach()[:8].clone()}
+    out.update({"grad." + k: named[k].grad.detach().clone() for k in spot[:1]})
+    out.update({"gradsum." + k: named[k].grad.detach().double().sum() for k in spot})
+    # forward() contract on the updated state (moco2_module.py:224-270), before the second step changes it
+    with torch.no_grad():
+        lg, lb, kk, qq = model(xq2, xk2, model.queue)
+    assert lg.shape == (B, 1 + K) and lb.shape == (B,) and kk.shape == (B, 1024) and qq.shape == (B, 1024)
+    # second step: the oracle continues from its own state
+    model.zero_grad()
+    loss2 = model.training_step(((xq2, xk2), 0), 1)
+    for k in qkeys:
+        osd[k].grad = None
+    with torch.no_grad():   # (forward() above advanced the BatchNorm buffers of both encoders once more: so does the oracle)
+        OM.encoder_gap(xq2, osd, "encoder_q.", True)
+        OM.encoder_gap(xk2, osd, "encoder_k.", True)
+    ol2, _, _ = OM.training_step(xq2, xk2, osd, queue, ptr, T, EM)
+    close(ol2.detach(), loss2.detach(), what="moco loss step 2")
+    close(queue, model.queue, tol=1e-5, what="moco queue step 2")
+    assert int(ptr) == int(model.queue_ptr) == 2 * B
+    out.update({"fwd.logits": lg, "fwd.labels": lb, "loss2": loss2.detach(), "keys2": model.queue[:, B:2 * B].t().clone(),
+                "queue_ptr2": model.queue_ptr.clone()})
+    save("moco_ref", **out)
+
 def gen_cldice(M):
     """soft_cldice of the reference (metrics.py:401-431, the driver's configuration train.py:464) on vessel-like masks."""
     from oracle import losses as OL
@@ -537,6 +680,9 @@ def main():
         return
     if "--only-cldice" in sys.argv:
         gen_cldice(M)
+        return
+    if "--only-moco" in sys.argv:       # tests/golden/moco_ref.npz alone (the reference's Moco_v2 behind the lightning stand-in)
+        gen_moco()
         return
     if "--only-cmunet" in sys.argv:     # tests/golden/cmunet_ref.npz alone (the reference's cmae modules behind the mmengine stand-in)
         gen_cmunet()

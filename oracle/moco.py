@@ -1,8 +1,9 @@
 """Oracle: MoCo-v2 step on the UNet encoder, restated on CPU.  TEST INFRASTRUCTURE ONLY.
 
-The reference module needs pytorch-lightning / lightning-bolts (absent here: SURVEY 8c), so it is
-restated.  PARITY UNPINNED BY THE REFERENCE beyond the shared conv blocks (oracle/unet.py) and
-torch.nn.functional.cross_entropy.
+PINNED BY THE REFERENCE: oracle/gen_golden.py::gen_moco runs the reference's own Moco_v2 (moco2_module.py, UNet_encoder of
+moco_data_module.py) in the build container behind a pytorch-lightning / torchvision plumbing stand-in, asserts this file
+equal on two training steps and writes tests/golden/moco_ref.npz (one rank: the DDP-only shuffle-BN and key gather stay
+restated and are covered by the two-rank tests).
 
 Follows /root/reference/Pretraining/MoCo/pl_bolts/models/self_supervised/moco/:
   encoder (+ global average pool)   moco_data_module.py:47-66  (UNet down path + bottleneck, mean over H,W)
@@ -66,3 +67,21 @@ def training_step(img_q, img_k, sd, queue, queue_ptr, temperature=0.07, m=0.999,
     dequeue_and_enqueue(keys_all, queue, queue_ptr, queue.shape[1])
     loss = F.cross_entropy(logits.float(), labels.long())
     return loss, logits, k
+
+
+def make_moco_sd(seed, num_negatives=64, emb_dim=1024):
+    """Seeded state of Moco_v2 in the reference's key names (encoder_q.* / encoder_k.* = the UNet encoder of
+    moco_data_module.py:47-66, queue (emb, K), queue_ptr (1,)): what oracle/gen_golden.py::gen_moco loaded into the reference's own
+    module for tests/golden/moco_ref.npz; regenerated from the seed by the tests."""
+    sd = {}
+    for prefix, s in (("encoder_q.", seed), ("encoder_k.", seed + 1)):
+        part = U.make_state_dict(base_ch=64, depth=5, seed=s, encoder=True, decoder=False)
+        sd.update({prefix + k: v for k, v in part.items()})
+    sd["queue"] = init_queue(emb_dim, num_negatives, seed + 2)
+    sd["queue_ptr"] = torch.zeros(1, dtype=torch.long)
+    return sd
+
+
+def moco_fixture_inputs(seed, B=4, S=64):
+    g = torch.Generator().manual_seed(seed + 3)
+    return tuple(torch.randn(B, 1, S, S, generator=g) for _ in range(4))      # (query, key) of step 1, (query, key) of step 2

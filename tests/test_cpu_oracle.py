@@ -1,5 +1,6 @@
 """CPU suite (-m "not gpu"): the oracle restatement against the golden vectors produced by the reference
-(tests/golden/*.npz), plus closed-form checks of the parts the reference cannot run here (CM-UNet head, MoCo)."""
+(tests/golden/*.npz: dense UNet, losses, SparK, LAMB, soft-clDice, and -- cmunet_ref.npz / moco_ref.npz -- the reference's own CM_UNet and
+Moco_v2 modules), plus closed-form checks of the CM-UNet head and MoCo pieces."""
 import os
 
 import numpy as np
@@ -314,3 +315,41 @@ def test_cmunet_oracle_vs_reference_fixture(golden_dir):
     assert abs(float(hl["loss_rc"]) - float(f["head.loss_rc"])) <= 2e-5 * max(1.0, abs(float(f["head.loss_rc"])))
     assert abs(float(hl["loss_ct"]) - float(f["head.loss_ct"])) <= 1e-4 * max(1.0, abs(float(f["head.loss_ct"])))
     assert close(pred.grad, f["head.dpred"], 1e-4) and close(ps.grad, f["head.dproj_s"], 2e-4)
+
+
+def test_moco_oracle_vs_reference_fixture(golden_dir):
+    """tests/golden/moco_ref.npz holds what the REFERENCE's own Moco_v2 produced in the build container (moco2_module.py behind the
+    lightning / torchvision plumbing stand-in of oracle/gen_golden.py::import_moco): two training steps at bs 4, 64 x 64, K = 64,
+    tau 0.2, m 0.99.  The oracle restatement on the regenerated state and inputs must reproduce them: row a13 is pinned by the
+    reference."""
+    f = fx(golden_dir, "moco_ref")
+    seed, B, S, K, T, EM = int(f["seed"]), int(f["B"]), int(f["S"]), int(f["K"]), float(f["T"]), float(f["EM"])
+    sd = OM.make_moco_sd(seed, K)
+    xq, xk, xq2, xk2 = OM.moco_fixture_inputs(seed, B, S)
+    qkeys = [str(k) for k in f["qkeys"]]
+    osd = {k: (v.clone().requires_grad_(True) if k in set(qkeys) else v.clone()) for k, v in sd.items()}
+    queue, ptr = sd["queue"].clone(), sd["queue_ptr"].clone()
+    loss, logits, k = OM.training_step(xq, xk, osd, queue, ptr, T, EM)
+    loss.backward()
+    assert abs(float(loss) - float(f["loss"])) <= 2e-5 * max(1.0, abs(float(f["loss"])))
+    assert close(queue[:, :B].t(), f["keys"], 1e-5) and int(ptr) == int(f["queue_ptr"]) == B
+    assert close(queue[:, B:], sd["queue"][:, B:], 0.0)                       # the rest of the queue is untouched
+    norms = torch.stack([osd[q].grad.double().norm() for q in qkeys])
+    live = torch.tensor([not q.endswith((".0.bias", ".3.bias")) for q in qkeys])          # (conv bias under training-mode BN: noise)
+    assert ((norms - f["grad_norms"].double()).abs() / f["grad_norms"].double().clamp_min(1e-30))[live].max().item() <= 2e-3
+    for name in f:
+        if name.startswith("grad."):
+            assert (osd[name[5:]].grad - f[name]).norm().item() <= 2e-3 * f[name].norm().item(), name
+    kk = [str(q) for q in f["kkeys"]]
+    en = torch.stack([osd[q].double().norm() for q in kk])
+    assert ((en - f["ema_norms"].double()).abs() / f["ema_norms"].double()).max().item() <= 1e-6
+    assert close(osd["encoder_k.double_conv.double_conv.0.weight"][:8], f["ema_sample"], 1e-6)
+    # forward() on the updated state (no enqueue), then the second step
+    with torch.no_grad():
+        q2 = OM.encoder_gap(xq2, osd, "encoder_q.", True)
+        k2 = OM.encoder_gap(xk2, osd, "encoder_k.", True)
+    lg, lb, _, _ = OM.logits_from_embeddings(q2, k2, queue, T)
+    assert close(lg, f["fwd.logits"], 1e-4) and int(lb.sum()) == int(f["fwd.labels"].sum()) == 0
+    loss2, _, _ = OM.training_step(xq2, xk2, osd, queue, ptr, T, EM)
+    assert abs(float(loss2) - float(f["loss2"])) <= 2e-5 * max(1.0, abs(float(f["loss2"])))
+    assert close(queue[:, B:2 * B].t(), f["keys2"], 1e-5) and int(ptr) == int(f["queue_ptr2"]) == 2 * B

@@ -223,6 +223,53 @@ def test_moco_step_vs_oracle(cuda):
     assert rel(pq[kname].grad, osd2[kname].grad) <= 5e-3
 
 
+def test_moco_step_vs_reference_fixture(cuda, golden_dir):
+    """The HIP path against what the REFERENCE's own Moco_v2 produced (tests/golden/moco_ref.npz, oracle/gen_golden.py::gen_moco):
+    the same seeded state under the reference's key names, two training steps (EMA before the forward, logits from the
+    pre-enqueue queue, enqueue before the loss: A-8) -- losses, enqueued keys, pointer, gradient norms of the query encoder, the
+    key encoder after its EMA -- and forward()'s (logits, labels, k, q) contract in between."""
+    from cmunet_amd import moco as M
+    from oracle import moco as OM
+    f = np.load(f"{golden_dir}/moco_ref.npz")
+    seed, B, S, K, T, EM = int(f["seed"]), int(f["B"]), int(f["S"]), int(f["K"]), float(f["T"]), float(f["EM"])
+    m = M.Moco_v2(emb_dim=1024, num_negatives=K, softmax_temperature=T, encoder_momentum=EM, dtype="f32").to(cuda).train()
+    sd = OM.make_moco_sd(seed, K)
+    have = m.state_dict()
+    assert set(sd) <= set(have) and set(have) - set(sd) <= {"val_queue", "val_queue_ptr"}, sorted(set(have) ^ set(sd))[:6]
+    m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=False)
+    xq, xk, xq2, xk2 = (t.to(cuda) for t in OM.moco_fixture_inputs(seed, B, S))
+    named = dict(m.named_parameters())
+    qkeys = [str(k) for k in f["qkeys"]]
+    assert sorted(k for k, p in named.items() if p.requires_grad) == qkeys
+    loss = m.training_step(((xq, xk), 0))
+    loss.backward()
+    print(f"Moco_v2 vs reference: loss {float(loss):.6f} (ref {float(f['loss']):.6f})")
+    assert abs(float(loss) - float(f["loss"])) <= 1e-3 * max(1.0, abs(float(f["loss"])))
+    assert rel(m.queue[:, :B].t(), torch.from_numpy(f["keys"])) <= 1e-4 and int(m.queue_ptr) == int(f["queue_ptr"]) == B
+    assert torch.equal(m.queue[:, B:].cpu(), sd["queue"][:, B:])
+    got = torch.stack([named[k].grad.double().norm().cpu() for k in qkeys])
+    ref = torch.from_numpy(f["grad_norms"]).double()
+    live = torch.tensor([not k.endswith((".0.bias", ".3.bias")) for k in qkeys])
+    relerr = ((got - ref).abs() / ref.clamp_min(1e-30))[live]
+    print(f"  gradient norms of {int(live.sum())} query-encoder parameters: worst relative difference {float(relerr.max()):.2e}")
+    assert float(relerr.max()) <= 5e-3
+    for name in f.files:
+        if name.startswith("grad."):
+            assert rel(named[name[5:]].grad, torch.from_numpy(f[name])) <= 5e-3, name
+    kk = [str(k) for k in f["kkeys"]]
+    en = torch.stack([named[k].detach().double().norm().cpu() for k in kk])
+    assert float(((en - torch.from_numpy(f["ema_norms"])).abs() / torch.from_numpy(f["ema_norms"])).max()) <= 1e-6
+    assert rel(named["encoder_k.double_conv.double_conv.0.weight"].detach()[:8], torch.from_numpy(f["ema_sample"])) <= 1e-6
+    with torch.no_grad():
+        lg, lb, k2, q2 = m(xq2, xk2, m.queue)
+    assert lg.shape == (B, 1 + K) and k2.shape == (B, 1024) and q2.shape == (B, 1024) and int(lb.sum()) == 0
+    assert rel(lg, torch.from_numpy(f["fwd.logits"])) <= 1e-3
+    m.zero_grad()
+    loss2 = m.training_step(((xq2, xk2), 0))
+    assert abs(float(loss2) - float(f["loss2"])) <= 1e-3 * max(1.0, abs(float(f["loss2"])))
+    assert rel(m.queue[:, B:2 * B].t(), torch.from_numpy(f["keys2"])) <= 1e-4 and int(m.queue_ptr) == int(f["queue_ptr2"]) == 2 * B
+
+
 def test_masked_recon_trainer_matches_autograd_path(cuda):
     """The fused trainer (arena gradients, fused AdamW) and the drop-in autograd path agree after 3 steps."""
     from cmunet_amd import model as M
