@@ -103,7 +103,8 @@ _SIGS = {
     "cmu_conv3x3_rows_supported": (_I, [_I, _I, _I, _I, _I, _I]),
     "cmu_conv3x3_fwd_rows": (_I, [_P, _L, _P, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
     "cmu_conv3x3_fwd_tiles": (_I, [_P, _L, _P, _P, _I, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "cmu_conv3x3_wgrad_tiles": (_I, [_P, _L, _P, _P, _I, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "cmu_conv3x3_wgrad_tile_h": (_I, [_I, _I, _I, _I, _I, _I]),
+    "cmu_conv3x3_wgrad_tiles": (_I, [_P, _L, _P, _P, _I, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "cmu_spark_loss_ws_bytes": (_L, [_I, _I]),
     "cmu_spark_loss_fwd_bwd": (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P]),
     "cmu_gap_fwd": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

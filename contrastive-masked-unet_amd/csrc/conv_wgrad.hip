@@ -720,21 +720,40 @@ extern "C" int cmu_conv3x3_wgrad(const void* x, int64_t ldx, const float* in_sca
     CMU_DISPATCH_DT(dt, wgrad3_t, p, dW, (hipStream_t)stream);
 }
 
-// Sparse (SparK) weight gradient: the first kernel over a device-side list of 16 x 16 pixel tiles (cmu_sparse_tile_list with
-// tile_h = tile_w = 16).  ws: cmu_conv3x3_wgrad_ws_bytes.
+// Sparse (SparK) weight gradient over a device-side tile list (cmu_sparse_tile_list).  The list's tile height says which kernel
+// walks it: 16 (16 x 16 pixel tiles) = the first kernel, any shape; 8 (8 x 16 tiles, the wide kernel's K tile) = the wide kernel,
+// for the shapes cmu_conv3x3_wgrad_tile_h names.  ws: cmu_conv3x3_wgrad_ws_bytes.
+static bool wg2_list_ok(int B, int H, int W, int64_t ldx, int64_t ldd, int Cin, int Cout, int dt) {
+    const int64_t px = (int64_t)H * W;
+    return wg2_shape_ok(Cout, Cin, dt) && (px * ldd + Cout) * 2 < 0x7fff0000ll && ((px + W + 1) * ldx + Cin) * 2 < 0x7fff0000ll;
+}
+extern "C" int cmu_conv3x3_wgrad_tile_h(int B, int H, int W, int Cin, int Cout, int dt) {
+    if (cmu_dtype_size(dt) == 0 || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return -1;
+    return wg2_list_ok(B, H, W, Cin, Cout, Cin, Cout, dt) ? 8 : 16;   // (dense NHWC tensors: ld = C)
+}
 extern "C" int cmu_conv3x3_wgrad_tiles(const void* x, int64_t ldx, const float* in_scale, const float* in_shift, int relu_from,
-                                       const void* dY, int64_t ldd, float* dW, const int* tile_list, const int* tile_count, int B, int H,
-                                       int W, int Cin, int Cout, int dt, void* ws, void* stream) {
+                                       const void* dY, int64_t ldd, float* dW, const int* tile_list, const int* tile_count, int tile_h,
+                                       int B, int H, int W, int Cin, int Cout, int dt, void* ws, void* stream) {
     int rc;
     if ((rc = wg_check("cmu_conv3x3_wgrad_tiles(x)", x, ldx, Cin, dt))) return rc;
     if ((rc = wg_check("cmu_conv3x3_wgrad_tiles(dY)", dY, ldd, Cout, dt))) return rc;
     CMU_CHECK_ARG(dW && ws && tile_list && tile_count && B > 0 && H > 0 && W > 0, "cmu_conv3x3_wgrad_tiles: null argument / bad dims");
     CMU_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "cmu_conv3x3_wgrad_tiles: scale/shift must both be set");
     CMU_CHECK_ARG(relu_from >= 0 && relu_from % (16 / cmu_dtype_size(dt)) == 0, "cmu_conv3x3_wgrad_tiles: relu_from=%d must be a multiple of the 16-byte chunk", relu_from);
+    CMU_CHECK_ARG(tile_h == 16 || tile_h == 8, "cmu_conv3x3_wgrad_tiles: tile_h=%d (16: 16 x 16 tiles, 8: 8 x 16 tiles)", tile_h);
     WGParams p = {};
     p.a = dY; p.lda = ldd; p.b = x; p.ldb = ldx; p.b_scale = in_scale; p.b_shift = in_shift; p.relu_from = relu_from;
     p.ws = (float*)ws; p.B = B; p.H = H; p.W = W; p.CA = Cout; p.CB = Cin;
     p.tile_list = tile_list; p.tile_count = tile_count;
+    if (tile_h == 8) {
+        CMU_CHECK_ARG(wg2_list_ok(B, H, W, ldx, ldd, Cin, Cout, dt) &&
+                          (in_scale == nullptr || ((reinterpret_cast<uintptr_t>(in_scale) | reinterpret_cast<uintptr_t>(in_shift)) & 3) == 0),
+                      "cmu_conv3x3_wgrad_tiles: an 8 x 16 tile list needs a shape of the wide kernel (16-bit, Cout %% 128 == 0, Cin %% 64 == 0; "
+                      "cmu_conv3x3_wgrad_tile_h), got %d -> %d", Cin, Cout);
+        wg2_geometry(B, H, W, Cout, Cin, p);
+        if (dt == CMU_F16) return wgrad3_wide_t<F16Traits, false>(p, dW, (hipStream_t)stream);
+        return wgrad3_wide_t<BF16Traits, false>(p, dW, (hipStream_t)stream);
+    }
     wg_geometry(B, H, W, Cout, Cin, dt, 1, p);
     CMU_DISPATCH_DT(dt, wgrad3_t, p, dW, (hipStream_t)stream);
 }

@@ -441,11 +441,18 @@ def conv3x3_fwd_tiles(x, wpacked, out, tiles, active_fraction=1.0):
          work=2.0 * 9 * x.C * out.C * x.B * x.H * x.W * active_fraction)
 
 
+def conv3x3_wgrad_tile_h(B, H, W, Cin, Cout, dt):
+    """Tile height of the list ``conv3x3_wgrad_tiles`` wants for this shape: 8 (8 x 16 tiles, wide kernel) or 16 (16 x 16 tiles)."""
+    return int(_lib.lib().cmu_conv3x3_wgrad_tile_h(B, H, W, Cin, Cout, dt_code(dt)))
+
+
 def conv3x3_wgrad_tiles(x, dY, dW, ws, tiles, active_fraction=1.0):
+    """Weight gradient with the contraction restricted to the listed tiles (``dY`` is zero elsewhere): 16 x 16 tiles on the first
+    kernel, 8 x 16 tiles on the wide kernel (``conv3x3_wgrad_tile_h`` says which list a shape wants)."""
     Cout, Cin = dW.shape[0], dW.shape[1]
-    assert x.C == Cin and dY.C == Cout and (tiles.tile_h, tiles.tile_w) == (16, 16)
+    assert x.C == Cin and dY.C == Cout and tiles.tile_w == 16 and tiles.tile_h in (8, 16)
     call("cmu_conv3x3_wgrad_tiles", x.ptr(), x.ld, _p(x.scale), _p(x.shift), x.relu_from, dY.ptr(), dY.ld, _p(_f32c(dW)),
-         _p(tiles.list), _p(tiles.count), x.B, x.H, x.W, Cin, Cout, x.dt, _p(ws), _stream(),
+         _p(tiles.list), _p(tiles.count), tiles.tile_h, x.B, x.H, x.W, Cin, Cout, x.dt, _p(ws), _stream(),
          work=2.0 * 9 * Cin * Cout * x.B * x.H * x.W * active_fraction)
 
 

@@ -183,12 +183,26 @@ class SparK(_EngineOwner, nn.Module):
         keep = 1.0 - self.mask_ratio
         conv = ops.TileList(active, H, W, 16, 32)
         cf = 1.0 - (1.0 - keep) ** max(1, (16 // ps) * (32 // ps))          # expected share of listed tiles (profiler only)
-        wg, wf = None, 1.0
-        if ps >= 16:
-            wg = ops.TileList(active, H, W, 16, 16)
-            wf = 1.0 - (1.0 - keep) ** max(1, (16 // ps) ** 2)
+        # weight gradients: tile lists by tile height -- 16 x 16 tiles of the first kernel where a patch fills them (level 1), 8 x 16
+        # tiles (the wide kernel's K tile = two 8 x 8 patches at level 2: 44 % listed at mask ratio 0.75); built on first use
+        wg = {"active": active, "H": H, "W": W, "lists": {}, "ps": ps, "keep": keep}
         # (where both apply -- level 2: 90 % of the tiles against 25 % of the rows -- the gather kernel is taken first)
-        return {"conv": conv, "wgrad": wg, "cf": cf, "wf": wf, "pix": pix, "gather": pix is not None}
+        return {"conv": conv, "wgrad": wg, "cf": cf, "wf": 1.0, "pix": pix, "gather": pix is not None}
+
+    @staticmethod
+    def _wgrad_list(tiles, tile_h):
+        """(TileList, expected listed share) of a level for the weight-gradient kernel that walks ``tile_h`` x 16 tiles, or None when
+        such tiles cannot skip anything worth a list (more than two patches per tile side)."""
+        wg = tiles["wgrad"] if tiles is not None else None
+        if wg is None:
+            return None
+        ps = wg["ps"]
+        if ps < tile_h or ps < 8:
+            return None
+        if tile_h not in wg["lists"]:
+            share = 1.0 - (1.0 - wg["keep"]) ** max(1, (tile_h // ps) * (16 // ps))
+            wg["lists"][tile_h] = (ops.TileList(wg["active"], wg["H"], wg["W"], tile_h, 16), share)
+        return wg["lists"][tile_h]
 
     def _sp_convbn_fwd(self, eng, sd, pconv, pbn, x, x_img, inv_pix, active, count, B, H, W, training, sync=False, tiles=None):
         w = sd[pconv + "weight"]
@@ -253,8 +267,9 @@ class SparK(_EngineOwner, nn.Module):
             ops.conv3x3_c1_wgrad(s["x_img"], dY, dW, eng.scratch.get("wg", eng.lib.cmu_conv3x3_c1_wgrad_ws_bytes(B, H, W, C)), s["mask"], True)
         else:
             wsb = eng.scratch.get("wg", eng.lib.cmu_conv3x3_wgrad_ws_bytes(B, H, W, w.shape[1], C, eng.dt))
-            if tiles is not None and tiles["wgrad"] is not None:
-                ops.conv3x3_wgrad_tiles(s["x"], dY, dW, wsb, tiles["wgrad"], tiles["wf"])      # dY is zero outside the listed tiles
+            lst = self._wgrad_list(tiles, ops.conv3x3_wgrad_tile_h(B, H, W, w.shape[1], C, eng.dt))
+            if lst is not None:
+                ops.conv3x3_wgrad_tiles(s["x"], dY, dW, wsb, lst[0], lst[1])      # dY is zero outside the listed tiles
             else:
                 ops.conv3x3_wgrad(s["x"], dY, dW, wsb)
         grads[s["pconv"] + "weight"] = dW

@@ -270,7 +270,8 @@ int cmu_bn_bwd_apply_masked(const void* dA, int64_t ldd, const void* y, int64_t 
  *   cmu_conv3x3_fwd_tiles   cmu_conv3x3_fwd (forward and, with the flipped pack, data gradient) over a 16 x 32 tile list;
  *                           y outside the listed tiles is left untouched (its consumers select by the mask).  Shapes the
  *                           persistent kernel serves (cmu_conv3x3_tiles_supported != 0): whole tiles, whole channel blocks.
- *   cmu_conv3x3_wgrad_tiles cmu_conv3x3_wgrad with the contraction restricted to a 16 x 16 tile list (dY is zero elsewhere).
+ *   cmu_conv3x3_wgrad_tiles cmu_conv3x3_wgrad with the contraction restricted to a tile list (dY is zero elsewhere): 16 x 16 tiles
+ *                           (tile_h 16, the first kernel) or 8 x 16 tiles (tile_h 8, the wide kernel: cmu_conv3x3_wgrad_tile_h).
  *
  * Gather form for the levels whose patches are smaller than a tile (every dense tile holds an active pixel there): the
  * convolution over the LIST of active pixels -- GEMM rows = active pixels (rows[r] = dense pixel index (b*H + y)*W + x, patch-
@@ -296,8 +297,11 @@ int cmu_conv3x3_tiles_supported(int B, int H, int W, int Cin, int Cout, int dt);
 int cmu_conv3x3_fwd_tiles(const void* x, int64_t ldx, const float* in_scale, const float* in_shift, int relu_from,
                           const void* wpacked, void* y, int64_t ldy, const int* tile_list, const int* tile_count,
                           int B, int H, int W, int Cin, int Cout, int dt, void* stream);
+/* tile height of the list cmu_conv3x3_wgrad_tiles wants for this shape: 8 (8 x 16 pixel tiles: the wide weight-gradient kernel
+ * serves it) or 16 (16 x 16 tiles: the first kernel)                                                                       */
+int cmu_conv3x3_wgrad_tile_h(int B, int H, int W, int Cin, int Cout, int dt);
 int cmu_conv3x3_wgrad_tiles(const void* x, int64_t ldx, const float* in_scale, const float* in_shift, int relu_from,
-                            const void* dY, int64_t ldd, float* dW, const int* tile_list, const int* tile_count,
+                            const void* dY, int64_t ldd, float* dW, const int* tile_list, const int* tile_count, int tile_h,
                             int B, int H, int W, int Cin, int Cout, int dt, void* ws, void* stream);
 
 /* SparK loss (spark.py:112-123): p x p patches, target patch normalised with its own mean / unbiased variance

@@ -106,6 +106,42 @@ def test_wgrad_tiles_equals_dense_when_dy_is_masked(ops, dt, shape):
     assert (dWt.double().cpu() - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 128, 8), (3, 96, 128, 128, 12), (2, 128, 64, 256, 16), (1, 32, 128, 128, 2)])
+def test_wgrad_tiles_wide_kernel_8x16_list(ops, dt, shape):
+    """The wide weight-gradient kernel over a list of 8 x 16 pixel tiles (its K tile; SparK level 2: one tile = two 8 x 8 patches):
+    equal to the dense launch when dY vanishes outside the active patches, and to float64.  Lists longer and shorter than the
+    split count, a batch of three, 8-pixel and larger patches; ``conv3x3_wgrad_tile_h`` names the list a shape wants."""
+    from cmunet_amd import _lib
+    B, S, Cin, Cout, f = shape
+    assert ops.conv3x3_wgrad_tile_h(B, S, S, Cin, Cout, dt) == 8 and ops.conv3x3_wgrad_tile_h(B, S, S, 64, 64, dt) == 16
+    assert ops.conv3x3_wgrad_tile_h(B, S, S, Cin, Cout, "f32") == 16
+    tdt = ops.TORCH_DT[ops.dt_code(dt)]
+    g = torch.Generator(device="cuda").manual_seed(4)
+    act = _active(B, f, max(1, f * f // 4), seed=S + Cout + f).cuda()
+    pix = act.bool().repeat_interleave(S // f, 1).repeat_interleave(S // f, 2).unsqueeze(-1)
+    x = torch.randn(B, S, S, Cin, generator=g, device="cuda").to(tdt)
+    sc, sh = (1 + 0.2 * torch.randn(Cin, generator=g, device="cuda")).contiguous(), (0.1 * torch.randn(Cin, generator=g, device="cuda")).contiguous()
+    dy = (torch.randn(B, S, S, Cout, generator=g, device="cuda") * pix).to(tdt)
+    ws = torch.empty(_lib.lib().cmu_conv3x3_wgrad_ws_bytes(B, S, S, Cin, Cout, ops.dt_code(dt)), dtype=torch.uint8, device="cuda")
+    xa = ops.Act(x, 0, Cin, sc, sh, 0)                       # pending BatchNorm + ReLU on X, as in the encoder
+    dW = torch.empty(Cout, Cin, 3, 3, device="cuda")
+    ops.conv3x3_wgrad(xa, ops.Act(dy), dW, ws)
+    tl = ops.TileList(act, S, S, 8, 16)
+    n = int(tl.count.item())
+    assert 0 < n < tl.n_dense
+    dWt = torch.full_like(dW, 7.0)
+    ops.conv3x3_wgrad_tiles(xa, ops.Act(dy), dWt, ws, tl)
+    e = (dW - dWt).abs().max().item() / dW.abs().max().item()
+    assert e <= 1e-5, e
+    xt = torch.relu(x.double().cpu() * sc.double().cpu() + sh.double().cpu())
+    ref = torch.nn.grad.conv2d_weight(xt.permute(0, 3, 1, 2), (Cout, Cin, 3, 3), dy.double().cpu().permute(0, 3, 1, 2), padding=1)
+    assert (dWt.double().cpu() - ref).abs().max().item() <= (2e-3 if dt == "f16" else 1.6e-2) * ref.abs().max().item()
+    # a 16 x 16 list is refused for nothing: it runs the first kernel; an 8 x 16 list on a shape of the first kernel is refused
+    with pytest.raises(Exception, match="8 x 16 tile list needs"):
+        ops.conv3x3_wgrad_tiles(ops.Act(x[..., :64].contiguous()), ops.Act(dy[..., :64].contiguous()), torch.empty(64, 64, 3, 3, device="cuda"), ws, tl)
+
+
 @pytest.mark.parametrize("case", [(2, 4, 32, 4), (3, 8, 32, 16), (2, 8, 8, 64), (1, 4, 64, 5), (2, 16, 16, 0)])
 def test_pixel_list_matches_numpy(ops, case):
     """cmu_sparse_pixel_list: active pixels in patch-major order (patches ascending, pixels row-major inside a patch), -1 padding."""
