@@ -80,6 +80,7 @@ _SIGS = {
     "cmu_convT2x2_wgrad_ws_bytes": (_L, [_I, _I, _I, _I, _I, _I]),
     "cmu_convT2x2_wgrad": (_I, [_P, _L, _P, _P, _I, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "cmu_conv1x1_head_bwd_ws_bytes": (_L, [_I, _I, _I, _I, _I]),
+    "cmu_conv1x1_head_bn_apply": (_I, [_P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
     "cmu_conv1x1_head_bwd": (_I, [_P, _P, _L, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "cmu_masked_mse_ws_bytes": (_L, [_I, _I]),
     "cmu_masked_mse_fwd_bwd": (_I, [_P, _I, _I, _P, _P, _P, _P, _F, _P, _I, _I, _I, _P, _P]),

@@ -215,7 +215,8 @@ __global__ void bn_bwd_apply_kernel(const unsigned char* __restrict__ dA, int64_
                                     int64_t ldy, const float* __restrict__ scale, const float* __restrict__ shift,
                                     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ coef,
                                     unsigned char* __restrict__ dY, int64_t ldo, int64_t npix, int C, int cpb, int ppb,
-                                    const uint8_t* __restrict__ amask, int f, int sbits, int H, int W) {
+                                    const uint8_t* __restrict__ amask, int f, int sbits, int H, int W,
+                                    const float* __restrict__ hd_dlogits = nullptr, const float* __restrict__ hd_w = nullptr) {
     constexpr int EPC = TR::EPC;
     constexpr int ES = (int)sizeof(typename TR::elem_t);
     const int tid = threadIdx.x;
@@ -230,13 +231,29 @@ __global__ void bn_bwd_apply_kernel(const unsigned char* __restrict__ dA, int64_
         sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; is[e] = invstd[c];
         c1[e] = coef[c]; c2[e] = coef[C + c];
     }
+    // head mode (hd_dlogits != NULL, two classes): dA is not in memory -- it is the rank-2 product dlogits[p][0..1] * w[0..1][c]
+    // of the 1x1 head this layer feeds, recomputed here and rounded as the head backward would have stored it
+    float w0[EPC], w1[EPC];
+    if (hd_dlogits != nullptr) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { w0[e] = hd_w[ch * EPC + e]; w1[e] = hd_w[C + ch * EPC + e]; }
+    }
+    const unsigned HWu = (unsigned)H * (unsigned)W;
     for (int64_t p = (int64_t)blockIdx.x * ppb + prow; p < npix; p += (int64_t)gridDim.x * ppb) {
         if (amask && !sp_active(amask, f, sbits, (int)(p / ((int64_t)W * H)), (int)((p / W) % H), (int)(p % W), 0)) {
             st_global16(dY + (p * ldo + ch * EPC) * ES, u32x4{0u, 0u, 0u, 0u});   // sparse BN: no gradient at masked positions
             continue;
         }
         float g[EPC], v[EPC], o[EPC];
-        TR::unpack(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(dA + (p * ldd + ch * EPC) * ES)), g);
+        if (hd_dlogits != nullptr) {
+            const unsigned bq = (unsigned)p / HWu, r = (unsigned)p - bq * HWu;      // (the launcher keeps npix below 2^31 here)
+            const float d0 = hd_dlogits[(int64_t)(2 * bq) * HWu + r], d1 = hd_dlogits[(int64_t)(2 * bq + 1) * HWu + r];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o[e] = fmaf(d1, w1[e], fmaf(d0, w0[e], 0.f));
+            TR::unpack(TR::pack(o), g);
+        } else {
+            TR::unpack(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(dA + (p * ldd + ch * EPC) * ES)), g);
+        }
         TR::unpack(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(y + (p * ldy + ch * EPC) * ES)), v);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
@@ -250,7 +267,8 @@ __global__ void bn_bwd_apply_kernel(const unsigned char* __restrict__ dA, int64_
 template <class TR>
 static int bn_bwd_apply_t(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift,
                           const float* mean, const float* invstd, const float* coef, void* dY, int64_t ldo, int B, int H, int W,
-                          int C, const uint8_t* active, int f, hipStream_t st) {
+                          int C, const uint8_t* active, int f, hipStream_t st, const float* hd_dlogits = nullptr,
+                          const float* hd_w = nullptr) {
     int cpb, ppb, gy;
     chunk_geometry(C / TR::EPC, &cpb, &ppb, &gy);
     const int64_t npix = (int64_t)B * H * W;
@@ -264,7 +282,7 @@ static int bn_bwd_apply_t(const void* dA, int64_t ldd, const void* y, int64_t ld
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL((bn_bwd_apply_kernel<TR>), dim3(gx, gy), dim3(256), 0, st, (const unsigned char*)dA, ldd,
                        (const unsigned char*)y, ldy, scale, shift, mean, invstd, coef, (unsigned char*)dY, ldo, npix, C, cpb, ppb, active, f,
-                       sbits, H, W);
+                       sbits, H, W, hd_dlogits, hd_w);
     CMU_CHECK_LAUNCH("cmu_bn_bwd_apply");
     return CMU_OK;
 }
@@ -443,8 +461,13 @@ __global__ __launch_bounds__(256) void conv1x1_head_bwd_kernel(const float* __re
         }
     }
     const int64_t HW = (int64_t)H * W;
-    for (int64_t pix = (int64_t)blockIdx.x * ppb + prow; pix < npix; pix += (int64_t)gridDim.x * ppb) {
-        const int64_t b = pix / HW, r = pix % HW;
+    // (image, pixel-in-image) carried along the grid-stride loop instead of a 64-bit division per pixel and thread
+    const int64_t stride = (int64_t)gridDim.x * ppb;
+    const int64_t sb = stride / HW, sr = stride % HW;
+    int64_t pix = (int64_t)blockIdx.x * ppb + prow;
+    int64_t b = pix / HW, r = pix % HW;
+    for (; pix < npix; pix += stride, b += sb, r += sr) {
+        if (r >= HW) { r -= HW; ++b; }
         float f[EPC], o[EPC], dl[KT];
         TR::unpack(ld_global16(x + (pix * ldx + ch * EPC) * ES), f);
 #pragma unroll
@@ -551,7 +574,7 @@ extern "C" int cmu_conv1x1_head_bwd(const float* dlogits, const void* x, int64_t
                                     const float* w, void* dX, int64_t ldo, float* dW, float* dbias, const float* save_mean,
                                     const float* save_invstd, void* bn_ws, int B, int H, int W, int C, int K, int dt, void* ws,
                                     void* stream) {
-    CMU_CHECK_ARG(bn_ws == nullptr || (save_mean && save_invstd && dX && in_scale), "cmu_conv1x1_head_bwd: fused BN statistics need dX, the transform and save_mean / save_invstd");
+    CMU_CHECK_ARG(bn_ws == nullptr || (save_mean && save_invstd && in_scale), "cmu_conv1x1_head_bwd: fused BN statistics need the transform and save_mean / save_invstd");
     const int es = cmu_dtype_size(dt);
     CMU_CHECK_ARG(es > 0 && dlogits && x && w && dW && dbias && ws && B > 0 && H > 0 && W > 0, "cmu_conv1x1_head_bwd: bad args");
     const int epc = 16 / es;
@@ -563,6 +586,108 @@ extern "C" int cmu_conv1x1_head_bwd(const float* dlogits, const void* x, int64_t
     CMU_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "cmu_conv1x1_head_bwd: scale/shift must both be set");
     CMU_DISPATCH_DT(dt, conv1x1_head_bwd_t, dlogits, x, ldx, in_scale, in_shift, w, dX, ldo, dW, dbias, B, H, W, C, K, ws, save_mean,
                     save_invstd, bn_ws, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1x1 head backward + BatchNorm+ReLU backward of the layer that fed the head, second half: dY written straight from dlogits.
+// The head's input gradient has rank K (dA[p][c] = sum_k dlogits[p][k] * w[k][c]): it never needs to exist in memory.
+// cmu_conv1x1_head_bwd with dX = NULL leaves the BN-backward partial sums (taken on dA rounded to the storage type, as the
+// two-pass form stores it) and the head's parameter gradients; after the finalisation this pass recomputes dA per pixel chunk
+// and applies  dY = scale * (gate * dA - c1 - xhat * c2)  -- x is read twice and dY written once (3.2 GB at 32 x 512 x 512 x 64
+// f16) where head backward + cmu_bn_bwd_apply read x twice, wrote and re-read dA and wrote dY (5.4 GB).  Same bits as the two passes.
+// ---------------------------------------------------------------------------------------------
+template <class TR, int KT>
+__global__ __launch_bounds__(256) void conv1x1_head_bn_apply_kernel(const float* __restrict__ dlogits, const unsigned char* __restrict__ x,
+                                                                   int64_t ldx, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, const float* __restrict__ w,
+                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                   const float* __restrict__ coef, unsigned char* __restrict__ dY,
+                                                                   int64_t ldo, int H, int W, int C, int K, int64_t npix) {
+    constexpr int EPC = TR::EPC;
+    constexpr int ES = (int)sizeof(typename TR::elem_t);
+    const int tid = threadIdx.x;
+    const int nchunk = C / EPC;  // power of two <= 64
+    const int ch = tid % nchunk;
+    const int ppb = 256 / nchunk;
+    const int prow = tid / nchunk;
+    float sc[EPC], sh[EPC], wk[KT][EPC], mu[EPC], is[EPC], c1[EPC], c2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const int c = ch * EPC + e;
+        sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; is[e] = invstd[c];
+        c1[e] = coef[c]; c2[e] = coef[C + c];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) wk[k][e] = (k < K) ? w[k * C + c] : 0.f;
+    }
+    const int64_t HW = (int64_t)H * W;
+    // (image, pixel-in-image) of the thread's pixel, carried along the grid-stride loop: a 64-bit division per pixel and thread
+    // was what bound this pass (1.07 ms for 2.2 GB)
+    const int64_t stride = (int64_t)gridDim.x * ppb;
+    const int64_t sb = stride / HW, sr = stride % HW;
+    int64_t pix = (int64_t)blockIdx.x * ppb + prow;
+    int64_t b = pix / HW, r = pix % HW;
+    for (; pix < npix; pix += stride, b += sb, r += sr) {
+        if (r >= HW) { r -= HW; ++b; }
+        float f[EPC], o[EPC], dl[KT];
+        TR::unpack(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(x + (pix * ldx + ch * EPC) * ES)), f);
+#pragma unroll
+        for (int k = 0; k < KT; ++k) dl[k] = (k < K) ? dlogits[(b * K + k) * HW + r] : 0.f;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float d = 0.f;
+#pragma unroll
+            for (int k = 0; k < KT; ++k) d = fmaf(dl[k], wk[k][e], d);
+            o[e] = d;
+        }
+        float g[EPC];
+        TR::unpack(TR::pack(o), g);                    // dA as the two-pass form stores it
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float dz = fmaf(f[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
+            const float xh = (f[e] - mu[e]) * is[e];
+            o[e] = sc[e] * (dz - c1[e] - xh * c2[e]);
+        }
+        __builtin_nontemporal_store(TR::pack(o), reinterpret_cast<u32x4*>(dY + (pix * ldo + ch * EPC) * ES));
+    }
+}
+template <class TR>
+static int conv1x1_head_bn_apply_t(const float* dlogits, const void* x, int64_t ldx, const float* scale, const float* shift, const float* w,
+                                   const float* mean, const float* invstd, const float* coef, void* dY, int64_t ldo, int B, int H, int W,
+                                   int C, int K, hipStream_t st) {
+    const int nchunk = C / TR::EPC;
+    const int ppb = 256 / nchunk;
+    const int64_t npix = (int64_t)B * H * W;
+    int gx = (int)(cmu_div_up64(npix, ppb * 4) < (1 << 20) ? cmu_div_up64(npix, ppb * 4) : (1 << 20));   // four pixel chunks per thread (cmu_bn_bwd_apply)
+    if (gx < 1) gx = 1;
+    if (K <= 2)
+        hipLaunchKernelGGL((conv1x1_head_bn_apply_kernel<TR, 2>), dim3(gx), dim3(256), 0, st, dlogits, (const unsigned char*)x, ldx, scale, shift, w,
+                           mean, invstd, coef, (unsigned char*)dY, ldo, H, W, C, K, npix);
+    else
+        hipLaunchKernelGGL((conv1x1_head_bn_apply_kernel<TR, HEAD_MAX_K>), dim3(gx), dim3(256), 0, st, dlogits, (const unsigned char*)x, ldx, scale,
+                           shift, w, mean, invstd, coef, (unsigned char*)dY, ldo, H, W, C, K, npix);
+    CMU_CHECK_LAUNCH("cmu_conv1x1_head_bn_apply");
+    return CMU_OK;
+}
+extern "C" int cmu_conv1x1_head_bn_apply(const float* dlogits, const void* x, int64_t ldx, const float* in_scale, const float* in_shift,
+                                         const float* w, const float* save_mean, const float* save_invstd, const float* coef, void* dY,
+                                         int64_t ldo, int B, int H, int W, int C, int K, int dt, void* stream) {
+    const int es = cmu_dtype_size(dt);
+    CMU_CHECK_ARG(es > 0 && dlogits && x && w && in_scale && in_shift && save_mean && save_invstd && coef && dY && B > 0 && H > 0 && W > 0,
+                  "cmu_conv1x1_head_bn_apply: bad args");
+    const int epc = 16 / es;
+    const int nchunk = C / epc;
+    CMU_CHECK_ARG(K >= 1 && K <= HEAD_MAX_K, "cmu_conv1x1_head_bn_apply: K=%d must be in 1..%d", K, HEAD_MAX_K);
+    CMU_CHECK_ARG(C % epc == 0 && nchunk > 0 && (nchunk & (nchunk - 1)) == 0 && nchunk <= 64, "cmu_conv1x1_head_bn_apply: C=%d unsupported", C);
+    CMU_CHECK_ARG(cmu_aligned16(x) && ldx % epc == 0 && ldx >= C && cmu_aligned16(dY) && ldo % epc == 0 && ldo >= C,
+                  "cmu_conv1x1_head_bn_apply: alignment / stride");
+    if (K == 2 && (int64_t)B * H * W < (1ll << 31)) {
+        // two classes (every head of the reference): the BatchNorm-backward apply kernel itself, with dA recomputed from dlogits
+        // in its load slot (same grid, same loop: it runs at the HBM rate; the generic kernel below measured 1.07 ms against 0.56)
+        CMU_DISPATCH_DT(dt, bn_bwd_apply_t, nullptr, ldx, x, ldx, in_scale, in_shift, save_mean, save_invstd, coef, dY, ldo, B, H, W, C,
+                        (const uint8_t*)nullptr, 0, (hipStream_t)stream, dlogits, w);
+    }
+    CMU_DISPATCH_DT(dt, conv1x1_head_bn_apply_t, dlogits, x, ldx, in_scale, in_shift, w, save_mean, save_invstd, coef, dY, ldo, B, H, W, C, K,
+                    (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------

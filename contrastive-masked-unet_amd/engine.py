@@ -28,6 +28,7 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
 
+_FUSE_HEAD = os.environ.get("CMU_HEAD_FUSE", "1") != "0"   # A/B: "0" = the head's input gradient is stored and re-read by cmu_bn_bwd_apply
 _FUSE_DGRAD_BN = os.environ.get("CMU_DGRAD_BN", "1")    # A/B: "0" = BN-backward sums as a separate pass, "64"/"128" = fused up to C
 
 
@@ -193,12 +194,14 @@ class UNetEngine:
         n = ops.ntiles(y.B, y.H, y.W)
         return self.scratch.get("bst", n * 2 * y.C * 4)[:n * 2 * y.C * 4].view(torch.float32).view(n, 2, y.C)
 
-    def _convbn_bwd(self, sd, s, dA, grads, need_dx, dx_out=None, fused_stats=False, next_bn=None):
+    def _convbn_bwd(self, sd, s, dA, grads, need_dx, dx_out=None, fused_stats=False, next_bn=None, head=None):
         """``fused_stats``: the kernel that produced dA already wrote this layer's BN-backward partial sums into
         the shared slab (max-pool / head backward) -- only the finalisation is left of phase 1.  The same holds when the
         producer was a data-gradient kernel, which leaves a per-tile slab in ``s["bstats"]``.
         ``next_bn``: saved state of the conv+BN layer whose activated output is this conv's input: its BN-backward
-        partial sums are produced by this layer's data-gradient kernel (consumed by the next ``_convbn_bwd`` call)."""
+        partial sums are produced by this layer's data-gradient kernel (consumed by the next ``_convbn_bwd`` call).
+        ``head``: (dlogits, w) of the 1x1 head this layer feeds, with ``dA`` None: the head's rank-K input gradient was never
+        stored (its BN-backward sums were: ``fused_stats``) -- dY comes straight from dlogits (``conv1x1_head_bn_apply``)."""
         y = s["y"]
         B, H, W, C = y.B, y.H, y.W, y.C
         w = sd[s["pconv"] + "weight"]
@@ -214,9 +217,14 @@ class UNetEngine:
         else:
             ops.bn_bwd_reduce(dA, y, s["mean"], s["invstd"], dgamma, dbeta, coef, ws)
         first = s["x_img"] is not None                        # first layer: no data gradient, BN apply fused in its wgrad
-        dY = Act(dA.buf, dA.coff, dA.C)                       # in place over dA (out of place measures the same 4.3 ms)
-        if not first:
-            ops.bn_bwd_apply(dA, y, s["mean"], s["invstd"], coef, dY)
+        if head is not None:
+            assert dA is None and fused_stats and not first
+            dY = self._new(B, H, W, C)
+            ops.conv1x1_head_bn_apply(head[0], y, head[1], s["mean"], s["invstd"], coef, dY)
+        else:
+            dY = Act(dA.buf, dA.coff, dA.C)                   # in place over dA (out of place measures the same 4.3 ms)
+            if not first:
+                ops.bn_bwd_apply(dA, y, s["mean"], s["invstd"], coef, dY)
         grads[s["pbn"] + "weight"] = dgamma
         grads[s["pbn"] + "bias"] = dbeta
         # conv bias: followed by training-mode BN, its gradient is identically zero (sum of dY over pixels)
@@ -382,11 +390,14 @@ class UNetEngine:
         x = ctx["out"]
         K = sd[prefix + "conv_last.weight"].shape[0]
         wl = sd[prefix + "conv_last.weight"]
-        dA = self._new(x.B, x.H, x.W, x.C)
         dWl, dbl = self._gbuf(prefix + "conv_last.weight", wl), self._gbuf(prefix + "conv_last.bias", sd[prefix + "conv_last.bias"])
         ws = self.scratch.get("head", self.lib.cmu_conv1x1_head_bwd_ws_bytes(x.B, x.H, x.W, x.C, K))
         last = ctx["levels"][0]["s2"] if ctx["levels"] else None      # the conv+BN layer that produced ``x``
         fused = last is not None and last["y"] is x
+        # the head's input gradient has rank K: when it flows straight into ``last``'s BatchNorm backward it is never stored -- the
+        # head backward leaves the BN-backward sums, the apply pass recomputes it from dlogits (CMU_HEAD_FUSE=0: stored, A/B switch)
+        head = (dlogits.contiguous(), wl.detach().reshape(K, -1)) if (fused and _FUSE_HEAD) else None
+        dA = None if head is not None else self._new(x.B, x.H, x.W, x.C)
         ops.conv1x1_head_bwd(dlogits.contiguous(), x, wl.detach().reshape(K, -1), dA, dWl.view(K, -1), dbl, ws,
                              last["mean"] if fused else None, last["invstd"] if fused else None, self._bn_ws(x.C) if fused else None)
         grads[prefix + "conv_last.weight"] = dWl
@@ -398,7 +409,8 @@ class UNetEngine:
             p = f"{prefix}up_conv{i}."
             cat = lv["cat"]
             Cup, Cs = cat["Cup"], cat["Cskip"]
-            dA1 = self._convbn_bwd(sd, lv["s2"], dA, grads, True, fused_stats=(fused and i == 1), next_bn=lv["s1"])
+            dA1 = self._convbn_bwd(sd, lv["s2"], dA, grads, True, fused_stats=(fused and i == 1), next_bn=lv["s1"],
+                                   head=head if i == 1 else None)
             dcat = self._convbn_bwd(sd, lv["s1"], dA1, grads, True)
             d_skips[i - 1] = Act(dcat.buf, Cup, Cs)
             dleft = Act(dcat.buf, 0, Cup)

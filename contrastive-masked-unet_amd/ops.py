@@ -304,8 +304,22 @@ def convT2x2_wgrad(x, dOut, dW, dbias, ws):
          _p(_f32c(dbias)), x.B, x.H, x.W, Cin, Cout, x.dt, _p(ws), _stream(), work=2.0 * 4 * Cin * Cout * x.B * x.H * x.W)
 
 
-def conv1x1_head_bwd(dlogits, x, w, dX, dW, dbias, ws, save_mean=None, save_invstd=None, bn_ws=None):
+def conv1x1_head_bn_apply(dlogits, x, w, save_mean, save_invstd, coef, dY):
+    """dY of the conv+BN+ReLU layer that fed the 1x1 head, straight from dlogits (the head's input gradient has rank K and is never
+    stored): second half of ``conv1x1_head_bwd(..., dX=None, bn_ws=...)`` + ``bn_bwd_finalize``."""
     K = w.shape[0]
+    call("cmu_conv1x1_head_bn_apply", _p(_f32c(dlogits)), x.ptr(), x.ld, _p(x.scale), _p(x.shift), _p(_f32c(w)), _p(save_mean),
+         _p(save_invstd), _p(_f32c(coef)), dY.ptr(), dY.ld, x.B, x.H, x.W, x.C, K, x.dt, _stream())
+
+
+def conv1x1_head_bwd(dlogits, x, w, dX, dW, dbias, ws, save_mean=None, save_invstd=None, bn_ws=None):
+    """``dX`` None (with ``bn_ws``): parameter gradients and BatchNorm-backward sums only (see ``conv1x1_head_bn_apply``)."""
+    K = w.shape[0]
+    if dX is None:
+        call("cmu_conv1x1_head_bwd", _p(_f32c(dlogits)), x.ptr(), x.ld, _p(x.scale), _p(x.shift), _p(_f32c(w)), None, 0,
+             _p(_f32c(dW)), _p(_f32c(dbias)), _p(save_mean), _p(save_invstd), _p(bn_ws), x.B, x.H, x.W, x.C, K, x.dt, _p(ws),
+             _stream())
+        return
     call("cmu_conv1x1_head_bwd", _p(_f32c(dlogits)), x.ptr(), x.ld, _p(x.scale), _p(x.shift), _p(_f32c(w)), dX.ptr(), dX.ld,
          _p(_f32c(dW)), _p(_f32c(dbias)), _p(save_mean), _p(save_invstd), _p(bn_ws), x.B, x.H, x.W, x.C, K, x.dt, _p(ws),
          _stream())

@@ -194,6 +194,13 @@ int cmu_conv1x1_head_bwd(const float* dlogits, const void* x, int64_t ldx, const
                          const float* w, void* dX, int64_t ldo, float* dW, float* dbias,
                          const float* save_mean, const float* save_invstd, void* bn_ws /* optional, as cmu_maxpool_bwd */,
                          int B, int H, int W, int C, int K, int dt, void* ws, void* stream);
+/* Second half of the fused form: cmu_conv1x1_head_bwd with dX = NULL and bn_ws set leaves only the parameter gradients and the
+ * BatchNorm-backward partial sums of the layer that fed the head (the rank-K input gradient is never stored); after
+ * cmu_bn_bwd_finalize this pass recomputes it per pixel from dlogits and writes that layer's dY = scale * (gate * dA - coef[0] -
+ * xhat * coef[1]) -- the same bits as cmu_conv1x1_head_bwd (dX stored) + cmu_bn_bwd_apply, 3.2 instead of 5.4 GB at the bench size. */
+int cmu_conv1x1_head_bn_apply(const float* dlogits, const void* x, int64_t ldx, const float* in_scale, const float* in_shift,
+                              const float* w, const float* save_mean, const float* save_invstd, const float* coef, void* dY,
+                              int64_t ldo, int B, int H, int W, int C, int K, int dt, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Losses / pretraining heads

@@ -229,6 +229,50 @@ def test_conv1x1_head_bwd(ops, dt, C):
     check(from_act(dX), a.grad, TOL[dt], "head dX")
     check(dW.cpu(), wd.grad, 1e-4, "head dW")
     check(db.cpu(), bd.grad, 1e-4, "head dbias")
+    # the fused form: the rank-K input gradient is never stored -- head backward leaves sums + parameter gradients (dX None),
+    # cmu_conv1x1_head_bn_apply writes the producing layer's dY straight from dlogits: the same bits as stored dX + bn_bwd_apply
+    dY_ref = ops.new_act(B, H, W, C, dt, "cuda")
+    ops.bn_bwd_apply(dX, xa, mean.cuda(), invstd.cuda(), coef_f, dY_ref)
+    dW2, db2 = torch.empty(K, C, device="cuda"), torch.empty(K, device="cuda")
+    bws2 = ws_bytes(_lib.lib().cmu_bn_bwd_ws_bytes(C))
+    ops.conv1x1_head_bwd(dl.cuda(), xa, w.cuda(), None, dW2, db2, ws, mean.cuda(), invstd.cuda(), bws2)
+    coef2, dg2, db2b = torch.empty(2, C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ops.bn_bwd_finalize(bws2, B * H * W, dg2, db2b, coef2)
+    assert torch.equal(coef2, coef_f) and torch.equal(dg2, dg_f) and torch.equal(dW2, dW) and torch.equal(db2, db)
+    dY = ops.new_act(B, H, W, C, dt, "cuda")
+    ops.conv1x1_head_bn_apply(dl.cuda(), xa, w.cuda(), mean.cuda(), invstd.cuda(), coef2, dY)
+    assert torch.equal(dY.buf.view(torch.uint8), dY_ref.buf.view(torch.uint8)), "fused head + BN apply differs from the two passes"
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
+@pytest.mark.parametrize("K", [1, 3])
+def test_conv1x1_head_bn_apply_other_class_counts(ops, dt, K):
+    """The fused head backward + BatchNorm apply for class counts other than two (the generic kernel): bit-identical to the stored form."""
+    from cmunet_amd import _lib
+    B, H, W, C = 3, 12, 20, 64
+    g = torch.Generator().manual_seed(19 + K)
+    x = q(torch.randn(B, C, H, W, generator=g), dt, ops)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    w = torch.randn(K, C, generator=g) / C ** 0.5
+    dl = torch.randn(B, K, H, W, generator=g)
+    mean, invstd = (torch.randn(C, generator=g) * 0.1).cuda(), (torch.rand(C, generator=g) + 0.5).cuda()
+    xa = to_act(x, dt, ops).with_transform(sc.cuda(), sh.cuda(), 0)
+    outs = []
+    for fused in (False, True):
+        dX = None if fused else ops.new_act(B, H, W, C, dt, "cuda")
+        dW, db = torch.empty(K, C, device="cuda"), torch.empty(K, device="cuda")
+        ws, bws = ws_bytes(_lib.lib().cmu_conv1x1_head_bwd_ws_bytes(B, H, W, C, K)), ws_bytes(_lib.lib().cmu_bn_bwd_ws_bytes(C))
+        ops.conv1x1_head_bwd(dl.cuda(), xa, w.cuda(), dX, dW, db, ws, mean, invstd, bws)
+        coef, dg, dbt = torch.empty(2, C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        ops.bn_bwd_finalize(bws, B * H * W, dg, dbt, coef)
+        dY = ops.new_act(B, H, W, C, dt, "cuda")
+        if fused:
+            ops.conv1x1_head_bn_apply(dl.cuda(), xa, w.cuda(), mean, invstd, coef, dY)
+        else:
+            ops.bn_bwd_apply(dX, xa, mean, invstd, coef, dY)
+        outs.append((dY.buf.clone(), dW, db, coef))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))
 
 
 def test_masked_mse(ops):
