@@ -561,6 +561,104 @@ def gen_moco(seed=5200):
                 "queue_ptr2": model.queue_ptr.clone()})
     save("moco_ref", **out)
 
+
+def _moco_2rank_worker(rank, port, outdir, seed):
+    """One of two gloo ranks running the reference's own Moco_v2 with a DDP strategy: shuffle-BN, gathered keys, enqueue."""
+    import types
+    import torch.distributed as dist
+    from oracle import moco as OM
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=2)
+    m2 = import_moco()
+    torch.Tensor.cuda = lambda self, *a, **k: self       # (_batch_shuffle_ddp: torch.randperm(n).cuda(), moco2_module.py:191)
+    B, S, K, T, EM = 4, 64, 64, 0.2, 0.99
+    torch.manual_seed(0)
+    model = m2.Moco_v2(emb_dim=1024, num_negatives=K, encoder_momentum=EM, softmax_temperature=T)
+    ddp = sys.modules["pytorch_lightning.plugins"].DDPPlugin()
+    model.trainer = types.SimpleNamespace(datamodule=types.SimpleNamespace(name="synthetic"), strategy=ddp)
+    model.load_state_dict({k: v.clone() for k, v in OM.make_moco_sd(seed, K).items()}, strict=False)
+    model.train()
+    xq, xk, _, _ = OM.moco_fixture_inputs(seed + 50 * (rank + 1), B, S)        # every rank its own images
+    torch.manual_seed(seed + 7)          # rank 0's permutation (torch.randperm on the CPU generator) is the one that is broadcast
+    loss = model.training_step(((xq, xk), 0), 0)
+    loss.backward()
+    named = dict(model.named_parameters())
+    qkeys = sorted(k for k, p in named.items() if p.requires_grad)
+    torch.save({"loss": loss.detach(), "queue": model.queue.clone(), "ptr": model.queue_ptr.clone(), "qkeys": qkeys,
+                "grad_norms": torch.stack([named[k].grad.double().norm() for k in qkeys]),
+                "grad0": named["encoder_q.down_conv1.double_conv.double_conv.0.weight"].grad.clone(),
+                "bn_k": model.state_dict()["encoder_k.down_conv1.double_conv.double_conv.1.running_mean"].clone()},
+               os.path.join(outdir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def gen_moco_2rank(seed=5300):
+    """tests/golden/moco_ref_2rank.npz: the reference's own Moco_v2 on TWO gloo ranks (strategy = DDPPlugin, so _use_ddp_or_ddp2
+    is true): _batch_shuffle_ddp / _batch_unshuffle_ddp around the key encoder (rank 0's torch.randperm broadcast), concat_all_gather
+    of the keys, 2B rows enqueued on both ranks.  Per rank: loss, local (not yet averaged) gradient norms of the query encoder, the
+    queue and pointer after the step, a key-encoder BatchNorm buffer (its batch = the shuffled mixture of both ranks' images).  The
+    oracle emulation (the same permutation redrawn from the seed, the key encoder per shuffled group) is asserted equal first."""
+    import socket
+    import subprocess
+    import torch.nn.functional as F
+    from oracle import moco as OM
+    B, S, K, T, EM = 4, 64, 64, 0.2, 0.99
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    outdir = tempfile.mkdtemp(prefix="moco2rank_")
+    procs = [subprocess.Popen([sys.executable, "-m", "oracle.gen_golden", "--moco-worker", str(r), str(port), outdir, str(seed)],
+                              cwd=os.path.dirname(os.path.dirname(OUT))) for r in range(2)]
+    try:
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    res = [torch.load(os.path.join(outdir, f"rank{r}.pt")) for r in range(2)]
+    assert torch.equal(res[0]["queue"], res[1]["queue"]) and int(res[0]["ptr"]) == int(res[1]["ptr"]) == 2 * B
+    # ---- oracle emulation of the two ranks in one process ------------------------------------------------------------------
+    sd0 = OM.make_moco_sd(seed, K)
+    ins = [OM.moco_fixture_inputs(seed + 50 * (r + 1), B, S) for r in range(2)]
+    torch.manual_seed(seed + 7)
+    idx = torch.randperm(2 * B)
+    un = torch.argsort(idx)
+    xk_all = torch.cat([ins[0][1], ins[1][1]])
+    losses, gnorms, bn_k, queue_after = [], [], [], None
+    ksh = []
+    sds = []
+    for r in range(2):
+        sd = {k: v.clone() for k, v in sd0.items()}
+        OM.momentum_update(sd, EM)
+        with torch.no_grad():
+            ksh.append(OM.encoder_gap(xk_all[idx.view(2, -1)[r]], sd, "encoder_k.", True))
+        sds.append(sd)
+    k_all = F.normalize(torch.cat(ksh)[un], dim=1)                                   # keys back with their owners, rank-major
+    for r in range(2):
+        sd = sds[r]
+        qkeys = res[r]["qkeys"]
+        for k in qkeys:
+            sd[k] = sd[k].clone().requires_grad_(True)
+        q = F.normalize(OM.encoder_gap(ins[r][0], sd, "encoder_q.", True), dim=1)
+        k_own = k_all[r * B:(r + 1) * B]
+        logits = torch.cat([(q * k_own).sum(1, keepdim=True), q @ sd0["queue"]], 1) / T
+        loss = F.cross_entropy(logits, torch.zeros(B, dtype=torch.long))
+        loss.backward()
+        close(loss.detach(), res[r]["loss"], what=f"2-rank moco loss (rank {r})")
+        gn = torch.stack([sd[k].grad.double().norm() for k in qkeys])
+        live = torch.tensor([not k.endswith((".0.bias", ".3.bias")) for k in qkeys])
+        assert ((gn - res[r]["grad_norms"]).abs() / res[r]["grad_norms"].clamp_min(1e-30))[live].max().item() <= 2e-3
+        close(sd["encoder_k.down_conv1.double_conv.double_conv.1.running_mean"], res[r]["bn_k"], tol=1e-5, what="key-encoder BN buffer")
+    queue = sd0["queue"].clone()
+    queue[:, :2 * B] = k_all.t()
+    close(queue, res[0]["queue"], tol=1e-5, what="2-rank queue")
+    save("moco_ref_2rank", seed=np.array(seed), B=np.array(B), S=np.array(S), K=np.array(K), T=np.array(T), EM=np.array(EM),
+         perm=idx, keys=res[0]["queue"][:, :2 * B].t().clone(), queue_ptr=res[0]["ptr"],
+         loss=torch.stack([res[0]["loss"], res[1]["loss"]]), qkeys=np.array(res[0]["qkeys"]),
+         grad_norms=torch.stack([res[0]["grad_norms"], res[1]["grad_norms"]]), grad0=torch.stack([res[0]["grad0"], res[1]["grad0"]]),
+         bn_k=torch.stack([res[0]["bn_k"], res[1]["bn_k"]]))
+
 def gen_cldice(M):
     """soft_cldice of the reference (metrics.py:401-431, the driver's configuration train.py:464) on vessel-like masks."""
     from oracle import losses as OL
@@ -680,6 +778,13 @@ def main():
         return
     if "--only-cldice" in sys.argv:
         gen_cldice(M)
+        return
+    if "--moco-worker" in sys.argv:     # (child of gen_moco_2rank)
+        i = sys.argv.index("--moco-worker")
+        _moco_2rank_worker(int(sys.argv[i + 1]), int(sys.argv[i + 2]), sys.argv[i + 3], int(sys.argv[i + 4]))
+        return
+    if "--only-moco2" in sys.argv:      # tests/golden/moco_ref_2rank.npz alone
+        gen_moco_2rank()
         return
     if "--only-moco" in sys.argv:       # tests/golden/moco_ref.npz alone (the reference's Moco_v2 behind the lightning stand-in)
         gen_moco()

@@ -85,3 +85,37 @@ def make_moco_sd(seed, num_negatives=64, emb_dim=1024):
 def moco_fixture_inputs(seed, B=4, S=64):
     g = torch.Generator().manual_seed(seed + 3)
     return tuple(torch.randn(B, 1, S, S, generator=g) for _ in range(4))      # (query, key) of step 1, (query, key) of step 2
+
+
+def two_rank_step(sd0, inputs, perm, temperature, m):
+    """One Moco_v2.training_step on TWO data-parallel ranks, emulated in one process (moco2_module.py:177-222, 224-285 with
+    _use_ddp_or_ddp2 true): EMA first; the key images of both ranks gathered and permuted with rank 0's ``perm``; each rank's key
+    encoder sees its shuffled share (its BatchNorm batch is a mixture of both ranks' images); the keys are un-shuffled back to their
+    owners; every rank's logits use its own keys and the pre-enqueue queue; all 2B keys are enqueued on both ranks.
+    ``inputs[r]`` = (query images, key images) of rank r.  Returns ([(loss_r, sd_r with .grad on the query parameters)], queue)."""
+    B = inputs[0][0].shape[0]
+    un = torch.argsort(perm)
+    xk_all = torch.cat([inputs[0][1], inputs[1][1]])
+    sds, ksh = [], []
+    for r in range(2):
+        sd = {k: v.clone() for k, v in sd0.items()}
+        momentum_update(sd, m)
+        with torch.no_grad():
+            ksh.append(encoder_gap(xk_all[perm.view(2, -1)[r]], sd, "encoder_k.", True))
+        sds.append(sd)
+    k_all = F.normalize(torch.cat(ksh)[un], dim=1)
+    out = []
+    for r in range(2):
+        sd = sds[r]
+        for k in list(sd):
+            if k.startswith("encoder_q.") and sd[k].is_floating_point() and "running" not in k:
+                sd[k] = sd[k].clone().requires_grad_(True)
+        q = F.normalize(encoder_gap(inputs[r][0], sd, "encoder_q.", True), dim=1)
+        k_own = k_all[r * B:(r + 1) * B]
+        logits = torch.cat([(q * k_own).sum(1, keepdim=True), q @ sd0["queue"]], 1) / temperature
+        loss = F.cross_entropy(logits, torch.zeros(B, dtype=torch.long))
+        loss.backward()
+        out.append((loss.detach(), sd))
+    queue = sd0["queue"].clone()
+    queue[:, :2 * B] = k_all.t()
+    return out, queue

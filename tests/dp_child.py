@@ -102,6 +102,24 @@ def main():
         torch.manual_seed(1234)
         _, _, k, _ = m(xq.to(dev), xk.to(dev), m.queue)
         res.update({"k": k.cpu(), "xk": xk})
+    elif mode == "moco_ref2":
+        # the reference's own two-rank run (tests/golden/moco_ref_2rank.npz): the same seeded state, every rank its own images,
+        # rank 0's permutation from the global CPU generator seeded as the generator seeded it
+        from cmunet_amd import moco as MO
+        from oracle import moco as OM
+        seed, B, S, K = int(opts["seed"]), 4, 64, 64
+        m = MO.Moco_v2(emb_dim=1024, num_negatives=K, softmax_temperature=0.2, encoder_momentum=0.99, dtype="f32").to(dev).train()
+        m.load_state_dict({k: v.clone() for k, v in OM.make_moco_sd(seed, K).items()}, strict=False)
+        xq, xk, _, _ = OM.moco_fixture_inputs(seed + 50 * (rank + 1), B, S)
+        torch.manual_seed(seed + 7)
+        loss = m.training_step(((xq.to(dev), xk.to(dev)), 0))
+        loss.backward()
+        named = dict(m.named_parameters())
+        qkeys = sorted(k for k, p in named.items() if p.requires_grad)
+        res = {"loss": float(loss), "queue": m.queue.cpu(), "ptr": int(m.queue_ptr), "qkeys": qkeys,
+               "grad_norms": torch.stack([named[k].grad.double().norm().cpu() for k in qkeys]),
+               "grad0": named["encoder_q.down_conv1.double_conv.double_conv.0.weight"].grad.cpu(),
+               "bn_k": m.state_dict()["encoder_k.down_conv1.double_conv.double_conv.1.running_mean"].cpu()}
     elif mode == "spark":
         from cmunet_amd import spark as S
         torch.manual_seed(5)

@@ -353,3 +353,27 @@ def test_moco_oracle_vs_reference_fixture(golden_dir):
     loss2, _, _ = OM.training_step(xq2, xk2, osd, queue, ptr, T, EM)
     assert abs(float(loss2) - float(f["loss2"])) <= 2e-5 * max(1.0, abs(float(f["loss2"])))
     assert close(queue[:, B:2 * B].t(), f["keys2"], 1e-5) and int(ptr) == int(f["queue_ptr2"]) == 2 * B
+
+
+def test_moco_two_rank_oracle_vs_reference_fixture(golden_dir):
+    """tests/golden/moco_ref_2rank.npz: the REFERENCE's own Moco_v2 run on two gloo ranks in the build container (DDP strategy:
+    shuffle-BN around the key encoder with rank 0's broadcast permutation, gathered keys, 2B rows enqueued).  The one-process oracle
+    emulation of the two ranks reproduces every rank's loss, local gradient norms, key-encoder BatchNorm buffer and the queue."""
+    f = fx(golden_dir, "moco_ref_2rank")
+    seed, B, S, K, T, EM = int(f["seed"]), int(f["B"]), int(f["S"]), int(f["K"]), float(f["T"]), float(f["EM"])
+    torch.manual_seed(seed + 7)
+    perm = torch.randperm(2 * B)
+    assert torch.equal(perm, f["perm"])                                   # rank 0's torch.randperm under the same seed
+    sd0 = OM.make_moco_sd(seed, K)
+    ins = [OM.moco_fixture_inputs(seed + 50 * (r + 1), B, S)[:2] for r in range(2)]
+    out, queue = OM.two_rank_step(sd0, ins, perm, T, EM)
+    qkeys = [str(k) for k in f["qkeys"]]
+    live = torch.tensor([not k.endswith((".0.bias", ".3.bias")) for k in qkeys])
+    for r, (loss, sd) in enumerate(out):
+        assert abs(float(loss) - float(f["loss"][r])) <= 2e-5 * max(1.0, abs(float(f["loss"][r])))
+        gn = torch.stack([sd[k].grad.double().norm() for k in qkeys])
+        assert ((gn - f["grad_norms"][r].double()).abs() / f["grad_norms"][r].double().clamp_min(1e-30))[live].max().item() <= 2e-3
+        assert (sd["encoder_q.down_conv1.double_conv.double_conv.0.weight"].grad - f["grad0"][r]).norm().item() <= 2e-3 * f["grad0"][r].norm().item()
+        assert close(sd["encoder_k.down_conv1.double_conv.double_conv.1.running_mean"], f["bn_k"][r], 1e-5)
+    assert close(queue[:, :2 * B].t(), f["keys"], 1e-5) and int(f["queue_ptr"]) == 2 * B
+    assert float((f["loss"][0] - f["loss"][1]).abs()) > 1e-4              # the ranks had different images

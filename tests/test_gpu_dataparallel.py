@@ -234,6 +234,29 @@ def test_moco_shuffle_bn_two_ranks_vs_oracle(cuda):
     assert rel(two[0]["k"], plain) > 1e-3
 
 
+def test_moco_two_ranks_vs_reference_two_rank_fixture(cuda):
+    """Two ranks of the HIP Moco_v2 against what the REFERENCE's own Moco_v2 produced on two gloo ranks
+    (tests/golden/moco_ref_2rank.npz, oracle/gen_golden.py::gen_moco_2rank): shuffle-BN with rank 0's broadcast permutation, keys
+    gathered from both ranks and enqueued on both (pointer += 2B), per-rank losses and local gradient norms."""
+    f = np.load(os.path.join(HERE, "golden", "moco_ref_2rank.npz"))
+    two = run_ranks("moco_ref2", 2, seed=int(f["seed"]))
+    B = int(f["B"])
+    qkeys = [str(k) for k in f["qkeys"]]
+    live = torch.tensor([not k.endswith((".0.bias", ".3.bias")) for k in qkeys])
+    for rk in range(2):
+        r = two[rk]
+        assert r["qkeys"] == qkeys
+        assert abs(r["loss"] - float(f["loss"][rk])) <= 1e-3 * max(1.0, abs(float(f["loss"][rk]))), (rk, r["loss"], float(f["loss"][rk]))
+        assert r["ptr"] == int(f["queue_ptr"].reshape(-1)[0]) == 2 * B
+        assert rel(r["queue"][:, :2 * B].t(), torch.from_numpy(f["keys"])) <= 1e-4
+        ref = torch.from_numpy(f["grad_norms"][rk]).double()
+        e = ((r["grad_norms"] - ref).abs() / ref.clamp_min(1e-30))[live]
+        assert float(e.max()) <= 5e-3, (rk, float(e.max()))
+        assert rel(r["grad0"], torch.from_numpy(f["grad0"][rk])) <= 5e-3
+        assert rel(r["bn_k"], torch.from_numpy(f["bn_k"][rk])) <= 1e-4            # the key encoder's BatchNorm saw the shuffled mixture
+    assert torch.equal(two[0]["queue"], two[1]["queue"])
+
+
 def test_spark_trainer_two_ranks_equals_one_rank(cuda):
     """SparKPretrainer (LAMB) with grad-less ``densify_projs`` parameters in the arena (SURVEY A-10): two ranks fed the same
     batches match one rank; a static loss scale inside the fused step leaves the update unchanged."""
