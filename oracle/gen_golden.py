@@ -659,6 +659,76 @@ def gen_moco_2rank(seed=5300):
          grad_norms=torch.stack([res[0]["grad_norms"], res[1]["grad_norms"]]), grad0=torch.stack([res[0]["grad0"], res[1]["grad0"]]),
          bn_k=torch.stack([res[0]["bn_k"], res[1]["bn_k"]]))
 
+
+def gen_finetune(ref, M, seed=6100):
+    """tests/golden/finetune_ref.npz: the reference's OWN training loop -- Finetuning/train.py's TrainEpoch / ValidEpoch / train()
+    imported behind empty cv2 / albumentations stand-ins (dataset.py imports them at the top; the Dataset class itself is not used)
+    -- driving the reference UNet (31 M parameters) with the reference's DiceLoss + CrossEntropyLoss criterion (train.py:455), the
+    tensor metrics of train.py:458-465 and torch.optim.Adam([dict(params=model.parameters(), lr=1e-3)]) (train.py:341) for two
+    epochs over a synthetic split (6 + 2 images of 64 x 64, bs 2).  Stored: the per-epoch log dictionaries train() returns (their
+    keys are the log-key contract), parameter norms after training.  The oracle loop is asserted equal first."""
+    import types
+    from oracle import losses as OL, unet as OU
+    for name in ("cv2", "albumentations"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    if not any(q.rstrip("/").endswith("Finetuning") for q in sys.path):
+        sys.path.insert(0, os.path.join(REF, "Finetuning"))
+    for clash in ("utils", "config", "dataset", "train"):
+        sys.modules.pop(clash, None)
+    import train as ref_train  # noqa
+    torch.manual_seed(0)
+    sd = OU.make_state_dict(base_ch=64, depth=5, seed=seed)
+    train_loader, valid_loader = OU.finetune_fixture_data(seed + 1)
+    model = ref.UNet()
+    model.load_state_dict({k: v.clone() for k, v in sd.items()})
+    mk = dict(activation="softmax", threshold=0.5, ignore_channels=[0])
+    loss = M.DiceLoss(**mk) + M.CrossEntropyLoss()
+    metrics = [M.DiceLoss(**mk), M.CrossEntropyLoss(), M.IoU(**mk), M.soft_cldice(**mk)]
+    opt = torch.optim.Adam([dict(params=model.parameters(), lr=1e-3)])
+    tr = ref_train.TrainEpoch(model, loss=loss, metrics=metrics, optimizer=opt, device="cpu", verbose=False)
+    va = ref_train.ValidEpoch(model, loss=loss, metrics=metrics, device="cpu", verbose=False)
+    tmp = tempfile.mkdtemp(prefix="ft_ref_")
+    tl, vl = ref_train.train(model, train_loader, valid_loader, tr, va, True, 2, name=os.path.join(tmp, "best_model.pth"))
+    assert os.path.exists(os.path.join(tmp, "best_model.pth"))
+    keys = sorted(tl[0])
+    assert keys == sorted(vl[0]) and "dice_loss + cross_entropy_loss" in keys
+    # ---- oracle loop == reference loop -------------------------------------------------------------------------------------
+    osd = OU.clone_sd(sd, requires_grad=True)
+    oopt = torch.optim.Adam([v for v in osd.values() if v.requires_grad], lr=1e-3)
+
+    def run(loader, training):
+        acc = {k: [] for k in ("dice_loss + cross_entropy_loss", "dice_loss", "cross_entropy_loss", "iou_loss")}
+        for x, y in loader:
+            if training:
+                oopt.zero_grad()
+                lo = OU.unet_forward(x, osd, training=True)
+                l = OL.dice_ce_loss(lo, y)
+                l.backward()
+                oopt.step()
+            else:
+                with torch.no_grad():
+                    lo = OU.unet_forward(x, osd, training=False)
+                    l = OL.dice_ce_loss(lo, y)
+            lo = lo.detach()
+            acc["dice_loss + cross_entropy_loss"].append(float(l)); acc["dice_loss"].append(float(OL.dice_loss(lo, y)))
+            acc["cross_entropy_loss"].append(float(OL.cross_entropy_prob(lo, y))); acc["iou_loss"].append(float(OL.iou_loss(lo, y)))
+        return {k: float(np.mean(v)) for k, v in acc.items()}
+    for ep in range(2):
+        ot, ov = run(train_loader, True), run(valid_loader, False)
+        for got, refl, what in ((ot, tl[ep], "train"), (ov, vl[ep], "valid")):
+            for k in got:
+                assert abs(got[k] - float(refl[k])) <= 2e-4 * max(1.0, abs(float(refl[k]))), (ep, what, k, got[k], float(refl[k]))
+    named = dict(model.named_parameters())
+    pk = sorted(named)
+    for k in pk:
+        d = (osd[k].detach() - named[k].detach()).norm().item()
+        assert d <= 2e-3 * max(named[k].detach().norm().item(), 1e-6) + 1e-6, (k, d)
+    save("finetune_ref", seed=np.array(seed), log_keys=np.array(keys),
+         train_logs=np.array([[float(tl[ep][k]) for k in keys] for ep in range(2)], dtype=np.float64),
+         valid_logs=np.array([[float(vl[ep][k]) for k in keys] for ep in range(2)], dtype=np.float64),
+         param_keys=np.array(pk), param_norms=torch.stack([named[k].detach().double().norm() for k in pk]),
+         conv_last_weight=named["conv_last.weight"].detach().clone())
+
 def gen_cldice(M):
     """soft_cldice of the reference (metrics.py:401-431, the driver's configuration train.py:464) on vessel-like masks."""
     from oracle import losses as OL
@@ -778,6 +848,9 @@ def main():
         return
     if "--only-cldice" in sys.argv:
         gen_cldice(M)
+        return
+    if "--only-finetune" in sys.argv:   # tests/golden/finetune_ref.npz alone (the reference's own TrainEpoch / ValidEpoch / train())
+        gen_finetune(ref, M)
         return
     if "--moco-worker" in sys.argv:     # (child of gen_moco_2rank)
         i = sys.argv.index("--moco-worker")

@@ -146,3 +146,18 @@ def clone_sd(sd, requires_grad=False):
             t.requires_grad_(True)
         out[k] = t
     return out
+
+
+def finetune_fixture_data(seed, n_train=6, n_valid=2, S=64, bs=2):
+    """Synthetic finetuning split behind tests/golden/finetune_ref.npz: z-scored random images and blob-like vessel masks
+    (one-hot (2,H,W) float64, as dataset.py:48 hands them over), batched as lists of (x (B,S,S) f32, y (B,2,S,S) f64)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(seed)
+    n = n_train + n_valid
+    x = torch.randn(n, S, S, generator=g)
+    blob = F.avg_pool2d(torch.randn(n, 1, S, S, generator=g), 7, 1, 3)[:, 0]
+    y1 = (blob > blob.flatten(1).quantile(0.8, dim=1).view(-1, 1, 1)).double()
+    y = torch.stack([1 - y1, y1], 1)
+    x = x + 0.8 * y1.float()                                   # (something to learn)
+    mk = lambda lo, hi: [(x[i:i + bs].clone(), y[i:i + bs].clone()) for i in range(lo, hi, bs)]
+    return mk(0, n_train), mk(n_train, n)

@@ -111,6 +111,50 @@ def test_finetune_unet_small_vs_oracle(golden_dir):
         assert torch.equal(net(x), net2.cuda()(x))
 
 
+def test_finetune_loop_vs_reference_loop_fixture(golden_dir):
+    """The drop-in Epoch classes and train() on the HIP path against the logs the REFERENCE's own TrainEpoch / ValidEpoch / train()
+    produced (tests/golden/finetune_ref.npz; reference UNet, DiceLoss + CrossEntropyLoss, the tensor metrics of train.py:458-465,
+    Adam lr 1e-3, two epochs on a synthetic 6 + 2 image split): the same log keys, every value within the trajectory bar."""
+    import os
+    import tempfile
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cmunet_amd import metrics as M, model as Mod, train as T
+    from oracle import unet as OU
+    d = np.load(f"{golden_dir}/finetune_ref.npz")
+    seed = int(d["seed"])
+    keys = [str(k) for k in d["log_keys"]]
+    train_loader, valid_loader = OU.finetune_fixture_data(seed + 1)
+    net = Mod.UNet(dtype="f32")
+    net.load_state_dict(OU.make_state_dict(base_ch=64, depth=5, seed=seed))
+    mk = dict(activation="softmax", threshold=0.5, ignore_channels=[0])
+    crit = M.DiceLoss(**mk) + M.CrossEntropyLoss()
+    mets = [M.DiceLoss(**mk), M.CrossEntropyLoss(), M.IoU(**mk), M.soft_cldice(**mk)]
+    opt = torch.optim.Adam([dict(params=net.parameters(), lr=1e-3)])
+    tr = T.TrainEpoch(net, loss=crit, metrics=mets, optimizer=opt, device="cuda", verbose=False)
+    va = T.ValidEpoch(net, loss=crit, metrics=mets, device="cuda", verbose=False)
+    with tempfile.TemporaryDirectory() as td:
+        tl, vl = T.train(net, train_loader, valid_loader, tr, va, True, 2, name=os.path.join(td, "best_model.pth"))
+        assert os.path.exists(os.path.join(td, "best_model.pth"))
+    for ep in range(2):
+        for logs, ref, what in ((tl[ep], d["train_logs"][ep], "train"), (vl[ep], d["valid_logs"][ep], "valid")):
+            assert sorted(logs) == keys, (sorted(logs), keys)
+            for k, b in zip(keys, ref):
+                print(f"[finetune vs reference loop] epoch {ep} {what} {k}: {float(logs[k]):.6f} vs reference {float(b):.6f} "
+                      f"(delta {abs(float(logs[k]) - float(b)):.2e})")
+                # (two training trajectories; soft-clDice compares skeletons of THRESHOLDED masks: a few flipped pixels move it most)
+                bar = 1e-2 if k == "soft_clDice" else 3e-3
+                assert abs(float(logs[k]) - float(b)) <= bar * max(1.0, abs(float(b))), (ep, what, k, float(logs[k]), float(b))
+    named = dict(net.named_parameters())
+    pk = [str(k) for k in d["param_keys"]]
+    norms = torch.stack([named[k].detach().double().norm().cpu() for k in pk])
+    ref = torch.from_numpy(d["param_norms"])
+    # (a conv bias in front of a training-mode BatchNorm has a zero gradient up to rounding noise, and Adam normalises noise to full
+    # steps of lr: those parameters random-walk on both sides)
+    live = torch.tensor([not k.endswith((".0.bias", ".3.bias")) for k in pk])
+    assert float(((norms - ref).abs() / ref.clamp_min(1e-9))[live].max()) <= 5e-3
+
+
 def test_soft_cldice_vs_reference_fixture(golden_dir):
     """Device soft-clDice (skeleton kernels + sums) against the value and the skeleton the reference's classes produced."""
     import numpy as np
