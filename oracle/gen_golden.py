@@ -729,6 +729,45 @@ def gen_finetune(ref, M, seed=6100):
          param_keys=np.array(pk), param_norms=torch.stack([named[k].detach().double().norm() for k in pk]),
          conv_last_weight=named["conv_last.weight"].detach().clone())
 
+
+def gen_load_model(seed=1):
+    """tests/golden/load_model_ref.npz: the reference's own load_model (Finetuning/train.py:240-308) run on synthetic checkpoints in
+    each of the five layouts it dispatches on -> for every key of UNet().state_dict(), whether the loaded model carries the
+    checkpoint's tensor.  (train.py imported as in gen_finetune; torch.load's hard-coded map_location="cuda:1" redirected to the CPU.)"""
+    import types
+    from oracle import unet as OU
+    for name in ("cv2", "albumentations"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    if not any(q.rstrip("/").endswith("Finetuning") for q in sys.path):
+        sys.path.insert(0, os.path.join(REF, "Finetuning"))
+    for clash in ("utils", "config", "dataset", "train"):
+        sys.modules.pop(clash, None)
+    import train as ref_train  # noqa
+    orig = torch.load
+    torch.load = lambda f, map_location=None, **k: orig(f, map_location="cpu", weights_only=False)
+    try:
+        sd = OU.make_state_dict(base_ch=64, depth=5, seed=seed)
+        cases = OU.checkpoint_layout_cases(sd)
+        tmp = tempfile.mkdtemp(prefix="lm_ref_")
+        keys = None
+        table = []
+        for name, ck in cases.items():
+            path = os.path.join(tmp, name)
+            torch.save(ck, path)
+            torch.manual_seed(123)
+            m = ref_train.load_model(types.SimpleNamespace(pretrained=path))
+            got = m.state_dict()
+            if keys is None:
+                keys = list(got.keys())
+            table.append([bool(torch.equal(got[k], sd[k])) if not k.endswith("num_batches_tracked") else True for k in keys])
+        m0 = ref_train.load_model(types.SimpleNamespace(pretrained=None))
+        assert sum(p.numel() for p in m0.parameters()) == 31042434
+    finally:
+        torch.load = orig
+    save("load_model_ref", seed=np.array(seed), layouts=np.array(list(cases.keys())), keys=np.array(keys), loaded=np.array(table, dtype=np.uint8))
+    for name, row in zip(cases, table):
+        print(f"    {name}: {sum(row)} of {len(row)} keys carry the checkpoint's tensor")
+
 def gen_cldice(M):
     """soft_cldice of the reference (metrics.py:401-431, the driver's configuration train.py:464) on vessel-like masks."""
     from oracle import losses as OL
@@ -848,6 +887,9 @@ def main():
         return
     if "--only-cldice" in sys.argv:
         gen_cldice(M)
+        return
+    if "--only-loadmodel" in sys.argv:  # tests/golden/load_model_ref.npz alone (the reference's own load_model on the five layouts)
+        gen_load_model()
         return
     if "--only-finetune" in sys.argv:   # tests/golden/finetune_ref.npz alone (the reference's own TrainEpoch / ValidEpoch / train())
         gen_finetune(ref, M)

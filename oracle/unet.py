@@ -161,3 +161,22 @@ def finetune_fixture_data(seed, n_train=6, n_valid=2, S=64, bs=2):
     x = x + 0.8 * y1.float()                                   # (something to learn)
     mk = lambda lo, hi: [(x[i:i + bs].clone(), y[i:i + bs].clone()) for i in range(lo, hi, bs)]
     return mk(0, n_train), mk(n_train, n)
+
+
+def checkpoint_layout_cases(sd):
+    """Synthetic checkpoints in the five foreign layouts load_model accepts (train.py:240-308), built from a full UNet state dict:
+    file name -> object for torch.save.  Used by gen_golden.py::gen_load_model (the reference's own load_model) and by the tests."""
+    enc = {k: v for k, v in sd.items() if "down_conv" in k or k.startswith("double_conv")}
+    dec = {k: v for k, v in sd.items() if "up_conv" in k or "conv_last" in k}
+    return {
+        "spark.pth": {"module": {**{"sparse_encoder.sp_cnn." + k: v for k, v in enc.items()}, **{"dense_decoder." + k: v for k, v in dec.items()},
+                                 "mask_tokens.0": torch.zeros(1)}, "epoch": 3},
+        "cmunet.pth": {"meta": {"mmengine_version": "0.10.5"},
+                       "state_dict": {**{"backbone." + k: v for k, v in enc.items()}, **{"pixel_decoder." + k: v for k, v in dec.items()},
+                                      **{"target_backbone." + k: v * 0 for k, v in enc.items()}}},
+        # (a raw encoder dict reaches the reference's "encoder only" branch only if it ALSO has a "meta" entry without
+        # mmengine_version: train.py:262 indexes checkpoint["meta"] before it gets there -- a plain dict raises KeyError('meta'))
+        "encoder.pth": {"meta": {}, **{"module." + k: v for k, v in enc.items()}},
+        "moco.ckpt": {"state_dict": {**{"encoder_q." + k: v for k, v in enc.items()}, "queue": torch.zeros(4, 4)}},
+        "genesis.pt": {"epoch": 1, "state_dict": {"module." + k: v for k, v in sd.items()}},
+    }

@@ -35,29 +35,26 @@ def test_segmentation_dataset_contract(tmp_path):
     assert it["img"].shape == it["img_t"].shape == (224, 224) and it["img"].dtype == np.float32   # cmunet_dataset.py:60-88
 
 
-def test_load_model_checkpoint_layouts(tmp_path):
-    """Synthetic checkpoints in each of the five foreign layouts -> the keys that must land in UNet()."""
+def test_load_model_checkpoint_layouts(tmp_path, golden_dir):
+    """Synthetic checkpoints in each of the five foreign layouts -> the keys that must land in UNet(): exactly the keys the
+    REFERENCE's own load_model loaded from the same files (tests/golden/load_model_ref.npz, oracle/gen_golden.py::gen_load_model)."""
     from cmunet_amd import train as T
-    sd = OU.make_state_dict(base_ch=64, depth=5, seed=1)
-    enc = {k: v for k, v in sd.items() if "down_conv" in k or k.startswith("double_conv")}
-    dec = {k: v for k, v in sd.items() if "up_conv" in k or "conv_last" in k}
-    cases = {
-        "spark.pth": {"module": {**{"sparse_encoder.sp_cnn." + k: v for k, v in enc.items()}, **{"dense_decoder." + k: v for k, v in dec.items()},
-                                 "mask_tokens.0": torch.zeros(1)}, "epoch": 3},
-        "cmunet.pth": {"meta": {"mmengine_version": "0.10.5"},
-                       "state_dict": {**{"backbone." + k: v for k, v in enc.items()}, **{"pixel_decoder." + k: v for k, v in dec.items()},
-                                      **{"target_backbone." + k: v * 0 for k, v in enc.items()}}},
-        "encoder.pth": {"module." + k: v for k, v in enc.items()},
-        "moco.ckpt": {"state_dict": {**{"encoder_q." + k: v for k, v in enc.items()}, "queue": torch.zeros(4, 4)}},
-        "genesis.pt": {"epoch": 1, "state_dict": {"module." + k: v for k, v in sd.items()}},
-    }
+    ref = np.load(f"{golden_dir}/load_model_ref.npz")
+    sd = OU.make_state_dict(base_ch=64, depth=5, seed=int(ref["seed"]))
+    cases = OU.checkpoint_layout_cases(sd)
+    assert list(cases) == [str(n) for n in ref["layouts"]]
+    keys = [str(k) for k in ref["keys"]]
     expect_decoder = {"spark.pth": True, "cmunet.pth": True, "encoder.pth": False, "moco.ckpt": False, "genesis.pt": True}
-    for name, ck in cases.items():
+    for row, (name, ck) in zip(ref["loaded"], cases.items()):
         path = str(tmp_path / name)
         torch.save(ck, path)
         args = T.get_args(["-p", path])
         m = T.load_model(args)
         got = m.state_dict()
+        assert list(got.keys()) == keys
+        mine = [bool(torch.equal(got[k], sd[k])) if not k.endswith("num_batches_tracked") else True for k in keys]
+        diff = [k for k, a, b in zip(keys, mine, row) if a != bool(b)]
+        assert not diff, (name, diff[:6])
         w_enc = "down_conv3.double_conv.double_conv.3.weight"
         w_dec = "up_conv2.double_conv.double_conv.0.weight"
         assert torch.equal(got[w_enc], sd[w_enc]), name
@@ -65,6 +62,12 @@ def test_load_model_checkpoint_layouts(tmp_path):
         assert not torch.equal(got["conv_last.weight"], sd["conv_last.weight"]), name      # head always dropped
         if name == "cmunet.pth":                                                            # target copy must not win
             assert got["down_conv1.double_conv.double_conv.0.weight"].abs().sum() > 0
+    # deviation, on purpose: a plain encoder state dict WITHOUT a "meta" entry makes the reference raise KeyError('meta')
+    # (train.py:262 indexes checkpoint["meta"] before its "encoder only" branch); here it loads as the encoder layout
+    plain = {"module." + k: v for k, v in sd.items() if "down_conv" in k or k.startswith("double_conv")}
+    torch.save(plain, str(tmp_path / "plain.pth"))
+    got = T.load_model(T.get_args(["-p", str(tmp_path / "plain.pth")])).state_dict()
+    assert torch.equal(got["down_conv3.double_conv.double_conv.3.weight"], sd["down_conv3.double_conv.double_conv.3.weight"])
     m = T.load_model(T.get_args([]))
     assert sum(p.numel() for p in m.parameters()) == 31042434
 
