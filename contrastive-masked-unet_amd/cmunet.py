@@ -284,11 +284,15 @@ class _BN1dFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, y, mean, invstd, weight = ctx.saved_tensors
         dy = dy.contiguous().float()
-        if not ctx.training:                    # eval mode: a fixed affine map
-            k = invstd if weight is None else invstd * weight
-            dz = dy * (y > 0) if ctx.relu else dy
-            return dz * k, None, None, None, None, None
         sums = None
+        if not ctx.training:
+            # eval mode: y = gamma * (x - running_mean) * invstd + beta is a fixed affine map -- the same kernel with zero batch sums:
+            # dx = gamma * invstd * dz, dgamma = sum dz * xhat, dbeta = sum dz (mean / invstd = the running statistics the forward
+            # stored).  (Found by the reference's two-rank head fixture: this branch used to read an unwritten invstd.)
+            sums = torch.zeros(2, x.shape[1], dtype=torch.float32, device=x.device)
+            dx, dg, db = ops.bn1d_relu_bwd(dy, x, y, mean, invstd, None if weight is None else weight.detach(), ctx.relu, sums, 1,
+                                           affine=weight is not None)
+            return dx, dg, db, None, None, None
         if ctx.world > 1:
             sums = ops.bn1d_bwd_colsums(dy, x, y, mean, invstd, ctx.relu)
             dist.all_reduce(sums)

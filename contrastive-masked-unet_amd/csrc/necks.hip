@@ -57,9 +57,10 @@ __global__ void bn1d_fwd_kernel(const float* __restrict__ x, const float* __rest
         count = (float)M;
     }
     const float invstd = 1.f / sqrtf(var + eps);
+    // (eval mode too: the backward of the fixed affine map needs the mean and 1/sqrt(running_var + eps) it was taken with)
+    if (save_mean) save_mean[n] = mean;
+    if (save_invstd) save_invstd[n] = invstd;
     if (training) {
-        if (save_mean) save_mean[n] = mean;
-        if (save_invstd) save_invstd[n] = invstd;
         if (running_mean) running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * mean;
         if (running_var) running_var[n] = (1.f - momentum) * running_var[n] + momentum * var * (count > 1.f ? count / (count - 1.f) : 1.f);
     }

@@ -428,8 +428,10 @@ int cmu_skinny16_gemm_wgrad(const float* dy, const float* x, float* dw, float* d
  *   cmu_bn1d_colsums      sums[2][N] = (sum x, sum x^2)                       -> all-reduce -> cmu_bn1d_relu_fwd(sums, count)
  *   cmu_bn1d_relu_fwd     y = [relu](gamma * (x - mean) * invstd + beta); sums == NULL: statistics of the M rows (two-pass
  *                         variance, as F.batch_norm), else mean = sums[0]/count, var = sums[1]/count - mean^2; training:
- *                         save_mean / save_invstd written, running statistics updated (unbiased variance, momentum);
- *                         training == 0: running statistics used.  gamma / beta nullable (affine=False).
+ *                         running statistics updated (unbiased variance, momentum); training == 0: running statistics used.
+ *                         save_mean / save_invstd (nullable) are written in both modes (eval: running_mean and
+ *                         1/sqrt(running_var + eps): what cmu_bn1d_relu_bwd needs for the fixed affine map, with zero sums).
+ *                         gamma / beta nullable (affine=False).
  *   cmu_bn1d_bwd_colsums  sums[2][N] = (sum dz, sum dz * xhat), dz = dy * [y > 0] when relu   -> all-reduce
  *   cmu_bn1d_relu_bwd     dx = gamma * invstd * (dz - S0/count - xhat * S1/count) with (S0, S1) = sums or, if NULL, the local
  *                         sums (count = M); dgamma / dbeta (nullable) = LOCAL sums (the gradient exchange averages them).   */

@@ -202,3 +202,14 @@ def cmunet_fixture_inputs(seed, B=4, S=224):
     rc = torch.nn.Conv2d(1024, 256, kernel_size=1)
     torch.set_rng_state(state)
     return img, img_t, mask, rc.weight.detach().clone(), rc.bias.detach().clone()
+
+
+def head_fixture_inputs(seed, B=4, H=32, W=48):
+    """(x, pred_pixel, mask, proj_s, proj_t) of one rank for tests/golden/cmunet_head_2rank.npz."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, H, W, generator=g) * 2 + 0.5
+    pred = torch.randn(B, H, W, generator=g)
+    mk = (torch.rand(B, H, W, generator=g) > 0.4).to(torch.uint8)
+    ps = torch.randn(B, 1, 256, generator=g)
+    pt = torch.randn(B, 1, 256, generator=g)
+    return x, pred, mk, ps, pt

@@ -768,6 +768,82 @@ def gen_load_model(seed=1):
     for name, row in zip(cases, table):
         print(f"    {name}: {sum(row)} of {len(row)} keys carry the checkpoint's tensor")
 
+
+def _cmunet_head_2rank_worker(rank, port, outdir, seed):
+    """One of two gloo ranks running the reference's own CMUNetPretrainHead.forward (cmunet_head.py:47-91): concat_all_gather of the
+    normalised target projections, labels arange(B) + B * rank.  The predictor's BatchNorm runs in eval mode (running statistics:
+    SyncBatchNorm and BatchNorm1d are the same function there, so the stand-in's norm layer changes nothing) -- what is pinned is
+    the head's own multi-rank arithmetic."""
+    import torch.distributed as dist
+    from oracle import cmunet as OC
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=2)
+    MODELS, model_cfg, _ = import_cmae()
+    sys.modules["mmengine.dist"].all_gather = lambda t: (lambda out: (dist.all_gather(out, t), out)[1])([torch.zeros_like(t) for _ in range(2)])
+    import importlib
+    importlib.import_module("cmae.models.heads.cmunet_head").all_gather = sys.modules["mmengine.dist"].all_gather
+    head = MODELS.build(model_cfg["head"])
+    hsd = OC.make_neck_sd("predictor.", 256, 1536, 256, seed)
+    g0 = torch.Generator().manual_seed(seed + 1)
+    hsd["predictor.bn0.running_mean"] = 0.1 * torch.randn(1536, generator=g0)
+    hsd["predictor.bn0.running_var"] = 0.5 + torch.rand(1536, generator=g0)
+    head.load_state_dict({k: v.clone() for k, v in hsd.items()}, strict=True)
+    head.train()
+    head.predictor.bn0.eval()
+    x, pred, mk, ps, pt = OC.head_fixture_inputs(seed + 10 * (rank + 1))
+    pred.requires_grad_(True); ps.requires_grad_(True)
+    out = head(x, pred, mk, ps, pt)
+    (out["loss_ct"] + out["loss_rc"]).backward()
+    torch.save({"loss_ct": out["loss_ct"].detach(), "loss_rc": out["loss_rc"].detach(), "dpred": pred.grad.clone(), "dproj_s": ps.grad.clone(),
+                "dfc1": head.predictor.fc1.weight.grad.clone()}, os.path.join(outdir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def gen_cmunet_head_2rank(seed=4300):
+    """tests/golden/cmunet_head_2rank.npz: the reference's own CMUNetPretrainHead on TWO gloo ranks, every rank its own tensors.
+    The oracle's head with the gather emulated (rank r sees the keys of both ranks, labels i + B*r) is asserted equal first."""
+    import socket
+    import subprocess
+    import torch.nn.functional as F
+    from oracle import cmunet as OC
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    outdir = tempfile.mkdtemp(prefix="head2rank_")
+    procs = [subprocess.Popen([sys.executable, "-m", "oracle.gen_golden", "--head-worker", str(r), str(port), outdir, str(seed)],
+                              cwd=os.path.dirname(os.path.dirname(OUT))) for r in range(2)]
+    try:
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    res = [torch.load(os.path.join(outdir, f"rank{r}.pt")) for r in range(2)]
+    hsd0 = OC.make_neck_sd("head.predictor.", 256, 1536, 256, seed)
+    g0 = torch.Generator().manual_seed(seed + 1)
+    hsd0["head.predictor.bn0.running_mean"] = 0.1 * torch.randn(1536, generator=g0)
+    hsd0["head.predictor.bn0.running_var"] = 0.5 + torch.rand(1536, generator=g0)
+    ins = [OC.head_fixture_inputs(seed + 10 * (r + 1)) for r in range(2)]
+    keys_all = torch.cat([F.normalize(ins[r][4].squeeze(1), dim=1, p=2) for r in range(2)])
+    for r in range(2):
+        x, pred, mk, ps, pt = ins[r]
+        hsd = {k: (v.clone().requires_grad_(v.is_floating_point() and "running" not in k)) for k, v in hsd0.items()}
+        po, pso = pred.clone().requires_grad_(True), ps.clone().requires_grad_(True)
+        # eval-mode BatchNorm in the predictor: training=False for the neck only
+        loss_rc = OC.masked_mse(po, x, mk)
+        pred_s = OC.nonlinear_neck(pso, hsd, "head.predictor.", training=False)
+        loss_ct = OC.infonce_inbatch(pred_s.squeeze(1), keys_all, 0.07, rank=r, ct_weight=1.0)
+        (loss_ct + loss_rc).backward()
+        close(loss_rc.detach(), res[r]["loss_rc"], what=f"2-rank head loss_rc (rank {r})")
+        close(loss_ct.detach(), res[r]["loss_ct"], tol=1e-4, what=f"2-rank head loss_ct (rank {r})")
+        close(po.grad, res[r]["dpred"], tol=1e-4, what="2-rank head dpred")
+        close(pso.grad, res[r]["dproj_s"], tol=2e-4, what="2-rank head dproj_s")
+        close(hsd["head.predictor.fc1.weight"].grad, res[r]["dfc1"], tol=2e-4, what="2-rank head dfc1")
+    save("cmunet_head_2rank", seed=np.array(seed), loss_ct=torch.stack([res[r]["loss_ct"] for r in range(2)]),
+         loss_rc=torch.stack([res[r]["loss_rc"] for r in range(2)]), dpred=torch.stack([res[r]["dpred"] for r in range(2)]),
+         dproj_s=torch.stack([res[r]["dproj_s"] for r in range(2)]), dfc1_norm=torch.stack([res[r]["dfc1"].double().norm() for r in range(2)]))
+
 def gen_cldice(M):
     """soft_cldice of the reference (metrics.py:401-431, the driver's configuration train.py:464) on vessel-like masks."""
     from oracle import losses as OL
@@ -893,6 +969,13 @@ def main():
         return
     if "--only-finetune" in sys.argv:   # tests/golden/finetune_ref.npz alone (the reference's own TrainEpoch / ValidEpoch / train())
         gen_finetune(ref, M)
+        return
+    if "--head-worker" in sys.argv:     # (child of gen_cmunet_head_2rank)
+        i = sys.argv.index("--head-worker")
+        _cmunet_head_2rank_worker(int(sys.argv[i + 1]), int(sys.argv[i + 2]), sys.argv[i + 3], int(sys.argv[i + 4]))
+        return
+    if "--only-head2" in sys.argv:      # tests/golden/cmunet_head_2rank.npz alone
+        gen_cmunet_head_2rank()
         return
     if "--moco-worker" in sys.argv:     # (child of gen_moco_2rank)
         i = sys.argv.index("--moco-worker")

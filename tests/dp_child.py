@@ -102,6 +102,27 @@ def main():
         torch.manual_seed(1234)
         _, _, k, _ = m(xq.to(dev), xk.to(dev), m.queue)
         res.update({"k": k.cpu(), "xk": xk})
+    elif mode == "head_ref2":
+        # the reference's own two-rank head run (tests/golden/cmunet_head_2rank.npz): predictor BatchNorm in eval mode
+        from cmunet_amd import cmunet as C
+        from oracle import cmunet as OC
+        seed = int(opts["seed"])
+        cfg = C.cmunet_config(img_size=32, dtype="f32")["head"]
+        head = C.build_model(cfg).to(dev)
+        hsd = OC.make_neck_sd("predictor.", 256, 1536, 256, seed)
+        g0 = torch.Generator().manual_seed(seed + 1)
+        hsd["predictor.bn0.running_mean"] = 0.1 * torch.randn(1536, generator=g0)
+        hsd["predictor.bn0.running_var"] = 0.5 + torch.rand(1536, generator=g0)
+        head.load_state_dict({k: v.clone() for k, v in hsd.items()}, strict=True)
+        head.train()
+        head.predictor.bn0.eval()
+        x, pred, mk, ps, pt = (t.to(dev) for t in OC.head_fixture_inputs(seed + 10 * (rank + 1)))
+        logits = torch.stack([torch.zeros_like(pred), pred], 1).contiguous().requires_grad_(True)
+        ps.requires_grad_(True)
+        hl = head(x, logits, mk, ps, pt)
+        (hl["loss_ct"] + hl["loss_rc"]).backward()
+        res = {"loss_ct": float(hl["loss_ct"].detach()), "loss_rc": float(hl["loss_rc"].detach()), "dpred": logits.grad[:, 1].cpu(), "dproj_s": ps.grad.cpu(),
+               "dfc1_norm": float(head.predictor.fc1.weight.grad.double().norm())}
     elif mode == "moco_ref2":
         # the reference's own two-rank run (tests/golden/moco_ref_2rank.npz): the same seeded state, every rank its own images,
         # rank 0's permutation from the global CPU generator seeded as the generator seeded it

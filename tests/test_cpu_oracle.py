@@ -425,3 +425,33 @@ def test_finetune_loop_oracle_vs_reference_fixture(golden_dir):
     # steps of lr: those parameters random-walk on both sides)
     live = torch.tensor([not k.endswith((".0.bias", ".3.bias")) for k in pk])
     assert ((norms - ref).abs() / ref.clamp_min(1e-9))[live].max().item() <= 2e-3
+
+
+def test_cmunet_head_two_rank_oracle_vs_reference_fixture(golden_dir):
+    """tests/golden/cmunet_head_2rank.npz: the REFERENCE's own CMUNetPretrainHead.forward on two gloo ranks (concat_all_gather of the
+    target projections, labels arange(B) + B * rank; predictor BatchNorm in eval mode).  The oracle's head with the gather emulated
+    reproduces every rank's losses and gradients."""
+    f = fx(golden_dir, "cmunet_head_2rank")
+    seed = int(f["seed"])
+    hsd0 = OC.make_neck_sd("head.predictor.", 256, 1536, 256, seed)
+    g0 = torch.Generator().manual_seed(seed + 1)
+    hsd0["head.predictor.bn0.running_mean"] = 0.1 * torch.randn(1536, generator=g0)
+    hsd0["head.predictor.bn0.running_var"] = 0.5 + torch.rand(1536, generator=g0)
+    ins = [OC.head_fixture_inputs(seed + 10 * (r + 1)) for r in range(2)]
+    keys_all = torch.cat([F.normalize(ins[r][4].squeeze(1), dim=1, p=2) for r in range(2)])
+    for r in range(2):
+        x, pred, mk, ps, pt = ins[r]
+        hsd = {k: (v.clone().requires_grad_(v.is_floating_point() and "running" not in k)) for k, v in hsd0.items()}
+        po, pso = pred.clone().requires_grad_(True), ps.clone().requires_grad_(True)
+        loss_rc = OC.masked_mse(po, x, mk)
+        loss_ct = OC.infonce_inbatch(OC.nonlinear_neck(pso, hsd, "head.predictor.", training=False).squeeze(1), keys_all, 0.07, rank=r)
+        (loss_ct + loss_rc).backward()
+        assert abs(float(loss_rc) - float(f["loss_rc"][r])) <= 2e-5 * max(1.0, abs(float(f["loss_rc"][r])))
+        assert abs(float(loss_ct) - float(f["loss_ct"][r])) <= 1e-4 * max(1.0, abs(float(f["loss_ct"][r])))
+        assert close(po.grad, f["dpred"][r], 1e-4) and close(pso.grad, f["dproj_s"][r], 2e-4)
+        assert abs(float(hsd["head.predictor.fc1.weight"].grad.double().norm()) - float(f["dfc1_norm"][r])) <= 2e-4 * float(f["dfc1_norm"][r])
+    # the label offset matters: with rank 0's labels on rank 1 the loss is another one
+    x, pred, mk, ps, pt = ins[1]
+    hsd = {k: v.clone() for k, v in hsd0.items()}
+    wrong = OC.infonce_inbatch(OC.nonlinear_neck(ps, hsd, "head.predictor.", training=False).squeeze(1), keys_all, 0.07, rank=0)
+    assert abs(float(wrong) - float(f["loss_ct"][1])) > 1e-3

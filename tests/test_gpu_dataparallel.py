@@ -234,6 +234,21 @@ def test_moco_shuffle_bn_two_ranks_vs_oracle(cuda):
     assert rel(two[0]["k"], plain) > 1e-3
 
 
+def test_cmunet_head_two_ranks_vs_reference_two_rank_fixture(cuda):
+    """Two ranks of the HIP CMUNetPretrainHead against what the REFERENCE's own head produced on two gloo ranks
+    (tests/golden/cmunet_head_2rank.npz): gathered target projections, labels arange(B) + B * rank, per-rank losses and gradients."""
+    f = np.load(os.path.join(HERE, "golden", "cmunet_head_2rank.npz"))
+    two = run_ranks("head_ref2", 2, seed=int(f["seed"]))
+    for rk in range(2):
+        r = two[rk]
+        assert abs(r["loss_rc"] - float(f["loss_rc"][rk])) <= 2e-5 * max(1.0, abs(float(f["loss_rc"][rk])))
+        assert abs(r["loss_ct"] - float(f["loss_ct"][rk])) <= 2e-4 * max(1.0, abs(float(f["loss_ct"][rk]))), (rk, r["loss_ct"], float(f["loss_ct"][rk]))
+        assert rel(r["dpred"], torch.from_numpy(f["dpred"][rk])) <= 1e-4
+        assert rel(r["dproj_s"], torch.from_numpy(f["dproj_s"][rk])) <= 1e-3
+        assert abs(r["dfc1_norm"] - float(f["dfc1_norm"][rk])) <= 1e-3 * float(f["dfc1_norm"][rk])
+    assert abs(two[0]["loss_ct"] - two[1]["loss_ct"]) > 1e-4
+
+
 def test_moco_two_ranks_vs_reference_two_rank_fixture(cuda):
     """Two ranks of the HIP Moco_v2 against what the REFERENCE's own Moco_v2 produced on two gloo ranks
     (tests/golden/moco_ref_2rank.npz, oracle/gen_golden.py::gen_moco_2rank): shuffle-BN with rank 0's broadcast permutation, keys

@@ -151,6 +151,39 @@ def test_cmunet_joint_step_vs_reference_fixture(cuda, golden_dir):
     assert rel(ps.grad, torch.from_numpy(f["head.dproj_s"])) <= 1e-3
 
 
+def test_nonlinear_neck_eval_mode_gradients(cuda):
+    """NonLinearNeck with its BatchNorm in eval mode (running statistics: a fixed affine map): output, input gradient and the
+    gradients of fc / norm parameters against torch autograd of the same functions (nonlinear_neck.py:88-102).  (The eval-mode
+    backward once read an unwritten invstd -- found by the reference's two-rank head fixture.)"""
+    from cmunet_amd import cmunet as C
+    g = torch.Generator().manual_seed(12)
+    neck = C.NonLinearNeck(in_channels=96, hid_channels=128, out_channels=32, num_layers=2, with_bias=True, with_last_bn=False,
+                           with_avg_pool=False).to(cuda)
+    with torch.no_grad():
+        neck.bn0.running_mean.copy_(0.2 * torch.randn(128, generator=g)); neck.bn0.running_var.copy_(0.5 + torch.rand(128, generator=g))
+        neck.bn0.weight.copy_(1 + 0.2 * torch.randn(128, generator=g)); neck.bn0.bias.copy_(0.1 * torch.randn(128, generator=g))
+    neck.train()
+    neck.bn0.eval()
+    x = torch.randn(6, 1, 96, generator=g)
+    go = torch.randn(6, 1, 32, generator=g)
+    xg = x.to(cuda).requires_grad_(True)
+    y = neck(xg)
+    (y * go.to(cuda)).sum().backward()
+    # torch reference on the CPU
+    import torch.nn.functional as F
+    p = {k: v.detach().cpu().double().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in neck.state_dict().items()}
+    xr = x.double().requires_grad_(True)
+    h = F.linear(xr[:, 0, :], p["fc0.weight"], p["fc0.bias"])
+    h = F.batch_norm(h, p["bn0.running_mean"], p["bn0.running_var"], p["bn0.weight"], p["bn0.bias"], False, 0.1, 1e-6)
+    yr = F.linear(F.relu(h), p["fc1.weight"]).unsqueeze(1)
+    (yr * go.double()).sum().backward()
+    assert rel(y, yr) <= 1e-5 and rel(xg.grad, xr.grad) <= 1e-4
+    named = dict(neck.named_parameters())
+    for k in ("fc0.weight", "fc0.bias", "bn0.weight", "bn0.bias", "fc1.weight"):
+        assert rel(named[k].grad, p[k].grad) <= 2e-4, k
+    assert int(neck.bn0.num_batches_tracked) == 0                       # eval mode: buffers untouched
+
+
 def test_cmunet_modules_standalone(cuda):
     """UNet_encoder / MUNetPretrainDecoder used on their own keep the reference's tensor contract."""
     from cmunet_amd import cmunet as C
