@@ -200,6 +200,15 @@ class FusedLAMB:
         for p in self.flat.params.values():
             p.grad = None
 
+    def set_lr_wd(self, lr, weight_decay=None):
+        """Learning rate and weight decay of the next step (the reference anneals both every iteration, lr_control.py:11-29: the
+        decayed tensors get ``weight_decay``, the no-decay group stays at 0 -- its weight_decay_scale)."""
+        self.lr = float(lr)
+        if weight_decay is not None:
+            if not hasattr(self, "_wd_mask"):
+                self._wd_mask = (self.tables[4] != 0).to(torch.float32)
+            self.tables = self.tables[:4] + (self._wd_mask * float(weight_decay),)
+
     @property
     def global_grad_norm(self):
         """The reference exposes this for logging (lamb.py:91); reading it synchronises."""

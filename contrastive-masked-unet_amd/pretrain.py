@@ -264,6 +264,13 @@ class MocoPretrainer(ArenaTrainer):
         assert a is not None and b is not None and a[1] - a[0] == b[1] - b[0]
         model._ema_arenas = (self.kflat.arena[b[0]:b[1]], self.flat.arena[a[0]:a[1]])     # used by _momentum_update_key_encoder
 
+    def set_epoch(self, epoch, max_epochs):
+        """moco2_module.py:345-348: the cosine learning rate of ``epoch`` (0-based: CosineAnnealingLR after ``epoch`` scheduler steps)."""
+        if not hasattr(self, "_base_lr"):
+            self._base_lr = self.opt.lr
+        self.opt.lr = moco_cosine_lr(self._base_lr, epoch, max_epochs)
+        return self.opt.lr
+
     def step(self, img_q, img_k):
         loss = self.model.training_step((img_q, img_k))
         self.backward_and_step(loss)
@@ -283,6 +290,12 @@ class SparKPretrainer(ArenaTrainer):
                         decay_filter=lambda n, p: not (p.dim() == 1 or n.endswith(".bias") or any(k in n for k in nowd)))
         super().__init__(model, opt, process_group)
 
+    def anneal(self, peak_lr, wd, wd_end, cur_it, wp_it, max_it):
+        """main.py:192: set this iteration's learning rate and weight decay (``spark_lr_wd``); returns them."""
+        lr, cur_wd = spark_lr_wd(peak_lr, wd, wd_end, cur_it, wp_it, max_it)
+        self.opt.set_lr_wd(lr, cur_wd)
+        return lr, cur_wd
+
     def step(self, inp_bchw, active_b1ff=None, loss_scale=1.0):
         """``loss_scale``: static scale applied to the loss gradient INSIDE the fused step (the activations' gradients are
         stored in the model's dtype) and divided out again by the optimiser kernel."""
@@ -293,6 +306,23 @@ class SparKPretrainer(ArenaTrainer):
         finally:
             self.model.grad_scale = 1.0
         return loss.detach()
+
+
+def spark_lr_wd(peak_lr, wd, wd_end, cur_it, wp_it, max_it):
+    """SparK's per-iteration schedule (Spark/utils/lr_control.py:11-22, called at main.py:192 with cur_it = it + ep * iters,
+    wp_it = wp_ep * iters, max_it = ep * iters): linear warm-up from 0.5 % of the peak learning rate, then a cosine to 0.1 % of it;
+    the weight decay follows a cosine from ``wd`` to ``wd_end`` over the whole run.  Returns (lr, weight_decay)."""
+    wp_it = round(wp_it)
+    if cur_it < wp_it:
+        lr = peak_lr * (0.005 + 0.995 * cur_it / wp_it)
+    else:
+        lr = peak_lr * (0.001 + 0.999 * 0.5 * (1.0 + math.cos(math.pi * (cur_it - wp_it) / (max_it - 1 - wp_it))))
+    return lr, wd_end + (wd - wd_end) * 0.5 * (1.0 + math.cos(math.pi * cur_it / (max_it - 1)))
+
+
+def moco_cosine_lr(base_lr, epoch, max_epochs, eta_min=0.0):
+    """MoCo's schedule (moco2_module.py:345-348: CosineAnnealingLR(optimizer, trainer.max_epochs), stepped once per epoch)."""
+    return eta_min + (base_lr - eta_min) * 0.5 * (1.0 + math.cos(math.pi * epoch / max_epochs))
 
 
 def cosine_warmup_lr(base_lr, it, warmup_iters, total_iters, start_factor=1e-4):

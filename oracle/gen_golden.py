@@ -912,6 +912,58 @@ def gen_optim():
                 close(om[i], ps[i].detach(), tol=2e-6, what=f"sgd {tag} step {k} tensor {i}")
         for i, prm in enumerate(ps):
             out[f"sgd_{tag}.{i}"] = prm.detach().clone()
+    # ---- SparK's per-iteration lr / weight-decay annealing: the reference's own lr_wd_annealing + get_param_groups
+    # (Spark/utils/lr_control.py, pure Python) driving the reference's LAMB class over four steps (main.py:107-140,192) -----------
+    spec2 = importlib.util.spec_from_file_location("ref_lr_control", os.path.join(REF, "Pretraining", "Spark", "utils", "lr_control.py"))
+    ref_lrc = importlib.util.module_from_spec(spec2)
+    spec2.loader.exec_module(ref_lrc)
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w0 = torch.nn.Parameter(p0[0].clone()); self.b0 = torch.nn.Parameter(p0[1].clone())
+            self.w2 = torch.nn.Parameter(p0[2].clone().view(50, 100)); self.mask_token = torch.nn.Parameter(p0[3].clone())
+    hold = Holder()
+    import contextlib
+    import io as _io
+    with contextlib.redirect_stdout(_io.StringIO()):
+        groups = ref_lrc.get_param_groups(hold, nowd_keys={"cls_token", "pos_embed", "mask_token", "gamma"})
+    wd_scales = {id(q): gr["weight_decay_scale"] for gr in groups for q in gr["params"]}
+    sched_scales = [wd_scales[id(q)] for q in (hold.w0, hold.b0, hold.w2, hold.mask_token)]
+    assert sched_scales == [1.0, 0.0, 1.0, 0.0]           # 1-D tensors, biases and nowd keys: no decay (lr_control.py:39)
+    opt = ref_lamb.TheSameAsTimmLAMB(groups, lr=2e-2, weight_decay=0.0, betas=(0.9, 0.95), max_grad_norm=5.0)
+    peak, wd, wde, wp_it, max_it = 2e-2, 0.04, 0.2, 2, 9
+    its = (0, 1, 2, 5)
+    sched = []
+    om = [t.clone() for t in p0]
+    ms, vs = [torch.zeros_like(t) for t in p0], [torch.zeros_like(t) for t in p0]
+    from cmunet_amd.pretrain import spark_lr_wd            # (host arithmetic of the product: asserted equal to the reference's here)
+    for k, it in enumerate(its):
+        mn_lr, mx_lr, mn_wd, mx_wd = ref_lrc.lr_wd_annealing(opt, peak, wd, wde, it, wp_it, max_it)
+        sched.append((it, mx_lr, mx_wd))
+        lr_p, wd_p = spark_lr_wd(peak, wd, wde, it, wp_it, max_it)
+        assert abs(lr_p - mx_lr) < 1e-15 and abs(wd_p - mx_wd) < 1e-15 and mn_wd == 0.0
+        gk = grads[k % 3]
+        for prm, gr in zip((hold.w0, hold.b0, hold.w2, hold.mask_token), gk):
+            prm.grad = gr.clone().view_as(prm)
+        opt.step()
+        OO.lamb_step(om, gk, ms, vs, mx_lr, [mx_wd * sc for sc in sched_scales], betas=(0.9, 0.95), eps=1e-6, max_grad_norm=5.0, step=k + 1)
+        for i, prm in enumerate((hold.w0, hold.b0, hold.w2, hold.mask_token)):
+            close(om[i], prm.detach().view_as(om[i]), tol=2e-6, what=f"lamb annealed step {k} tensor {i}")
+    out["sched_args"] = np.array([peak, wd, wde, wp_it, max_it], dtype=np.float64)
+    out["sched"] = np.array(sched, dtype=np.float64)
+    out["sched_wd_scale"] = np.array(sched_scales)
+    for i, prm in enumerate((hold.w0, hold.b0, hold.w2, hold.mask_token)):
+        out[f"lamb_sched.{i}"] = prm.detach().clone().view_as(p0[i])
+    # a table of the schedule itself over a whole run (lr_control.py:11-22)
+    tab = []
+    for (pk, w0_, w1_, wp, mx) in ((2e-4, 0.04, 0.2, 40.0, 1600), (1.0, 0.05, 0.05, 0.6, 11), (3e-3, 0.1, 0.0, 0, 5)):
+        dummy = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.1)
+        for it in sorted({0, 1, round(wp), round(wp) + 1, mx // 2, mx - 2, mx - 1}):
+            if 0 <= it < mx:
+                _, lr_, _, wd_ = ref_lrc.lr_wd_annealing(dummy, pk, w0_, w1_, it, wp, mx)
+                tab.append((pk, w0_, w1_, wp, mx, it, lr_, wd_))
+    out["sched_table"] = np.array(tab, dtype=np.float64)
     save("optim_traces", **out)
 
 

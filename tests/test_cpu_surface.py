@@ -125,3 +125,22 @@ def test_loss_algebra_names(golden_dir):
         M.CrossEntropyLoss() + 3
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         crit(torch.zeros(1, 2, 4, 4), torch.zeros(1, 2, 4, 4, dtype=torch.float64))
+
+
+def test_lr_schedules_vs_reference(golden_dir):
+    """SparK's per-iteration learning-rate / weight-decay annealing against a table the REFERENCE's own lr_wd_annealing produced
+    (Spark/utils/lr_control.py:11-29, tests/golden/optim_traces.npz), and MoCo's cosine learning rate against
+    torch.optim.lr_scheduler.CosineAnnealingLR as moco2_module.py:345-348 configures it."""
+    from cmunet_amd.pretrain import moco_cosine_lr, spark_lr_wd
+    d = np.load(f"{golden_dir}/optim_traces.npz")
+    for pk, wd, wde, wp, mx, it, lr, cur_wd in d["sched_table"]:
+        got = spark_lr_wd(float(pk), float(wd), float(wde), int(it), float(wp), int(mx))
+        assert abs(got[0] - lr) <= 1e-15 + 1e-12 * abs(lr) and abs(got[1] - cur_wd) <= 1e-15 + 1e-12 * abs(cur_wd), (pk, wp, mx, it)
+    assert len(d["sched_table"]) >= 15
+    prm = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([prm], lr=0.03, momentum=0.9, weight_decay=1e-4)
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, 7)
+    for ep in range(8):
+        assert abs(moco_cosine_lr(0.03, ep, 7) - opt.param_groups[0]["lr"]) < 1e-12, ep
+        opt.step()
+        sch.step()

@@ -558,6 +558,22 @@ def test_fused_sgd_and_lamb_vs_reference_traces(golden_dir):
         for i, name in enumerate(flat.names):
             check(flat.views[name].cpu().flatten(), torch.from_numpy(d[f"lamb_{tag}.{i}"]).flatten(), 2e-5, f"lamb {tag} tensor {i}")
         assert opt.global_grad_norm > 0
+    # SparK's annealed run: learning rate and weight decay set per iteration (FusedLAMB.set_lr_wd) to what the reference's own
+    # lr_wd_annealing handed its LAMB class; tensors 1 and 3 are the no-decay group of the reference's get_param_groups
+    scales = [float(v) for v in d["sched_wd_scale"]]
+    flat = FlatParams(Holder().cuda())
+    opt = FusedLAMB(flat, lr=1.0, betas=(0.9, 0.95), eps=1e-6, weight_decay=1.0, max_grad_norm=5.0,
+                    decay_filter=lambda name, prm: scales[int(name.split(".")[-1])] != 0.0)
+    from cmunet_amd.pretrain import spark_lr_wd
+    pk, wd0, wde, wp_it, max_it = (float(v) for v in d["sched_args"])
+    for k, (it, lr, cur_wd) in enumerate(d["sched"]):
+        got = spark_lr_wd(pk, wd0, wde, int(it), wp_it, int(max_it))
+        assert abs(got[0] - lr) < 1e-15 and abs(got[1] - cur_wd) < 1e-15
+        opt.set_lr_wd(*got)
+        load_grads(flat, k % 3)
+        opt.step()
+    for i, name in enumerate(flat.names):
+        check(flat.views[name].cpu().flatten(), torch.from_numpy(d[f"lamb_sched.{i}"]).flatten(), 2e-5, f"annealed lamb tensor {i}")
     for tag, kw in (("a", dict(momentum=0.9, weight_decay=1e-4)), ("b", dict(momentum=0.9, weight_decay=1e-2, nesterov=True)),
                     ("c", dict(momentum=0.0, weight_decay=0.0))):
         flat = FlatParams(Holder().cuda())
