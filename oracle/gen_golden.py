@@ -416,6 +416,38 @@ def gen_cmunet(seed=4100):
            "head.loss_ct": hl["loss_ct"].detach(), "head.loss_rc": hl["loss_rc"].detach(), "head.dpred": pred.grad, "head.dproj_s": ps.grad}
     out.update(spot_grads)
     out.update({"after." + k: v for k, v in after_bn.items()})
+    # ---- the patch mask generator over more geometries (UNet_encoder.py:106-139; the encoder object only carries patch_size / ratio) ----
+    mcases = [(3, 224, 0.65), (2, 256, 0.6), (2, 512, 0.75), (2, 512, 0.6), (1, 64, 0.0), (2, 64, 1.0), (3, 96, 0.33), (2, 128, 0.999)]
+    enc = model.backbone
+    for ci, (mb, ms_, mr) in enumerate(mcases):
+        enc.mask_ratio = mr
+        np.random.seed(seed + 300 + ci)
+        mref = enc.create_random_patch_mask(mb, ms_)
+        np.random.seed(seed + 300 + ci)
+        assert np.array_equal(OC.create_random_patch_mask(mb, ms_, 16, mr), mref), (mb, ms_, mr)
+        assert np.array_equal(np.repeat(np.repeat(mref[:, ::16, ::16], 16, 1), 16, 2), mref)
+        out[f"mask{ci}"] = mref[:, ::16, ::16].copy()
+    enc.mask_ratio = 0.65
+    out["mask_cases"] = np.array(mcases, dtype=np.float64)
+    # ---- the head with other hyper-parameters (cmunet_head.py:39-44: temperature, ct_weight, rc_weight) ------------------------------
+    import copy
+    head2 = copy.deepcopy(model.head)
+    head2.load_state_dict({k[len("head."):]: v.clone() for k, v in sd.items() if k.startswith("head.")})
+    head2.t, head2.ct_weight, head2.rc_weight = 0.2, 0.5, 2.0
+    head2.train()
+    pred2, ps2 = out["head.pred"].clone().requires_grad_(True), out["head.proj_s"].clone().requires_grad_(True)
+    hl2 = head2(out["head.x"], pred2, out["head.mask"], ps2, out["head.proj_t"])
+    (hl2["loss_ct"] + hl2["loss_rc"]).backward()
+    hsd2 = {k: (v.clone().requires_grad_(v.is_floating_point() and "running" not in k)) for k, v in sd.items() if k.startswith("head.")}
+    po2, pso2 = out["head.pred"].clone().requires_grad_(True), out["head.proj_s"].clone().requires_grad_(True)
+    oh2 = OC.head(out["head.x"], po2, out["head.mask"], pso2, out["head.proj_t"], hsd2, "head.", 0.2, 0.5, 2.0)
+    (oh2["loss_ct"] + oh2["loss_rc"]).backward()
+    close(oh2["loss_rc"].detach(), hl2["loss_rc"].detach(), what="head2 loss_rc")
+    close(oh2["loss_ct"].detach(), hl2["loss_ct"].detach(), tol=1e-4, what="head2 loss_ct")
+    close(po2.grad, pred2.grad, tol=1e-4, what="head2 dpred")
+    close(pso2.grad, ps2.grad, tol=2e-4, what="head2 dproj_s")
+    out.update({"head2.hyper": np.array([0.2, 0.5, 2.0]), "head2.loss_ct": hl2["loss_ct"].detach(), "head2.loss_rc": hl2["loss_rc"].detach(),
+                "head2.dpred": pred2.grad, "head2.dproj_s": ps2.grad})
     save("cmunet_ref", **out)
 
 

@@ -307,6 +307,22 @@ def test_cmunet_oracle_vs_reference_fixture(golden_dir):
     # MomentumUpdateHook's schedule (momentum_update_hook.py:29-40)
     for (it, mx, base, end), m in zip(f["hook_cases"].numpy(), f["hook_momentum"].numpy()):
         assert abs(OC.momentum_schedule(int(it), int(mx), float(base), float(end)) - float(m)) < 1e-12
+    # the patch mask over more geometries and ratios (incl. 0 and 1), oracle and the product's vectorised host generator
+    from cmunet_amd.pretrain import create_random_patch_mask as product_mask
+    for ci, (mb, ms_, mr) in enumerate(f["mask_cases"].numpy()):
+        mb, ms_ = int(mb), int(ms_)
+        want = np.repeat(np.repeat(f[f"mask{ci}"].numpy(), 16, 1), 16, 2)
+        assert np.array_equal(OC.create_random_patch_mask(mb, ms_, 16, float(mr), np.random.RandomState(seed + 300 + ci)), want), ci
+        assert np.array_equal(product_mask(mb, ms_, 16, float(mr), np.random.RandomState(seed + 300 + ci)), want), ci
+    # the head with other hyper-parameters (temperature 0.2, ct_weight 0.5, rc_weight 2)
+    t2, cw2, rw2 = (float(v) for v in f["head2.hyper"])
+    hsd2 = {k: (v.clone().requires_grad_(v.is_floating_point() and "running" not in k)) for k, v in sd.items() if k.startswith("head.")}
+    p2, s2 = f["head.pred"].clone().requires_grad_(True), f["head.proj_s"].clone().requires_grad_(True)
+    h2 = OC.head(f["head.x"], p2, f["head.mask"], s2, f["head.proj_t"], hsd2, "head.", t2, cw2, rw2)
+    (h2["loss_ct"] + h2["loss_rc"]).backward()
+    assert abs(float(h2["loss_rc"]) - float(f["head2.loss_rc"])) <= 2e-5 * max(1.0, abs(float(f["head2.loss_rc"])))
+    assert abs(float(h2["loss_ct"]) - float(f["head2.loss_ct"])) <= 1e-4 * max(1.0, abs(float(f["head2.loss_ct"])))
+    assert close(p2.grad, f["head2.dpred"], 1e-4) and close(s2.grad, f["head2.dproj_s"], 2e-4)
     # the head alone (cmunet_head.py:47-91)
     hsd = {k: (v.clone().requires_grad_(v.is_floating_point() and "running" not in k)) for k, v in sd.items() if k.startswith("head.")}
     pred, ps = f["head.pred"].clone().requires_grad_(True), f["head.proj_s"].clone().requires_grad_(True)

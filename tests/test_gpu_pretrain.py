@@ -149,6 +149,18 @@ def test_cmunet_joint_step_vs_reference_fixture(cuda, golden_dir):
     assert abs(float(hl["loss_ct"]) - float(f["head.loss_ct"])) <= 1e-4 * max(1.0, abs(float(f["head.loss_ct"])))
     assert rel(logits.grad[:, 1], torch.from_numpy(f["head.dpred"])) <= 1e-4 and float(logits.grad[:, 0].abs().max()) == 0.0
     assert rel(ps.grad, torch.from_numpy(f["head.dproj_s"])) <= 1e-3
+    # ... and with other hyper-parameters (temperature 0.2, ct_weight 0.5, rc_weight 2), as the reference's head computed them
+    t2, cw2, rw2 = (float(v) for v in f["head2.hyper"])
+    cfg2 = C.cmunet_config(img_size=S, dtype="f32", temperature=t2, ct_weight=cw2, rc_weight=rw2)["head"]
+    head2 = C.build_model(cfg2).to(cuda).train()
+    head2.load_state_dict({k[len("head."):]: v.clone() for k, v in sd.items() if k.startswith("head.")}, strict=True)
+    lg2 = torch.stack([torch.zeros_like(pred), pred], 1).contiguous().requires_grad_(True)
+    ps2 = torch.from_numpy(f["head.proj_s"]).to(cuda).requires_grad_(True)
+    h2 = head2(x, lg2, mk, ps2, torch.from_numpy(f["head.proj_t"]).to(cuda))
+    (h2["loss_ct"] + h2["loss_rc"]).backward()
+    assert abs(float(h2["loss_rc"]) - float(f["head2.loss_rc"])) <= 2e-5 * max(1.0, abs(float(f["head2.loss_rc"])))
+    assert abs(float(h2["loss_ct"]) - float(f["head2.loss_ct"])) <= 1e-4 * max(1.0, abs(float(f["head2.loss_ct"])))
+    assert rel(lg2.grad[:, 1], torch.from_numpy(f["head2.dpred"])) <= 1e-4 and rel(ps2.grad, torch.from_numpy(f["head2.dproj_s"])) <= 1e-3
 
 
 def test_nonlinear_neck_eval_mode_gradients(cuda):
