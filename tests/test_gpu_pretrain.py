@@ -268,6 +268,41 @@ def test_moco_step_vs_oracle(cuda):
     assert rel(pq[kname].grad, osd2[kname].grad) <= 5e-3
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_cmunet_joint_step_16bit_vs_reference_fixture(cuda, golden_dir, dt):
+    """The AMP arithmetic (16-bit storage / MFMA operands incl. the 16-bit-operand projector GEMMs, fp32 accumulation) of the joint
+    step at the reference's shipped 224 x 224 geometry against the reference's own fp32 CM_UNet (tests/golden/cmunet_ref.npz): the two
+    losses and the gradient norms of all trainable tensors, with the bars of 16-bit storage."""
+    from cmunet_amd import cmunet as C
+    from oracle import cmunet as OC
+    f = np.load(f"{golden_dir}/cmunet_ref.npz")
+    seed, B, S = int(f["seed"]), int(f["B"]), int(f["S"])
+    img, img_t, mask, rw, rb = OC.cmunet_fixture_inputs(seed, B, S)
+    model = C.build_model(C.cmunet_config(img_size=S, dtype=dt)).to(cuda).train()
+    model.load_state_dict({k: v.clone() for k, v in OC.make_cmunet_sd(seed, S).items()}, strict=True)
+    losses = model(img.to(cuda), mode='loss', img_t=img_t.to(cuda), mask=torch.from_numpy(mask).to(cuda), reduce_w=rw.to(cuda), reduce_b=rb.to(cuda))
+    # (f16: a static loss scale, as AMP training uses one -- the masked-MSE gradient per pixel is ~1e-5 here, below f16's normals)
+    scale = 4096.0 if dt == "f16" else 1.0
+    ((losses['loss_ct'] + losses['loss_rc']) * scale).backward()
+    e_rc = abs(float(losses['loss_rc'].detach()) - float(f["loss_rc"])) / abs(float(f["loss_rc"]))
+    e_ct = abs(float(losses['loss_ct'].detach()) - float(f["loss_ct"])) / abs(float(f["loss_ct"]))
+    trainable = [str(k) for k in f["trainable"]]
+    named = dict(model.named_parameters())
+    ref = torch.from_numpy(f["grad_norms"]).double()
+    got = torch.stack([named[k].grad.double().norm().cpu() for k in trainable]) / scale
+    noise = torch.tensor([k.endswith((".0.bias", ".3.bias", "fc0.bias")) or k == "feature_decoder.conv_last.bias" for k in trainable])
+    relerr = ((got - ref).abs() / ref.clamp_min(1e-30))[~noise]
+    worst = sorted(zip(relerr.tolist(), [k for k, n in zip(trainable, noise) if not n]))[-3:]
+    print("  worst:", [(f"{e:.2e}", k) for e, k in worst])
+    print(f"CM_UNet {dt} vs the reference's fp32 run: loss_rc {e_rc:.2e}, loss_ct {e_ct:.2e} relative; gradient norms worst {float(relerr.max()):.2e}, "
+          f"median {float(relerr.median()):.2e}")
+    # measured: f16 loss_rc 1e-5, loss_ct 5e-3, gradient norms median 7e-3; bf16 (8 significand bits against 11) 1e-4, 2.5e-2, 9e-2 --
+    # the contrastive gradient goes through a BatchNorm over bs 4 rows and a softmax at temperature 0.07, which amplify operand rounding
+    bar_l, bar_g, bar_m = (5e-3, 1e-1, 2e-2) if dt == "f16" else (3e-2, 3.5e-1, 1.5e-1)
+    assert e_rc <= bar_l and e_ct <= 10 * bar_l, (e_rc, e_ct)
+    assert float(relerr.max()) <= bar_g and float(relerr.median()) <= bar_m
+
+
 def test_moco_step_vs_reference_fixture(cuda, golden_dir):
     """The HIP path against what the REFERENCE's own Moco_v2 produced (tests/golden/moco_ref.npz, oracle/gen_golden.py::gen_moco):
     the same seeded state under the reference's key names, two training steps (EMA before the forward, logits from the
