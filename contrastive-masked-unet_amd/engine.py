@@ -396,9 +396,10 @@ class UNetEngine:
         fused = last is not None and last["y"] is x
         # the head's input gradient has rank K: when it flows straight into ``last``'s BatchNorm backward it is never stored -- the
         # head backward leaves the BN-backward sums, the apply pass recomputes it from dlogits (CMU_HEAD_FUSE=0: stored, A/B switch)
-        head = (dlogits.contiguous(), wl.detach().reshape(K, -1)) if (fused and _FUSE_HEAD) else None
+        dl, wl2 = dlogits.contiguous(), wl.detach().reshape(K, -1)
+        head = (dl, wl2) if (fused and _FUSE_HEAD) else None
         dA = None if head is not None else self._new(x.B, x.H, x.W, x.C)
-        ops.conv1x1_head_bwd(dlogits.contiguous(), x, wl.detach().reshape(K, -1), dA, dWl.view(K, -1), dbl, ws,
+        ops.conv1x1_head_bwd(dl, x, wl2, dA, dWl.view(K, -1), dbl, ws,
                              last["mean"] if fused else None, last["invstd"] if fused else None, self._bn_ws(x.C) if fused else None)
         grads[prefix + "conv_last.weight"] = dWl
         grads[prefix + "conv_last.bias"] = dbl
