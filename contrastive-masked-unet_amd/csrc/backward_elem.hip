@@ -62,8 +62,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const unsigned char*
             if (rows != nullptr) {
                 p = rows[pp];
                 if (p < 0) continue;
-            } else if (amask && !sp_active(amask, f, sbits, (int)(p / ((int64_t)W * H)), (int)((p / W) % H), (int)(p % W), 0)) {
-                continue;
+            } else if (amask) {
+                int b_, y_, x_;
+                cmu_pixel_coords(p, W, H, npix <= 0x7fffffffll, b_, y_, x_);
+                if (!sp_active(amask, f, sbits, b_, y_, x_, 0)) continue;
             }
             float g[EPC], v[EPC];
             TR::unpack(ld_global16(dA + (p * ldd + ch * EPC) * ES), g);
@@ -247,9 +249,13 @@ __global__ void bn_bwd_apply_kernel(const unsigned char* __restrict__ dA, int64_
     // (the launcher caps the grid at 2^20 workgroups: ranges beyond it are taken grid-stride)
     for (int64_t rng = (int64_t)blockIdx.x * (ppb * CMU_APPLY_PPT); rng < npix; rng += (int64_t)gridDim.x * (ppb * CMU_APPLY_PPT))
     for (int64_t p = rng + prow; p < npix && p < rng + (int64_t)ppb * CMU_APPLY_PPT; p += ppb) {
-        if (amask && !sp_active(amask, f, sbits, (int)(p / ((int64_t)W * H)), (int)((p / W) % H), (int)(p % W), 0)) {
-            st_global16(dY + (p * ldo + ch * EPC) * ES, u32x4{0u, 0u, 0u, 0u});   // sparse BN: no gradient at masked positions
-            continue;
+        if (amask) {
+            int b_, y_, x_;
+            cmu_pixel_coords(p, W, H, npix <= 0x7fffffffll, b_, y_, x_);
+            if (!sp_active(amask, f, sbits, b_, y_, x_, 0)) {
+                st_global16(dY + (p * ldo + ch * EPC) * ES, u32x4{0u, 0u, 0u, 0u});   // sparse BN: no gradient at masked positions
+                continue;
+            }
         }
         float g[EPC], v[EPC], o[EPC];
         if (hd_dlogits != nullptr) {
@@ -345,7 +351,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
     }
     if (active)
         for (int64_t pp = (int64_t)blockIdx.x * ppb + prow; pp < npool; pp += (int64_t)gridDim.x * ppb) {
-            const int xo = (int)(pp % Wo), yo = (int)((pp / Wo) % Ho), b = (int)(pp / ((int64_t)Wo * Ho));
+            int xo, yo, b;
+            cmu_pixel_coords(pp, Wo, Ho, npool <= 0x7fffffffll, b, yo, xo);
             float best[EPC], g[EPC], f[4][EPC];
             int arg[EPC];
             TR::unpack(ld_global16_nt(dP + (pp * ldp + ch * EPC) * ES), g);

@@ -525,9 +525,17 @@ __global__ void bnrelu_maxpool_kernel(const unsigned char* __restrict__ y, int64
     const int nchunk = C / EPC;
     const int Ho = H / 2, Wo = W / 2;
     for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(o % nchunk);
-        const int64_t pix = o / nchunk;
-        const int xo = (int)(pix % Wo), yo = (int)((pix / Wo) % Ho), b = (int)(pix / ((int64_t)Wo * Ho));
+        int ch, xo, yo, b;
+        int64_t pix;
+        if (total <= 0x7fffffffll) {      // 32-bit index arithmetic where the tensor allows it (cmu_pixel_coords)
+            const unsigned ou = (unsigned)o, pq = ou / (unsigned)nchunk;
+            ch = (int)(ou - pq * (unsigned)nchunk);
+            pix = pq;
+        } else {
+            ch = (int)(o % nchunk);
+            pix = o / nchunk;
+        }
+        cmu_pixel_coords(pix, Wo, Ho, total <= 0x7fffffffll, b, yo, xo);
         float sc[EPC], sh[EPC], m[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {

@@ -39,7 +39,8 @@ __global__ __launch_bounds__(256) void masked_stats_kernel(const unsigned char* 
                 p = rows[pp];
                 if (p < 0) continue;
             } else {
-                const int xx = (int)(p % W), yy = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
+                int xx, yy, b;
+                cmu_pixel_coords(p, W, H, npix <= 0x7fffffffll, b, yy, xx);
                 if (!sp_active(active, f, sbits, b, yy, xx, invert)) continue;
             }
             float v[EPC];
@@ -130,8 +131,10 @@ __global__ void mask_select_kernel(const unsigned char* __restrict__ x, int64_t 
         fl[e] = fill ? fill[ch * EPC + e] : 0.f;
     }
     const u32x4 fillv = TR::pack(fl);
+    const bool small = npix <= 0x7fffffffll;
     for (int64_t p = (int64_t)blockIdx.x * ppb + prow; p < npix; p += (int64_t)gridDim.x * ppb) {
-        const int xx = (int)(p % W), yy = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
+        int xx, yy, b;
+        cmu_pixel_coords(p, W, H, small, b, yy, xx);
         u32x4 o = fillv;
         if (sp_active(active, f, sbits, b, yy, xx, invert)) {
             o = ld_global16(x + (p * ldx + ch * EPC) * ES);
