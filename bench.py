@@ -288,7 +288,7 @@ def build_workload(name, args, dev, rank, world):
         from cmunet_amd import cmunet as C
         m = C.build_model(C.cmunet_config(img_size=H, dtype=args.dtype, mask_ratio=0.6)).to(dev)
         m.init_weights()
-        tr = P.JointPretrainer(m, lr=1.5e-4 * lr_rule)
+        tr = P.JointPretrainer(m, lr=1.5e-4 * lr_rule, amp=(args.dtype == "f16"))
         tr.broadcast_parameters()
         xs = [(torch.randn(B, H, W, generator=g, device=dev), torch.randn(B, H, W, generator=g, device=dev)) for _ in range(nb)]
         masks = [P.random_patch_mask_device(B, H, W, 16, 0.6, g, dev) for _ in range(nb)]
@@ -296,7 +296,8 @@ def build_workload(name, args, dev, rank, world):
         def step(i):
             l = tr.step(xs[i % nb][0], xs[i % nb][1], masks[i % nb])
             return l["loss_ct"] + l["loss_rc"]
-        return step, {"workload": f"cmunet_joint_ct+rc_unet64x5_{H}x{W}_bs{B}_mask0.6_projector{H * W}x1536", "optimizer": "AdamW(fused) + EMA"}, tr
+        return step, {"workload": f"cmunet_joint_ct+rc_unet64x5_{H}x{W}_bs{B}_mask0.6_projector{H * W}x1536", "optimizer": "AdamW(fused) + EMA",
+                      "amp": "dynamic loss scale (device-side GradScaler protocol)" if tr.amp is not None else "off"}, tr
     if name == "spark":
         from cmunet_amd import spark as S
         enc = S.build_sparse_encoder("unet_sparse", input_size=H, dtype=args.dtype)

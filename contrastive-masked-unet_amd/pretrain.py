@@ -199,16 +199,28 @@ class ArenaTrainer:
             if b.is_floating_point():
                 dist.broadcast(b, src=src, group=self.group)
 
-    def backward_and_step(self, loss, loss_scale=1.0):
-        """``loss``: scalar tensor from the model's forward (already multiplied by ``loss_scale`` if one is used)."""
+    def backward_and_step(self, loss, loss_scale=1.0, amp=None):
+        """``loss``: scalar tensor from the model's forward (already multiplied by ``loss_scale`` if one is used).
+        ``amp``: an ``ops.AmpScaler`` -- dynamic loss scaling as mmengine's AmpOptimWrapper does it (cmunet_config.py:76-78): the loss
+        is multiplied by the scale held ON THE DEVICE (no host read), the inf / nan check runs on the exchanged gradients, the
+        optimiser kernel unscales or skips from the same state, the scale is updated afterwards."""
         for p in self.flat.params.values():
             p.grad = None
+        if amp is not None:
+            loss = loss * amp.state[:4].view(torch.float32)          # the current scale, a one-element device tensor
         loss.backward()
         self.flat.gather_autograd_grads()
         scale = 1.0
         if self.world() > 1:
             dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)
             scale = 1.0 / self.world()
+        if amp is not None:
+            amp.check(self.flat.grad)                                # after the exchange: every rank takes the same decision
+            self.opt.step(grad_scale=scale / loss_scale, amp=amp)
+            amp.update()
+            for p in self.flat.params.values():
+                p.grad = None
+            return
         self.opt.step(grad_scale=scale / loss_scale)
         for p in self.flat.params.values():       # the arena holds them; drop the per-tensor copies autograd made
             p.grad = None
@@ -219,11 +231,14 @@ class JointPretrainer(ArenaTrainer):
     cmunet_config.py:76-114): AdamW(lr, betas (0.9, 0.95), wd 0.05, no decay on bias / norm parameters), then the EMA of the
     target backbone + projector (MomentumUpdateHook.after_train_iter) as two launches between two arenas."""
 
-    def __init__(self, model, lr=1.5e-4, betas=(0.9, 0.95), weight_decay=0.05, eps=1e-8, process_group=None):
+    def __init__(self, model, lr=1.5e-4, betas=(0.9, 0.95), weight_decay=0.05, eps=1e-8, process_group=None, amp=None):
+        """``amp``: True (or an ``ops.AmpScaler``): the dynamic loss scaling of the reference's AmpOptimWrapper (cmunet_config.py:76-78);
+        wanted with f16 activations (the masked-MSE gradient per pixel is far below f16's normals)."""
         model.train()
         flat = self.trainable(model)
         opt = FusedAdam(flat, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decoupled=True, decay_filter=no_decay_bias_norm)
         super().__init__(model, opt, process_group)
+        self.amp = ops.AmpScaler(self.device) if amp is True else (amp or None)
         tnames = {n for n, _ in model.named_parameters() if n.startswith(("target_backbone.", "target_projector."))}
         self.tflat = FlatParams(model, names=lambda n: n in tnames)
         # identical layouts: (backbone, projector) inside the online arena <-> (target_backbone, target_projector)
@@ -242,7 +257,7 @@ class JointPretrainer(ArenaTrainer):
             from .cmunet import momentum_schedule
             self.model.momentum = momentum_schedule(cur_iter, max_iter, self.model.base_momentum, getattr(self.model, "end_momentum", self.model.base_momentum))
         losses = self.model(img, mode="loss", img_t=img_t, mask=mask, **kw)
-        self.backward_and_step(losses["loss_ct"] + losses["loss_rc"])
+        self.backward_and_step(losses["loss_ct"] + losses["loss_rc"], amp=self.amp)
         self.momentum_update()
         return {k: v.detach() for k, v in losses.items()}
 

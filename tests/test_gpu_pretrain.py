@@ -196,6 +196,37 @@ def test_nonlinear_neck_eval_mode_gradients(cuda):
     assert int(neck.bn0.num_batches_tracked) == 0                       # eval mode: buffers untouched
 
 
+def test_joint_trainer_dynamic_loss_scale(cuda):
+    """JointPretrainer with the AmpOptimWrapper protocol (cmunet_config.py:76-78) at f16: the loss is scaled by the device-side
+    scale, clean steps update and count, an overflowing step (scale 2^120) is skipped on the device -- parameters, Adam moments and
+    the step count untouched -- and the scale backs off."""
+    from cmunet_amd import cmunet as C, ops
+    from cmunet_amd.pretrain import JointPretrainer, create_random_patch_mask
+    torch.manual_seed(0)
+    B, S = 4, 32
+    model = C.build_model(C.cmunet_config(img_size=S, dtype="f16", base_ch=16, depth=3)).to(cuda).train()
+    tr = JointPretrainer(model, lr=1e-3, amp=True)
+    g = torch.Generator().manual_seed(3)
+    img, img_t = torch.randn(B, S, S, generator=g).to(cuda), torch.randn(B, S, S, generator=g).to(cuda)
+    mask = torch.from_numpy(create_random_patch_mask(B, S, 16, 0.65, np.random.RandomState(4))).to(cuda)
+    for _ in range(3):
+        l = tr.step(img, img_t, mask)
+        assert torch.isfinite(l["loss_ct"]) and torch.isfinite(l["loss_rc"])
+    scale, found, growth, good, skipped = tr.amp.read()
+    assert (scale, found, good, skipped) == (65536.0, 0.0, 3, 0) and growth == 3
+    # an overflowing step
+    tr.amp = ops.AmpScaler(cuda, init_scale=2.0 ** 120)
+    before, m_before = tr.flat.arena.clone(), tr.opt.m.clone()
+    tr.step(img, img_t, mask)
+    scale, found, growth, good, skipped = tr.amp.read()
+    assert skipped == 1 and good == 0 and scale == 2.0 ** 119
+    assert torch.equal(tr.flat.arena, before) and torch.equal(tr.opt.m, m_before)
+    # without the scaler the f16 step still runs (static scale 1): the trainer's amp is optional
+    tr.amp = None
+    tr.step(img, img_t, mask)
+    assert not torch.equal(tr.flat.arena, before)
+
+
 def test_cmunet_modules_standalone(cuda):
     """UNet_encoder / MUNetPretrainDecoder used on their own keep the reference's tensor contract."""
     from cmunet_amd import cmunet as C
