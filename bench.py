@@ -282,8 +282,9 @@ def build_workload(name, args, dev, rank, world):
         tr = P.MocoPretrainer(m, lr=0.03 * lr_rule)
         tr.broadcast_parameters()
         xs = [(torch.randn(B, 1, H, W, generator=g, device=dev), torch.randn(B, 1, H, W, generator=g, device=dev)) for _ in range(nb)]
-        return (lambda i: tr.step(*xs[i % nb])), {
-            "workload": f"moco_v2_unet64x5_encoder_{H}x{W}_bs{B}_K4096_tau0.2", "optimizer": "SGD-momentum(fused)"}, tr
+        ls = 1024.0 if args.dtype == "f16" else 1.0     # static loss scale (f16 stores the activation gradients)
+        return (lambda i: tr.step(*xs[i % nb], loss_scale=ls)), {
+            "workload": f"moco_v2_unet64x5_encoder_{H}x{W}_bs{B}_K4096_tau0.2", "optimizer": "SGD-momentum(fused)", "loss_scale": ls}, tr
     if name == "joint":
         from cmunet_amd import cmunet as C
         m = C.build_model(C.cmunet_config(img_size=H, dtype=args.dtype, mask_ratio=0.6)).to(dev)

@@ -286,9 +286,11 @@ class MocoPretrainer(ArenaTrainer):
         self.opt.lr = moco_cosine_lr(self._base_lr, epoch, max_epochs)
         return self.opt.lr
 
-    def step(self, img_q, img_k):
+    def step(self, img_q, img_k, loss_scale=1.0):
+        """``loss_scale``: static scale on the loss before backward (16-bit activations store their gradients in the model's dtype:
+        the InfoNCE gradient reaches the first layers at ~1e-6 per element), divided out again by the SGD kernel."""
         loss = self.model.training_step((img_q, img_k))
-        self.backward_and_step(loss)
+        self.backward_and_step(loss * float(loss_scale) if loss_scale != 1.0 else loss, loss_scale)
         return loss.detach()
 
 

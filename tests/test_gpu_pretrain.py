@@ -381,6 +381,25 @@ def test_moco_step_vs_reference_fixture(cuda, golden_dir):
     assert rel(m.queue[:, B:2 * B].t(), torch.from_numpy(f["keys2"])) <= 1e-4 and int(m.queue_ptr) == int(f["queue_ptr2"]) == 2 * B
 
 
+def test_moco_trainer_static_loss_scale_is_transparent(cuda):
+    """MocoPretrainer.step(loss_scale=s): the scale multiplies the loss before backward and is divided out by the SGD kernel -- at f32
+    the update equals the unscaled one (a power of two: to rounding of the momentum buffer only)."""
+    from cmunet_amd import moco as M
+    from cmunet_amd.pretrain import MocoPretrainer
+    outs = []
+    for ls in (1.0, 256.0):
+        torch.manual_seed(0)
+        m = M.Moco_v2(emb_dim=64, num_negatives=64, softmax_temperature=0.2, encoder_momentum=0.99, learning_rate=0.05, dtype="f32",
+                      base_ch=16, depth=3).to(cuda).train()
+        tr = MocoPretrainer(m)
+        g = torch.Generator().manual_seed(8)
+        xq, xk = torch.randn(4, 1, 32, 32, generator=g).to(cuda), torch.randn(4, 1, 32, 32, generator=g).to(cuda)
+        losses = [float(tr.step(xq, xk, loss_scale=ls)) for _ in range(2)]
+        outs.append((losses, tr.flat.arena.clone()))
+    assert np.allclose(outs[0][0], outs[1][0], rtol=1e-6)
+    assert rel(outs[1][1], outs[0][1].cpu()) <= 1e-6
+
+
 def test_masked_recon_trainer_matches_autograd_path(cuda):
     """The fused trainer (arena gradients, fused AdamW) and the drop-in autograd path agree after 3 steps."""
     from cmunet_amd import model as M
