@@ -349,7 +349,9 @@ def main():
     dev_index = 0 if (world == 1 or single_dev) else local_rank
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if world > 1:
+    # CMU_DP_REHEARSE=1 under a launcher with one rank: the RCCL group is built and every collective of the step runs on it
+    use_dist = world > 1 or (os.environ.get("CMU_DP_REHEARSE", "0") == "1" and "WORLD_SIZE" in os.environ)
+    if use_dist:
         torch.cuda.set_device(dev_index)
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))   # RCCL over xGMI
@@ -363,7 +365,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -401,7 +403,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     _lib.PROFILER = None
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -494,7 +496,7 @@ def main():
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -28,6 +28,7 @@ import torch.nn as nn
 from . import _lib, ops
 from .model import DoubleConv, DownBlock, UpBlock, _EngineOwner, _named_state, _param_args, _require_cuda
 from .ops import Act
+from .optim import dp_exchanges
 from .pretrain import create_random_patch_mask, random_patch_mask_device
 
 
@@ -94,7 +95,7 @@ class _InfoNCEFn(torch.autograd.Function):
 @torch.no_grad()
 def concat_all_gather(tensor):
     """cmunet_head.py:9-22 (mmengine all_gather -> cat) as one RCCL all-gather into a single tensor."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not dp_exchanges():
         return tensor
     out = torch.empty((dist.get_world_size() * tensor.shape[0],) + tuple(tensor.shape[1:]), dtype=tensor.dtype, device=tensor.device)
     dist.all_gather_into_tensor(out, tensor.contiguous())

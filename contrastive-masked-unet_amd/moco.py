@@ -21,6 +21,7 @@ import torch.nn.functional as F
 
 from . import _lib, ops
 from .cmunet import UNet_encoder as _MaskEncoder, concat_all_gather
+from .optim import dp_exchanges
 from .model import _EngineOwner, _named_state, _param_args, _require_cuda
 
 
@@ -195,7 +196,7 @@ class _MocoLossFn(torch.autograd.Function):
         K = queue.shape[1]
         dev = q_raw.device
         keys_all = None
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dp_exchanges():
             kn = torch.empty_like(k_raw)
             ops.l2_normalize_rows(k_raw.detach().contiguous(), kn)
             keys_all = concat_all_gather(kn)                       # moco2_module.py:163-164

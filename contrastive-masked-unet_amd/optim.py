@@ -6,16 +6,32 @@ re-homed into ONE contiguous fp32 arena (and its gradient into a second one): th
 HIP kernel over the arena, the data-parallel gradient exchange is one RCCL all-reduce over it, and the EMA
 of the momentum encoder is one kernel between two arenas with identical layout.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 from . import ops
 
 
+def dp_world(group=None):
+    """World size of the initialised data-parallel group, 1 without one."""
+    return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def dp_exchanges(group=None):
+    """True when collectives have to run: an initialised group of more than one rank.  CMU_DP_REHEARSE=1 makes a one-rank group run them
+    too -- the RCCL call sequence (async bucket all-reduces behind the backward, all-gathers, waits) on a one-GPU box, where a
+    second rank could only share the card over gloo."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("CMU_DP_REHEARSE", "0") == "1"
+
+
 def all_reduce_sum_scale(tensor, group=None):
     """SUM all-reduce of ``tensor`` in place over the data-parallel group (RCCL on the GPU, gloo in the CPU
     tests); returns the 1/world factor that turns it into the mean (folded into the optimiser kernel)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dp_exchanges(group):
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
         return 1.0 / dist.get_world_size(group)
     return 1.0
@@ -101,7 +117,7 @@ class FlatParams:
         """Start the SUM all-reduce of gradient elements [lo, hi); returns a work handle (``.wait()``) or None when
         there is nothing to exchange.  On RCCL the collective runs on the process group's stream after the kernels
         already queued on the current stream, concurrently with what is queued next."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 and hi > lo:
+        if dp_exchanges(group) and hi > lo:
             return dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True)
         return None
 

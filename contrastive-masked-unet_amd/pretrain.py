@@ -22,7 +22,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib, ops
-from .optim import FlatParams, FusedAdam, FusedLAMB, FusedSGD, no_decay_bias_norm
+from .optim import FlatParams, FusedAdam, FusedLAMB, FusedSGD, dp_exchanges, dp_world, no_decay_bias_norm
 
 
 def create_random_patch_mask(batch_size, img_size, patch_size=16, mask_ratio=0.65, rng=None):
@@ -93,7 +93,7 @@ class MaskedReconPretrainer:
         self._pending = []
 
     def broadcast_parameters(self, src=0):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if dp_exchanges(self.group):
             dist.broadcast(self.flat.arena, src=src, group=self.group)
             for n, b in self.model.named_buffers():
                 if b.is_floating_point():
@@ -130,8 +130,8 @@ class MaskedReconPretrainer:
 
     def exchange_gradients(self):
         """Finish the data-parallel gradient SUM (the decoder bucket may already be in flight) and return 1/world."""
-        world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
-        if world <= 1:
+        world = dp_world(self.group)
+        if not dp_exchanges(self.group):
             return 1.0
         if self._dec_off is not None:
             rest_hi = self._bott[0] if self._bott is not None else self._dec_off
@@ -184,11 +184,11 @@ class ArenaTrainer:
         return FlatParams(model, names=lambda n: n in want)
 
     def world(self):
-        return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+        return dp_world(self.group)
 
     def broadcast_parameters(self, src=0):
         """Rank ``src``'s parameters and floating-point buffers to every rank (DDP does this at construction)."""
-        if self.world() <= 1:
+        if not dp_exchanges(self.group):
             return
         dist.broadcast(self.flat.arena, src=src, group=self.group)
         held = {id(p) for p in self.flat.params.values()}
@@ -211,7 +211,7 @@ class ArenaTrainer:
         loss.backward()
         self.flat.gather_autograd_grads()
         scale = 1.0
-        if self.world() > 1:
+        if dp_exchanges(self.group):
             dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)
             scale = 1.0 / self.world()
         if amp is not None:

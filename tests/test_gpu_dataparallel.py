@@ -283,3 +283,28 @@ def test_spark_trainer_two_ranks_equals_one_rank(cuda):
         assert np.allclose(r["losses"], one["losses"], rtol=1e-6)
         assert rel(r["arena"], one["arena"]) <= 1e-6
     assert np.allclose(scaled["losses"], one["losses"], rtol=1e-6) and rel(scaled["arena"], one["arena"]) <= 1e-5
+
+
+@pytest.mark.parametrize("workload", ["recon", "joint", "moco", "spark"])
+def test_bench_step_on_a_one_rank_rccl_group(cuda, workload):
+    """The collectives of every trainer on RCCL itself (backend "nccl"): bench.py as ONE rank of an initialised group with
+    CMU_DP_REHEARSE=1 -- the overlapped bucket all-reduces behind the backward, the arena all-reduce, the embedding all-gathers,
+    the barrier and the MAX over ranks all run on the process group's stream -- must give the loss of the same steps without a group
+    (a SUM over one rank is the identity).  Two RCCL ranks cannot share the one card of this box; the two-rank tests above use gloo."""
+    import json
+    root = os.path.dirname(HERE)
+    argv = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "4", "--size", "128",
+            "--workload", workload, "--no-cpu-baseline", "--no-kernel-events"]
+    base = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "CMU_DP_REHEARSE", "CMU_DIST_BACKEND"):
+        base.pop(k, None)
+    lines = []
+    for env in (base, dict(base, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+                           CMU_DP_REHEARSE="1")):
+        r = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=420)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]))
+    plain, rccl = lines
+    assert rccl["n_gpus"] == 1 and rccl["config"]["parallelism"] == "dp1"
+    assert np.isfinite(rccl["config"]["loss"])
+    assert abs(rccl["config"]["loss"] - plain["config"]["loss"]) <= 1e-5 * max(1.0, abs(plain["config"]["loss"])), (plain["config"]["loss"], rccl["config"]["loss"])
