@@ -34,6 +34,10 @@ _SIGS = {
     "cmu_lamb_ws_bytes": (_L, [_I, _I]),
     "cmu_resize_bicubic_ws_bytes": (_L, [_I, _I, _I, _I, _I]),
     "cmu_resize_bicubic": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P]),
+    "cmu_resize_bicubic_u8_ws_bytes": (_L, [_I, _I, _I, _I, _I]),
+    "cmu_resize_bicubic_u8": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P]),
+    "cmu_resize_nearest_u8_ws_bytes": (_L, [_I, _I]),
+    "cmu_resize_nearest_u8": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P]),
     "cmu_two_view": (_I, [_P, _I, _I, _P, _P, _U64, _P, _P, _I, _P]),
     "cmu_philox_normal": (_I, [_P, _L, _U64, _U64, _P]),
     "cmu_random_patch_mask": (_I, [_P, _I, _I, _I, _I, _I, _U64, _U64, _P]),

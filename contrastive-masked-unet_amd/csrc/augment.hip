@@ -124,6 +124,117 @@ extern "C" int cmu_resize_bicubic(const float* src, int B, int Hs, int Ws, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// 8-bit images (PIL mode 'L': what Image.fromarray gives for a uint8 .npy; Finetuning/dataset.py:44-46, Spark/utils/dataset.py:25-27)
+// Pillow's 8-bit resampler: the double coefficients above as 22-bit fixed point (rounded half away from zero by the C cast),
+// int32 accumulation from 2^21, arithmetic shift by 22, clip to 0..255, a uint8 image between the passes.
+// ---------------------------------------------------------------------------------------------
+#define AUG_PREC 22
+__device__ static inline int aug_coeff_u8(const AugWin& w, int x) {
+    const double k = aug_coeff(w, x);
+    return k < 0.0 ? (int)__dadd_rn(-0.5, __dmul_rn(k, (double)(1 << AUG_PREC))) : (int)__dadd_rn(0.5, __dmul_rn(k, (double)(1 << AUG_PREC)));
+}
+__device__ static inline uint8_t aug_clip8(int acc) {
+    const int v = acc >> AUG_PREC;
+    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+__global__ void resize_h_u8_kernel(const uint8_t* __restrict__ src, int Hs, int Ws, const int* __restrict__ boxes, uint8_t* __restrict__ tmp,
+                                   int Wo, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % Wo);
+        const int y = (int)((i / Wo) % Hs);
+        const int b = (int)(i / ((int64_t)Wo * Hs));
+        const int x0 = boxes ? boxes[4 * b + 0] : 0, y0 = boxes ? boxes[4 * b + 1] : 0;
+        const int w = boxes ? boxes[4 * b + 2] : Ws, h = boxes ? boxes[4 * b + 3] : Hs;
+        if (y >= h) continue;
+        const uint8_t* row = src + ((int64_t)b * Hs + y0 + y) * Ws + x0;
+        uint8_t r;
+        if (w == Wo) {
+            r = row[xx];
+        } else {
+            const AugWin win = aug_window(xx, w, Wo);
+            int ss = 1 << (AUG_PREC - 1);
+            for (int x = 0; x < win.count; ++x) ss += (int)row[win.xmin + x] * aug_coeff_u8(win, x);
+            r = aug_clip8(ss);
+        }
+        tmp[i] = r;
+    }
+}
+__global__ void resize_v_u8_kernel(const uint8_t* __restrict__ tmp, int Hs, const int* __restrict__ boxes, const uint8_t* __restrict__ flip,
+                                   uint8_t* __restrict__ out, int Ho, int Wo, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % Wo);
+        const int yy = (int)((i / Wo) % Ho);
+        const int b = (int)(i / ((int64_t)Wo * Ho));
+        const int h = boxes ? boxes[4 * b + 3] : Hs;
+        const uint8_t* col = tmp + (int64_t)b * Hs * Wo + xx;
+        uint8_t r;
+        if (h == Ho) {
+            r = col[(int64_t)yy * Wo];
+        } else {
+            const AugWin win = aug_window(yy, h, Ho);
+            int ss = 1 << (AUG_PREC - 1);
+            for (int y = 0; y < win.count; ++y) ss += (int)col[(int64_t)(win.xmin + y) * Wo] * aug_coeff_u8(win, y);
+            r = aug_clip8(ss);
+        }
+        const int xo = (flip && flip[b]) ? Wo - 1 - xx : xx;
+        out[((int64_t)b * Ho + yy) * Wo + xo] = r;
+    }
+}
+extern "C" int64_t cmu_resize_bicubic_u8_ws_bytes(int B, int Hs, int Ws, int Ho, int Wo) {
+    (void)Ws; (void)Ho;
+    return (int64_t)B * Hs * Wo;
+}
+extern "C" int cmu_resize_bicubic_u8(const uint8_t* src, int B, int Hs, int Ws, const int* boxes, const uint8_t* flip, uint8_t* out, int Ho,
+                                     int Wo, void* ws, void* stream) {
+    CMU_CHECK_ARG(src && out && ws && B > 0 && Hs > 0 && Ws > 0 && Ho > 0 && Wo > 0, "cmu_resize_bicubic_u8: bad args");
+    const int64_t t1 = (int64_t)B * Hs * Wo, t2 = (int64_t)B * Ho * Wo;
+    const int g1 = (int)(cmu_div_up64(t1, 256) < 16384 ? cmu_div_up64(t1, 256) : 16384);
+    const int g2 = (int)(cmu_div_up64(t2, 256) < 16384 ? cmu_div_up64(t2, 256) : 16384);
+    hipLaunchKernelGGL(resize_h_u8_kernel, dim3(g1), dim3(256), 0, (hipStream_t)stream, src, Hs, Ws, boxes, (uint8_t*)ws, Wo, t1);
+    CMU_CHECK_LAUNCH("cmu_resize_bicubic_u8(horizontal)");
+    hipLaunchKernelGGL(resize_v_u8_kernel, dim3(g2), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)ws, Hs, boxes, flip, out, Ho, Wo, t2);
+    CMU_CHECK_LAUNCH("cmu_resize_bicubic_u8(vertical)");
+    return CMU_OK;
+}
+
+// Image.resize(size, NEAREST) of the label masks (Finetuning/dataset.py:47): Pillow's affine nearest path takes source index
+// int(x) of a running double x = scale / 2, += scale per output index (the running sum, not (i + .5) * scale: its roundings are
+// Pillow's).  One thread per axis builds the index table, a second launch gathers.
+__global__ void nearest_table_kernel(int Hs, int Ws, int Ho, int Wo, int* __restrict__ tab) {
+    const int axis = threadIdx.x;                       // 0: columns -> tab[0 .. Wo), 1: rows -> tab[Wo .. Wo + Ho)
+    if (axis > 1) return;
+    const int in_size = axis ? Hs : Ws, out_size = axis ? Ho : Wo;
+    int* t = tab + (axis ? Wo : 0);
+    const double scale = __ddiv_rn((double)in_size, (double)out_size);
+    double xo = __dmul_rn(scale, 0.5);
+    for (int x = 0; x < out_size; ++x) {
+        int v = xo < 0.0 ? -1 : (int)xo;
+        t[x] = v < in_size ? v : in_size - 1;          // (never taken for a whole-image box; keeps the gather in bounds)
+        xo = __dadd_rn(xo, scale);
+    }
+}
+__global__ void resize_nearest_u8_kernel(const uint8_t* __restrict__ src, int Hs, int Ws, const int* __restrict__ tab, uint8_t* __restrict__ out,
+                                         int Ho, int Wo, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % Wo);
+        const int yy = (int)((i / Wo) % Ho);
+        const int64_t b = i / ((int64_t)Wo * Ho);
+        out[i] = src[(b * Hs + tab[Wo + yy]) * Ws + tab[xx]];
+    }
+}
+extern "C" int64_t cmu_resize_nearest_u8_ws_bytes(int Ho, int Wo) { return (int64_t)(Ho + Wo) * (int64_t)sizeof(int); }
+extern "C" int cmu_resize_nearest_u8(const uint8_t* src, int B, int Hs, int Ws, uint8_t* out, int Ho, int Wo, void* ws, void* stream) {
+    CMU_CHECK_ARG(src && out && ws && B > 0 && Hs > 0 && Ws > 0 && Ho > 0 && Wo > 0, "cmu_resize_nearest_u8: bad args");
+    hipLaunchKernelGGL(nearest_table_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, Hs, Ws, Ho, Wo, (int*)ws);
+    CMU_CHECK_LAUNCH("cmu_resize_nearest_u8(table)");
+    const int64_t t = (int64_t)B * Ho * Wo;
+    const int g = (int)(cmu_div_up64(t, 256) < 16384 ? cmu_div_up64(t, 256) : 16384);
+    hipLaunchKernelGGL(resize_nearest_u8_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, src, Hs, Ws, (const int*)ws, out, Ho, Wo, t);
+    CMU_CHECK_LAUNCH("cmu_resize_nearest_u8");
+    return CMU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // two views of a batch: ShiftPixel crops + GaussNoise on the shifted one
 // ---------------------------------------------------------------------------------------------
 __device__ static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {

@@ -133,6 +133,27 @@ def random_resized_crop_params(h, w, rng, crop_ratio_range=(0.2, 1.0), aspect_ra
     return (w - cw) // 2, (h - ch) // 2, cw, ch
 
 
+class DeviceSegmentationBatch:
+    """SegmentationDataset.__getitem__'s resize and encoding (Finetuning/dataset.py:44-55) for a whole batch on the GPU: images
+    (B,H,W) float32 or uint8 -> bicubic resize to ``size`` in Pillow's arithmetic for that dtype (mode 'F' / mode 'L'); masks (B,H,W)
+    uint8 -> NEAREST resize -> one-hot over ``class_values`` as float64 (SURVEY A-5).  Returns (image (B,size,size) of the input
+    dtype -- (B,1,size,size) with ``last_axis`` --, mask (B,n_cls,size,size) float64).  Requires the HIP library (no CPU fallback)."""
+
+    def __init__(self, size=256, class_values=None, last_axis=False):
+        self.size, self.last_axis = size, last_axis
+        self.class_values = [int(np.asarray(v).reshape(-1)[0]) for v in (class_values if class_values is not None else [0, 1])]
+
+    def __call__(self, images, masks):
+        from . import ops
+        assert images.is_cuda and images.dim() == 3 and masks.is_cuda and masks.dtype == torch.uint8 and masks.shape[0] == images.shape[0]
+        S = self.size
+        img = ops.resize_bicubic(images.contiguous(), S, S)
+        lab = ops.resize_nearest(masks.contiguous(), S, S)
+        vals = torch.tensor(self.class_values, dtype=torch.uint8, device=lab.device).view(1, -1, 1, 1)
+        onehot = (lab[:, None] == vals).to(torch.float64)
+        return (img[:, None] if self.last_axis else img), onehot
+
+
 class DeviceTwoViewPipeline:
     """CMUNetDataset.__getitem__ (cmunet_dataset.py:60-88) for a whole batch on the GPU: bicubic resize to ``size`` ->
     RandomResizedCrop(size, crop_ratio (0.2, 1), bicubic) + RandomFlip(0.5) (cmunet_config.py:48-51) -> 'img' =
@@ -155,12 +176,14 @@ class DeviceTwoViewPipeline:
 
     def __call__(self, raw, params=None, noise=None):
         from . import ops
-        assert raw.is_cuda and raw.dtype == torch.float32 and raw.dim() == 3
+        assert raw.is_cuda and raw.dtype in (torch.float32, torch.uint8) and raw.dim() == 3
         raw = raw.contiguous()
         B = raw.shape[0]
         boxes, flips, shifts = params if params is not None else self.draw(B)
         base = raw if tuple(raw.shape[1:]) == (self.size, self.size) else ops.resize_bicubic(raw, self.size, self.size)
         crop = ops.resize_bicubic(base, self.size, self.size, torch.from_numpy(np.asarray(boxes)), torch.from_numpy(np.asarray(flips)))
+        if crop.dtype == torch.uint8:      # 8-bit sources: resized and cropped in Pillow's mode-'L' arithmetic, the views are float32
+            crop = crop.float()
         self.calls += 1
         img, img_t = ops.two_view(crop, torch.from_numpy(np.asarray(shifts)), self.out, noise=noise,
                                   seed=(self.seed << 32) | (self.calls & 0xFFFFFFFF))

@@ -547,9 +547,11 @@ def lamb_step(p, g, m, v, u, tables, lr, beta1, beta2, eps, bias_correction, gra
 
 # ---- input pipeline on the device ---------------------------------------------------------------------
 def resize_bicubic(src, out_h, out_w, boxes=None, flip=None):
-    """Pillow-convention bicubic resize of per-sample crop windows (+ optional horizontal flip): src (B,H,W) f32 cuda,
-    boxes (B,4) int32 (x0, y0, w, h) or None, flip (B,) uint8/bool or None -> (B,out_h,out_w) f32."""
-    assert src.dtype == torch.float32 and src.dim() == 3 and src.is_contiguous()
+    """Pillow-convention bicubic resize of per-sample crop windows (+ optional horizontal flip): src (B,H,W) f32 (PIL mode 'F') or
+    uint8 (mode 'L': Pillow's 22-bit fixed-point path) cuda, boxes (B,4) int32 (x0, y0, w, h) or None, flip (B,) uint8/bool or
+    None -> (B,out_h,out_w) of src's dtype."""
+    assert src.dtype in (torch.float32, torch.uint8) and src.dim() == 3 and src.is_contiguous()
+    u8 = src.dtype == torch.uint8
     B, H, W = src.shape
     if boxes is not None:
         bh = boxes.detach().cpu().to(torch.int64)
@@ -559,9 +561,21 @@ def resize_bicubic(src, out_h, out_w, boxes=None, flip=None):
         boxes = boxes.to(device=src.device, dtype=torch.int32).contiguous()
     if flip is not None:
         flip = flip.to(device=src.device, dtype=torch.uint8).contiguous()
-    out = torch.empty(B, out_h, out_w, dtype=torch.float32, device=src.device)
-    ws = torch.empty(_lib.lib().cmu_resize_bicubic_ws_bytes(B, H, W, out_h, out_w), dtype=torch.uint8, device=src.device)
-    call("cmu_resize_bicubic", _p(src), B, H, W, _p(boxes), _p(flip), _p(out), out_h, out_w, _p(ws), _stream())
+    out = torch.empty(B, out_h, out_w, dtype=src.dtype, device=src.device)
+    entry = "cmu_resize_bicubic_u8" if u8 else "cmu_resize_bicubic"
+    ws = torch.empty(getattr(_lib.lib(), entry + "_ws_bytes")(B, H, W, out_h, out_w), dtype=torch.uint8, device=src.device)
+    call(entry, _p(src), B, H, W, _p(boxes), _p(flip), _p(out), out_h, out_w, _p(ws), _stream())
+    return out
+
+
+def resize_nearest(src, out_h, out_w):
+    """``Image.resize(size, NEAREST)`` of a batch of uint8 label masks (Finetuning/dataset.py:47): src (B,H,W) uint8 cuda ->
+    (B,out_h,out_w) uint8."""
+    assert src.dtype == torch.uint8 and src.dim() == 3 and src.is_contiguous()
+    B, H, W = src.shape
+    out = torch.empty(B, out_h, out_w, dtype=torch.uint8, device=src.device)
+    ws = torch.empty(_lib.lib().cmu_resize_nearest_u8_ws_bytes(out_h, out_w), dtype=torch.uint8, device=src.device)
+    call("cmu_resize_nearest_u8", _p(src), B, H, W, _p(out), out_h, out_w, _p(ws), _stream())
     return out
 
 

@@ -387,6 +387,17 @@ int cmu_lamb_step(float* p, const float* g, float* m, float* v, float* u, const 
 int64_t cmu_resize_bicubic_ws_bytes(int B, int Hs, int Ws, int Ho, int Wo);
 int cmu_resize_bicubic(const float* src, int B, int Hs, int Ws, const int* boxes, const uint8_t* flip, float* out, int Ho, int Wo,
                        void* ws, void* stream);
+/* cmu_resize_bicubic_u8: the same call on 8-bit images (PIL mode 'L', what Image.fromarray makes of a uint8 .npy:
+ * Finetuning/dataset.py:44-46, Pretraining/Spark/utils/dataset.py:25-27, cmunet_dataset.py:74-75): Pillow's 8-bit resampler -- the
+ * double coefficients as 22-bit fixed point (rounded half away from zero), int32 accumulation from 2^21, arithmetic shift, clip to
+ * 0..255, a uint8 image between the passes.  src / out uint8, otherwise as cmu_resize_bicubic.  Bit-identical to Pillow 12.2.
+ * cmu_resize_nearest_u8: Image.resize(size, NEAREST) of the label masks (Finetuning/dataset.py:47): source index int(x) of Pillow's
+ * running double x = scale / 2, += scale per output index.  ws: cmu_resize_nearest_u8_ws_bytes (the two index tables).          */
+int64_t cmu_resize_bicubic_u8_ws_bytes(int B, int Hs, int Ws, int Ho, int Wo);
+int cmu_resize_bicubic_u8(const uint8_t* src, int B, int Hs, int Ws, const int* boxes, const uint8_t* flip, uint8_t* out, int Ho, int Wo,
+                          void* ws, void* stream);
+int64_t cmu_resize_nearest_u8_ws_bytes(int Ho, int Wo);
+int cmu_resize_nearest_u8(const uint8_t* src, int B, int Hs, int Ws, uint8_t* out, int Ho, int Wo, void* ws, void* stream);
 /* cmu_two_view: 'img' = src[b, :out, :out] (ShiftPixel(0), pipelines/processing.py:97-127); 'img_t' = src[b, dy:dy+out,
  * dx:dx+out] + (max of that crop / 10) * z evaluated in float64 and cast to float32 (GaussNoise,
  * pipelines/auto_augment.py:1136-1153).  shifts (B,2) int32 device (dy, dx); z = noise (B,out,out) f64 device, or, when

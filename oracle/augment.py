@@ -9,6 +9,12 @@
                         [int(c - s + .5), int(c + s + .5)) clipped to the image, coefficients normalised by their sum,
                         double accumulation, float32 store after each pass, horizontal pass first) and is pinned
                         bit-for-bit against Pillow itself in tests/test_cpu_oracle.py.
+  resize_bicubic_u8     the same call on a uint8 array (PIL mode 'L'; Finetuning/dataset.py:44-46, Spark/utils/dataset.py:25-27 take whatever
+                        dtype the .npy holds): Pillow's 8-bit path -- the same double coefficients turned into 22-bit fixed point
+                        (round half away from zero), int32 accumulation from 2^21, arithmetic shift, clip to 0..255, a uint8 image
+                        between the two passes.  Pinned bit-for-bit against Pillow (fixture + live).
+  resize_nearest        ``mask.resize((256, 256), resample=Image.NEAREST)`` of Finetuning/dataset.py:47: Pillow's affine nearest path
+                        (Geometry.c ImagingScaleAffine): source index int(x) of a running double x = scale/2, += scale per step.
   two_view              cmunet_dataset.py:76-88 + processing.py:97-127 (ShiftPixel: crop 224 x 224 at (dy, dx)) +
                         auto_augment.py:1136-1153 (GaussNoise: ``img + (max(img)/10) * randn`` in float64, cast back to
                         float32; applied whatever ``prob`` says, SURVEY A-11).
@@ -72,6 +78,68 @@ def resize_bicubic(img, out_h, out_w):
                 acc = acc + tmp[ymin + y, :].astype(np.float64) * k[y]
             out[yy, :] = acc.astype(np.float32)
     return out
+
+
+_PREC = 32 - 8 - 2          # Pillow PRECISION_BITS of the 8-bit resampler
+
+
+def _coeffs_u8(in_size, out_size):
+    """normalize_coeffs_8bpc: the double coefficients as 22-bit fixed point, rounded half away from zero (C cast truncation)."""
+    out = []
+    for xmin, k in _coeffs(in_size, out_size):
+        ki = [int(-0.5 + v * (1 << _PREC)) if v < 0 else int(0.5 + v * (1 << _PREC)) for v in k]
+        out.append((xmin, np.array(ki, dtype=np.int64)))
+    return out
+
+
+def _clip8(acc):
+    return np.clip(acc >> _PREC, 0, 255).astype(np.uint8)       # arithmetic shift on signed values, as C does on int32
+
+
+def resize_bicubic_u8(img, out_h, out_w):
+    """img (H, W) uint8 -> (out_h, out_w) uint8, Pillow mode-'L' BICUBIC semantics (Resample.c ImagingResampleHorizontal_8bpc /
+    Vertical_8bpc: horizontal pass first into a uint8 image, a pass whose sizes agree is skipped)."""
+    img = np.asarray(img)
+    assert img.dtype == np.uint8 and img.ndim == 2
+    H, W = img.shape
+    tmp = img
+    if W != out_w:
+        tmp = np.empty((H, out_w), np.uint8)
+        for xx, (xmin, k) in enumerate(_coeffs_u8(W, out_w)):
+            acc = np.full(H, 1 << (_PREC - 1), np.int64)
+            for x in range(len(k)):
+                acc = acc + img[:, xmin + x].astype(np.int64) * k[x]
+            assert np.all(np.abs(acc) < 2 ** 31)                  # Pillow accumulates in int32: no wrap to restate
+            tmp[:, xx] = _clip8(acc)
+    out = tmp
+    if H != out_h:
+        out = np.empty((out_h, tmp.shape[1]), np.uint8)
+        for yy, (ymin, k) in enumerate(_coeffs_u8(H, out_h)):
+            acc = np.full(tmp.shape[1], 1 << (_PREC - 1), np.int64)
+            for y in range(len(k)):
+                acc = acc + tmp[ymin + y, :].astype(np.int64) * k[y]
+            out[yy, :] = _clip8(acc)
+    return out
+
+
+def _nearest_index(in_size, out_size):
+    scale = in_size / out_size
+    idx = np.empty(out_size, np.int64)
+    xo = scale * 0.5                                   # a[2] + a[0] * 0.5 with a zero box origin
+    for x in range(out_size):
+        idx[x] = -1 if xo < 0.0 else int(xo)           # COORD()
+        xo += scale                                    # running sum in double, as Pillow accumulates it
+    return idx
+
+
+def resize_nearest(img, out_h, out_w):
+    """img (H, W) any dtype -> (out_h, out_w), Pillow NEAREST resize (source pixels outside the image do not occur for a whole-image
+    box; Pillow would leave them unwritten)."""
+    img = np.asarray(img)
+    H, W = img.shape
+    iy, ix = _nearest_index(H, out_h), _nearest_index(W, out_w)
+    assert iy.min() >= 0 and iy.max() < H and ix.min() >= 0 and ix.max() < W
+    return img[iy][:, ix]
 
 
 def resize_bicubic_crop(batch, boxes, flips, out_h, out_w):

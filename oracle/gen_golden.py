@@ -1013,6 +1013,19 @@ def gen_augment():
         ref = np.asarray(Image.fromarray(a).resize((ow, oh), resample=Image.BICUBIC))
         assert np.array_equal(OA.resize_bicubic(a, oh, ow).view(np.uint32), ref.view(np.uint32)), (h, w, oh, ow)
         out[f"resize{i}.in"], out[f"resize{i}.out"] = a, ref
+    # the same call on uint8 arrays (mode 'L': Finetuning/dataset.py:44-46) and the NEAREST resize of the masks (:47)
+    rng8 = np.random.RandomState(321)
+    for i, (h, w, oh, ow) in enumerate([(40, 56, 32, 24), (64, 64, 32, 32), (20, 30, 48, 40), (33, 33, 33, 20), (97, 15, 16, 16), (300, 200, 256, 256)]):
+        a = rng8.randint(0, 256, (h, w)).astype(np.uint8)
+        if i == 2:
+            a = np.where(rng8.rand(h, w) < 0.5, 0, 255).astype(np.uint8)          # overshoot on both sides of the 0..255 clip
+        ref = np.asarray(Image.fromarray(a).resize((ow, oh), resample=Image.BICUBIC))
+        assert ref.dtype == np.uint8 and np.array_equal(OA.resize_bicubic_u8(a, oh, ow), ref), (h, w, oh, ow)
+        m = rng8.randint(0, 2, (h, w)).astype(np.uint8)
+        refm = np.asarray(Image.fromarray(m).resize((ow, oh), resample=Image.NEAREST))
+        assert np.array_equal(OA.resize_nearest(m, oh, ow), refm), (h, w, oh, ow)
+        out[f"resize_u8_{i}.in"], out[f"resize_u8_{i}.out"] = a, ref
+        out[f"nearest{i}.in"], out[f"nearest{i}.out"] = m, refm
     # ShiftPixel + GaussNoise exactly as the reference's lines evaluate them
     img = rng.standard_normal((2, 40, 40)).astype(np.float32)
     shifts = np.array([[3, 7], [8, 0]], np.int32)

@@ -235,6 +235,12 @@ def test_augment_oracle_against_pillow_fixture_and_live(golden_dir):
         assert np.array_equal(OA.resize_bicubic(a, *ref.shape).view(np.uint32), ref.view(np.uint32)), i
         i += 1
     assert i == 5
+    i = 0
+    while f"resize_u8_{i}.in" in z:             # 8-bit images (PIL mode 'L') and the NEAREST resize of the masks
+        assert np.array_equal(OA.resize_bicubic_u8(z[f"resize_u8_{i}.in"], *z[f"resize_u8_{i}.out"].shape), z[f"resize_u8_{i}.out"]), i
+        assert np.array_equal(OA.resize_nearest(z[f"nearest{i}.in"], *z[f"nearest{i}.out"].shape), z[f"nearest{i}.out"]), i
+        i += 1
+    assert i == 6
     _, t = OA.two_view(z["tv_in"], z["tv_shifts"], z["tv_noise"], 32)
     assert np.array_equal(t.view(np.uint32), z["tv_img_t"].view(np.uint32))
     try:
@@ -247,6 +253,9 @@ def test_augment_oracle_against_pillow_fixture_and_live(golden_dir):
             a = rng.standard_normal((h, w)).astype(np.float32)
             ref = np.asarray(Image.fromarray(a).resize((ow, oh), resample=Image.BICUBIC))
             assert np.array_equal(OA.resize_bicubic(a, oh, ow).view(np.uint32), ref.view(np.uint32))
+            a8 = rng.randint(0, 256, (h, w)).astype(np.uint8)
+            assert np.array_equal(OA.resize_bicubic_u8(a8, oh, ow), np.asarray(Image.fromarray(a8).resize((ow, oh), resample=Image.BICUBIC)))
+            assert np.array_equal(OA.resize_nearest(a8, oh, ow), np.asarray(Image.fromarray(a8).resize((ow, oh), resample=Image.NEAREST)))
     kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
            ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]

@@ -125,3 +125,61 @@ def test_random_patch_mask_kernel(ops, shape, patch, ratio):
     if n_mask:
         other = ops.random_patch_mask(B, H, W, patch, ratio, seed=77, offset=12345 + B * (H // patch) * (W // patch)).cpu().numpy()
         assert not np.array_equal(other, got)
+
+
+@pytest.mark.parametrize("shape,out", [((3, 512, 512), (256, 256)), ((2, 300, 200), (256, 256)), ((2, 51, 77), (256, 256)),
+                                       ((2, 256, 256), (256, 256)), ((1, 100, 100), (64, 48)), ((1, 1024, 640), (256, 256)),
+                                       ((2, 1, 1), (8, 8)), ((1, 2, 3), (5, 7)), ((1, 37, 29), (1, 1))])
+def test_resize_bicubic_u8_and_nearest_match_pillow_arithmetic(ops, shape, out):
+    """8-bit images (PIL mode 'L': Finetuning/dataset.py:44-46 on a uint8 .npy) and the NEAREST resize of the label masks (:47):
+    byte-identical to the oracle (pinned to Pillow in tests/test_cpu_oracle.py), incl. black / white checker noise whose cubic
+    overshoot clips on both sides."""
+    from oracle.augment import resize_bicubic_u8, resize_nearest
+    rng = np.random.RandomState(hash(shape + out) % 2 ** 31)
+    a = rng.randint(0, 256, shape).astype(np.uint8)
+    a[0] = np.where(rng.rand(*shape[1:]) < 0.5, 0, 255)
+    got = ops.resize_bicubic(torch.from_numpy(a).cuda(), out[0], out[1])
+    assert got.dtype == torch.uint8
+    assert np.array_equal(got.cpu().numpy(), np.stack([resize_bicubic_u8(x, out[0], out[1]) for x in a]))
+    m = rng.randint(0, 3, shape).astype(np.uint8)
+    gm = ops.resize_nearest(torch.from_numpy(m).cuda(), out[0], out[1]).cpu().numpy()
+    assert np.array_equal(gm, np.stack([resize_nearest(x, out[0], out[1]) for x in m]))
+
+
+def test_resize_u8_golden_fixture_and_crop_windows(ops):
+    """The committed Pillow outputs (tests/golden/augment.npz) straight through the kernels; crop windows + flip on 8-bit images."""
+    import os
+    from oracle.augment import resize_bicubic_u8
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "augment.npz"))
+    i = 0
+    while f"resize_u8_{i}.in" in z:
+        a, ref = z[f"resize_u8_{i}.in"], z[f"resize_u8_{i}.out"]
+        assert np.array_equal(ops.resize_bicubic(torch.from_numpy(a[None]).cuda(), *ref.shape)[0].cpu().numpy(), ref), i
+        m, refm = z[f"nearest{i}.in"], z[f"nearest{i}.out"]
+        assert np.array_equal(ops.resize_nearest(torch.from_numpy(m[None]).cuda(), *refm.shape)[0].cpu().numpy(), refm), i
+        i += 1
+    assert i == 6
+    rng = np.random.RandomState(4)
+    a = rng.randint(0, 256, (3, 256, 256)).astype(np.uint8)
+    boxes = np.array([[0, 0, 256, 256], [17, 40, 100, 131], [200, 3, 56, 250]], np.int32)
+    flips = np.array([1, 0, 1], np.uint8)
+    got = ops.resize_bicubic(torch.from_numpy(a).cuda(), 256, 256, torch.from_numpy(boxes), torch.from_numpy(flips)).cpu().numpy()
+    for b in range(3):
+        x0, y0, w, h = boxes[b]
+        r = resize_bicubic_u8(a[b, y0:y0 + h, x0:x0 + w], 256, 256)
+        assert np.array_equal(got[b], r[:, ::-1] if flips[b] else r), b
+
+
+def test_device_segmentation_batch(ops):
+    """DeviceSegmentationBatch against the host item path of SegmentationDataset (Pillow resize + one_hot_encode), float32 and uint8."""
+    from cmunet_amd.dataset import DeviceSegmentationBatch, one_hot_encode
+    from oracle.augment import resize_bicubic, resize_bicubic_u8, resize_nearest
+    rng = np.random.RandomState(8)
+    masks = (rng.rand(3, 300, 280) < 0.2).astype(np.uint8)
+    for imgs, host in ((rng.standard_normal((3, 300, 280)).astype(np.float32), resize_bicubic),
+                       (rng.randint(0, 256, (3, 300, 280)).astype(np.uint8), resize_bicubic_u8)):
+        x, y = DeviceSegmentationBatch(256, class_values=np.array([[0], [1]]), last_axis=True)(torch.from_numpy(imgs).cuda(), torch.from_numpy(masks).cuda())
+        assert x.shape == (3, 1, 256, 256) and y.shape == (3, 2, 256, 256) and y.dtype == torch.float64
+        assert np.array_equal(x[:, 0].cpu().numpy(), np.stack([host(v, 256, 256) for v in imgs]))
+        ref = np.stack([one_hot_encode(resize_nearest(m, 256, 256), [0, 1]).astype('float') for m in masks])
+        assert np.array_equal(y.cpu().numpy(), ref)
