@@ -189,6 +189,31 @@ class Moco_v2(nn.Module):
         return _MocoLossFn.apply(q_raw, k_raw, self.queue, self.queue_ptr, self.hparams["softmax_temperature"])
 
 
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx=0):
+        """moco2_module.py:311-329: forward against ``val_queue``, enqueue the keys there, cross entropy and top-1 / top-5 precision.
+        ``batch`` = ((img_1, img_2), labels) or (img_1, img_2); call it with the module in eval mode, as Lightning's loop does."""
+        x = batch[0] if isinstance(batch[0], (tuple, list)) else batch
+        output, target, keys, _ = self(img_q=x[0], img_k=x[1], queue=self.val_queue)
+        self._dequeue_and_enqueue(keys, queue_ptr=self.val_queue_ptr, queue=self.val_queue)
+        loss = F.cross_entropy(output.float(), target)
+        acc1, acc5 = precision_at_k(output, target, top_k=(1, 5))
+        return {"val_loss": loss, "val_acc1": acc1, "val_acc5": acc5}
+
+    @staticmethod
+    def validation_epoch_end(outputs):
+        """moco2_module.py:331-337: the means of the per-batch results (returned instead of logged)."""
+        return {k: torch.stack([o[k].reshape(()) for o in outputs]).mean() for k in ("val_loss", "val_acc1", "val_acc5")}
+
+
+def precision_at_k(output, target, top_k=(1,)):
+    """pl_bolts/metrics/aggregation.py:19-32: for each k the percentage of rows whose target is among the k largest logits, as (1,)
+    tensors."""
+    kmax, rows = max(top_k), target.shape[0]
+    hit = output.topk(kmax, dim=1, largest=True, sorted=True).indices.eq(target.view(-1, 1))
+    return [hit[:, :k].any(dim=1).sum(dtype=torch.float32).reshape(1) * (100.0 / rows) for k in top_k]
+
+
 class _MocoLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q_raw, k_raw, queue, queue_ptr, temperature):

@@ -594,6 +594,40 @@ def gen_moco(seed=5200):
     save("moco_ref", **out)
 
 
+def gen_moco_val(seed=5400):
+    """tests/golden/moco_val_ref.npz: the reference's own Moco_v2.validation_step (moco2_module.py:311-329) with the module in eval
+    mode (what Lightning's validation loop sets), bs 8, 64 x 64, K = 64: val_loss, val_acc1, val_acc5, the keys enqueued into
+    val_queue and its pointer; a second batch against the updated val_queue.  The oracle is asserted equal first."""
+    import types
+    from oracle import moco as OM
+    m2 = import_moco()
+    B, S, K, T = 8, 64, 64, 0.2
+    torch.manual_seed(0)
+    model = m2.Moco_v2(emb_dim=1024, num_negatives=K, encoder_momentum=0.99, softmax_temperature=T)
+    model.trainer = types.SimpleNamespace(datamodule=types.SimpleNamespace(name="synthetic"), strategy=None)
+    sd = OM.make_moco_sd(seed, K)
+    sd["val_queue"], sd["val_queue_ptr"] = OM.init_queue(1024, K, seed + 1), torch.zeros(1, dtype=torch.long)
+    model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    model.eval()
+    a = OM.moco_fixture_inputs(seed, B, S)
+    b = OM.moco_fixture_inputs(seed + 1, B, S)
+    vq, vp = sd["val_queue"].clone(), sd["val_queue_ptr"].clone()
+    out = {"seed": np.array(seed), "B": np.array(B), "S": np.array(S), "K": np.array(K), "T": np.array(T)}
+    for i, (x1, x2) in enumerate(((a[0], a[1]), (b[0], b[1]))):
+        with torch.no_grad():
+            r = model.validation_step(((x1, x2), torch.zeros(B)), i)
+        ol, o1, o5 = OM.validation_step(x1, x2, sd, vq, vp, T)
+        close(ol, r["val_loss"], what=f"moco val loss {i}")
+        assert torch.equal(o1, r["val_acc1"]) and torch.equal(o5, r["val_acc5"]), (o1, r["val_acc1"], o5, r["val_acc5"])
+        close(vq, model.val_queue, tol=1e-5, what="moco val queue")
+        assert int(vp) == int(model.val_queue_ptr) == (i + 1) * B
+        out.update({f"val_loss{i}": r["val_loss"].detach(), f"val_acc1_{i}": r["val_acc1"], f"val_acc5_{i}": r["val_acc5"],
+                    f"keys{i}": model.val_queue[:, i * B:(i + 1) * B].t().clone()})
+    assert torch.equal(model.queue, sd["queue"]) and int(model.queue_ptr) == 0          # the training queue is untouched
+    out["val_queue_ptr"] = model.val_queue_ptr.clone()
+    save("moco_val_ref", **out)
+
+
 def _moco_2rank_worker(rank, port, outdir, seed):
     """One of two gloo ranks running the reference's own Moco_v2 with a DDP strategy: shuffle-BN, gathered keys, enqueue."""
     import types
@@ -1080,6 +1114,9 @@ def main():
         return
     if "--only-moco2" in sys.argv:      # tests/golden/moco_ref_2rank.npz alone
         gen_moco_2rank()
+        return
+    if "--only-mocoval" in sys.argv:    # tests/golden/moco_val_ref.npz alone (the reference's validation_step)
+        gen_moco_val()
         return
     if "--only-moco" in sys.argv:       # tests/golden/moco_ref.npz alone (the reference's Moco_v2 behind the lightning stand-in)
         gen_moco()

@@ -12,6 +12,9 @@ Follows /root/reference/Pretraining/MoCo/pl_bolts/models/self_supervised/moco/:
   forward (logits / labels)         moco2_module.py:224-270
   dequeue_and_enqueue               moco2_module.py:160-175    queue[:, ptr:ptr+B] = keys.T ; ptr = (ptr+B) % K
   loss                              moco2_module.py:272-285    enqueue first, then CE on the pre-enqueue logits
+  validation_step                   moco2_module.py:311-329    forward against val_queue (module in eval mode under Lightning),
+                                                                enqueue into val_queue, CE, precision_at_k (metrics/aggregation.py:19-32);
+                                                                pinned by tests/golden/moco_val_ref.npz (gen_golden.py::gen_moco_val)
 """
 import torch
 import torch.nn.functional as F
@@ -67,6 +70,26 @@ def training_step(img_q, img_k, sd, queue, queue_ptr, temperature=0.07, m=0.999,
     dequeue_and_enqueue(keys_all, queue, queue_ptr, queue.shape[1])
     loss = F.cross_entropy(logits.float(), labels.long())
     return loss, logits, k
+
+
+def precision_at_k(output, target, top_k=(1,)):
+    """pl_bolts/metrics/aggregation.py:19-32: percentage of rows whose target is among the k largest logits, one (1,) tensor per k."""
+    maxk, batch = max(top_k), target.size(0)
+    pred = output.topk(maxk, 1, True, True)[1]
+    hit = pred.eq(target.view(-1, 1))
+    return [hit[:, :k].any(dim=1).float().sum().reshape(1) * (100.0 / batch) for k in top_k]
+
+
+def validation_step(img_1, img_2, sd, val_queue, val_ptr, temperature=0.07, training=False):
+    """moco2_module.py:311-329 on one rank; ``val_queue`` / ``val_ptr`` are updated in place.  Returns (loss, acc1, acc5)."""
+    with torch.no_grad():
+        q_raw = encoder_gap(img_1, sd, "encoder_q.", training)
+        k_raw = encoder_gap(img_2, sd, "encoder_k.", training)
+        logits, labels, k, _ = logits_from_embeddings(q_raw, k_raw, val_queue, temperature)
+        dequeue_and_enqueue(k, val_queue, val_ptr, val_queue.shape[1])
+        loss = F.cross_entropy(logits, labels)
+        acc1, acc5 = precision_at_k(logits, labels, (1, 5))
+    return loss, acc1, acc5
 
 
 def make_moco_sd(seed, num_negatives=64, emb_dim=1024):

@@ -380,6 +380,22 @@ def test_moco_oracle_vs_reference_fixture(golden_dir):
     assert close(queue[:, B:2 * B].t(), f["keys2"], 1e-5) and int(ptr) == int(f["queue_ptr2"]) == 2 * B
 
 
+def test_moco_validation_oracle_vs_reference_fixture(golden_dir):
+    """tests/golden/moco_val_ref.npz: the REFERENCE's own Moco_v2.validation_step (eval mode, two batches against val_queue); the
+    oracle restatement on the regenerated state reproduces loss, top-1 / top-5 precision, enqueued keys and pointer."""
+    f = fx(golden_dir, "moco_val_ref")
+    seed, B, S, K, T = int(f["seed"]), int(f["B"]), int(f["S"]), int(f["K"]), float(f["T"])
+    sd = OM.make_moco_sd(seed, K)
+    vq, vp = OM.init_queue(1024, K, seed + 1), torch.zeros(1, dtype=torch.long)
+    for i, s_ in enumerate((seed, seed + 1)):
+        x1, x2 = OM.moco_fixture_inputs(s_, B, S)[:2]
+        loss, a1, a5 = OM.validation_step(x1, x2, sd, vq, vp, T)
+        assert abs(float(loss) - float(f[f"val_loss{i}"])) <= 2e-5 * max(1.0, abs(float(f[f"val_loss{i}"])))
+        assert float(a1) == float(f[f"val_acc1_{i}"].reshape(-1)[0]) and float(a5) == float(f[f"val_acc5_{i}"].reshape(-1)[0])
+        assert close(vq[:, i * B:(i + 1) * B].t(), f[f"keys{i}"], 1e-5)
+    assert int(vp) == int(f["val_queue_ptr"].reshape(-1)[0]) == 2 * B
+
+
 def test_moco_two_rank_oracle_vs_reference_fixture(golden_dir):
     """tests/golden/moco_ref_2rank.npz: the REFERENCE's own Moco_v2 run on two gloo ranks in the build container (DDP strategy:
     shuffle-BN around the key encoder with rank 0's broadcast permutation, gathered keys, 2B rows enqueued).  The one-process oracle

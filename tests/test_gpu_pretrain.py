@@ -381,6 +381,34 @@ def test_moco_step_vs_reference_fixture(cuda, golden_dir):
     assert rel(m.queue[:, B:2 * B].t(), torch.from_numpy(f["keys2"])) <= 1e-4 and int(m.queue_ptr) == int(f["queue_ptr2"]) == 2 * B
 
 
+def test_moco_validation_step_vs_reference_fixture(cuda, golden_dir):
+    """Moco_v2.validation_step against the REFERENCE's own (tests/golden/moco_val_ref.npz, gen_golden.py::gen_moco_val: module in eval
+    mode, two batches against val_queue): loss, top-1 / top-5 precision, the keys enqueued into val_queue, its pointer; the training
+    queue stays untouched."""
+    from cmunet_amd import moco as M
+    from oracle import moco as OM
+    f = np.load(f"{golden_dir}/moco_val_ref.npz")
+    seed, B, S, K, T = int(f["seed"]), int(f["B"]), int(f["S"]), int(f["K"]), float(f["T"])
+    m = M.Moco_v2(emb_dim=1024, num_negatives=K, softmax_temperature=T, dtype="f32").to(cuda)
+    sd = OM.make_moco_sd(seed, K)
+    sd["val_queue"], sd["val_queue_ptr"] = OM.init_queue(1024, K, seed + 1), torch.zeros(1, dtype=torch.long)
+    m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    m.eval()
+    outs = []
+    for i, s_ in enumerate((seed, seed + 1)):
+        x1, x2 = (t.to(cuda) for t in OM.moco_fixture_inputs(s_, B, S)[:2])
+        r = m.validation_step(((x1, x2), torch.zeros(B)), i)
+        outs.append(r)
+        print(f"Moco_v2.validation_step {i}: loss {float(r['val_loss']):.6f} (ref {float(f[f'val_loss{i}']):.6f}) acc1 {float(r['val_acc1']):.1f} acc5 {float(r['val_acc5']):.1f}")
+        assert abs(float(r["val_loss"]) - float(f[f"val_loss{i}"])) <= 1e-3 * max(1.0, abs(float(f[f"val_loss{i}"])))
+        assert r["val_acc1"].shape == (1,) and float(r["val_acc1"]) == float(f[f"val_acc1_{i}"].reshape(-1)[0]) and float(r["val_acc5"]) == float(f[f"val_acc5_{i}"].reshape(-1)[0])
+        assert rel(m.val_queue[:, i * B:(i + 1) * B].t(), torch.from_numpy(f[f"keys{i}"])) <= 1e-4
+    assert int(m.val_queue_ptr) == int(f["val_queue_ptr"].reshape(-1)[0]) == 2 * B
+    assert torch.equal(m.queue.cpu(), sd["queue"]) and int(m.queue_ptr) == 0
+    mean = m.validation_epoch_end(outs)
+    assert abs(float(mean["val_acc5"]) - 0.5 * (float(f["val_acc5_0"].reshape(-1)[0]) + float(f["val_acc5_1"].reshape(-1)[0]))) <= 1e-4
+
+
 def test_moco_trainer_static_loss_scale_is_transparent(cuda):
     """MocoPretrainer.step(loss_scale=s): the scale multiplies the loss before backward and is divided out by the SGD kernel -- at f32
     the update equals the unscaled one (a power of two: to rounding of the momentum buffer only)."""
