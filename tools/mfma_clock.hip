@@ -175,6 +175,75 @@ static void run_lds(const char* name, const u32x4* src, int cus, unsigned long l
     fflush(stdout);
 }
 
+// ONE wave per SIMD with a 128 x 128 wave tile (16 accumulators of 32 x 32 = 256 registers, which a lone wave may hold: the
+// unified file gives it 512): per step 4 A + 4 B fragment reads and 16 MFMAs -- 8 reads per 16 MFMAs against the conv kernel's 6
+// per 8, a third less LDS traffic per FLOP.  What would such a kernel's ceiling be?
+__global__ __launch_bounds__(256) void mfma_lds_wide_loop(const u32x4* __restrict__ src, int iters, unsigned long long* out, float* sink) {
+    __shared__ u32x4 lds[4096];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 4096; i += blockDim.x) lds[i] = src[i & 4095];
+    __syncthreads();
+    u32x4 fa[2][4], fb[2][4];
+    f32x16 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    auto rd = [&](int set, int it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[set][i] = lds[(tid + 64 * i + 331 * it) & 4095];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fb[set][i] = lds[(tid + 64 * (i + 4) + 173 * it) & 4095];
+    };
+    auto mm = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[set][i]), __builtin_bit_cast(f16x8, fb[set][j]), acc[i * 4 + j], 0, 0, 0);
+    };
+    rd(0, 0);
+    unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll 1
+    for (int it = 0; it < iters; it += 2) {
+        rd(1, it + 1);
+        mm(0);
+        rd(0, it + 2);
+        mm(1);
+    }
+    unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc[i][e];
+    if (s == 123.456f) sink[0] = s;
+    if (tid == 0 && blockIdx.x % 37 == 0 && blockIdx.x / 37 < 8) {
+        out[(blockIdx.x / 37) * 2 + 0] = c1 - c0;
+        out[(blockIdx.x / 37) * 2 + 1] = r1 - r0;
+    }
+}
+static void run_lds_wide(const char* name, const u32x4* src, int cus, unsigned long long* d_out, float* d_sink) {
+    const int iters = 600000;                                   // 16 MFMAs per step and wave, 4 waves per CU: the FLOPs of run_lds<0>
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipMemset(d_out, 0, 16 * 8));
+    hipLaunchKernelGGL(mfma_lds_wide_loop, dim3(cus), dim3(256), 0, 0, src, iters / 20, d_out, d_sink);
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(mfma_lds_wide_loop, dim3(cus), dim3(256), 0, 0, src, iters, d_out, d_sink);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long h[16];
+    CK(hipMemcpy(h, d_out, sizeof(h), hipMemcpyDeviceToHost));
+    double clk = 0; int n = 0;
+    for (int i = 0; i < 8; ++i) if (h[2 * i + 1] > 0) { clk += (double)h[2 * i] / (double)h[2 * i + 1] * 100.0; ++n; }
+    const double flop = (double)cus * 4.0 * (double)iters * 16.0 * 32768.0;
+    printf("%-60s %8.2f ms  %7.1f TFLOP/s  clock %5.0f MHz\n", name, ms, flop / ms * 1e-9, n ? clk / n : 0.0);
+    fflush(stdout);
+}
+
 // LDS-fed 32x32x16 loop with DIFFERENT data for the two operands (A = first MFMA source, rows; B = second, columns): is the power
 // limit symmetric in the operands?
 __global__ __launch_bounds__(512) void mfma_lds_ab_loop(const u32x4* __restrict__ srcA, const u32x4* __restrict__ srcB, int iters, unsigned long long* out, float* sink) {
@@ -311,6 +380,9 @@ int main() {
     run_lds<0>("f16 32x32x16 fed from LDS, ReLU'd N(0,1)", d_relu, cus, d_out, d_sink);
     run_lds<1>("f16 16x16x32 fed from LDS, ReLU'd N(0,1)", d_relu, cus, d_out, d_sink);
     run_lds<0>("f16 32x32x16 fed from LDS (again), N(0,1)", d_rand, cus, d_out, d_sink);
+    run_lds_wide("f16 32x32x16, ONE wave / SIMD, 128x128 wave tile (8 reads / 16 MFMA), N(0,1)", d_rand, cus, d_out, d_sink);
+    run_lds_wide("same, ReLU'd N(0,1)", d_relu, cus, d_out, d_sink);
+    run_lds<0>("f16 32x32x16 fed from LDS (6 / 8, 2 waves: once more), N(0,1)", d_rand, cus, d_out, d_sink);
     run_ab("LDS-fed 32x32x16: A dense, B dense", d_rand, d_rand, cus, d_out, d_sink);
     run_ab("LDS-fed 32x32x16: A ReLU'd, B dense", d_relu, d_rand, cus, d_out, d_sink);
     run_ab("LDS-fed 32x32x16: A dense, B ReLU'd", d_rand, d_relu, cus, d_out, d_sink);
