@@ -91,3 +91,41 @@ def test_world_size_2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def _one_rank_worker(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("CMU_DP_REHEARSE", None)
+    try:
+        from cmunet_amd.cmunet import concat_all_gather
+        from cmunet_amd.optim import all_reduce_sum_scale, dp_exchanges, dp_world
+        assert dp_world() == 1 and not dp_exchanges()               # no group at all
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        t = torch.arange(6.0)
+        assert dp_world() == 1 and not dp_exchanges()               # a one-rank group exchanges nothing ...
+        assert all_reduce_sum_scale(t.clone()) == 1.0 and concat_all_gather(t) is t
+        os.environ["CMU_DP_REHEARSE"] = "1"                         # ... unless the rehearsal knob asks for the call sequence
+        assert dp_exchanges() and dp_world() == 1
+        u = t.clone()
+        assert all_reduce_sum_scale(u) == 1.0 and torch.equal(u, t)         # SUM over one rank, scale 1 / 1
+        g = concat_all_gather(t.view(2, 3))
+        assert g is not t and torch.equal(g, t.view(2, 3))
+        q.put("ok")
+    except Exception as e:  # noqa: BLE001
+        q.put(repr(e))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_one_rank_group_and_the_rehearsal_knob():
+    """optim.dp_world / dp_exchanges: the single gate of every collective of the trainers.  One rank exchanges nothing; with
+    CMU_DP_REHEARSE=1 the collectives run on the one-rank group (how tests/test_gpu_dataparallel.py drives RCCL on a one-GPU box)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=180)
+    p.join(timeout=60)
+    assert res == "ok", res
