@@ -28,7 +28,7 @@ import torch.nn as nn
 from . import _lib, ops
 from .model import DoubleConv, DownBlock, UpBlock, _EngineOwner, _named_state, _param_args, _require_cuda
 from .ops import Act
-from .optim import dp_exchanges
+from .optim import claim_grad_sink, dp_exchanges
 from .pretrain import create_random_patch_mask, random_patch_mask_device
 
 
@@ -237,6 +237,7 @@ class _SkinnyLinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.compute_dt = compute_dt
+        ctx.weight_param = weight if isinstance(weight, torch.nn.Parameter) else None
         return ops.skinny_gemm_fwd(x.detach(), weight.detach(), None if bias is None else bias.detach())
 
     @staticmethod
@@ -244,7 +245,9 @@ class _SkinnyLinearFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
         dx = ops.skinny_gemm_dgrad(dy, weight.detach()) if ctx.needs_input_grad[0] else None
-        dw, db = (ops.skinny_gemm_wgrad(dy, x.detach(), ctx.has_bias, ctx.compute_dt) if ctx.needs_input_grad[1] else (None, None))
+        # a trainer's gradient arena as the destination (optim.claim_grad_sink): no 1.6 GB copy of the projector's gradient per step
+        sink = claim_grad_sink(ctx.weight_param) if ctx.needs_input_grad[1] else None
+        dw, db = (ops.skinny_gemm_wgrad(dy, x.detach(), ctx.has_bias, ctx.compute_dt, out=sink) if ctx.needs_input_grad[1] else (None, None))
         if ctx.has_bias and db is None and ctx.needs_input_grad[2]:
             db = dy.sum(0)
         return dx, dw, db, None
@@ -408,9 +411,17 @@ class _CMUNetFn(torch.autograd.Function):
         eng.prepack(sd)                # every conv / conv-transpose weight pack of the four networks in one launch
         tr = module.training
         x = img.detach().float().contiguous()
-        ectx = eng.encoder_forward(sd, x, tr, "backbone.", mask, not module.ref_compat)
+        # the online encoder writes its skips straight into the pixel decoder's concat buffers (as the fused UNet does); the feature
+        # decoder takes its copies of them
+        pcats = eng.decoder_alloc(sd, x.shape[0], x.shape[1], x.shape[2], "pixel_decoder.")
+        nd = eng.n_down(sd, "backbone.")
+        fits = len(pcats) == nd and all(c["Cskip"] == sd[f"backbone.down_conv{i + 1}.double_conv.double_conv.0.weight"].shape[0]
+                                        for i, c in enumerate(pcats))
+        skip_out = [Act(c["buf"], c["Cup"], c["Cskip"]) for c in pcats] if fits else None
+        skip_affine = [(c["scale"][c["Cup"]:], c["shift"][c["Cup"]:]) for c in pcats] if fits else None
+        ectx = eng.encoder_forward(sd, x, tr, "backbone.", mask, not module.ref_compat, skip_out, skip_affine)
         tctx = eng.encoder_forward(sd, img_t.detach().float().contiguous(), tr, "target_backbone.", None)
-        pctx = eng.decoder_forward(sd, ectx["latent"], ectx["skips"], tr, "pixel_decoder.", None, True)
+        pctx = eng.decoder_forward(sd, ectx["latent"], ectx["skips"], tr, "pixel_decoder.", pcats if fits else None, True)
         fctx = eng.decoder_forward(sd, ectx["latent"], ectx["skips"], tr, "feature_decoder.", None, True)
         # cmunet.py:128-129: the per-call Conv2d(C, C/4, 1) on the target latent, straight from the raw NHWC latent and its
         # pending BatchNorm+ReLU into the NCHW fp32 tensor the reference re-views as an image (no gradient: target branch)
@@ -429,9 +440,7 @@ class _CMUNetFn(torch.autograd.Function):
         dl_f, ds_f = eng.decoder_backward(sd, fctx, d_feat.contiguous().float(), grads, True)
         d_latent = Act(dl_p.buf + dl_f.buf)
 
-        def view(a):
-            return a.buf[..., a.coff:a.coff + a.C]
-        d_skips = [Act((view(a) + view(b)).contiguous()) for a, b in zip(ds_p, ds_f)]
+        d_skips = list(zip(ds_p, ds_f))          # summed inside the pool backward of each level (cmu_maxpool_bwd2): no add passes
         eng.encoder_backward(sd, ectx, d_latent, d_skips, grads)
         ctx.saved = None
         return (None, None, None, None, None, None, None, *[grads.get(n) for n in ctx.names])

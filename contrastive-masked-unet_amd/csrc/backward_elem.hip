@@ -324,6 +324,7 @@ extern "C" int cmu_bn_bwd_apply_masked(const void* dA, int64_t ldd, const void* 
 template <class TR>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* __restrict__ dP, int64_t ldp,
                                                          const unsigned char* __restrict__ dS, int64_t lds,
+                                                         const unsigned char* __restrict__ dS2, int64_t lds2,
                                                          const unsigned char* __restrict__ y, int64_t ldy,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          unsigned char* __restrict__ dA, int64_t lda, int B, int H, int W, int C,
@@ -375,6 +376,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) d[e] = 0.f;
                 }
+                if (dS2) {   // a second consumer of the skip (the joint model's two decoders): summed here in fp32, no add pass
+                    float d2[EPC];
+                    TR::unpack(ld_global16_nt(dS2 + (src[q] * lds2 + ch * EPC) * ES), d2);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) d[e] += d2[e];
+                }
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) d[e] += (arg[e] == q) ? g[e] : 0.f;
                 const u32x4 packed = TR::pack(d);
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
     }
 }
 template <class TR>
-static int maxpool_bwd_t(const void* dP, int64_t ldp, const void* dS, int64_t lds, const void* y, int64_t ldy, const float* scale,
+static int maxpool_bwd_t(const void* dP, int64_t ldp, const void* dS, int64_t lds, const void* dS2, int64_t lds2, const void* y, int64_t ldy, const float* scale,
                          const float* shift, void* dA, int64_t lda, int B, int H, int W, int C, const float* mean, const float* invstd,
                          void* bn_ws, hipStream_t st) {
     int cpb, ppb, gy;
@@ -415,22 +422,30 @@ static int maxpool_bwd_t(const void* dP, int64_t ldp, const void* dS, int64_t ld
     int gx = (int)(cmu_div_up64(npool, ppb * 2) < POOLB_MAX_BLOCKS ? cmu_div_up64(npool, ppb * 2) : POOLB_MAX_BLOCKS);
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL((maxpool_bwd_kernel<TR>), dim3(gx, gy), dim3(256), 0, st, (const unsigned char*)dP, ldp, (const unsigned char*)dS,
-                       lds, (const unsigned char*)y, ldy, scale, shift, (unsigned char*)dA, lda, B, H, W, C, cpb, ppb, mean, invstd,
+                       lds, (const unsigned char*)dS2, lds2, (const unsigned char*)y, ldy, scale, shift, (unsigned char*)dA, lda, B, H, W, C, cpb, ppb, mean, invstd,
                        (float*)bn_ws);
     CMU_CHECK_LAUNCH("cmu_maxpool_bwd");
     return CMU_OK;
 }
-extern "C" int cmu_maxpool_bwd(const void* dP, int64_t ldp, const void* dSkip, int64_t lds, const void* y, int64_t ldy,
-                               const float* scale, const float* shift, void* dA, int64_t lda, const float* save_mean,
-                               const float* save_invstd, void* bn_ws, int B, int H, int W, int C, int dt, void* stream) {
+extern "C" int cmu_maxpool_bwd2(const void* dP, int64_t ldp, const void* dSkip, int64_t lds, const void* dSkip2, int64_t lds2, const void* y,
+                                int64_t ldy, const float* scale, const float* shift, void* dA, int64_t lda, const float* save_mean,
+                                const float* save_invstd, void* bn_ws, int B, int H, int W, int C, int dt, void* stream) {
     CMU_CHECK_ARG(bn_ws == nullptr || (save_mean && save_invstd), "cmu_maxpool_bwd: fused BN statistics need save_mean / save_invstd");
+    CMU_CHECK_ARG(dSkip2 == nullptr || dSkip != nullptr, "cmu_maxpool_bwd2: dSkip2 without dSkip");
     int rc;
     if ((rc = check_pair("cmu_maxpool_bwd(dP,y)", dP, ldp, y, ldy, C, dt))) return rc;
     if ((rc = check_pair("cmu_maxpool_bwd(dA,y)", dA, lda, y, ldy, C, dt))) return rc;
     if (dSkip && (rc = check_pair("cmu_maxpool_bwd(dSkip,y)", dSkip, lds, y, ldy, C, dt))) return rc;
+    if (dSkip2 && (rc = check_pair("cmu_maxpool_bwd2(dSkip2,y)", dSkip2, lds2, y, ldy, C, dt))) return rc;
     CMU_CHECK_ARG(scale && shift && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "cmu_maxpool_bwd: bad dims (%d,%d)", H, W);
-    CMU_DISPATCH_DT(dt, maxpool_bwd_t, dP, ldp, dSkip, lds, y, ldy, scale, shift, dA, lda, B, H, W, C, save_mean, save_invstd, bn_ws,
-                    (hipStream_t)stream);
+    CMU_DISPATCH_DT(dt, maxpool_bwd_t, dP, ldp, dSkip, lds, dSkip2, lds2, y, ldy, scale, shift, dA, lda, B, H, W, C, save_mean, save_invstd,
+                    bn_ws, (hipStream_t)stream);
+}
+extern "C" int cmu_maxpool_bwd(const void* dP, int64_t ldp, const void* dSkip, int64_t lds, const void* y, int64_t ldy,
+                               const float* scale, const float* shift, void* dA, int64_t lda, const float* save_mean,
+                               const float* save_invstd, void* bn_ws, int B, int H, int W, int C, int dt, void* stream) {
+    return cmu_maxpool_bwd2(dP, ldp, dSkip, lds, nullptr, 0, y, ldy, scale, shift, dA, lda, save_mean, save_invstd, bn_ws, B, H, W, C, dt,
+                            stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -23,6 +23,7 @@ import torch
 
 from . import _lib, ops
 from .ops import Act
+from .optim import claim_grad_sink
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -89,6 +90,10 @@ class UNetEngine:
         if self.grad_target is not None:
             t = self.grad_target.get(self.grad_prefix + name)
             if t is not None:
+                return t
+        else:
+            t = claim_grad_sink(like)     # the autograd path: straight into the arena of the trainer that holds the parameter, if any
+            if t is not None and t.device == self.device:
                 return t
         return torch.empty(like.shape, dtype=torch.float32, device=self.device)
 
@@ -308,8 +313,9 @@ class UNetEngine:
             lv = ctx["levels"][i - 1]
             y2 = lv["s2"]["y"]
             dA2 = self._new(y2.B, y2.H, y2.W, y2.C)
-            ops.maxpool_bwd(dP, d_skips[i - 1] if d_skips is not None else None, y2, dA2, lv["s2"]["mean"], lv["s2"]["invstd"],
-                            self._bn_ws(y2.C))
+            ds = d_skips[i - 1] if d_skips is not None else None
+            ds, ds2 = ds if isinstance(ds, (tuple, list)) else (ds, None)     # two decoders on this encoder: both gradients of the skip
+            ops.maxpool_bwd(dP, ds, y2, dA2, lv["s2"]["mean"], lv["s2"]["invstd"], self._bn_ws(y2.C), dSkip2=ds2)
             dA1 = self._convbn_bwd(sd, lv["s2"], dA2, grads, True, fused_stats=True, next_bn=lv["s1"])
             dP = self._convbn_bwd(sd, lv["s1"], dA1, grads, i > 1)
         self.flush_zero_bias()

@@ -263,9 +263,10 @@ def conv3x3_c1_wgrad_bn(x_bhw, dA, yraw, scale, shift, save_mean, save_invstd, c
          _stream())
 
 
-def maxpool_bwd(dP, dSkip, y, dA, save_mean=None, save_invstd=None, bn_ws=None):
-    call("cmu_maxpool_bwd", dP.ptr(), dP.ld, None if dSkip is None else dSkip.ptr(), 0 if dSkip is None else dSkip.ld,
-         y.ptr(), y.ld, _p(y.scale), _p(y.shift), dA.ptr(), dA.ld, _p(save_mean), _p(save_invstd), _p(bn_ws),
+def maxpool_bwd(dP, dSkip, y, dA, save_mean=None, save_invstd=None, bn_ws=None, dSkip2=None):
+    """``dSkip2``: a second gradient of the same skip tensor (two decoders on one encoder), summed inside the pass."""
+    call("cmu_maxpool_bwd2", dP.ptr(), dP.ld, None if dSkip is None else dSkip.ptr(), 0 if dSkip is None else dSkip.ld,
+         None if dSkip2 is None else dSkip2.ptr(), 0 if dSkip2 is None else dSkip2.ld, y.ptr(), y.ld, _p(y.scale), _p(y.shift), dA.ptr(), dA.ld, _p(save_mean), _p(save_invstd), _p(bn_ws),
          y.B, y.H, y.W, y.C, y.dt, _stream())
 
 

@@ -7,11 +7,39 @@ HIP kernel over the arena, the data-parallel gradient exchange is one RCCL all-r
 of the momentum encoder is one kernel between two arenas with identical layout.
 """
 import os
+import weakref
 
 import torch
 import torch.distributed as dist
 
 from . import ops
+
+
+_GRAD_SINKS = {}      # id(Parameter) -> (weak reference to it, its slot in a trainer's gradient arena); entries die with the parameter
+
+
+def _register_grad_sink(param, view):
+    key = id(param)
+    _GRAD_SINKS[key] = (weakref.ref(param, lambda _r, k=key: _GRAD_SINKS.pop(k, None)), view)
+
+
+_SINKS_CLAIMED = set()
+
+
+def claim_grad_sink(param):
+    """For the package's autograd nodes, which produce a whole parameter gradient in one kernel: a fresh alias of ``param``'s slot in its
+    trainer's gradient arena to write that gradient into and hand to autograd (which adopts an unshared tensor as ``.grad`` without a
+    copy; ``gather_autograd_grads`` then finds it in place) -- or None, and the node allocates as usual: no arena holds the parameter,
+    it already has a ``.grad`` (autograd must accumulate into it), or the slot was already handed out since the last gather (a weight
+    used twice in one graph)."""
+    ent = _GRAD_SINKS.get(id(param)) if isinstance(param, torch.nn.Parameter) else None
+    if ent is None or ent[0]() is not param or param.grad is not None or id(param) in _SINKS_CLAIMED:
+        return None
+    view = ent[1]
+    if view.shape != param.shape or view.dtype != torch.float32 or not view.is_contiguous():
+        return None
+    _SINKS_CLAIMED.add(id(param))
+    return view.view_as(view)
 
 
 def dp_world(group=None):
@@ -60,6 +88,10 @@ class FlatParams:
             self.offsets[n] = (off, p.numel())
             self.views[n] = v
             self.grad_views[n] = self.grad[off:off + p.numel()].view_as(p)
+            # autograd nodes of the package that produce a whole parameter gradient in one kernel (the necks' Linear layers) write it
+            # here instead of into a fresh tensor: no 1.6 GB copy of the joint model's projector gradient per step
+            # (a registry rather than an attribute: attributes of a Parameter travel with torch.save(model))
+            _register_grad_sink(p, self.grad_views[n])
             off += sz
         self.params = dict(params)
 
@@ -74,13 +106,24 @@ class FlatParams:
 
     def gather_autograd_grads(self):
         """Copy ``p.grad`` tensors produced by autograd into the gradient arena (drop-in path)."""
+        dst, src, zero = [], [], []
+        _SINKS_CLAIMED.difference_update(id(p) for p in self.params.values())
         for n in self.names:
             g = self.params[n].grad
             gv = self.grad_views[n]
             if g is None:
-                gv.zero_()
+                zero.append(gv)
             elif g.data_ptr() != gv.data_ptr():
-                gv.copy_(g)
+                if g.dtype == gv.dtype and g.shape == gv.shape:
+                    dst.append(gv)
+                    src.append(g.detach())
+                else:
+                    gv.copy_(g)
+        # a few multi-tensor launches instead of one copy per parameter (the joint model has ~270 small ones: 1.8 ms of launches)
+        if zero:
+            torch._foreach_zero_(zero)
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     def all_reduce_mean(self, group=None):
         """Data-parallel gradient exchange: ONE RCCL all-reduce over the whole arena (C1 in SURVEY 2.5).

@@ -173,6 +173,12 @@ int cmu_maxpool_bwd(const void* dP, int64_t ldp, const void* dSkip, int64_t lds,
                     const float* scale, const float* shift, void* dA, int64_t lda,
                     const float* save_mean, const float* save_invstd, void* bn_ws,
                     int B, int H, int W, int C, int dt, void* stream);
+/* cmu_maxpool_bwd2: the same with a second skip gradient dSkip2 (or NULL) added in fp32 inside the pass -- the skips of CM_UNet's online
+ * encoder feed the pixel AND the feature decoder (cmunet.py:121-124 of the reference: autograd sums the two gradients).               */
+int cmu_maxpool_bwd2(const void* dP, int64_t ldp, const void* dSkip, int64_t lds, const void* dSkip2, int64_t lds2, const void* y,
+                     int64_t ldy, const float* scale, const float* shift, void* dA, int64_t lda,
+                     const float* save_mean, const float* save_invstd, void* bn_ws,
+                     int B, int H, int W, int C, int dt, void* stream);
 
 /* ConvTranspose2d 2x2 s2 backward.  data: dX (B,H,W,Cin) from dOut (B,2H,2W,ldd) (GEMM K = 4*Cout).
  * weight: dW (Cin,Cout,2,2) and dbias (Cout) fp32, overwritten.                                    */
