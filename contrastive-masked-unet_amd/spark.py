@@ -99,7 +99,12 @@ class _SparKFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         grads = ctx.grads or {}
-        out = [None if grads.get(n) is None else grads[n] * g for n in ctx.names]
+        # scaled in place by the incoming gradient in a few multi-tensor launches (one multiply per parameter was 86 launches a step);
+        # the tensors are the engine's: fresh ones, or aliases of the trainer's gradient arena that autograd adopts as they are
+        have = [grads[n] for n in ctx.names if grads.get(n) is not None]
+        if have:
+            torch._foreach_mul_(have, g.reshape(()).to(have[0].dtype))
+        out = [grads.get(n) for n in ctx.names]
         ctx.grads = None
         return (None, None, None, None, None, *out)
 
@@ -325,16 +330,24 @@ class SparK(_EngineOwner, nn.Module):
 
         # ---- densify (spark.py:98-111): feature maps from the smallest to the largest, mask_tokens[i] likewise ----
         feats = [b2["a"]] + [lv["s2"]["a"] for lv in reversed(levels)]
+        # the densified skips are written straight into the right halves of the decoder's concat buffers (no copy at the hand-over)
+        cats = eng.decoder_alloc(sd, B, H, W, dp)
+        nf = len(feats)
+        into_cats = len(cats) == nf - 1 and all(cats[nf - 1 - i]["Cskip"] == feats[i].C for i in range(1, nf))
         to_dec = []
         for i, a in enumerate(feats):
             tok = self.mask_tokens[i].detach().reshape(-1).contiguous()
-            d = eng._new(a.B, a.H, a.W, a.C)
+            if i > 0 and into_cats:
+                c = cats[nf - 1 - i]                             # feats[i] is the skip of up_conv{nf - i}
+                d = Act(c["buf"], c["Cup"], c["Cskip"])
+            else:
+                d = eng._new(a.B, a.H, a.W, a.C)
             ops.mask_select(a, active, d, relu=False, fill=tok, use_transform=False)
             to_dec.append(d)
 
         # ---- dense decoder (decoder.py:49-55) + loss (spark.py:112-123) ----
         skips = list(reversed(to_dec[1:]))                       # skips[i-1] belongs to up_conv{i}
-        dctx = eng.decoder_forward(sd, to_dec[0], skips, training, dp, None, True)
+        dctx = eng.decoder_forward(sd, to_dec[0], skips, training, dp, cats if into_cats else None, True)
         rec = dctx["logits"]                                     # (B,1,H,W)
         loss = torch.empty(1, dtype=torch.float32, device=eng.device)
         drec = torch.empty_like(rec) if need_grads else None
