@@ -303,3 +303,51 @@ def test_unet_reference_image_sizes_vs_oracle(M, size, dt):
         bar = max(8 * e2_cpu, 2e-3) if dt == "f32" else tol * 20
         assert e2 <= bar, f"d{k}: {e2:.3e} (oracle f32: {e2_cpu:.3e})"
     print(f"[unet {size}x{size} {dt}] logits err vs f64 {e:.2e} (oracle f32 {e_cpu:.2e}); worst gradient error ratio to the oracle's f32 {worst:.1f}")
+
+
+def test_parameter_gradients_land_in_the_arena_and_shared_weights_still_accumulate():
+    """optim.claim_grad_sink: with the parameters held by a FlatParams arena the UNet's autograd node writes every parameter gradient
+    into its arena slot and autograd adopts the alias as ``.grad`` (no copy at gather time); the same network applied twice in one
+    graph -- its weights used by two backward nodes -- still gets the SUM of both gradients (the second node must not overwrite
+    the slot), and gradient accumulation over two backward calls adds up.  Checked against the same network without an arena."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cmunet_amd import model as M
+    from cmunet_amd.optim import FlatParams
+    torch.manual_seed(3)
+    ref = M.UNet(base_ch=16, depth=3, dtype="f32").cuda().train()
+    net = M.UNet(base_ch=16, depth=3, dtype="f32").cuda().train()
+    net.load_state_dict(ref.state_dict())
+    flat = FlatParams(net)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x1 = torch.randn(2, 32, 32, generator=g, device="cuda")
+    x2 = torch.randn(2, 32, 32, generator=g, device="cuda")
+
+    def loss_of(m, a, b=None):
+        out = m(a).square().mean()
+        return out if b is None else out + 0.5 * m(b).square().mean()
+
+    # one use: adopted in place
+    loss_of(ref, x1).backward()
+    loss_of(net, x1).backward()
+    named = dict(net.named_parameters())
+    w = "down_conv1.double_conv.double_conv.0.weight"
+    assert named[w].grad.data_ptr() == flat.grad_views[w].data_ptr()
+    flat.gather_autograd_grads()
+    for n, p in ref.named_parameters():
+        assert torch.allclose(flat.grad_views[n], p.grad, rtol=1e-5, atol=1e-7), n
+    # gradient accumulation: a second backward adds into the adopted .grad
+    loss_of(ref, x2).backward()
+    loss_of(net, x2).backward()
+    flat.gather_autograd_grads()
+    for n, p in ref.named_parameters():
+        assert torch.allclose(flat.grad_views[n], p.grad, rtol=1e-5, atol=1e-7), n
+    # two uses of the same weights in one graph
+    for m in (ref, net):
+        for p in m.parameters():
+            p.grad = None
+    loss_of(ref, x1, x2).backward()
+    loss_of(net, x1, x2).backward()
+    flat.gather_autograd_grads()
+    for n, p in ref.named_parameters():
+        assert torch.allclose(flat.grad_views[n], p.grad, rtol=1e-5, atol=1e-7), n
