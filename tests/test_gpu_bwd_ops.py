@@ -175,6 +175,37 @@ def test_maxpool_bwd(ops, dt, with_skip):
 
 
 @pytest.mark.parametrize("dt", DTS)
+def test_maxpool_bwd_two_skip_gradients(ops, dt):
+    """cmu_maxpool_bwd2: two gradients of the same skip tensor (CM_UNet's pixel and feature decoders hang on one encoder,
+    cmunet.py:121-124 of the reference; autograd sums them) added in fp32 inside the pass, with different strides / channel offsets;
+    the fused BatchNorm-backward sums see the summed gradient."""
+    from cmunet_amd import _lib
+    B, C, H, W = 2, 32, 8, 12
+    g = torch.Generator().manual_seed(15)
+    y = q(torch.randn(B, C, H, W, generator=g), dt, ops)
+    sc, sh = torch.randn(C, generator=g), torch.randn(C, generator=g) * 0.2
+    dP = q(torch.randn(B, C, H // 2, W // 2, generator=g), dt, ops)
+    dS1 = q(torch.randn(B, C, H, W, generator=g), dt, ops)
+    dS2 = q(torch.randn(B, C, H, W, generator=g), dt, ops)
+    a = F.relu(y.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).requires_grad_(True)
+    (F.max_pool2d(a, 2) * dP.double()).sum().backward()
+    ref = a.grad + dS1.double() + dS2.double()
+    ya = to_act(y, dt, ops).with_transform(sc.cuda(), sh.cuda(), 0)
+    dA = ops.new_act(B, H, W, C, dt, "cuda")
+    mean, invstd = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    ws = ws_bytes(_lib.lib().cmu_bn_bwd_ws_bytes(C))
+    ops.maxpool_bwd(to_act(dP, dt, ops), to_act(dS1, dt, ops, ld=2 * C, coff=C), ya, dA, mean.cuda(), invstd.cuda(), ws,
+                    dSkip2=to_act(dS2, dt, ops, ld=3 * C, coff=2 * C))
+    gate = (a.detach() > 0).double()
+    check(from_act(dA).double() * gate, ref * gate, TOL[dt], "maxpool bwd, two skip gradients (gated)")
+    coef_f, coef_r = torch.empty(2, C, device="cuda"), torch.empty(2, C, device="cuda")
+    dg_f, db_f, dg_r, db_r = (torch.empty(C, device="cuda") for _ in range(4))
+    ops.bn_bwd_finalize(ws, B * H * W, dg_f, db_f, coef_f)
+    ops.bn_bwd_reduce(dA, ya, mean.cuda(), invstd.cuda(), dg_r, db_r, coef_r, ws_bytes(_lib.lib().cmu_bn_bwd_ws_bytes(C)))
+    check(dg_f.cpu(), dg_r.cpu(), 1e-5, "fused dgamma"); check(db_f.cpu(), db_r.cpu(), 1e-5, "fused dbeta")
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("case", [(2, 8, 8, 32, 16, True), (1, 5, 9, 64, 32, False), (2, 16, 16, 128, 64, True),
                                   # Cin % 128 == 0 and Cout % 64 == 0 -> wide kernel for the 16-bit dtypes (conv_wgrad2.inc)
                                   (1, 5, 9, 128, 64, True), (2, 7, 33, 256, 128, False), (3, 4, 16, 128, 192, True),
