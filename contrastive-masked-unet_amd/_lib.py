@@ -117,6 +117,7 @@ _SIGS = {
     "cmu_gap_bwd": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "cmu_ema_update": (_I, [_P, _P, _L, _F, _P]),
     "cmu_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _L, _F, _P, _P]),
+    "cmu_adam_ema_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _L, _F, _P, _I, _P, _P, _P, _F, _P]),
     "cmu_skinny16_gemm_ws_bytes": (_L, [_I, _I, _L]),
     "cmu_skinny16_gemm_fwd": (_I, [_P, _P, _P, _P, _I, _I, _L, _I, _P, _P]),
     "cmu_skinny16_gemm_dgrad": (_I, [_P, _P, _P, _I, _I, _L, _I, _P]),

@@ -139,7 +139,7 @@ class UNet_encoder(_EngineOwner, nn.Module):
     """
 
     def __init__(self, out_classes=2, up_sample_mode='conv_transpose', patch_size=16, mask_ratio=0.65,
-                 base_ch=64, depth=5, dtype="bf16", ref_compat=True):
+                 base_ch=64, depth=5, dtype="f16", ref_compat=True):
         super().__init__()
         self.up_sample_mode = up_sample_mode
         self.dtype = dtype
@@ -205,7 +205,7 @@ class _DecoderFn(torch.autograd.Function):
 class MUNetPretrainDecoder(_EngineOwner, nn.Module):
     """UNet up path + 1x1 head (munet_neck.py:52-82). forward(x, skip) with skip = [skip1..skip4]."""
 
-    def __init__(self, out_classes=2, up_sample_mode='conv_transpose', base_ch=64, depth=5, dtype="bf16"):
+    def __init__(self, out_classes=2, up_sample_mode='conv_transpose', base_ch=64, depth=5, dtype="f16"):
         super().__init__()
         self.up_sample_mode = up_sample_mode
         self.dtype = dtype
@@ -436,12 +436,20 @@ class _CMUNetFn(torch.autograd.Function):
         sd = _named_state(ctx.module)
         ectx, pctx, fctx = ctx.saved
         grads = {}
+        # a data-parallel trainer is told as soon as a sub-network's gradients are final (pretrain.ArenaTrainer.notify_ready): their
+        # all-reduce runs under the rest of this node instead of behind it
+        ready = getattr(ctx.module, "_grads_ready", None)
         dl_p, ds_p = eng.decoder_backward(sd, pctx, d_pix.contiguous().float(), grads, True)
+        if ready is not None:
+            ready("pixel_decoder.", grads)
         dl_f, ds_f = eng.decoder_backward(sd, fctx, d_feat.contiguous().float(), grads, True)
+        if ready is not None:
+            ready("feature_decoder.", grads)
         d_latent = Act(dl_p.buf + dl_f.buf)
 
         d_skips = list(zip(ds_p, ds_f))          # summed inside the pool backward of each level (cmu_maxpool_bwd2): no add passes
-        eng.encoder_backward(sd, ectx, d_latent, d_skips, grads)
+        eng.encoder_backward(sd, ectx, d_latent, d_skips, grads,
+                             after_bottleneck=(lambda: ready("backbone.double_conv.", grads)) if ready is not None else None)
         ctx.saved = None
         return (None, None, None, None, None, None, None, *[grads.get(n) for n in ctx.names])
 
@@ -454,7 +462,7 @@ class CM_UNet(_EngineOwner, nn.Module):
     forward(img, mode='loss', img_t=...) -> {'loss_ct', 'loss_rc'}.
     """
 
-    def __init__(self, backbone, neck, head, base_momentum=0.996, init_cfg=None, target_cls=True, dtype="bf16",
+    def __init__(self, backbone, neck, head, base_momentum=0.996, init_cfg=None, target_cls=True, dtype="f16",
                  ref_compat=True, **kwargs):
         super().__init__()
         assert neck is not None and head is not None
@@ -555,10 +563,12 @@ _TYPES.update({"UNet_encoder": UNet_encoder, "MUNetPretrainDecoder": MUNetPretra
                "CMUNetPretrainHead": CMUNetPretrainHead, "CM_UNet": CM_UNet})
 
 
-def cmunet_config(img_size=224, dtype="bf16", temperature=0.07, ct_weight=1.0, rc_weight=1.0, mask_ratio=0.65,
+def cmunet_config(img_size=224, dtype="f16", temperature=0.07, ct_weight=1.0, rc_weight=1.0, mask_ratio=0.65,
                   base_ch=64, depth=5):
     """The ``model`` dict of configs/cmunet_config.py:5-42 with the projector sized for ``img_size``
-    (in_channels = H*W: 50176 at 224, 262144 at 512)."""
+    (in_channels = H*W: 50176 at 224, 262144 at 512).  ``dtype`` defaults to 'f16': the reference trains this
+    model under AmpOptimWrapper(loss_scale='dynamic') (cmunet_config.py:76-78), i.e. fp16 operands with fp32 accumulation --
+    pair it with ``JointPretrainer(amp=True)`` (the device-side dynamic loss scaler); 'f32' / 'bf16' are opt-in."""
     neck = dict(type='NonLinearNeck', hid_channels=1536, out_channels=256, num_layers=2, with_bias=True, with_last_bn=False,
                 with_avg_pool=False)
     enc = dict(type='UNet_encoder', patch_size=16, base_ch=base_ch, depth=depth)

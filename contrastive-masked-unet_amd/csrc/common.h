@@ -101,6 +101,7 @@ struct F32Traits {
     __device__ static inline float to_float(float v) { return v; }
     __device__ static inline float from_float(float v) { return v; }
     __device__ static inline uint32_t pack2(float a, float) { return __float_as_uint(a); }   // (16-bit paths only; never called)
+    __device__ static inline void unpack2(uint32_t c, float& lo, float& hi) { lo = __uint_as_float(c); hi = 0.f; }   // (same)
 };
 
 struct F16Traits {
@@ -129,6 +130,12 @@ struct F16Traits {
         typedef __attribute__((ext_vector_type(2))) float f32x2_t;
         typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
         return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){a, b}, f16x2_t));
+    }
+    __device__ static inline void unpack2(uint32_t c, float& lo, float& hi) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+        const f16x2_t h = __builtin_bit_cast(f16x2_t, c);
+        lo = (float)h[0];
+        hi = (float)h[1];
     }
 };
 
@@ -159,6 +166,10 @@ struct BF16Traits {
         uint32_t r;
         asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
         return r;
+    }
+    __device__ static inline void unpack2(uint32_t c, float& lo, float& hi) {
+        lo = __uint_as_float(c << 16);
+        hi = __uint_as_float(c & 0xffff0000u);
     }
 };
 

@@ -392,6 +392,9 @@ extern "C" int cmu_infonce_inbatch_fwd_bwd(const float* pred, const float* keys,
 // ---------------------------------------------------------------------------------------------
 // EMA and Adam over flat fp32 arenas (float4 per lane)
 // ---------------------------------------------------------------------------------------------
+// cmunet.py:85-86 order: p_t*m + p_o*(1-m); the contraction is spelled out so that the stand-alone kernel and the form fused into the
+// AdamW kernel (cmu_adam_ema_step) round identically
+__device__ __forceinline__ float cmu_ema1(float t, float o, float m, float om) { return fmaf(t, m, o * om); }
 __global__ void ema_kernel(float* __restrict__ t, const float* __restrict__ o, int64_t n, float m) {
     const int64_t n4 = n >> 2;
     const float om = 1.f - m;
@@ -399,12 +402,12 @@ __global__ void ema_kernel(float* __restrict__ t, const float* __restrict__ o, i
         f32x4 a = reinterpret_cast<f32x4*>(t)[i];
         const f32x4 b = reinterpret_cast<const f32x4*>(o)[i];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) a[e] = a[e] * m + b[e] * om;   // cmunet.py:85-86 order: p_t*m + p_o*(1-m)
+        for (int e = 0; e < 4; ++e) a[e] = cmu_ema1(a[e], b[e], m, om);
         reinterpret_cast<f32x4*>(t)[i] = a;
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const int64_t i = (n4 << 2) + threadIdx.x;
-        t[i] = t[i] * m + o[i] * om;
+        t[i] = cmu_ema1(t[i], o[i], m, om);
     }
 }
 extern "C" int cmu_ema_update(float* target, const float* online, int64_t n, float momentum, void* stream) {
@@ -452,6 +455,98 @@ extern "C" int cmu_adam_step(float* p, const float* g, float* m, float* v, const
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, wd_mask, n, lr, beta1, beta2, eps,
                        weight_decay, decoupled, (float)bc1, (float)sqrt(bc2), grad_scale, (const CmuAmpState*)amp_state);
     CMU_CHECK_LAUNCH("cmu_adam_step");
+    return CMU_OK;
+}
+
+// AdamW + the EMA of the momentum networks in ONE pass over the arena (round 3; the joint CM-UNet step: 447 M parameters, of which
+// 422 M -- backbone and projector -- have a target copy): the EMA as its own launch re-reads the 1.7 GB of parameters the optimiser
+// has just written.  Up to two segments [lo, hi) of the online arena map onto target arrays; elements outside them are a plain
+// AdamW update.  Float4 per lane (every tensor of a FlatParams arena starts on a 16-byte boundary and the arena is a multiple of four
+// elements).  A skipped step (amp found_inf) still runs the EMA with the unchanged parameters, as MomentumUpdateHook.after_train_iter
+// does behind a skipped optimiser step.  Element arithmetic = adam_kernel's and ema_kernel's: bit-identical to the two launches.
+struct AdamEmaSeg {
+    int64_t lo4[2], hi4[2];   // segment bounds in float4 units
+    float* target[2];
+    int nseg;
+    float momentum;
+};
+__global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, const uint8_t* __restrict__ wd_mask, int64_t n4, float lr,
+                                                       float b1, float b2, float eps, float wd, int decoupled, float bc1, float bc2_sqrt,
+                                                       float gscale, const CmuAmpState* __restrict__ amp, const AdamEmaSeg seg) {
+    bool skip = false;
+    if (amp != nullptr) {
+        skip = amp->found_inf != 0.f;
+        gscale /= amp->scale;
+        const double t = (double)(amp->good_steps + 1);
+        bc1 = (float)(1.0 - pow((double)b1, t));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
+    }
+    const float em = seg.momentum, eom = 1.f - seg.momentum;
+    const float step_size = lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float* tp = nullptr;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (k < seg.nseg && i >= seg.lo4[k] && i < seg.hi4[k]) tp = seg.target[k] + ((i - seg.lo4[k]) << 2);
+        if (skip && tp == nullptr) continue;
+        f32x4 pv = reinterpret_cast<const f32x4*>(p)[i];
+        if (!skip) {
+            const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+            f32x4 mv = reinterpret_cast<const f32x4*>(m)[i], vv = reinterpret_cast<const f32x4*>(v)[i];
+            const uint32_t wm = wd_mask != nullptr ? reinterpret_cast<const uint32_t*>(wd_mask)[i] : 0x01010101u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float pi = pv[e], gi = gv[e] * gscale;
+                const float w = ((wm >> (8 * e)) & 0xffu) ? wd : 0.f;
+                if (decoupled) pi *= (1.f - lr * w);
+                else gi = fmaf(w, pi, gi);
+                const float mi = fmaf(b1, mv[e], (1.f - b1) * gi);
+                const float vi = fmaf(b2, vv[e], (1.f - b2) * gi * gi);
+                mv[e] = mi;
+                vv[e] = vi;
+                const float denom = sqrtf(vi) / bc2_sqrt + eps;
+                pv[e] = pi - step_size * (mi / denom);
+            }
+            reinterpret_cast<f32x4*>(m)[i] = mv;
+            reinterpret_cast<f32x4*>(v)[i] = vv;
+            reinterpret_cast<f32x4*>(p)[i] = pv;
+        }
+        if (tp != nullptr) {
+            f32x4 tv = *reinterpret_cast<const f32x4*>(tp);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tv[e] = cmu_ema1(tv[e], pv[e], em, eom);
+            *reinterpret_cast<f32x4*>(tp) = tv;
+        }
+    }
+}
+extern "C" int cmu_adam_ema_step(float* p, const float* g, float* m, float* v, const uint8_t* wd_mask, int64_t n, float lr, float beta1,
+                                 float beta2, float eps, float weight_decay, int decoupled, int64_t step, float grad_scale,
+                                 const void* amp_state, int nseg, const int64_t* seg_lo, const int64_t* seg_hi, float* const* seg_target,
+                                 float ema_momentum, void* stream) {
+    CMU_CHECK_ARG(p && g && m && v && n > 0 && step >= 1 && (n & 3) == 0, "cmu_adam_ema_step: bad args (n must be a multiple of 4)");
+    CMU_CHECK_ARG(cmu_aligned16(p) && cmu_aligned16(g) && cmu_aligned16(m) && cmu_aligned16(v) && (wd_mask == nullptr || ((uintptr_t)wd_mask & 3) == 0),
+                  "cmu_adam_ema_step: arenas must be 16-byte aligned");
+    CMU_CHECK_ARG(nseg >= 0 && nseg <= 2 && (nseg == 0 || (seg_lo && seg_hi && seg_target)), "cmu_adam_ema_step: at most two EMA segments");
+    AdamEmaSeg seg;
+    seg.nseg = nseg;
+    seg.momentum = ema_momentum;
+    for (int k = 0; k < 2; ++k) { seg.lo4[k] = seg.hi4[k] = 0; seg.target[k] = nullptr; }
+    for (int k = 0; k < nseg; ++k) {
+        CMU_CHECK_ARG(seg_lo[k] >= 0 && seg_hi[k] > seg_lo[k] && seg_hi[k] <= n && (seg_lo[k] & 3) == 0 && (seg_hi[k] & 3) == 0 && seg_target[k] &&
+                      cmu_aligned16(seg_target[k]), "cmu_adam_ema_step: segment bounds must be multiples of 4 inside [0, n], targets 16-byte aligned");
+        CMU_CHECK_ARG(k == 0 || seg_lo[k] >= seg_hi[k - 1], "cmu_adam_ema_step: segments must be ascending and disjoint");
+        seg.lo4[k] = seg_lo[k] >> 2;
+        seg.hi4[k] = seg_hi[k] >> 2;
+        seg.target[k] = seg_target[k];
+    }
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const int64_t nb = cmu_div_up64(n >> 2, 256);
+    const int grid = (int)(nb < 16384 ? nb : 16384);
+    hipLaunchKernelGGL(adam_ema_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, wd_mask, n >> 2, lr, beta1, beta2, eps,
+                       weight_decay, decoupled, (float)bc1, (float)sqrt(bc2), grad_scale, (const CmuAmpState*)amp_state, seg);
+    CMU_CHECK_LAUNCH("cmu_adam_ema_step");
     return CMU_OK;
 }
 

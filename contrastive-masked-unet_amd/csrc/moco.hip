@@ -44,12 +44,25 @@ struct MocoParams {
     int64_t kchunk;
 };
 
-__device__ static inline void moco_grid_barrier(unsigned* counter, unsigned target) {
+// Grid barrier between the phases.  It only ends when every workgroup of the grid is resident at once: the launcher sizes the grid
+// to at most one workgroup per CU (66 KB LDS, 256 threads), which holds on a stream that owns the whole device -- NOT under a CU mask
+// narrower than the CU count (tools/cu_partition.py's masked streams) or beside another resident kernel that holds the CUs it needs
+// (an RCCL kernel on the process-group stream, several ranks sharing one card): do not run this entry concurrently with other
+// kernels.  So that such a misuse fails instead of hanging the GPU, the spin is BOUNDED (~2 s of s_sleep polls): on expiry the
+// workgroup raises bar[7], leaves the barrier, and the launch ends with loss = NaN (the trainers' inf / nan checks see it).
+__device__ static inline void moco_grid_barrier(unsigned* counter, unsigned target, unsigned* timeout_flag) {
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
         __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+        unsigned spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 21) || __hip_atomic_load(timeout_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                __hip_atomic_store(timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
     }
     __syncthreads();
     __threadfence();   // every wave: what the other workgroups wrote before the barrier is visible to its loads
@@ -81,7 +94,8 @@ __global__ __launch_bounds__(256) void moco_fused_kernel(const MocoParams p) {
     const int B = p.B, D = p.D, K = p.K;
     const int RT = (B + 31) / 32;
     const unsigned G = gridDim.x;
-    const int ptr0 = (int)p.queue_ptr[0];   // read before anything in this launch can move it (the write is in the last phase)
+    int ptr0 = (int)p.queue_ptr[0];   // read before anything in this launch can move it (the write is in the last phase)
+    if (ptr0 < 0 || ptr0 >= p.K) ptr0 = 0;   // (a corrupted pointer cannot send the enqueue outside the queue)
 
     // ---- P0: row norms, normalised rows, the positive logit ---------------------------------------------------------------------
     for (int b = blockIdx.x; b < B; b += G) {
@@ -114,7 +128,7 @@ __global__ __launch_bounds__(256) void moco_fused_kernel(const MocoParams p) {
         const int m = B + (int)(o / D), d = (int)(o % D);
         p.qnT[((int64_t)(m >> 5) * D + d) * 32 + (m & 31)] = 0.f;
     }
-    moco_grid_barrier(p.bar + 0, G);
+    moco_grid_barrier(p.bar + 0, G, p.bar + 7);
 
     // ---- P1: L = qn . queue / T.  Work item = (row tile, 128 columns j): lane c holds columns 4c .. 4c+3 of four MFMA tiles, the four
     // waves take a quarter of the D rows each and are summed through LDS in wave order ------------------------------------------
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(256) void moco_fused_kernel(const MocoParams p) {
             }
         }
     }
-    moco_grid_barrier(p.bar + 1, G);
+    moco_grid_barrier(p.bar + 1, G, p.bar + 7);
 
     // ---- P2: per row: log-sum-exp over [pos, L[b][:]], the row's loss term, p = softmax / (B T) in place ----------------------------
     for (int b = blockIdx.x; b < B; b += G) {
@@ -185,7 +199,7 @@ __global__ __launch_bounds__(256) void moco_fused_kernel(const MocoParams p) {
             p.rowst[b * 4 + 3] = (m + logf(se) - pos) / (float)B;                     // CE with label 0, mean over the batch
         }
     }
-    moco_grid_barrier(p.bar + 2, G);
+    moco_grid_barrier(p.bar + 2, G, p.bar + 7);
 
     // ---- P3: G = p . queue^T, split over K.  Work item = (row tile, 128 rows d of the queue, K range): wave = 32 rows ---------------
     if (p.dq != nullptr) {
@@ -226,7 +240,7 @@ __global__ __launch_bounds__(256) void moco_fused_kernel(const MocoParams p) {
             }
         }
     }
-    moco_grid_barrier(p.bar + 3, G);
+    moco_grid_barrier(p.bar + 3, G, p.bar + 7);
 
     // ---- P4: dq = (I - qn qn^T) (gpos kn + G) / |q|;  enqueue;  pointer;  loss ------------------------------------------------------
     if (p.dq != nullptr) {
@@ -249,13 +263,19 @@ __global__ __launch_bounds__(256) void moco_fused_kernel(const MocoParams p) {
         const int Nk = p.Nk;
         for (int64_t o = (int64_t)blockIdx.x * 256 + tid; o < (int64_t)Nk * D; o += (int64_t)G * 256) {
             const int d = (int)(o / Nk), i = (int)(o % Nk);        // consecutive threads -> consecutive columns of one queue row
-            p.queue[(int64_t)d * K + ptr0 + i] = keys[(int64_t)i * D + d];
+            // (ring semantics: a pointer that is not a multiple of the batch -- a batch size that changed between calls, which the
+            // reference refuses with a shape error at moco2_module.py:172 and Moco_v2.training_step refuses on the host -- wraps
+            // instead of writing into the next row or past the buffer)
+            int col = ptr0 + i;
+            if (col >= K) col -= K;
+            p.queue[(int64_t)d * K + col] = keys[(int64_t)i * D + d];
         }
     }
     if (blockIdx.x == 0 && tid == 0) {
         double tot = 0.0;
         for (int r = 0; r < B; ++r) tot += (double)p.rowst[r * 4 + 3];
-        p.loss[0] = (float)tot;
+        const bool timed_out = __hip_atomic_load(p.bar + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        p.loss[0] = timed_out ? __builtin_nanf("") : (float)tot;
         p.queue_ptr[0] = (int64_t)((ptr0 + p.Nk) % K);
     }
 }

@@ -49,7 +49,9 @@ class _EncoderGapFn(torch.autograd.Function):
         dA = eng._new(lat.B, lat.H, lat.W, lat.C)
         ops.gap_bwd(dout.contiguous().float(), dA)
         grads = {}
-        eng.encoder_backward(sd, ectx, dA, None, grads)
+        ready = getattr(ctx.module, "_grads_ready", None)      # pretrain.ArenaTrainer.notify_ready: the bottleneck's exchange starts early
+        eng.encoder_backward(sd, ectx, dA, None, grads,
+                             after_bottleneck=(lambda: ready("double_conv.", grads)) if ready is not None else None)
         ctx.ectx = None
         return (None, None, None, *[grads.get(n) for n in ctx.names])
 
@@ -57,7 +59,7 @@ class _EncoderGapFn(torch.autograd.Function):
 class UNet_encoder(_MaskEncoder):
     """moco_data_module.py:47-66: the UNet encoder followed by torch.mean(x, dim=[2,3]); input (B,1,H,W)."""
 
-    def __init__(self, out_classes=2, up_sample_mode='conv_transpose', base_ch=64, depth=5, dtype="bf16"):
+    def __init__(self, out_classes=2, up_sample_mode='conv_transpose', base_ch=64, depth=5, dtype="f32"):
         super().__init__(out_classes, up_sample_mode, patch_size=16, mask_ratio=0.0, base_ch=base_ch, depth=depth, dtype=dtype)
 
     def forward(self, x):
@@ -92,7 +94,7 @@ def queue_logits(q, queue):
 class Moco_v2(nn.Module):
     def __init__(self, base_encoder=None, emb_dim=1024, num_negatives=65536, encoder_momentum=0.999,
                  softmax_temperature=0.07, learning_rate=0.03, momentum=0.9, weight_decay=1e-4, batch_size=256,
-                 use_mlp=False, dtype="bf16", base_ch=64, depth=5, shuffle_bn=True, **kwargs):
+                 use_mlp=False, dtype="f32", base_ch=64, depth=5, shuffle_bn=True, **kwargs):
         super().__init__()
         self.hparams = dict(emb_dim=emb_dim, num_negatives=num_negatives, encoder_momentum=encoder_momentum,
                             softmax_temperature=softmax_temperature, learning_rate=learning_rate, momentum=momentum,
@@ -140,6 +142,27 @@ class Moco_v2(nn.Module):
     def _world():
         return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
+    def _check_enqueue(self, n_keys):
+        """The reference's enqueue asserts ``num_negatives % batch_size == 0`` and writes ``queue[:, ptr:ptr + bs]`` -- a pointer
+        that is not a multiple of the (gathered) batch fails there with a shape error (moco2_module.py:169-172).  Same loud failure
+        here, from a host-side shadow of the pointer (no device read per step; re-read from the buffer after a ``load_state_dict``
+        or when the batch size changes)."""
+        K = self.hparams["num_negatives"]
+        if K % n_keys != 0:
+            raise AssertionError(f"num_negatives={K} must be a multiple of the enqueued batch {n_keys} (moco2_module.py:169)")
+        sh = self.__dict__.get("_ptr_shadow")
+        if sh is None or sh[1] != n_keys or sh[2] != self.queue_ptr.data_ptr():
+            sh = [int(self.queue_ptr.item()), n_keys, self.queue_ptr.data_ptr()]
+        if sh[0] % n_keys != 0:
+            raise RuntimeError(f"queue pointer {sh[0]} is not a multiple of the enqueued batch {n_keys}: the reference's "
+                               "queue[:, ptr:ptr + bs] = keys.T (moco2_module.py:172) fails here too")
+        sh[0] = (sh[0] + n_keys) % K
+        self.__dict__["_ptr_shadow"] = sh
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.__dict__.pop("_ptr_shadow", None)
+        return super()._load_from_state_dict(*args, **kwargs)
+
     @torch.no_grad()
     def _batch_shuffle_ddp(self, x):
         """moco2_module.py:177-201: gather the key images of all ranks, draw ONE permutation on rank 0 (global CPU generator,
@@ -174,7 +197,13 @@ class Moco_v2(nn.Module):
         with torch.no_grad():
             k = F.normalize(self._encode_keys(img_k), dim=1)
         l_pos = (q * k).sum(dim=1, keepdim=True)                     # einsum("nc,nc->n")
-        l_neg = queue_logits(q, queue.detach())                     # (the reference's queue.clone() is dropped: A-8)
+        # moco2_module.py:262 multiplies by queue.clone().detach(): the reference's order is forward -> _dequeue_and_enqueue ->
+        # loss.backward(), and the backward needs the PRE-enqueue queue.  The copy is only made where a backward can follow (grad
+        # mode on and q in the graph); validation (no_grad) reads the live buffer.  The fused training_step needs neither.
+        qd = queue.detach()
+        if torch.is_grad_enabled() and q.requires_grad:
+            qd = qd.clone()
+        l_neg = queue_logits(q, qd)
         logits = torch.cat([l_pos, l_neg], dim=1) / self.hparams["softmax_temperature"]
         labels = torch.zeros(logits.shape[0], dtype=torch.long, device=logits.device)
         return logits, labels, k, q
@@ -183,6 +212,7 @@ class Moco_v2(nn.Module):
         """Fused step; ``batch`` = (img_q, img_k) or ((img_q, img_k), _) like the reference's loader output."""
         x = batch[0] if isinstance(batch[0], (tuple, list)) else batch
         img_q, img_k = x[0], x[1]
+        self._check_enqueue(img_q.shape[0] * (self._world() if dp_exchanges() else 1))
         self._momentum_update_key_encoder()
         q_raw = self.encoder_q(img_q)
         k_raw = self._encode_keys(img_k)

@@ -490,6 +490,13 @@ def gap_bwd(dout, dA):
 PARAM_GENERATION = 0
 
 
+def bump_param_generation():
+    """Call after any raw or bulk write into a parameter arena that PyTorch's version counters do not see (a collective into
+    the arena, a checkpoint copied into it): the engine's packed-weight caches key on this counter."""
+    global PARAM_GENERATION
+    PARAM_GENERATION += 1
+
+
 def ema_update(target, online, momentum):
     global PARAM_GENERATION
     PARAM_GENERATION += 1
@@ -503,6 +510,23 @@ def adam_step(p, g, m, v, wd_mask, lr, beta1, beta2, eps, weight_decay, decouple
     call("cmu_adam_step", _p(_f32c(p)), _p(_f32c(g)), _p(_f32c(m)), _p(_f32c(v)), _p(wd_mask), p.numel(), float(lr),
          float(beta1), float(beta2), float(eps), float(weight_decay), int(decoupled), int(step), float(grad_scale),
          _p(None if amp is None else amp.state), _stream())
+
+
+def adam_ema_step(p, g, m, v, wd_mask, lr, beta1, beta2, eps, weight_decay, decoupled, step, grad_scale, amp, segments, momentum):
+    """``adam_step`` + the EMA of the momentum networks in one pass (cmu_adam_ema_step).  ``segments``: up to two
+    (lo, hi, target fp32 tensor of hi - lo elements), ascending element ranges of the arena ``p``."""
+    global PARAM_GENERATION
+    PARAM_GENERATION += 1
+    n = len(segments)
+    assert 1 <= n <= 2
+    lo = (ctypes.c_int64 * n)(*[int(s[0]) for s in segments])
+    hi = (ctypes.c_int64 * n)(*[int(s[1]) for s in segments])
+    for s in segments:
+        assert s[2].numel() == s[1] - s[0] and s[2].device == p.device
+    tg = (ctypes.c_void_p * n)(*[_f32c(s[2]).data_ptr() for s in segments])
+    call("cmu_adam_ema_step", _p(_f32c(p)), _p(_f32c(g)), _p(_f32c(m)), _p(_f32c(v)), _p(wd_mask), p.numel(), float(lr),
+         float(beta1), float(beta2), float(eps), float(weight_decay), int(decoupled), int(step), float(grad_scale),
+         _p(None if amp is None else amp.state), n, lo, hi, tg, float(momentum), _stream())
 
 
 class AmpScaler:
@@ -526,6 +550,24 @@ class AmpScaler:
         f = raw[:8].view(torch.float32)
         i = raw[8:20].view(torch.int32)
         return float(f[0]), float(f[1]), int(i[0]), int(i[1]), int(i[2])
+
+    def state_dict(self):
+        """GradScaler.state_dict's fields (mmengine's AmpOptimWrapper saves them as ``loss_scaler``) plus the two counters the
+        optimiser kernel reads: ``good_steps`` is the step number of Adam's bias corrections, so a resume without it would
+        restart them at 1 on steady-state moments (first updates ~2x too large at betas (0.9, 0.95)).  Synchronises."""
+        scale, _, tracker, good, skipped = self.read()
+        return {"scale": scale, "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": tracker, "good_steps": good, "skipped_steps": skipped}
+
+    def load_state_dict(self, sd):
+        import struct
+        self.growth_factor = sd.get("growth_factor", self.growth_factor)
+        self.backoff_factor = sd.get("backoff_factor", self.backoff_factor)
+        self.growth_interval = sd.get("growth_interval", self.growth_interval)
+        raw = struct.pack("<ffiii", float(sd["scale"]), 0.0, int(sd.get("_growth_tracker", 0)), int(sd.get("good_steps", 0)),
+                          int(sd.get("skipped_steps", 0)))
+        raw = raw + b"\0" * (self.state.numel() - len(raw))
+        self.state.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
 
 
 def sgd_step(p, g, buf, wd_mask, lr, momentum, dampening, weight_decay, nesterov, step, grad_scale=1.0):

@@ -125,6 +125,48 @@ class FlatParams:
         if dst:
             torch._foreach_copy_(dst, src)
 
+    def gather_names(self, names):
+        """``gather_autograd_grads`` restricted to ``names`` (one bucket of an overlapped exchange): their ``p.grad`` tensors into the
+        arena (nothing to do for a gradient the producing kernel already wrote in place), zeros for parameters without one."""
+        dst, src, zero = [], [], []
+        for n in names:
+            p = self.params[n]
+            _SINKS_CLAIMED.discard(id(p))
+            g, gv = p.grad, self.grad_views[n]
+            if g is None:
+                zero.append(gv)
+            elif g.data_ptr() != gv.data_ptr():
+                if g.dtype == gv.dtype and g.shape == gv.shape:
+                    dst.append(gv)
+                    src.append(g.detach())
+                else:
+                    gv.copy_(g)
+        if zero:
+            torch._foreach_zero_(zero)
+        if dst:
+            torch._foreach_copy_(dst, src)
+
+    def buckets(self, key=None):
+        """Contiguous runs of the arena whose parameters share ``key(name)`` -> [(lo, hi, [names])] in arena order.  Default key:
+        the top-level module name, with an encoder's bottleneck (``<top>.double_conv.*``: 60 % of its parameters, the first to be
+        complete in a backward pass) apart from its down blocks."""
+        if key is None:
+            def key(n):
+                top, _, rest = n.partition(".")
+                return top + (".double_conv" if rest.startswith("double_conv.") else "")
+        out, cur = [], None
+        for n in self.names:
+            k = key(n)
+            off, cnt = self.offsets[n]
+            hi = off + ((cnt + 3) // 4) * 4
+            if cur is not None and cur[0] == k:
+                cur[2] = hi
+                cur[3].append(n)
+            else:
+                cur = [k, off, hi, [n]]
+                out.append(cur)
+        return [(lo, hi, names) for _, lo, hi, names in out]
+
     def all_reduce_mean(self, group=None):
         """Data-parallel gradient exchange: ONE RCCL all-reduce over the whole arena (C1 in SURVEY 2.5).
         Returns the scale (1/world) the optimiser kernel folds into its gradient load."""
@@ -181,26 +223,51 @@ class FusedAdam:
         self.v = torch.zeros_like(flat.arena)
         self.wd_mask = flat.wd_mask(decay_filter) if (decay_filter is not None and weight_decay != 0.0) else None
         self.step_count = 0
+        self.amp = None          # the ops.AmpScaler the steps run under (set by the trainer or by the first step(amp=...))
 
     def zero_grad(self, set_to_none=True):
         for p in self.flat.params.values():
             p.grad = None
 
-    def step(self, grad_scale=1.0, amp=None):
+    def step(self, grad_scale=1.0, amp=None, ema=None):
         """``amp``: an ``ops.AmpScaler`` -- the kernel then skips / unscales from its device state (and takes the step number
-        of the bias corrections from it)."""
+        of the bias corrections from it).  ``ema``: (segments, momentum) -- the EMA of the momentum networks in the same pass
+        (``ops.adam_ema_step``; segments = up to two (lo, hi, target tensor) ranges of the arena)."""
         self.step_count += 1
+        if amp is not None:
+            self.amp = amp
+        if ema is not None:
+            ops.adam_ema_step(self.flat.arena, self.flat.grad, self.m, self.v, self.wd_mask, self.lr, self.betas[0], self.betas[1],
+                              self.eps, self.weight_decay, self.decoupled, self.step_count, grad_scale, amp, ema[0], ema[1])
+            return
         ops.adam_step(self.flat.arena, self.flat.grad, self.m, self.v, self.wd_mask, self.lr, self.betas[0],
                       self.betas[1], self.eps, self.weight_decay, self.decoupled, self.step_count, grad_scale, amp)
         # ops.adam_step bumps ops.PARAM_GENERATION: the engine's packed-weight caches see the raw-kernel write
 
     def state_dict(self):
-        return {"m": self.m, "v": self.v, "step": self.step_count, "lr": self.lr}
+        """Moments, host step count and -- when the steps run under a loss scaler -- the scaler's state (``loss_scaler``, the key
+        mmengine's AmpOptimWrapper.state_dict uses): under amp the kernel takes the bias-correction step from the scaler's
+        ``good_steps``, so the optimiser cannot be resumed without it."""
+        sd = {"m": self.m, "v": self.v, "step": self.step_count, "lr": self.lr}
+        if self.amp is not None:
+            sd["loss_scaler"] = self.amp.state_dict()
+        return sd
 
-    def load_state_dict(self, sd):
+    def load_state_dict(self, sd, amp=None):
+        """``amp``: the scaler the resumed steps will run under (defaults to the one already attached).  A checkpoint without
+        ``loss_scaler`` (written by a run without amp, or by an older build) seeds the scaler's step counter from ``step``."""
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])
         self.step_count = int(sd["step"])
+        amp = amp if amp is not None else self.amp
+        if amp is not None:
+            self.amp = amp
+            if "loss_scaler" in sd:
+                amp.load_state_dict(sd["loss_scaler"])
+            else:
+                cur = amp.state_dict()
+                cur["good_steps"] = self.step_count
+                amp.load_state_dict(cur)
 
 
 class FusedSGD:

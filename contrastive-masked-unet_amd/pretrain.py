@@ -77,6 +77,7 @@ class MaskedReconPretrainer:
         self.group = process_group
         self.loss_scale = loss_scale
         self.amp = ops.AmpScaler(self.device) if amp is True else (amp or None)
+        self.opt.amp = self.amp
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._dlogits = None
         self._ws = None
@@ -95,9 +96,18 @@ class MaskedReconPretrainer:
     def broadcast_parameters(self, src=0):
         if dp_exchanges(self.group):
             dist.broadcast(self.flat.arena, src=src, group=self.group)
+            ops.bump_param_generation()          # a raw write into the arena: packed-weight caches must not survive it
             for n, b in self.model.named_buffers():
                 if b.is_floating_point():
                     dist.broadcast(b, src=src, group=self.group)
+
+    def state_dict(self):
+        """Optimiser moments + step + the loss scaler's state (``optimizer``), next to the model's own ``state_dict()``."""
+        return {"optimizer": self.opt.state_dict()}
+
+    def load_state_dict(self, sd):
+        self.opt.load_state_dict(sd["optimizer"], amp=self.amp)
+        ops.bump_param_generation()
 
     def forward_backward(self, img, mask):
         """img (B,H,W) fp32 cuda, mask (B,H,W) uint8 cuda (1 = masked).  Leaves gradients in the arena and
@@ -177,6 +187,81 @@ class ArenaTrainer:
         self.flat = optimizer.flat
         self.opt = optimizer
         self.device = self.flat.arena.device
+        # Backward-overlapped gradient exchange (what DDP's bucketed all-reduce gives the reference: Spark/main.py:102,
+        # dist_train.sh:9-17 + cmunet_config.py:120, Lightning's DDP): the arena is cut into buckets along the top-level modules
+        # (an encoder's bottleneck apart from its down blocks); a bucket's all-reduce starts as soon as its last gradient has
+        # landed -- told either by autograd's post-accumulate hooks or, earlier, by the fused autograd nodes themselves
+        # (``notify_ready`` from inside _CMUNetFn / _EncoderGapFn.backward, which finish a decoder or the bottleneck long before
+        # the node returns) -- and runs under the rest of the backward pass; everything is waited for before the inf check.
+        # For the joint model the 1.6 GB projector gradient, produced first, is exchanged under the whole conv backward.
+        # CMU_DDP_OVERLAP=0: one all-reduce of the whole arena after loss.backward() (A/B and fallback switch).
+        self._overlap = os.environ.get("CMU_DDP_OVERLAP", "1") != "0"
+        self._buckets = [dict(lo=lo, hi=hi, names=names, pending=0, launched=False) for lo, hi, names in self.flat.buckets()]
+        self._bucket_of = {n: b for b in self._buckets for n in b["names"]}
+        self._ov_active = False
+        self._works = []
+        for n, p in self.flat.params.items():
+            p.register_post_accumulate_grad_hook(lambda _p, n=n: self._on_grad(n))
+
+    # ---- overlapped exchange ----------------------------------------------------------------------------------------------
+    def _begin_overlap(self):
+        for b in self._buckets:
+            b["pending"], b["launched"] = len(b["names"]), False
+        self._works = []
+        self._ov_active = True
+        self.last_exchange = {"buckets": len(self._buckets), "early": 0, "in_backward": 0, "flushed": 0}
+
+    def _launch(self, b):
+        """Gradients of bucket ``b`` are final: bring stragglers into the arena, start its all-reduce (async, on the group's stream)."""
+        b["launched"] = True
+        self.flat.gather_names(b["names"])
+        w = self.flat.all_reduce_range_async(b["lo"], b["hi"], self.group)
+        if w is not None:
+            self._works.append(w)
+
+    def _on_grad(self, name):
+        if not self._ov_active:
+            return
+        b = self._bucket_of[name]
+        b["pending"] -= 1
+        if b["pending"] == 0 and not b["launched"]:
+            self.last_exchange["in_backward"] += 1
+            self._launch(b)
+
+    def notify_ready(self, prefix, grads):
+        """Called from inside a fused autograd node: every parameter gradient under ``prefix`` is final and sits in ``grads``.  Buckets
+        made only of such parameters whose gradients were all written straight into the arena start their exchange now."""
+        if not self._ov_active:
+            return
+        for b in self._buckets:
+            if b["launched"] or not all(n.startswith(prefix) for n in b["names"]):
+                continue
+            ok = True
+            for n in b["names"]:
+                g = grads.get(n)
+                if g is None or g.data_ptr() != self.flat.grad_views[n].data_ptr():
+                    ok = False
+                    break
+            if ok:
+                b["launched"] = True          # (their hooks fire when the node returns: nothing left to do then)
+                self.last_exchange["early"] += 1
+                w = self.flat.all_reduce_range_async(b["lo"], b["hi"], self.group)
+                if w is not None:
+                    self._works.append(w)
+
+    def _finish_overlap(self):
+        """After loss.backward(): buckets that never completed (parameters without a gradient: SparK's ``densify_projs``) in arena
+        order -- the same order on every rank --, then wait for everything."""
+        self._ov_active = False
+        for b in self._buckets:
+            if not b["launched"]:
+                self.last_exchange["flushed"] += 1
+                self._launch(b)
+        from .optim import _SINKS_CLAIMED
+        _SINKS_CLAIMED.difference_update(id(p) for p in self.flat.params.values())
+        for w in self._works:
+            w.wait()
+        self._works = []
 
     @staticmethod
     def trainable(model):
@@ -191,6 +276,7 @@ class ArenaTrainer:
         if not dp_exchanges(self.group):
             return
         dist.broadcast(self.flat.arena, src=src, group=self.group)
+        ops.bump_param_generation()              # raw write into the arena (advisor, round 2): stale packed weights otherwise
         held = {id(p) for p in self.flat.params.values()}
         for p in self.model.parameters():
             if id(p) not in held:
@@ -199,8 +285,9 @@ class ArenaTrainer:
             if b.is_floating_point():
                 dist.broadcast(b, src=src, group=self.group)
 
-    def backward_and_step(self, loss, loss_scale=1.0, amp=None):
+    def backward_and_step(self, loss, loss_scale=1.0, amp=None, ema=None):
         """``loss``: scalar tensor from the model's forward (already multiplied by ``loss_scale`` if one is used).
+        ``ema``: (segments, momentum) handed to the optimiser kernel (``FusedAdam.step``): the momentum networks' EMA in the same pass.
         ``amp``: an ``ops.AmpScaler`` -- dynamic loss scaling as mmengine's AmpOptimWrapper does it (cmunet_config.py:76-78): the loss
         is multiplied by the scale held ON THE DEVICE (no host read), the inf / nan check runs on the exchanged gradients, the
         optimiser kernel unscales or skips from the same state, the scale is updated afterwards."""
@@ -208,20 +295,30 @@ class ArenaTrainer:
             p.grad = None
         if amp is not None:
             loss = loss * amp.state[:4].view(torch.float32)          # the current scale, a one-element device tensor
-        loss.backward()
-        self.flat.gather_autograd_grads()
         scale = 1.0
-        if dp_exchanges(self.group):
-            dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)
+        if self._overlap and dp_exchanges(self.group):
+            self._begin_overlap()
+            try:
+                loss.backward()
+            finally:
+                self._ov_active = False
+            self._finish_overlap()
             scale = 1.0 / self.world()
+        else:
+            loss.backward()
+            self.flat.gather_autograd_grads()
+            if dp_exchanges(self.group):
+                dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)
+                scale = 1.0 / self.world()
+        kw = {} if ema is None else {"ema": ema}
         if amp is not None:
             amp.check(self.flat.grad)                                # after the exchange: every rank takes the same decision
-            self.opt.step(grad_scale=scale / loss_scale, amp=amp)
+            self.opt.step(grad_scale=scale / loss_scale, amp=amp, **kw)
             amp.update()
             for p in self.flat.params.values():
                 p.grad = None
             return
-        self.opt.step(grad_scale=scale / loss_scale)
+        self.opt.step(grad_scale=scale / loss_scale, **kw)
         for p in self.flat.params.values():       # the arena holds them; drop the per-tensor copies autograd made
             p.grad = None
 
@@ -239,6 +336,7 @@ class JointPretrainer(ArenaTrainer):
         opt = FusedAdam(flat, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decoupled=True, decay_filter=no_decay_bias_norm)
         super().__init__(model, opt, process_group)
         self.amp = ops.AmpScaler(self.device) if amp is True else (amp or None)
+        self.opt.amp = self.amp
         tnames = {n for n, _ in model.named_parameters() if n.startswith(("target_backbone.", "target_projector."))}
         self.tflat = FlatParams(model, names=lambda n: n in tnames)
         # identical layouts: (backbone, projector) inside the online arena <-> (target_backbone, target_projector)
@@ -247,18 +345,34 @@ class JointPretrainer(ArenaTrainer):
             a, b = self.flat.prefix_range(src), self.tflat.prefix_range(dst)
             assert a is not None and b is not None and a[1] - a[0] == b[1] - b[0], "online / target layouts differ"
             self._ema.append((a, b))
+        self._ema.sort()
+        object.__setattr__(model, "_grads_ready", self.notify_ready)     # fused node -> trainer: "these gradients are final"
+        # the EMA rides in the AdamW kernel (cmu_adam_ema_step: one pass over the 1.7 GB of parameters instead of two);
+        # CMU_EMA_FUSE=0 keeps the two stand-alone EMA launches behind the optimiser (A/B switch, bit-identical)
+        self._fuse_ema = os.environ.get("CMU_EMA_FUSE", "1") != "0"
 
     def momentum_update(self):
         for (a0, a1), (b0, b1) in self._ema:
             ops.ema_update(self.tflat.arena[b0:b1], self.flat.arena[a0:a1], self.model.momentum)
+
+    def state_dict(self):
+        return {"optimizer": self.opt.state_dict()}
+
+    def load_state_dict(self, sd):
+        self.opt.load_state_dict(sd["optimizer"], amp=self.amp)
+        ops.bump_param_generation()
 
     def step(self, img, img_t, mask=None, cur_iter=None, max_iter=None, **kw):
         if cur_iter is not None and max_iter:
             from .cmunet import momentum_schedule
             self.model.momentum = momentum_schedule(cur_iter, max_iter, self.model.base_momentum, getattr(self.model, "end_momentum", self.model.base_momentum))
         losses = self.model(img, mode="loss", img_t=img_t, mask=mask, **kw)
-        self.backward_and_step(losses["loss_ct"] + losses["loss_rc"], amp=self.amp)
-        self.momentum_update()
+        if self._fuse_ema:
+            segs = [(a0, a1, self.tflat.arena[b0:b1]) for (a0, a1), (b0, b1) in self._ema]
+            self.backward_and_step(losses["loss_ct"] + losses["loss_rc"], amp=self.amp, ema=(segs, self.model.momentum))
+        else:
+            self.backward_and_step(losses["loss_ct"] + losses["loss_rc"], amp=self.amp)
+            self.momentum_update()
         return {k: v.detach() for k, v in losses.items()}
 
 
@@ -278,6 +392,9 @@ class MocoPretrainer(ArenaTrainer):
         a, b = self.flat.prefix_range("encoder_q."), self.kflat.prefix_range("encoder_k.")
         assert a is not None and b is not None and a[1] - a[0] == b[1] - b[0]
         model._ema_arenas = (self.kflat.arena[b[0]:b[1]], self.flat.arena[a[0]:a[1]])     # used by _momentum_update_key_encoder
+        # the query encoder's fused node names its parameters without the "encoder_q." prefix
+        object.__setattr__(model.encoder_q, "_grads_ready",
+                           lambda prefix, grads: self.notify_ready("encoder_q." + prefix, {"encoder_q." + k: v for k, v in grads.items()}))
 
     def set_epoch(self, epoch, max_epochs):
         """moco2_module.py:345-348: the cosine learning rate of ``epoch`` (0-based: CosineAnnealingLR after ``epoch`` scheduler steps)."""

@@ -41,7 +41,7 @@ from .ops import Act
 class UNET_MAE_SPARSE(nn.Module):
     """Parameter container with the reference's names (models/custom.py:113-182); executed by SparK."""
 
-    def __init__(self, in_chans=1, base_ch=64, depth=5, dtype="bf16", **kwargs):
+    def __init__(self, in_chans=1, base_ch=64, depth=5, dtype="f32", **kwargs):
         super().__init__()
         chans = [base_ch * 2 ** i for i in range(depth)]
         cin = in_chans
@@ -69,14 +69,14 @@ class SparseEncoder(nn.Module):
         self.input_size, self.downsample_raito, self.enc_feat_map_chs = input_size, cnn.get_downsample_ratio(), cnn.get_feature_map_channels()
 
 
-def build_sparse_encoder(name, input_size, sbn=False, drop_path_rate=0.0, verbose=False, base_ch=64, depth=5, dtype="bf16"):
+def build_sparse_encoder(name, input_size, sbn=False, drop_path_rate=0.0, verbose=False, base_ch=64, depth=5, dtype="f32"):
     if name not in ("unet_sparse", "unet"):
         raise NotImplementedError(f"only the UNet encoders of the reference's hot path are built here (got {name})")
     return SparseEncoder(UNET_MAE_SPARSE(base_ch=base_ch, depth=depth, dtype=dtype), input_size=input_size, sbn=sbn, verbose=verbose)
 
 
 class UnetDecoder(nn.Module):
-    def __init__(self, width=768, in_chans=1, base_ch=64, depth=5, dtype="bf16"):
+    def __init__(self, width=768, in_chans=1, base_ch=64, depth=5, dtype="f32"):
         super().__init__()
         self.width = width
         self.up_sample_mode = 'conv_transpose'
@@ -110,7 +110,7 @@ class _SparKFn(torch.autograd.Function):
 
 
 class SparK(_EngineOwner, nn.Module):
-    def __init__(self, sparse_encoder, dense_decoder, mask_ratio=0.6, densify_norm='', sbn=False, dtype="bf16"):
+    def __init__(self, sparse_encoder, dense_decoder, mask_ratio=0.6, densify_norm='', sbn=False, dtype="f32"):
         super().__init__()
         if densify_norm.lower() not in ("", "identity", "none"):
             raise NotImplementedError("the UNet configuration of the reference uses densify_norm='' (arg_util.py:124-130)")

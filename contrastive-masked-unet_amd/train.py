@@ -1,8 +1,9 @@
 """Drop-in for the finetuning driver surface of the reference's ``Finetuning/train.py``: the per-batch
 hot loop (``Epoch.run`` / ``TrainEpoch.batch_update`` / ``ValidEpoch.batch_update``, train.py:81-190),
-``train`` / ``eval`` (train.py:193-226), the CLI flags (train.py:229-238) and ``load_model`` with its five
-checkpoint key layouts (train.py:240-308).  The k-fold / LR sweep script body (train.py:311-471) is thin
-host glue around these and is not rebuilt.
+``train`` / ``eval`` (train.py:193-226), the CLI flags (train.py:229-238), ``load_model`` with its five
+checkpoint key layouts (train.py:240-308) and the k-fold / LR sweep ``main_finetuning`` (train.py:311-378: the second leg of
+BASELINE config 4 -- pretrain, load the checkpoint, 3-fold finetune on a small split).  The rest of the script body
+(train.py:379-471: data listing, the final test run) is host glue around these and is not rebuilt.
 
 Differences that matter on MI355X (results identical):
   * loss and metrics of a batch come from one fused kernel pass (metrics.py); their values stay on the
@@ -151,7 +152,8 @@ def get_args(argv=None):
     p.add_argument('--pretrained', '-p', dest='pretrained', type=str, default=None, help='Path to a pretrained model')
     p.add_argument('--name', '-n', dest='name', type=str, default="base", help='name of the trained model to save')
     p.add_argument('--ratio', '-r', dest='ratio', type=float, default=0.1, help='Ratio of finetuning dataset')
-    p.add_argument('--dtype', dest='dtype', type=str, default="bf16", help='activation storage dtype on the HIP path')
+    p.add_argument('--dtype', dest='dtype', type=str, default="f32",
+                   help="activation storage / MFMA operand type on the HIP path: 'f32' (default, the reference's finetuning arithmetic), 'f16', 'bf16'")
     return p.parse_args(argv)
 
 
@@ -238,9 +240,86 @@ def export_checkpoint(state_dict, path, layout, epoch=0, optimizer_state=None, e
     return path
 
 
+def kfold_indices(n, n_splits=3, seed=42):
+    """sklearn.model_selection.KFold(n_splits, shuffle=True, random_state=seed).split(range(n)) (train.py:326,330) without the
+    dependency: the shuffled index array is cut into n_splits consecutive test folds (the first n % n_splits one longer); both index
+    arrays of a fold come back in ascending order, as sklearn's mask-based split returns them."""
+    idx = np.arange(n)
+    np.random.RandomState(seed).shuffle(idx)
+    sizes = np.full(n_splits, n // n_splits, dtype=int)
+    sizes[:n % n_splits] += 1
+    out, start = [], 0
+    for sz in sizes:
+        test = np.zeros(n, dtype=bool)
+        test[idx[start:start + sz]] = True
+        out.append((np.arange(n)[~test], np.arange(n)[test]))
+        start += sz
+    return out
+
+
+def find_best_epochs(valid_logs_list, EPOCH, LR, BATCH, runtime, metric='dice_loss + cross_entropy_loss'):
+    """utils.py:4-60: the validation logs of the epoch with the smallest ``metric`` (default: the training criterion, as there)
+    plus the run's hyper-parameters.  Differences: the first epoch may be the best one (the reference leaves ``best_result``
+    unbound then and raises); 'hausdorff' / 'radius_arteries' (CPU geometry metrics, out of scope: SURVEY 2.1) are passed
+    through only when the logs hold them."""
+    key = metric if metric in valid_logs_list[0] else "dice_loss"
+    best = min(range(len(valid_logs_list)), key=lambda i: (valid_logs_list[i][key], i))
+    out = {"epochs": EPOCH, "lr": LR, "batch_size": BATCH, "runtime": runtime}
+    out.update(valid_logs_list[best])
+    return out
+
+
+def main_finetuning(args, loss, metrics, DEVICE, select_class_values, X_finetuning, y_finetuning, make_loaders=None,
+                    work_dir="./work_dir", save_best=True):
+    """train.py:311-378, same loop order and the same quirk (A-6): ONE ``load_model(args)`` per (LR, EPOCH, BATCH) whose weights
+    are trained on through all three folds; KFold(3, shuffle, random_state 42); a fresh Adam per fold; ``train()`` keeps the
+    checkpoint with the best validation dice_loss.  ``make_loaders(train_idx, val_idx, BATCH) -> (train_loader, test_loader)``
+    replaces the reference's SegmentationDataset + albumentations + DataLoader construction (file-based, train.py:333-349) for
+    in-memory / synthetic data; without it the drop-in ``dataset.SegmentationDataset`` is used on the given path lists.
+    Returns (best [lr, batch_size, epochs], result list) -- the reference pickles ``result`` and returns the first."""
+    import os
+    import time
+    from torch.utils.data import DataLoader
+    result, score = [], []
+    for LR in args.lr:
+        for EPOCH in args.epochs:
+            for BATCH in args.batch_size:
+                model = load_model(args)
+                cv_results = []
+                for fold, (train_idx, val_idx) in enumerate(kfold_indices(len(X_finetuning), 3, 42)):
+                    print(f"Fold {fold + 1}/{3}")
+                    name = os.path.join(work_dir, f"{args.name}_{LR}_{BATCH}_{fold + 1}.pth")
+                    if make_loaders is not None:
+                        train_loader, test_loader = make_loaders(train_idx, val_idx, BATCH)
+                    else:
+                        from .dataset import SegmentationDataset
+                        tr_ds = SegmentationDataset([X_finetuning[i] for i in train_idx], [y_finetuning[i] for i in train_idx],
+                                                    class_values=select_class_values)
+                        va_ds = SegmentationDataset([X_finetuning[i] for i in val_idx], [y_finetuning[i] for i in val_idx],
+                                                    class_values=select_class_values)
+                        train_loader = DataLoader(tr_ds, batch_size=BATCH, shuffle=True, num_workers=0)
+                        test_loader = DataLoader(va_ds, batch_size=BATCH, shuffle=False, num_workers=0)
+                    optimizer = torch.optim.Adam([dict(params=model.parameters(), lr=LR)])
+                    train_epoch = TrainEpoch(model, loss=loss, metrics=metrics, optimizer=optimizer, device=DEVICE, verbose=True)
+                    test_epoch = ValidEpoch(model, loss=loss, metrics=metrics, device=DEVICE, verbose=True)
+                    start_time = time.time()
+                    if save_best:
+                        os.makedirs(work_dir, exist_ok=True)
+                    train_logs_list, valid_logs_list = train(model, train_loader, test_loader, train_epoch, test_epoch, True, EPOCH,
+                                                             name if save_best else os.devnull)
+                    runtime = time.time() - start_time
+                    cv_results.append(find_best_epochs(valid_logs_list, EPOCH, LR, BATCH, runtime)["dice_loss"])
+                    result.append({"epochs": EPOCH, "lr": LR, "batch_size": BATCH, "runtime": runtime, "fold": fold + 1,
+                                   "train_logs_list": train_logs_list, "valid_logs_list": valid_logs_list, "model": model})
+                score.append({"epochs": EPOCH, "lr": LR, "batch_size": BATCH, "dice_loss": float(np.mean(cv_results))})
+    best = min(score, key=lambda x: x["dice_loss"])
+    return [best[key] for key in ["lr", "batch_size", "epochs"]], result
+
+
 def load_model(args, map_location="cpu"):
-    """train.py:240-308: UNet() initialised from ``args.pretrained`` (strict=False, head dropped)."""
-    model = UNet(dtype=getattr(args, "dtype", "bf16"))
+    """train.py:240-308: UNet() initialised from ``args.pretrained`` (strict=False, head dropped).  ``args.base_ch`` /
+    ``args.depth`` (build extensions; absent in the reference's flags) default to the reference structure."""
+    model = UNet(dtype=getattr(args, "dtype", "f32"), base_ch=getattr(args, "base_ch", 64), depth=getattr(args, "depth", 5))
     if args.pretrained is not None:
         checkpoint = torch.load(args.pretrained, map_location=map_location, weights_only=False)
         sd, label = remap_checkpoint(checkpoint, args.pretrained)

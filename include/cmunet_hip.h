@@ -344,6 +344,18 @@ int cmu_adam_step(float* p, const float* g, float* m, float* v, const uint8_t* w
                   float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled,
                   int64_t step, float grad_scale, const void* amp_state, void* stream);
 
+/* cmu_adam_step + the EMA of the momentum networks in ONE pass over the arena: what the reference runs as AdamW.step
+ * (cmunet_config.py:76-91) followed by MomentumUpdateHook.after_train_iter -> CM_UNet.momentum_update (cmunet.py:78-92,
+ * momentum_update_hook.py:42-47).  Up to two ascending, disjoint element ranges [seg_lo[k], seg_hi[k]) of the online arena
+ * (multiples of 4) have a target array seg_target[k] (16-byte aligned, hi - lo elements): after the element's AdamW update,
+ * target = target*m + p_new*(1-m).  A step skipped by amp_state still runs the EMA with the unchanged parameters (the hook
+ * runs behind a skipped optimiser step too).  n must be a multiple of 4, all arenas 16-byte aligned, wd_mask 4-byte aligned.
+ * Bit-identical to cmu_adam_step followed by cmu_ema_update per segment.                                             */
+int cmu_adam_ema_step(float* p, const float* g, float* m, float* v, const uint8_t* wd_mask, int64_t n,
+                      float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled,
+                      int64_t step, float grad_scale, const void* amp_state, int nseg, const int64_t* seg_lo,
+                      const int64_t* seg_hi, float* const* seg_target, float ema_momentum, void* stream);
+
 /* Dynamic loss scaling: AmpOptimWrapper(loss_scale='dynamic') of Pretraining/CM-UNet/configs/cmunet_config.py:76-78, i.e.
  * torch.cuda.amp.GradScaler(init_scale 2^16, growth 2, backoff 0.5, growth_interval 2000), with the state on the device
  * (cmu_amp_state_bytes() = 32 bytes: float scale, float found_inf, int32 growth_tracker, int32 good_steps,

@@ -104,17 +104,19 @@ def import_spark():
 _SPARK_MODS = None
 
 
-def gen_spark(ref, S=64, ratio=0.6, name="spark_unet", seed=71):
+def gen_spark(ref, S=64, ratio=0.6, name="spark_unet", seed=71, B=2):
     """``S`` = image side (f = S/16 patches per side; the reference model is size-agnostic), ``ratio`` = mask ratio.
     spark_unet: 64 px, ratio 0.6 (6 of 16 patches active).  spark_unet_m75: 128 px at BASELINE config 5's ratio 0.75
-    (16 of 64 patches active per image; arg_util.py:30 / spark.py:82-86)."""
+    (16 of 64 patches active per image; arg_util.py:30 / spark.py:82-86).  spark_unet_m75_b8: the same at batch 8 -- 128
+    active positions per channel in the bottleneck's sparse BatchNorm instead of 32: a well-conditioned case, on which the 16-bit
+    paths are held to a per-tensor gradient-norm bar without slack (round-2 review)."""
     global _SPARK_MODS
     from oracle import unet as OU, spark as OS
     if _SPARK_MODS is None:
         _SPARK_MODS = import_spark()
     enc_mod, dec_mod, spark_mod, build_sparse_encoder = _SPARK_MODS
     torch.manual_seed(0)
-    B, f = 2, S // 16
+    f = S // 16
     senc = build_sparse_encoder("unet_sparse", input_size=S, sbn=False)
     model = spark_mod.SparK(sparse_encoder=senc, dense_decoder=dec_mod.UnetDecoder(), mask_ratio=ratio, densify_norm='', sbn=False)
     assert model.fmap_h == f and model.len_keep == round(f * f * (1 - ratio)) and model.hierarchy == 5
@@ -910,6 +912,49 @@ def gen_cmunet_head_2rank(seed=4300):
          loss_rc=torch.stack([res[r]["loss_rc"] for r in range(2)]), dpred=torch.stack([res[r]["dpred"] for r in range(2)]),
          dproj_s=torch.stack([res[r]["dproj_s"] for r in range(2)]), dfc1_norm=torch.stack([res[r]["dfc1"].double().norm() for r in range(2)]))
 
+def gen_neck_syncbn_2rank(seed=4400):
+    """tests/golden/neck_syncbn_2rank.npz (round-2 review): the necks' TRAINING-mode SyncBatchNorm across two ranks.  torch's
+    SyncBatchNorm refuses CPU tensors, but what it computes is fixed: batch statistics over the rows of ALL ranks, and a backward
+    whose sums run over all ranks too -- i.e. the reference's own NonLinearNeck (cmae/models/necks/nonlinear_neck.py:35-102, norm
+    layer = the BatchNorm1d that SyncBN is on one process) applied to the CONCATENATED 2B rows, with the loss the sum of both ranks'
+    losses.  Stored: per-rank inputs and upstream gradients, the outputs, the input gradients (rows of the concatenated run), the
+    parameter gradients of the concatenated run (= the SUM of the two ranks' local parameter gradients) and the running
+    statistics.  Geometry: the shipped projector (hid 1536, out 256, with_bias, no last BN, no average pool) on 32 x 32 inputs."""
+    from oracle import cmunet as OC
+    MODELS, _, _ = import_cmae()
+    B, S = 4, 32
+    cfg = dict(type='NonLinearNeck', in_channels=S * S, hid_channels=1536, out_channels=256, num_layers=2, with_bias=True,
+               with_last_bn=False, with_avg_pool=False)
+    neck = MODELS.build(cfg)
+    sd = OC.make_neck_sd("", S * S, 1536, 256, seed)
+    assert set(neck.state_dict()) == set(sd)
+    neck.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    neck.train()
+    g = torch.Generator().manual_seed(seed + 1)
+    xs = [torch.randn(B, 1, S, S, generator=g) for _ in range(2)]
+    gos = [torch.randn(B, 1, 256, generator=g) for _ in range(2)]
+    x_all = torch.cat(xs).requires_grad_(True)
+    y_all = neck(x_all)
+    (y_all * torch.cat(gos)).sum().backward()
+    # oracle restatement on the same concatenated batch
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+    xo = torch.cat(xs).requires_grad_(True)
+    yo = OC.nonlinear_neck(xo, osd, "", training=True)
+    (yo * torch.cat(gos)).sum().backward()
+    close(yo.detach(), y_all.detach(), what="2-rank neck output")
+    close(xo.grad, x_all.grad, tol=2e-4, what="2-rank neck dx")
+    named = dict(neck.named_parameters())
+    for k in ("fc0.weight", "fc0.bias", "bn0.weight", "bn0.bias", "fc1.weight"):
+        close(osd[k].grad, named[k].grad, tol=2e-4, what=f"2-rank neck d{k}")
+    save("neck_syncbn_2rank", seed=np.array(seed), B=np.array(B), S=np.array(S), x=torch.stack(xs), go=torch.stack(gos),
+         y=y_all.detach().view(2, B, 1, 256), dx=x_all.grad.view(2, B, 1, S, S),
+         dfc0_bias=named["fc0.bias"].grad, dbn0_weight=named["bn0.weight"].grad, dbn0_bias=named["bn0.bias"].grad,
+         dfc1_weight_rows=named["fc1.weight"].grad[:16].clone(), dfc1_weight_norm=named["fc1.weight"].grad.double().norm(),
+         dfc0_weight_norm=named["fc0.weight"].grad.double().norm(),
+         dfc0_weight_rows=named["fc0.weight"].grad[:8].clone(),
+         running_mean=neck.bn0.running_mean.clone(), running_var=neck.bn0.running_var.clone())
+
+
 def gen_cldice(M):
     """soft_cldice of the reference (metrics.py:401-431, the driver's configuration train.py:464) on vessel-like masks."""
     from oracle import losses as OL
@@ -1083,6 +1128,9 @@ def main():
     ref, M = import_reference()
     torch.manual_seed(0)
     torch.set_num_threads(4)
+    if "--only-spark75b8" in sys.argv:  # tests/golden/spark_unet_m75_b8.npz alone (config 5's mask ratio at batch 8)
+        gen_spark(None, S=128, ratio=0.75, name="spark_unet_m75_b8", seed=271, B=8)
+        sys.exit(0)
     if "--only-spark75" in sys.argv:    # tests/golden/spark_unet_m75.npz alone (BASELINE config 5's mask ratio)
         gen_spark(None, S=128, ratio=0.75, name="spark_unet_m75", seed=171)
         return
@@ -1104,6 +1152,9 @@ def main():
     if "--head-worker" in sys.argv:     # (child of gen_cmunet_head_2rank)
         i = sys.argv.index("--head-worker")
         _cmunet_head_2rank_worker(int(sys.argv[i + 1]), int(sys.argv[i + 2]), sys.argv[i + 3], int(sys.argv[i + 4]))
+        return
+    if "--only-neck2" in sys.argv:      # tests/golden/neck_syncbn_2rank.npz alone
+        gen_neck_syncbn_2rank()
         return
     if "--only-head2" in sys.argv:      # tests/golden/cmunet_head_2rank.npz alone
         gen_cmunet_head_2rank()
@@ -1327,6 +1378,7 @@ def main():
     # ---- 7. SparK (sparse masked conv) -- reference imported behind the stubs of SURVEY Appendix C-3 ---------
     gen_spark(ref)
     gen_spark(ref, S=128, ratio=0.75, name="spark_unet_m75", seed=171)
+    gen_spark(ref, S=128, ratio=0.75, name="spark_unet_m75_b8", seed=271, B=8)
     gen_optim()
     gen_cldice(M)
     print("all fixtures written; oracle == reference on every case")

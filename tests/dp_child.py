@@ -37,8 +37,15 @@ def main():
     if mode == "recon":
         from cmunet_amd import model as M
         net = M.UNet(base_ch=16, depth=3, dtype=opts.get("dtype", "f32"))
-        net.load_state_dict(OU.make_state_dict(base_ch=16, depth=3, seed=9))
+        # init=rank: every rank starts from its own weights (what DDP's construction-time broadcast is for)
+        net.load_state_dict(OU.make_state_dict(base_ch=16, depth=3, seed=9 + (rank if opts.get("init") == "rank" else 0)))
         tr = P.MaskedReconPretrainer(net.to(dev), lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05, amp=opts.get("amp") == "1")
+        if opts.get("prefwd") == "1":
+            # a forward BEFORE the broadcast fills the engine's packed-weight caches with this rank's own weights
+            with torch.no_grad():
+                net.eval()
+                net(torch.randn(2, 32, 64, generator=torch.Generator().manual_seed(1)).to(dev))
+                net.train()
         tr.broadcast_parameters()
         losses = []
         for it in range(steps):
@@ -71,7 +78,8 @@ def main():
         model.momentum = 0.9
         l = tr.step(img.to(dev), img_t.to(dev), mask.to(dev), reduce_w=rw.to(dev), reduce_b=rb.to(dev))
         res.update({"loss_ct": float(l["loss_ct"]), "loss_rc": float(l["loss_rc"]), "img": img, "img_t": img_t, "mask": mask, "rw": rw, "rb": rb,
-                    "final": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}})
+                    "final": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
+                    "exchange": getattr(tr, "last_exchange", None)})
     elif mode == "moco":
         from cmunet_amd import moco as MO
         torch.manual_seed(0)
@@ -88,7 +96,8 @@ def main():
         tr.broadcast_parameters()
         xq, xk = torch.randn(B, 1, S, S, generator=g), torch.randn(B, 1, S, S, generator=g)
         loss = tr.step(xq.to(dev), xk.to(dev))
-        res.update({"loss": float(loss), "xq": xq, "xk": xk, "final": {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}})
+        res.update({"loss": float(loss), "xq": xq, "xk": xk, "final": {k: v.detach().cpu().clone() for k, v in m.state_dict().items()},
+                    "exchange": getattr(tr, "last_exchange", None)})
     elif mode == "moco_shuffle":
         # shuffle-BN (moco2_module.py:177-222): every rank has its own key images; rank 0's permutation comes from the global
         # CPU generator, seeded here so that the test can redraw it
@@ -123,6 +132,20 @@ def main():
         (hl["loss_ct"] + hl["loss_rc"]).backward()
         res = {"loss_ct": float(hl["loss_ct"].detach()), "loss_rc": float(hl["loss_rc"].detach()), "dpred": logits.grad[:, 1].cpu(), "dproj_s": ps.grad.cpu(),
                "dfc1_norm": float(head.predictor.fc1.weight.grad.double().norm())}
+    elif mode == "neck_ref2":
+        # tests/golden/neck_syncbn_2rank.npz: the reference's NonLinearNeck over the concatenated rows of both ranks = SyncBN semantics
+        from cmunet_amd import cmunet as C
+        from oracle import cmunet as OC
+        f = np.load(os.path.join(ROOT, "tests", "golden", "neck_syncbn_2rank.npz"))
+        S = int(f["S"])
+        neck = C.NonLinearNeck(in_channels=S * S, hid_channels=1536, out_channels=256, num_layers=2, with_bias=True, with_last_bn=False,
+                               with_avg_pool=False).to(dev).train()
+        neck.load_state_dict({k: v.clone() for k, v in OC.make_neck_sd("", S * S, 1536, 256, int(f["seed"])).items()}, strict=True)
+        x = torch.from_numpy(f["x"][rank]).to(dev).requires_grad_(True)
+        y = neck(x)
+        (y * torch.from_numpy(f["go"][rank]).to(dev)).sum().backward()
+        res = {"y": y.detach().cpu(), "dx": x.grad.cpu(), "grads": {n: p.grad.cpu() for n, p in neck.named_parameters()},
+               "running_mean": neck.bn0.running_mean.cpu(), "running_var": neck.bn0.running_var.cpu()}
     elif mode == "moco_ref2":
         # the reference's own two-rank run (tests/golden/moco_ref_2rank.npz): the same seeded state, every rank its own images,
         # rank 0's permutation from the global CPU generator seeded as the generator seeded it
@@ -156,7 +179,7 @@ def main():
             for b in range(4):
                 active[b, 0].view(-1)[torch.randperm(f * f, generator=g)[:model.len_keep]] = True
             losses.append(float(tr.step(x.to(dev), active.to(dev), loss_scale=float(opts.get("loss_scale", "1")))))
-        res = {"losses": losses, "arena": tr.flat.arena.cpu(), "names": list(tr.flat.names)}
+        res = {"losses": losses, "arena": tr.flat.arena.cpu(), "names": list(tr.flat.names), "exchange": getattr(tr, "last_exchange", None)}
     else:
         raise SystemExit(f"unknown mode {mode}")
     torch.save(res, f"{out}.{rank}")

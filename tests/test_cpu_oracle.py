@@ -160,7 +160,7 @@ def test_oracle_vs_imported_reference():
         assert close(OU.unet_forward(x, OU.clone_sd(sd), training=True), m(x), 1e-4)
 
 
-@pytest.mark.parametrize("fixture", ["spark_unet", "spark_unet_m75"])
+@pytest.mark.parametrize("fixture", ["spark_unet", "spark_unet_m75", "spark_unet_m75_b8"])
 def test_spark_golden(golden_dir, fixture):
     """oracle/spark.py reproduces the loss the reference's SparK produced (fixtures written by gen_golden.py: 64 px at mask
     ratio 0.6, 128 px at BASELINE config 5's ratio 0.75)."""
@@ -178,10 +178,27 @@ def test_spark_golden(golden_dir, fixture):
         toks.append(tok[off:off + c].view(1, c, 1, 1)); off += c
     loss, rec = OS.forward(torch.from_numpy(d["x"]), torch.from_numpy(d["active"]).bool(), osd, toks)
     assert abs(float(loss) - float(d["loss"])) < 1e-5 and rec.shape == tuple(d["x"].shape)
-    if fixture == "spark_unet_m75":
-        assert float(d["mask_ratio"]) == 0.75 and int(d["active"].sum()) == 2 * 16
+    if fixture.startswith("spark_unet_m75"):
+        assert float(d["mask_ratio"]) == 0.75 and int(d["active"].sum()) == d["x"].shape[0] * 16
     a = OS.make_active(3, 16, 0.6, torch.Generator().manual_seed(0))
     assert a.shape == (3, 1, 16, 16) and a.view(3, -1).sum(1).tolist() == [round(256 * 0.4)] * 3     # spark.py:29,82-86
+
+
+def test_neck_syncbn_two_rank_golden(golden_dir):
+    """oracle/cmunet.py::nonlinear_neck on the concatenated rows of both ranks reproduces what the reference's NonLinearNeck gave
+    there (tests/golden/neck_syncbn_2rank.npz): the SyncBN semantics the two-rank GPU test is held to."""
+    from oracle import cmunet as OC
+    d = np.load(f"{golden_dir}/neck_syncbn_2rank.npz")
+    S, B = int(d["S"]), int(d["B"])
+    sd = OC.make_neck_sd("", S * S, 1536, 256, int(d["seed"]))
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+    x = torch.from_numpy(d["x"]).reshape(2 * B, 1, S, S).clone().requires_grad_(True)
+    y = OC.nonlinear_neck(x, osd, "", training=True)
+    (y * torch.from_numpy(d["go"]).reshape(2 * B, 1, 256)).sum().backward()
+    assert close(y.detach().view(2, B, 1, 256), torch.from_numpy(d["y"]), 1e-5)
+    assert close(x.grad.view(2, B, 1, S, S), torch.from_numpy(d["dx"]), 2e-4)
+    assert close(osd["bn0.weight"].grad, torch.from_numpy(d["dbn0_weight"]), 2e-4)
+    assert close(osd["bn0.running_var"], torch.from_numpy(d["running_var"]), 1e-5)
 
 
 def test_optimizer_traces_golden(golden_dir):

@@ -78,6 +78,18 @@ def test_masked_recon_two_ranks_same_batch_equals_one_rank(cuda):
                 assert torch.equal(r["bufs"][k], v), k
 
 
+def test_broadcast_after_a_forward_invalidates_packed_weights(cuda):
+    """Advisor (round 2): ``broadcast_parameters`` rewrites the arena with a collective that neither the Parameters' version
+    counters nor (before the fix) ``ops.PARAM_GENERATION`` see.  Ranks that start from DIFFERENT weights and run a forward before the
+    broadcast must still train on rank 0's weights afterwards: both ranks end bit-identical to a single process started from rank
+    0's weights (stale packed conv weights on rank 1 would change its loss and, through the all-reduce, everybody's update)."""
+    one = run_ranks("recon", 1)[0]
+    two = run_ranks("recon", 2, init="rank", prefwd="1")
+    for r in two:
+        assert r["losses"] == one["losses"], (r["losses"], one["losses"])
+        assert torch.equal(r["arena"], one["arena"])
+
+
 def test_masked_recon_two_ranks_amp_and_f16(cuda):
     """The same with f16 storage and the dynamic loss scaler: the inf / nan check runs on the exchanged gradients, so both
     ranks take the same decision and stay bit-identical to each other and to one rank."""
@@ -249,6 +261,31 @@ def test_cmunet_head_two_ranks_vs_reference_two_rank_fixture(cuda):
     assert abs(two[0]["loss_ct"] - two[1]["loss_ct"]) > 1e-4
 
 
+def test_neck_syncbn_two_ranks_vs_reference_fixture(cuda):
+    """The necks' TRAINING-mode SyncBatchNorm on two ranks (nonlinear_neck.py:45,58 under norm_cfg SyncBN) against the reference's own
+    NonLinearNeck run over the CONCATENATED rows of both ranks (tests/golden/neck_syncbn_2rank.npz, oracle/gen_golden.py::
+    gen_neck_syncbn_2rank) -- what SyncBN computes: statistics and backward sums over all ranks.  Per rank: outputs and input gradients
+    are the fixture's rows; the two ranks' local parameter gradients SUM to the concatenated run's; running statistics agree on both."""
+    f = np.load(os.path.join(HERE, "golden", "neck_syncbn_2rank.npz"))
+    two = run_ranks("neck_ref2", 2)
+    for rk in range(2):
+        assert rel(two[rk]["y"], torch.from_numpy(f["y"][rk])) <= 2e-5, rk
+        assert rel(two[rk]["dx"], torch.from_numpy(f["dx"][rk])) <= 2e-4, rk
+        assert rel(two[rk]["running_mean"], torch.from_numpy(f["running_mean"])) <= 1e-5
+        assert rel(two[rk]["running_var"], torch.from_numpy(f["running_var"])) <= 1e-5
+    tot = {n: two[0]["grads"][n] + two[1]["grads"][n] for n in two[0]["grads"]}
+    assert rel(tot["fc0.bias"], torch.from_numpy(f["dfc0_bias"])) <= 2e-4
+    assert rel(tot["bn0.weight"], torch.from_numpy(f["dbn0_weight"])) <= 2e-4
+    assert rel(tot["bn0.bias"], torch.from_numpy(f["dbn0_bias"])) <= 2e-4
+    assert rel(tot["fc1.weight"][:16], torch.from_numpy(f["dfc1_weight_rows"])) <= 2e-4
+    assert abs(float(tot["fc1.weight"].double().norm()) - float(f["dfc1_weight_norm"])) <= 2e-4 * float(f["dfc1_weight_norm"])
+    assert rel(tot["fc0.weight"][:8], torch.from_numpy(f["dfc0_weight_rows"])) <= 2e-4
+    assert abs(float(tot["fc0.weight"].double().norm()) - float(f["dfc0_weight_norm"])) <= 2e-4 * float(f["dfc0_weight_norm"])
+    # and it is not the per-rank BatchNorm: one rank alone normalises with its own four rows
+    one = run_ranks("neck_ref2", 1)[0]
+    assert rel(one["y"], torch.from_numpy(f["y"][0])) > 1e-2
+
+
 def test_moco_two_ranks_vs_reference_two_rank_fixture(cuda):
     """Two ranks of the HIP Moco_v2 against what the REFERENCE's own Moco_v2 produced on two gloo ranks
     (tests/golden/moco_ref_2rank.npz, oracle/gen_golden.py::gen_moco_2rank): shuffle-BN with rank 0's broadcast permutation, keys
@@ -283,6 +320,32 @@ def test_spark_trainer_two_ranks_equals_one_rank(cuda):
         assert np.allclose(r["losses"], one["losses"], rtol=1e-6)
         assert rel(r["arena"], one["arena"]) <= 1e-6
     assert np.allclose(scaled["losses"], one["losses"], rtol=1e-6) and rel(scaled["arena"], one["arena"]) <= 1e-5
+
+
+@pytest.mark.parametrize("mode", ["joint", "moco", "spark"])
+def test_arena_trainers_overlapped_exchange_is_bit_identical(cuda, mode):
+    """ArenaTrainer's backward-overlapped bucket exchange (what DDP's bucketed all-reduce does for the reference: Spark/main.py:102,
+    cmunet_config.py:120) against ONE all-reduce of the whole arena behind loss.backward() (CMU_DDP_OVERLAP=0), two ranks each: a SUM
+    over two ranks is the same number whatever the cut of the arena, so parameters, momentum networks and buffers must agree bit for
+    bit -- and the overlapped run must really have started buckets before the backward pass was over (joint / MoCo: the decoders
+    and the bottleneck are announced from inside the fused node; the projector / predictor by autograd's hooks)."""
+    ov = run_ranks(mode, 2, extra_env={"CMU_DDP_OVERLAP": "1"})
+    plain = run_ranks(mode, 2, extra_env={"CMU_DDP_OVERLAP": "0"})
+    for rk in range(2):
+        a, b = ov[rk], plain[rk]
+        if mode == "spark":
+            assert a["losses"] == b["losses"]
+            assert torch.equal(a["arena"], b["arena"]), float((a["arena"] - b["arena"]).abs().max())
+        else:
+            for k, v in a["final"].items():
+                assert torch.equal(v, b["final"][k]), k
+    ex = ov[0]["exchange"]
+    assert ex is not None and ex["buckets"] >= 2 and ex["early"] + ex["in_backward"] + ex["flushed"] == ex["buckets"]
+    if mode == "joint":
+        assert ex["early"] >= 3 and ex["in_backward"] >= 2, ex        # pixel / feature decoder + bottleneck; projector + predictor
+    elif mode == "moco":
+        assert ex["early"] >= 1, ex                                      # the query encoder's bottleneck
+    assert plain[0]["exchange"] is None or plain[0]["exchange"].get("early", 0) == 0
 
 
 @pytest.mark.parametrize("workload", ["recon", "joint", "moco", "spark"])

@@ -5,6 +5,18 @@ import numpy as np
 import pytest
 import torch
 
+def _parity_record(line):
+    """Achieved parity numbers of this run -> gpurun_out/parity_record.txt (copied to profiles/r03_parity.txt)."""
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_record.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+
+
 pytestmark = pytest.mark.gpu
 
 
@@ -96,6 +108,8 @@ def test_finetune_unet_small_vs_oracle(golden_dir):
         dd, di = abs(logs["dice_loss"] - ref_dice), abs(logs["iou_loss"] - ref_iou)
         print(f"[finetune Dice parity, identical weights, {dt}] dice {logs['dice_loss']:.6f} vs {ref_dice:.6f} (delta {dd:.2e}), "
               f"iou delta {di:.2e}, max logit err {worst:.2e}, argmax flips {flips} / {total}")
+        _parity_record(f"finetune Dice parity on identical weights (BASELINE config 1: UNet-small, 8 synthetic 256x256 images), {dt}: dice_loss {logs['dice_loss']:.6f} vs "
+                       f"oracle {ref_dice:.6f} (|dDice| {dd:.2e}), |dIoU| {di:.2e}, max logit error {worst:.2e}, argmax flips {flips} of {total} pixels")
         assert worst <= ltol and dd <= dtol and di <= 2 * dtol, (dt, worst, dd, di)
         if dt == "f32":
             assert dd <= 1e-4 and flips <= 2, (dd, flips)            # the stated bar; (flips only inside 2x the fp32 logit tolerance)

@@ -324,3 +324,156 @@ def test_spark_full_size_step_f16_mask075():
     assert l1 == l2 and torch.equal(g1, g2) and torch.isfinite(g1).all() and 0.3 < l1 < 3.0, (l1, l2)
     gn = float(g1.norm()) / 4096.0
     assert 1e-3 < gn < 1e3, gn
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE configs 3 and 4 at the size their numbers are quoted on (bs 32, 512 x 512; projector 262,144 -> 1,536)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cdt", [None, "f16", "bf16"])
+def test_skinny_gemm_projector_size_sampled_fp64(ops, cdt):
+    """The projector's Linear of config 4 (cmunet_config.py:18-26 with in_channels = H*W = 262,144 at 512 x 512): M = 32
+    rows, K = 262,144, N = 1,536 -- 1.6 GB of fp32 weights.  64 sampled output columns / input-gradient columns / weight-gradient
+    rows (first, last, seams of the kernels' 128-row / 32-k blocks, random) against float64 products of the same operands (rounded
+    to the 16-bit type for the AMP variants: the error is accumulation order only), plus bitwise reproducibility."""
+    M, K, N = 32, 262144, 1536
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(11)
+    x = torch.randn(M, K, generator=g, device=dev)
+    w = torch.randn(N, K, generator=g, device=dev) / K ** 0.5
+    b = torch.randn(N, generator=g, device=dev)
+    dy = torch.randn(M, N, generator=g, device=dev)
+    gi = torch.Generator().manual_seed(5)
+    cols = torch.unique(torch.cat([torch.tensor([0, 1, 127, 128, 129, N - 129, N - 128, N - 1]), torch.randint(0, N, (56,), generator=gi)])).to(dev)
+    ks = torch.unique(torch.cat([torch.tensor([0, 1, 31, 32, 4095, 4096, K - 33, K - 32, K - 1]), torch.randint(0, K, (55,), generator=gi)])).to(dev)
+    tdt = None if cdt is None else ops.TORCH_DT[ops.dt_code(cdt)]
+    rq = (lambda t: t.double()) if tdt is None else (lambda t: t.to(tdt).double())
+
+    def close(got, ref, depth, what):
+        err, scale = (got.double() - ref).abs().max().item(), ref.abs().max().item()
+        assert err <= 2e-6 * scale * max(1.0, depth ** 0.5 / 8), f"{what}: {err:.3e} vs scale {scale:.3e}"
+
+    y = ops.skinny_gemm_fwd(x, w, b, compute_dt=cdt)
+    close(y[:, cols], rq(x) @ rq(w[cols]).t() + b[cols].double(), K, "y")
+    assert torch.equal(y, ops.skinny_gemm_fwd(x, w, b, compute_dt=cdt))
+    dx = ops.skinny_gemm_dgrad(dy, w, compute_dt=cdt)
+    close(dx[:, ks], rq(dy) @ rq(w[:, ks]), N, "dx")
+    assert torch.equal(dx, ops.skinny_gemm_dgrad(dy, w, compute_dt=cdt))
+    dw, db = ops.skinny_gemm_wgrad(dy, x, with_bias=True, compute_dt=cdt)
+    close(dw[cols], rq(dy[:, cols]).t() @ rq(x), M, "dw")
+    close(db, dy.double().sum(0), M, "db")
+    dw2, _ = ops.skinny_gemm_wgrad(dy, x, with_bias=True, compute_dt=cdt)
+    assert torch.equal(dw, dw2)
+    assert bool(torch.isfinite(dw).all()) and float(dw.abs().max()) > 0
+
+
+def test_moco_step_full_size_f16():
+    """BASELINE config 3 as stated (moco2_module.py:224-285 with K = 4,096, tau = 0.2, emb 1,024; bs 32, 512 x 512, f16 storage, the
+    bench's static loss scale): one fused MocoPretrainer step.  The loss equals the oracle's InfoNCE (oracle/moco.py::
+    logits_from_embeddings + cross entropy, i.e. moco2_module.py:236-285) evaluated on the HIP path's OWN embeddings and pre-step queue;
+    the enqueue is exact (32 normalised keys at the pointer, every other column untouched, pointer += 32); the key encoder is the EMA of
+    the query encoder taken BEFORE the forward (A-8); two runs from the same seed agree bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cmunet_amd import moco as MO, pretrain as P
+    from oracle import moco as OM
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(21)
+    xq, xk = torch.randn(B, 1, H, W, generator=g, device=dev), torch.randn(B, 1, H, W, generator=g, device=dev)
+
+    def run():
+        torch.manual_seed(0)
+        m = MO.Moco_v2(emb_dim=1024, num_negatives=4096, softmax_temperature=0.2, encoder_momentum=0.999, dtype="f16").to(dev).train()
+        with torch.no_grad():
+            for pk in m.encoder_k.parameters():
+                pk.mul_(0.97)                                  # key != query, so that the EMA is visible
+        m.queue_ptr.fill_(4096 - 64)                           # near the end of the ring
+        tr = P.MocoPretrainer(m, lr=0.03 * B / 256.0)
+        cap = {}
+        hq = m.encoder_q.register_forward_hook(lambda mod, i, o: cap.__setitem__("q", o.detach().clone()))
+        hk = m.encoder_k.register_forward_hook(lambda mod, i, o: cap.__setitem__("k", o.detach().clone()))
+        queue0, k0 = m.queue.clone(), {n: p.detach().clone() for n, p in m.encoder_k.named_parameters()}
+        q0 = {n: p.detach().clone() for n, p in m.encoder_q.named_parameters()}
+        loss = tr.step(xq, xk, loss_scale=1024.0)
+        hq.remove(); hk.remove()
+        return m, tr, cap, queue0, k0, q0, float(loss)
+
+    m, tr, cap, queue0, k0, q0, loss = run()
+    logits, labels, k, _ = OM.logits_from_embeddings(cap["q"].float().cpu(), cap["k"].float().cpu(), queue0.cpu(), 0.2)
+    ref = float(F.cross_entropy(logits.float(), labels.long()))
+    assert abs(loss - ref) <= 1e-4 * max(1.0, abs(ref)), (loss, ref)
+    assert int(m.queue_ptr) == (4096 - 64 + 32) % 4096
+    assert (m.queue[:, 4096 - 64:4096 - 32].t().cpu() - k).abs().max().item() <= 1e-6
+    keep = torch.ones(4096, dtype=torch.bool)
+    keep[4096 - 64:4096 - 32] = False
+    assert torch.equal(m.queue[:, keep.to(dev)], queue0[:, keep.to(dev)])
+    for n, p in m.encoder_k.named_parameters():                # EMA before the forward, from the PRE-step query weights
+        exp = k0[n] * 0.999 + q0[n] * (1.0 - 0.999)
+        assert (p.detach() - exp).abs().max().item() <= 1e-6 * max(1.0, float(exp.abs().max())), n
+    moved = max(float((p.detach() - q0[n]).abs().max()) for n, p in m.encoder_q.named_parameters())
+    assert 0 < moved < 1.0 and bool(torch.isfinite(tr.flat.grad).all())
+    m2, tr2, _, _, _, _, loss2 = run()
+    assert loss2 == loss and torch.equal(tr2.flat.arena, tr.flat.arena) and torch.equal(tr2.flat.grad, tr.flat.grad) and torch.equal(m2.queue, m.queue)
+
+
+def test_joint_step_full_size_f16():
+    """BASELINE config 4's pretraining step as stated (configs/cmunet_config.py:5-42 scaled to 512 x 512 per SURVEY F5: projector
+    262,144 -> 1,536 -> 256; bs 32, f16 + dynamic loss scale = AmpOptimWrapper, cmunet_config.py:76-78): one JointPretrainer step.
+    Both losses equal the oracle's head (oracle/cmunet.py::head = cmunet_head.py:47-91) evaluated on the HIP path's OWN head inputs
+    (pixel logits, projections) with the pre-step predictor weights; the target networks are the EMA of the POST-step online networks
+    (MomentumUpdateHook.after_train_iter) -- with the EMA fused into the AdamW launch and, bit for bit the same, as separate launches
+    (CMU_EMA_FUSE=0); two runs from the same seed agree bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import os
+    from cmunet_amd import cmunet as C, pretrain as P
+    from oracle import cmunet as OC
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(31)
+    img, img_t = torch.randn(B, H, W, generator=g, device=dev), torch.randn(B, H, W, generator=g, device=dev)
+    mask = P.random_patch_mask_device(B, H, W, 16, 0.6, g, dev)
+    gw = torch.Generator().manual_seed(7)
+    rw, rb = (torch.randn(256, 1024, 1, 1, generator=gw) * 0.03).to(dev), (torch.randn(256, generator=gw) * 0.1).to(dev)
+
+    def run(fuse):
+        os.environ["CMU_EMA_FUSE"] = fuse
+        try:
+            torch.manual_seed(0)
+            m = C.build_model(C.cmunet_config(img_size=H, mask_ratio=0.6)).to(dev)       # dtype: the default ("f16")
+            assert m.dtype == "f16" and m.projector.fc0.weight.shape == (1536, H * W)
+            m.init_weights()
+            with torch.no_grad():
+                for p in list(m.target_backbone.parameters()) + list(m.target_projector.parameters()):
+                    p.mul_(0.98)
+            tr = P.JointPretrainer(m, lr=1.5e-4 * B / 256.0, amp=True)
+        finally:
+            os.environ.pop("CMU_EMA_FUSE", None)
+        cap = {}
+        hh = m.head.register_forward_pre_hook(lambda mod, args: cap.__setitem__("head_in", [a.detach().clone() if torch.is_tensor(a) else a for a in args]))
+        pred_sd = {"head." + k: v.detach().clone().cpu() for k, v in m.head.state_dict().items()}
+        t0 = tr.tflat.arena.clone()
+        m.momentum = 0.99
+        losses = tr.step(img, img_t, mask, reduce_w=rw, reduce_b=rb)
+        hh.remove()
+        return m, tr, cap, pred_sd, t0, {k: float(v) for k, v in losses.items()}
+
+    m, tr, cap, pred_sd, t0, losses = run("1")
+    x, pred_logits, mask_s, proj_s, proj_t = cap["head_in"][:5]
+    ref = OC.head(x.cpu(), pred_logits[:, 1].float().cpu(), mask_s.cpu(), proj_s.float().cpu(), proj_t.float().cpu(), pred_sd, "head.",
+                  temperature=0.07, ct_weight=1.0, rc_weight=1.0, training=True)
+    assert abs(losses["loss_rc"] - float(ref["loss_rc"])) <= 2e-4 * max(1.0, abs(float(ref["loss_rc"]))), (losses, float(ref["loss_rc"]))
+    # (the predictor's Linear layers multiply f16-rounded operands under this configuration: 2e-3)
+    assert abs(losses["loss_ct"] - float(ref["loss_ct"])) <= 2e-3 * max(1.0, abs(float(ref["loss_ct"]))), (losses, float(ref["loss_ct"]))
+    sc, _, _, good, skipped = tr.amp.read()
+    assert (good, skipped) == (1, 0) and sc == 65536.0
+    # EMA of the post-step online arena, segment by segment (sampled: first / last MiB of each)
+    for (a0, a1), (b0, b1) in tr._ema:
+        for lo in (0, max(0, (a1 - a0) - (1 << 18))):
+            n = min(1 << 18, a1 - a0 - lo)
+            exp = t0[b0 + lo:b0 + lo + n] * 0.99 + tr.flat.arena[a0 + lo:a0 + lo + n] * (1.0 - 0.99)
+            assert (tr.tflat.arena[b0 + lo:b0 + lo + n] - exp).abs().max().item() <= 1e-6 * max(1.0, float(exp.abs().max()))
+    assert bool(torch.isfinite(tr.flat.grad).all()) and float(tr.flat.grad.abs().max()) > 0
+    arena, tarena, grad = tr.flat.arena.clone(), tr.tflat.arena.clone(), tr.flat.grad.clone()
+    del m, tr
+    torch.cuda.empty_cache()
+    m2, tr2, _, _, _, losses2 = run("0")                           # separate EMA launches: the same bits
+    assert losses2 == losses and torch.equal(tr2.flat.arena, arena) and torch.equal(tr2.tflat.arena, tarena) and torch.equal(tr2.flat.grad, grad)

@@ -10,6 +10,19 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
+def _parity_record(line):
+    """Achieved parity numbers of this run -> gpurun_out/parity_record.txt (copied to profiles/r03_parity.txt): what the bars
+    passed BY, not only that they passed."""
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_record.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+
+
 @pytest.fixture(scope="module")
 def cuda():
     if not torch.cuda.is_available():
@@ -409,6 +422,60 @@ def test_moco_validation_step_vs_reference_fixture(cuda, golden_dir):
     assert abs(float(mean["val_acc5"]) - 0.5 * (float(f["val_acc5_0"].reshape(-1)[0]) + float(f["val_acc5_1"].reshape(-1)[0]))) <= 1e-4
 
 
+def test_moco_forward_enqueue_backward_order_and_batch_size_change(cuda):
+    """Advisor (round 2).  (i) The reference's order is forward -> _dequeue_and_enqueue(keys) -> loss.backward() (moco2_module.py:
+    287-309): ``Moco_v2.forward`` must therefore hand autograd a copy of the queue (moco2_module.py:262 ``queue.clone().detach()``),
+    or the enqueue trips 'modified by an inplace operation' -- and the gradient must be the one of the PRE-enqueue queue.
+    (ii) A batch size that changes between fused steps leaves the ring pointer off a multiple of the new batch: the reference fails
+    with a shape error at moco2_module.py:172; here the host-side check raises and the kernel's own enqueue wraps inside the queue."""
+    import torch.nn.functional as F
+    from cmunet_amd import moco as MO, ops
+    torch.manual_seed(0)
+    m = MO.Moco_v2(emb_dim=64, num_negatives=48, softmax_temperature=0.2, dtype="f32", base_ch=16, depth=3).to(cuda).train()
+    g = torch.Generator().manual_seed(1)
+    xq, xk = torch.randn(8, 1, 32, 32, generator=g).to(cuda), torch.randn(8, 1, 32, 32, generator=g).to(cuda)
+    queue0 = m.queue.clone()
+    logits, labels, k, q = m(xq, xk, m.queue)
+    q.retain_grad()
+    m._dequeue_and_enqueue(k, queue_ptr=m.queue_ptr, queue=m.queue)
+    assert not torch.equal(m.queue, queue0)
+    F.cross_entropy(logits.float(), labels).backward()              # must not raise
+    # d loss / d q through l_neg uses the queue as it was at forward time
+    p = torch.softmax(logits.detach().float(), 1)
+    p[:, 0] -= 1.0
+    dq_ref = (p[:, :1] * k + p[:, 1:] @ queue0.t()) / (0.2 * 8)
+    assert (q.grad - dq_ref).abs().max().item() <= 1e-5 * max(1.0, dq_ref.abs().max().item())
+    # validation path (no_grad): no copy is made
+    with torch.no_grad():
+        m.eval()
+        m(xq, xk, m.val_queue)
+        m.train()
+    # (ii) fused steps: 8 keys, then 16 keys with the pointer at 8 -> 16 | 48 but 8 % 16 != 0
+    m.zero_grad()
+    m.queue_ptr.zero_()
+    m.training_step((xq, xk)).backward()
+    assert int(m.queue_ptr) == 8
+    xq2, xk2 = torch.randn(16, 1, 32, 32, generator=g).to(cuda), torch.randn(16, 1, 32, 32, generator=g).to(cuda)
+    with pytest.raises(RuntimeError, match="not a multiple"):
+        m.training_step((xq2, xk2))
+    with pytest.raises(AssertionError):
+        m.training_step((xq2[:5], xk2[:5]))                         # 48 % 5 != 0: the reference's assert (moco2_module.py:169)
+    # the kernel itself stays inside the queue for any pointer: ptr 40, 16 keys -> columns 40..47 and 0..7
+    D, K = 64, 48
+    qd, pd = F.normalize(torch.randn(D, K, generator=g), dim=0).to(cuda), torch.tensor([40], dtype=torch.int64, device=cuda)
+    guard = torch.full((D * K + 64,), 7.0, device=cuda)
+    guard[:D * K] = qd.reshape(-1)
+    qv = guard[:D * K].view(D, K)
+    qr, kr = torch.randn(16, D, generator=g).to(cuda), torch.randn(16, D, generator=g).to(cuda)
+    loss, dq = torch.empty(1, device=cuda), torch.empty(16, D, device=cuda)
+    ws = torch.empty(ops._lib.lib().cmu_moco_ws_bytes(16, D, K), dtype=torch.uint8, device=cuda)
+    ops.moco_infonce_enqueue(qr, kr, None, qv, pd, loss, dq, None, 0.2, ws)
+    kn = F.normalize(kr, dim=1)
+    assert torch.equal(guard[D * K:], torch.full((64,), 7.0, device=cuda))       # nothing past the buffer
+    assert (qv[:, 40:48] - kn[:8].t()).abs().max().item() <= 1e-6 and (qv[:, 0:8] - kn[8:].t()).abs().max().item() <= 1e-6
+    assert torch.equal(qv[:, 8:40], qd[:, 8:40]) and int(pd) == (40 + 16) % 48 and bool(torch.isfinite(loss).all())
+
+
 def test_moco_trainer_static_loss_scale_is_transparent(cuda):
     """MocoPretrainer.step(loss_scale=s): the scale multiplies the loss before backward and is divided out by the SGD kernel -- at f32
     the update equals the unscaled one (a power of two: to rounding of the momentum buffer only)."""
@@ -483,14 +550,17 @@ def _spark_from_fixture(d, dt, cuda):
     return model.to(cuda).train()
 
 
-@pytest.mark.parametrize("fixture", ["spark_unet", "spark_unet_m75"])
+@pytest.mark.parametrize("fixture", ["spark_unet", "spark_unet_m75", "spark_unet_m75_b8"])
 @pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
 def test_spark_step_vs_reference_fixture(cuda, golden_dir, dt, fixture):
     """SparK sparse masked-conv step against fixtures produced by the reference's own SparK code (oracle/gen_golden.py:
     Pretraining/Spark imported behind stubs): ``spark_unet`` = 64 px at mask ratio 0.6, ``spark_unet_m75`` = 128 px at BASELINE
     config 5's ratio 0.75 (16 of 64 patches kept per image; the tile-skipping conv path has whole tiles to skip there).
-    f32: max-norm 2e-3; f16 / bf16: loss 1.5e-2 / 3e-2 and gradient norms 10 % / 15 % (storage rounding through 18 sparse
-    BatchNorms over as few as 6 active positions)."""
+    ``spark_unet_m75_b8`` = the same configuration at batch 8 (round-2 review): 128 active positions per channel in the
+    bottleneck's sparse BatchNorm instead of 32 -- well conditioned, so here every tensor's gradient norm is held to the stated
+    bar itself (f16 10 %, bf16 15 %, f32 2e-3) with no slack; on the two small fixtures (6 - 32 positions per channel: the
+    reference's own f32 gradients sit 3e-3 from its float64 run) the per-tensor bar keeps its factor of 5.
+    f32: max-norm 2e-3; f16 / bf16: loss 1.5e-2 / 3e-2 (storage rounding through 18 sparse BatchNorms)."""
     d = np.load(f"{golden_dir}/{fixture}.npz")
     x, active = torch.from_numpy(d["x"]), torch.from_numpy(d["active"]).bool()
     model = _spark_from_fixture(d, dt, cuda)
@@ -498,6 +568,8 @@ def test_spark_step_vs_reference_fixture(cuda, golden_dir, dt, fixture):
         assert model.fmap_h == 4 and model.len_keep == 6 and model.hierarchy == 5
     else:
         assert model.fmap_h == 8 and model.len_keep == 16 and model.mask_ratio == 0.75
+        assert x.shape[0] == (8 if fixture.endswith("_b8") else 2)
+    slack = 1.0 if fixture.endswith("_b8") else 5.0
     loss = model(x.to(cuda), active_b1ff=active.to(cuda))
     loss.backward()
     ltol, gtol = {"f32": (2e-4, 2e-3), "f16": (1.5e-2, 0.10), "bf16": (3e-2, 0.15)}[dt]
@@ -510,7 +582,7 @@ def test_spark_step_vs_reference_fixture(cuda, golden_dir, dt, fixture):
             continue
         e = abs(named[k].grad.norm().item() - float(n)) / float(n)
         worst = max(worst, e)
-        assert e <= gtol * 5, f"|d{k}| {named[k].grad.norm().item():.4e} vs {float(n):.4e}"
+        assert e <= gtol * slack, f"|d{k}| {named[k].grad.norm().item():.4e} vs {float(n):.4e} ({e:.3e})"
     tg = torch.cat([p.grad.flatten() for p in model.mask_tokens]).cpu()
     # Sparse BatchNorm here normalises as few as 6 active positions per channel, so the reference's OWN f32 gradients sit
     # ~3e-3 from its float64 run (fixture keys *64).  The f32 bar is therefore stated against the float64 truth:
@@ -530,6 +602,8 @@ def test_spark_step_vs_reference_fixture(cuda, golden_dir, dt, fixture):
     else:
         assert rel(tg, tg64) <= 0.3
     print(f"[spark {dt} {fixture}] loss {float(loss):.5f} vs {float(d['loss']):.5f}, worst grad-norm err {worst:.2e}")
+    _parity_record(f"spark step vs reference fixture {fixture} {dt}: loss {float(loss):.6f} vs {float(d['loss']):.6f}, "
+                   f"worst per-tensor gradient-norm error {worst:.3e} (bar {gtol * slack:.2g})")
 
 
 def test_spark_sync_batchnorm_two_ranks(cuda):

@@ -88,6 +88,93 @@ def test_amp_scaler_protocol(cuda):
     assert amp.read()[1] == 1.0
 
 
+def test_adam_ema_fused_is_bit_identical_to_two_launches(cuda):
+    """cmu_adam_ema_step (AdamW + the momentum networks' EMA in one pass over the arena: JointPretrainer's optimiser launch) against
+    cmu_adam_step followed by cmu_ema_update per segment: identical bits in parameters, moments and targets, over three steps, with
+    a weight-decay mask, under the loss scaler (one step skipped by an inf: the EMA still runs, as MomentumUpdateHook does behind
+    a skipped optimiser step), and for elements outside every segment."""
+    from cmunet_amd import ops
+    n = 4096 + 512
+    segs = [(256, 1280), (2048, 4096)]
+    g = torch.Generator().manual_seed(3)
+    p0, t0 = torch.randn(n, generator=g), [torch.randn(hi - lo, generator=g) for lo, hi in segs]
+    wd_mask = (torch.rand(n, generator=g) > 0.3).to(torch.uint8).to(cuda)
+    for use_amp in (False, True):
+        pa, pb = p0.clone().to(cuda), p0.clone().to(cuda)
+        ma, va, mb, vb = (torch.zeros(n, device=cuda) for _ in range(4))
+        ta, tb = [t.clone().to(cuda) for t in t0], [t.clone().to(cuda) for t in t0]
+        amp_a = ops.AmpScaler(cuda, init_scale=256.0) if use_amp else None
+        amp_b = ops.AmpScaler(cuda, init_scale=256.0) if use_amp else None
+        for step in range(1, 5):
+            gr = (torch.randn(n, generator=g) * (256.0 if use_amp else 1.0)).to(cuda)
+            if use_amp and step == 2:
+                gr[100] = float("inf")
+            for amp in (amp_a, amp_b):
+                if amp is not None:
+                    amp.check(gr)
+            ops.adam_step(pa, gr, ma, va, wd_mask, 1e-2, 0.9, 0.95, 1e-8, 0.05, True, step, 0.5, amp_a)
+            for (lo, hi), t in zip(segs, ta):
+                ops.ema_update(t, pa[lo:hi], 0.99)
+            ops.adam_ema_step(pb, gr, mb, vb, wd_mask, 1e-2, 0.9, 0.95, 1e-8, 0.05, True, step, 0.5, amp_b,
+                              [(lo, hi, t) for (lo, hi), t in zip(segs, tb)], 0.99)
+            for amp in (amp_a, amp_b):
+                if amp is not None:
+                    amp.update()
+            assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb), (use_amp, step)
+            for x, y in zip(ta, tb):
+                assert torch.equal(x, y), (use_amp, step)
+        assert not torch.equal(pa.cpu(), p0) and not torch.equal(ta[0].cpu(), t0[0])
+        if use_amp:
+            assert amp_b.read()[3:] == (3, 1)                  # three updates taken, one skipped
+    from cmunet_amd._lib import CmuError
+    with pytest.raises(CmuError):                              # segments must be multiples of four inside the arena
+        ops.adam_ema_step(pb, gr, mb, vb, None, 1e-2, 0.9, 0.95, 1e-8, 0.0, True, 1, 1.0, None, [(2, 6, torch.zeros(4, device=cuda))], 0.9)
+
+
+def test_amp_state_survives_a_checkpoint(cuda):
+    """Advisor (round 2): under amp the AdamW kernel takes the bias-correction step from the scaler's ``good_steps``, so the scaler's
+    state belongs in the optimiser checkpoint (mmengine's AmpOptimWrapper.state_dict carries ``loss_scaler``).  Train 6 steps, or 3 +
+    save + restore into a FRESH trainer + 3: identical parameters.  A checkpoint without the scaler's state (an older build's) seeds
+    the counter from the saved step number instead of restarting the bias corrections at 1."""
+    from cmunet_amd import model as M, ops
+    from cmunet_amd.pretrain import MaskedReconPretrainer, random_patch_mask_device
+    from oracle import unet as OU
+    sd = OU.make_state_dict(base_ch=16, depth=3, seed=4)
+    g = torch.Generator(device=cuda).manual_seed(1)
+    batches = [(torch.randn(4, 64, 64, generator=g, device=cuda), random_patch_mask_device(4, 64, 64, 16, 0.5, g, cuda)) for _ in range(6)]
+
+    def trainer(state=None):
+        n = M.UNet(base_ch=16, depth=3, dtype="f16")
+        n.load_state_dict(sd if state is None else state)
+        return n, MaskedReconPretrainer(n.to(cuda).train(), lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05, amp=ops.AmpScaler(cuda, growth_interval=2))
+
+    _, full = trainer()
+    for x, m in batches:
+        full.step(x, m)
+    net, first = trainer()
+    for x, m in batches[:3]:
+        first.step(x, m)
+    ck = {"model": {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, "trainer": first.state_dict()}
+    assert ck["trainer"]["optimizer"]["loss_scaler"]["good_steps"] == 3 and ck["trainer"]["optimizer"]["loss_scaler"]["scale"] == 2 * 65536.0
+    ck = {"model": ck["model"], "trainer": {"optimizer": {k: (v.detach().cpu().clone() if torch.is_tensor(v) else v)
+                                                         for k, v in ck["trainer"]["optimizer"].items()}}}
+    _, second = trainer(ck["model"])
+    second.load_state_dict(ck["trainer"])
+    assert second.amp.read() == first.amp.read()
+    for x, m in batches[3:]:
+        second.step(x, m)
+    assert torch.equal(second.flat.arena, full.flat.arena), float((second.flat.arena - full.flat.arena).abs().max())
+    assert second.amp.read() == full.amp.read()
+    # an older checkpoint: no scaler state -> the step counter comes from the saved step, not from 0
+    old = {"optimizer": {k: v for k, v in ck["trainer"]["optimizer"].items() if k != "loss_scaler"}}
+    _, third = trainer(ck["model"])
+    third.load_state_dict(old)
+    assert third.amp.read()[3] == 3
+    for x, m in batches[3:]:
+        third.step(x, m)
+    assert (third.flat.arena - full.flat.arena).abs().max().item() <= 1e-3     # (only the scale history differs: 65536 against 131072)
+
+
 def test_masked_recon_trainer_f16_amp_tracks_f32(cuda):
     """The bench's default arithmetic on a small model: f16 storage + dynamic loss scale follows the f32 trainer (loss within
     2 %), never skips a step from an overflow at the initial scale, and without the scale the f16 gradients of a large batch of
