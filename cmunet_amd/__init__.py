@@ -1,6 +1,7 @@
-"""Import alias for the package directory ``contrastive-masked-unet_amd/`` (a hyphen is not importable)."""
-import os as _os
+"""cmunet_amd -- MI355X-native hot path of CM-UNet (UNet conv blocks + contrastive / masked-reconstruction pretraining step)
+behind the reference's Python surface.  (``contrastive-masked-unet_amd`` at the repo root is a symbolic link to this directory:
+the hyphenated name of the build brief is not importable.)
+"""
+from . import _lib  # noqa: F401
 
-__path__ = [_os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "contrastive-masked-unet_amd")]
-with open(_os.path.join(__path__[0], "__init__.py")) as _f:
-    exec(compile(_f.read(), _os.path.join(__path__[0], "__init__.py"), "exec"))
+__all__ = ["_lib"]

@@ -3,7 +3,7 @@
 Nothing under ``oracle/`` is part of the product.  Only ``tests/``,
 ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
 import it, and only as the checker.  The product path
-(``contrastive-masked-unet_amd``) never imports this package and fails loudly
+(``cmunet_amd``) never imports this package and fails loudly
 when its HIP library is missing.
 
 The reference's arithmetic for this path is floating point and lives in

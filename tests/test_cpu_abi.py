@@ -45,7 +45,7 @@ def test_product_has_no_cpu_fallback():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(1, 16, 16))
     # and nothing in the product package imports the oracle
-    pkg = os.path.join(ROOT, "contrastive-masked-unet_amd")
+    pkg = os.path.join(ROOT, "cmunet_amd")
     for fn in os.listdir(pkg):
         if fn.endswith(".py"):
             assert "oracle" not in open(os.path.join(pkg, fn)).read().replace("the oracle", ""), fn

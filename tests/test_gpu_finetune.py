@@ -191,3 +191,42 @@ def test_soft_cldice_vs_reference_fixture(golden_dir):
     assert torch.allclose(sk.cpu(), torch.from_numpy(d["skel_pred"])[:, 0], atol=1e-6)
     with pytest.raises(NotImplementedError):
         PM.soft_cldice(activation=None)
+
+
+def test_config4_chain_pretrain_checkpoint_finetune_small():
+    """BASELINE config 4 as a chain at a small size (tools/chain_config4.py is the measured, full-size form): two joint CM-UNet
+    steps -> ``export_checkpoint(layout='cmunet')`` (the mmengine layout, train.py:262-273) -> ``load_model`` -> ``main_finetuning``
+    (train.py:311-378: 3 folds of an 18-image split, one model trained on through the folds, Adam 1e-3).  Asserted: every encoder /
+    decoder tensor of the pretrained backbone + pixel decoder lands in the finetuning UNet and the 1x1 head does not (train.py:306-307
+    drops it); the folds are sklearn's KFold(3, shuffle, random_state 42); and the Dice of the finetuned model on its last validation
+    fold equals the oracle's evaluation of the SAME weights within the north-star 1e-4."""
+    import os
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    try:
+        from chain_config4 import run_chain
+    finally:
+        sys.path.pop(0)
+    from cmunet_amd import metrics as M, train as T
+    from oracle import losses as OL, unet as OU
+    r = run_chain(pre_steps=2, pre_size=64, pre_batch=4, ft_images=18, ft_size=64, ft_epochs=2, ft_batch=6, lr=1e-3, base_ch=16, depth=3,
+                  pre_dtype="f32", ft_dtype="f32")
+    ck = r["checkpoint"]
+    assert ck["keys_loaded"] == ck["keys_of_unet"] - 2 and ck["head_reinitialised"], ck       # all but conv_last.{weight,bias}
+    assert np.isfinite(r["pretrain"]["loss_ct"]) and np.isfinite(r["pretrain"]["loss_rc"])
+    ft = r["finetune"]
+    assert len(ft["best_valid_dice_per_fold"]) == 3 and all(0.0 <= d <= 1.0 for d in ft["best_valid_dice_per_fold"])
+    folds = T.kfold_indices(18, 3, 42)
+    assert sorted(int(i) for _, te in folds for i in te) == list(range(18)) and all(len(tr_) == 12 and len(te) == 6 for tr_, te in folds)
+    model, val = r["_model"], r["_val_batches"]
+    trained = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    mk = dict(activation="softmax", threshold=0.5, ignore_channels=[0])
+    logs = T.ValidEpoch(model, loss=M.DiceLoss(**mk) + M.CrossEntropyLoss(), metrics=[M.DiceLoss(**mk)], device="cuda", verbose=False).run(val)
+    with torch.no_grad():
+        ref = float(np.mean([float(OL.dice_loss(OU.unet_forward(x, trained, training=False), y)) for x, y in val]))
+    _parity_record(f"config 4 chain (small): finetuned model on its last validation fold, dice_loss {logs['dice_loss']:.6f} vs oracle {ref:.6f} "
+                   f"(|dDice| {abs(logs['dice_loss'] - ref):.2e}); best validation Dice per fold {ft['best_valid_dice_per_fold']}")
+    assert abs(logs["dice_loss"] - ref) <= 1e-4, (logs["dice_loss"], ref)

@@ -4,7 +4,7 @@ import sys
 
 import torch
 
-lib = ctypes.CDLL(sys.argv[1] if len(sys.argv) > 1 else "contrastive-masked-unet_amd/csrc/libcmunet_hip.so")
+lib = ctypes.CDLL(sys.argv[1] if len(sys.argv) > 1 else "cmunet_amd/csrc/libcmunet_hip.so")
 lib.cmu_pack_convT2x2_elems.restype = ctypes.c_int64
 lib.cmu_last_error.restype = ctypes.c_char_p
 lib.cmu_last_kernel.restype = ctypes.c_char_p
