@@ -321,7 +321,12 @@ extern "C" int cmu_bn_bwd_apply_masked(const void* dA, int64_t ldd, const void* 
 // ---------------------------------------------------------------------------------------------
 // MaxPool2d(2) backward + skip-gradient add (autograd of model.py:42-45 where both outputs are used)
 // ---------------------------------------------------------------------------------------------
-template <class TR>
+// MODE 0: dA is written (+ the BatchNorm-backward sums when bn_ws is given).  Round 3: when the gradient flows straight into this
+// layer's BatchNorm backward (the UNet encoder: always), dA is never stored -- MODE 1 leaves only the sums (same values, rounded to the
+// storage type as they would have been stored), and after their finalisation MODE 2 recomputes the pooled / skip sum and writes
+// dY = scale * (gate * dA - c1 - xhat * c2) (cmu_bn_bwd_apply's arithmetic: bit-identical to MODE 0 + cmu_bn_bwd_apply).  Per element
+// of the layer: 2.25 reads + 2.25 reads + 1 write instead of (2.25 reads + 1 write) + (2 reads + 1 write).
+template <class TR, int MODE>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* __restrict__ dP, int64_t ldp,
                                                          const unsigned char* __restrict__ dS, int64_t lds,
                                                          const unsigned char* __restrict__ dS2, int64_t lds2,
@@ -329,7 +334,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          unsigned char* __restrict__ dA, int64_t lda, int B, int H, int W, int C,
                                                          int cpb, int ppb, const float* __restrict__ mean,
-                                                         const float* __restrict__ invstd, float* __restrict__ bn_ws) {
+                                                         const float* __restrict__ invstd, float* __restrict__ bn_ws,
+                                                         const float* __restrict__ coef) {
     constexpr int EPC = TR::EPC;
     constexpr int ES = (int)sizeof(typename TR::elem_t);
     __shared__ float red[256];
@@ -340,14 +346,16 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
     const bool active = prow < ppb && ch < nchunk;
     const int Ho = H / 2, Wo = W / 2;
     const int64_t npool = (int64_t)B * Ho * Wo;
-    float sc[EPC], sh[EPC], mu[EPC], is[EPC], s1[EPC], s2[EPC];
+    float sc[EPC], sh[EPC], mu[EPC], is[EPC], s1[EPC], s2[EPC], c1[EPC], c2[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
         const int c = active ? ch * EPC + e : 0;
         sc[e] = scale[c];
         sh[e] = shift[c];
-        mu[e] = bn_ws ? mean[c] : 0.f;
-        is[e] = bn_ws ? invstd[c] : 0.f;
+        mu[e] = (bn_ws || MODE == 2) ? mean[c] : 0.f;
+        is[e] = (bn_ws || MODE == 2) ? invstd[c] : 0.f;
+        c1[e] = MODE == 2 ? coef[c] : 0.f;
+        c2[e] = MODE == 2 ? coef[C + c] : 0.f;
         s1[e] = s2[e] = 0.f;
     }
     if (active)
@@ -385,8 +393,18 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) d[e] += (arg[e] == q) ? g[e] : 0.f;
                 const u32x4 packed = TR::pack(d);
-                st_global16(dA + (src[q] * lda + ch * EPC) * ES, packed);
-                if (bn_ws) {   // BatchNorm+ReLU backward statistics of this layer, on the values as stored
+                if (MODE == 0) st_global16(dA + (src[q] * lda + ch * EPC) * ES, packed);
+                if (MODE == 2) {   // dY straight from the recomputed dA (rounded as MODE 0 would have stored it)
+                    float dr[EPC], o[EPC];
+                    TR::unpack(packed, dr);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const float dz = fmaf(f[q][e], sc[e], sh[e]) > 0.f ? dr[e] : 0.f;
+                        const float xh = (f[q][e] - mu[e]) * is[e];
+                        o[e] = sc[e] * (dz - c1[e] - xh * c2[e]);
+                    }
+                    __builtin_nontemporal_store(TR::pack(o), reinterpret_cast<u32x4*>(dA + (src[q] * lda + ch * EPC) * ES));
+                } else if (bn_ws) {   // BatchNorm+ReLU backward statistics of this layer, on the values as stored
                     float dr[EPC];
                     TR::unpack(packed, dr);
 #pragma unroll
@@ -398,7 +416,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
                 }
             }
         }
-    if (bn_ws == nullptr) return;
+    if (MODE == 2 || bn_ws == nullptr) return;
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *reinterpret_cast<int*>(bn_ws) = (int)gridDim.x;
     float* ws = bn_ws + BNWS_HDR / 4;
 #pragma unroll
@@ -415,15 +433,20 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
 template <class TR>
 static int maxpool_bwd_t(const void* dP, int64_t ldp, const void* dS, int64_t lds, const void* dS2, int64_t lds2, const void* y, int64_t ldy, const float* scale,
                          const float* shift, void* dA, int64_t lda, int B, int H, int W, int C, const float* mean, const float* invstd,
-                         void* bn_ws, hipStream_t st) {
+                         void* bn_ws, hipStream_t st, const float* coef = nullptr) {
     int cpb, ppb, gy;
     chunk_geometry(C / TR::EPC, &cpb, &ppb, &gy);
     const int64_t npool = (int64_t)B * (H / 2) * (W / 2);
     int gx = (int)(cmu_div_up64(npool, ppb * 2) < POOLB_MAX_BLOCKS ? cmu_div_up64(npool, ppb * 2) : POOLB_MAX_BLOCKS);
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL((maxpool_bwd_kernel<TR>), dim3(gx, gy), dim3(256), 0, st, (const unsigned char*)dP, ldp, (const unsigned char*)dS,
-                       lds, (const unsigned char*)dS2, lds2, (const unsigned char*)y, ldy, scale, shift, (unsigned char*)dA, lda, B, H, W, C, cpb, ppb, mean, invstd,
-                       (float*)bn_ws);
+#define CMU_POOLB_LAUNCH(MODE_)                                                                                                            \
+    hipLaunchKernelGGL((maxpool_bwd_kernel<TR, MODE_>), dim3(gx, gy), dim3(256), 0, st, (const unsigned char*)dP, ldp, (const unsigned char*)dS, lds, \
+                       (const unsigned char*)dS2, lds2, (const unsigned char*)y, ldy, scale, shift, (unsigned char*)dA, lda, B, H, W, C, cpb, ppb, \
+                       mean, invstd, (float*)bn_ws, coef)
+    if (coef != nullptr) CMU_POOLB_LAUNCH(2);
+    else if (dA == nullptr) CMU_POOLB_LAUNCH(1);
+    else CMU_POOLB_LAUNCH(0);
+#undef CMU_POOLB_LAUNCH
     CMU_CHECK_LAUNCH("cmu_maxpool_bwd");
     return CMU_OK;
 }
@@ -434,12 +457,27 @@ extern "C" int cmu_maxpool_bwd2(const void* dP, int64_t ldp, const void* dSkip, 
     CMU_CHECK_ARG(dSkip2 == nullptr || dSkip != nullptr, "cmu_maxpool_bwd2: dSkip2 without dSkip");
     int rc;
     if ((rc = check_pair("cmu_maxpool_bwd(dP,y)", dP, ldp, y, ldy, C, dt))) return rc;
-    if ((rc = check_pair("cmu_maxpool_bwd(dA,y)", dA, lda, y, ldy, C, dt))) return rc;
+    CMU_CHECK_ARG(dA != nullptr || bn_ws != nullptr, "cmu_maxpool_bwd: dA may only be NULL in the statistics-only form (bn_ws given)");
+    if (dA && (rc = check_pair("cmu_maxpool_bwd(dA,y)", dA, lda, y, ldy, C, dt))) return rc;
     if (dSkip && (rc = check_pair("cmu_maxpool_bwd(dSkip,y)", dSkip, lds, y, ldy, C, dt))) return rc;
     if (dSkip2 && (rc = check_pair("cmu_maxpool_bwd2(dSkip2,y)", dSkip2, lds2, y, ldy, C, dt))) return rc;
     CMU_CHECK_ARG(scale && shift && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "cmu_maxpool_bwd: bad dims (%d,%d)", H, W);
     CMU_DISPATCH_DT(dt, maxpool_bwd_t, dP, ldp, dSkip, lds, dSkip2, lds2, y, ldy, scale, shift, dA, lda, B, H, W, C, save_mean, save_invstd,
                     bn_ws, (hipStream_t)stream);
+}
+extern "C" int cmu_maxpool_bwd_apply(const void* dP, int64_t ldp, const void* dSkip, int64_t lds, const void* dSkip2, int64_t lds2, const void* y,
+                                     int64_t ldy, const float* scale, const float* shift, const float* save_mean, const float* save_invstd,
+                                     const float* coef, void* dY, int64_t ldo, int B, int H, int W, int C, int dt, void* stream) {
+    CMU_CHECK_ARG(scale && shift && save_mean && save_invstd && coef && dY, "cmu_maxpool_bwd_apply: null argument");
+    CMU_CHECK_ARG(dSkip2 == nullptr || dSkip != nullptr, "cmu_maxpool_bwd_apply: dSkip2 without dSkip");
+    int rc;
+    if ((rc = check_pair("cmu_maxpool_bwd_apply(dP,y)", dP, ldp, y, ldy, C, dt))) return rc;
+    if ((rc = check_pair("cmu_maxpool_bwd_apply(dY,y)", dY, ldo, y, ldy, C, dt))) return rc;
+    if (dSkip && (rc = check_pair("cmu_maxpool_bwd_apply(dSkip,y)", dSkip, lds, y, ldy, C, dt))) return rc;
+    if (dSkip2 && (rc = check_pair("cmu_maxpool_bwd_apply(dSkip2,y)", dSkip2, lds2, y, ldy, C, dt))) return rc;
+    CMU_CHECK_ARG(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "cmu_maxpool_bwd_apply: bad dims (%d,%d)", H, W);
+    CMU_DISPATCH_DT(dt, maxpool_bwd_t, dP, ldp, dSkip, lds, dSkip2, lds2, y, ldy, scale, shift, dY, ldo, B, H, W, C, save_mean, save_invstd,
+                    nullptr, (hipStream_t)stream, coef);
 }
 extern "C" int cmu_maxpool_bwd(const void* dP, int64_t ldp, const void* dSkip, int64_t lds, const void* y, int64_t ldy,
                                const float* scale, const float* shift, void* dA, int64_t lda, const float* save_mean,

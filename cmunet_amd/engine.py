@@ -31,6 +31,7 @@ BN_MOMENTUM = 0.1
 
 _FUSE_HEAD = os.environ.get("CMU_HEAD_FUSE", "1") != "0"   # A/B: "0" = the head's input gradient is stored and re-read by cmu_bn_bwd_apply
 _FUSE_DGRAD_BN = os.environ.get("CMU_DGRAD_BN", "1")    # A/B: "0" = BN-backward sums as a separate pass, "64"/"128" = fused up to C
+_FUSE_POOL = os.environ.get("CMU_POOL_FUSE", "1") != "0"   # A/B: "0" = the pool's input gradient is stored and re-read by cmu_bn_bwd_apply
 
 
 class _Scratch:
@@ -199,14 +200,16 @@ class UNetEngine:
         n = ops.ntiles(y.B, y.H, y.W)
         return self.scratch.get("bst", n * 2 * y.C * 4)[:n * 2 * y.C * 4].view(torch.float32).view(n, 2, y.C)
 
-    def _convbn_bwd(self, sd, s, dA, grads, need_dx, dx_out=None, fused_stats=False, next_bn=None, head=None):
+    def _convbn_bwd(self, sd, s, dA, grads, need_dx, dx_out=None, fused_stats=False, next_bn=None, head=None, pool=None):
         """``fused_stats``: the kernel that produced dA already wrote this layer's BN-backward partial sums into
         the shared slab (max-pool / head backward) -- only the finalisation is left of phase 1.  The same holds when the
         producer was a data-gradient kernel, which leaves a per-tile slab in ``s["bstats"]``.
         ``next_bn``: saved state of the conv+BN layer whose activated output is this conv's input: its BN-backward
         partial sums are produced by this layer's data-gradient kernel (consumed by the next ``_convbn_bwd`` call).
         ``head``: (dlogits, w) of the 1x1 head this layer feeds, with ``dA`` None: the head's rank-K input gradient was never
-        stored (its BN-backward sums were: ``fused_stats``) -- dY comes straight from dlogits (``conv1x1_head_bn_apply``)."""
+        stored (its BN-backward sums were: ``fused_stats``) -- dY comes straight from dlogits (``conv1x1_head_bn_apply``).
+        ``pool``: (dP, dSkip, dSkip2) of the max-pool this layer feeds, with ``dA`` None: the pool's input gradient was never stored
+        either (``maxpool_bwd(dA=None)`` left the sums) -- dY comes from ``maxpool_bwd_apply``."""
         y = s["y"]
         B, H, W, C = y.B, y.H, y.W, y.C
         w = sd[s["pconv"] + "weight"]
@@ -226,6 +229,10 @@ class UNetEngine:
             assert dA is None and fused_stats and not first
             dY = self._new(B, H, W, C)
             ops.conv1x1_head_bn_apply(head[0], y, head[1], s["mean"], s["invstd"], coef, dY)
+        elif pool is not None:
+            assert dA is None and fused_stats and not first
+            dY = self._new(B, H, W, C)
+            ops.maxpool_bwd_apply(pool[0], pool[1], y, s["mean"], s["invstd"], coef, dY, dSkip2=pool[2])
         else:
             dY = Act(dA.buf, dA.coff, dA.C)                   # in place over dA (out of place measures the same 4.3 ms)
             if not first:
@@ -312,11 +319,17 @@ class UNetEngine:
         for i in range(len(ctx["levels"]), 0, -1):
             lv = ctx["levels"][i - 1]
             y2 = lv["s2"]["y"]
-            dA2 = self._new(y2.B, y2.H, y2.W, y2.C)
             ds = d_skips[i - 1] if d_skips is not None else None
             ds, ds2 = ds if isinstance(ds, (tuple, list)) else (ds, None)     # two decoders on this encoder: both gradients of the skip
-            ops.maxpool_bwd(dP, ds, y2, dA2, lv["s2"]["mean"], lv["s2"]["invstd"], self._bn_ws(y2.C), dSkip2=ds2)
-            dA1 = self._convbn_bwd(sd, lv["s2"], dA2, grads, True, fused_stats=True, next_bn=lv["s1"])
+            if _FUSE_POOL and ds2 is None:
+                # the pool's input gradient is never stored: sums first, dY recomputed from (dP, skip gradient) after their finalisation
+                # -- one tensor pass less (with two skip gradients the recomputation reads more than the stored form: not fused)
+                ops.maxpool_bwd(dP, ds, y2, None, lv["s2"]["mean"], lv["s2"]["invstd"], self._bn_ws(y2.C))
+                dA1 = self._convbn_bwd(sd, lv["s2"], None, grads, True, fused_stats=True, next_bn=lv["s1"], pool=(dP, ds, None))
+            else:
+                dA2 = self._new(y2.B, y2.H, y2.W, y2.C)
+                ops.maxpool_bwd(dP, ds, y2, dA2, lv["s2"]["mean"], lv["s2"]["invstd"], self._bn_ws(y2.C), dSkip2=ds2)
+                dA1 = self._convbn_bwd(sd, lv["s2"], dA2, grads, True, fused_stats=True, next_bn=lv["s1"])
             dP = self._convbn_bwd(sd, lv["s1"], dA1, grads, i > 1)
         self.flush_zero_bias()
         return None

@@ -264,10 +264,20 @@ def conv3x3_c1_wgrad_bn(x_bhw, dA, yraw, scale, shift, save_mean, save_invstd, c
 
 
 def maxpool_bwd(dP, dSkip, y, dA, save_mean=None, save_invstd=None, bn_ws=None, dSkip2=None):
-    """``dSkip2``: a second gradient of the same skip tensor (two decoders on one encoder), summed inside the pass."""
+    """``dSkip2``: a second gradient of the same skip tensor (two decoders on one encoder), summed inside the pass.
+    ``dA`` None (with ``bn_ws``): only the BatchNorm-backward sums are produced -- follow with ``maxpool_bwd_apply``."""
     call("cmu_maxpool_bwd2", dP.ptr(), dP.ld, None if dSkip is None else dSkip.ptr(), 0 if dSkip is None else dSkip.ld,
-         None if dSkip2 is None else dSkip2.ptr(), 0 if dSkip2 is None else dSkip2.ld, y.ptr(), y.ld, _p(y.scale), _p(y.shift), dA.ptr(), dA.ld, _p(save_mean), _p(save_invstd), _p(bn_ws),
+         None if dSkip2 is None else dSkip2.ptr(), 0 if dSkip2 is None else dSkip2.ld, y.ptr(), y.ld, _p(y.scale), _p(y.shift),
+         None if dA is None else dA.ptr(), 0 if dA is None else dA.ld, _p(save_mean), _p(save_invstd), _p(bn_ws),
          y.B, y.H, y.W, y.C, y.dt, _stream())
+
+
+def maxpool_bwd_apply(dP, dSkip, y, save_mean, save_invstd, coef, dY, dSkip2=None):
+    """dY of the conv+BN+ReLU layer in front of a max-pool, straight from the pooled gradient and the skip gradient(s): the second
+    half of ``maxpool_bwd(..., dA=None, bn_ws=...)`` + ``bn_bwd_finalize`` (the pool's input gradient is never stored)."""
+    call("cmu_maxpool_bwd_apply", dP.ptr(), dP.ld, None if dSkip is None else dSkip.ptr(), 0 if dSkip is None else dSkip.ld,
+         None if dSkip2 is None else dSkip2.ptr(), 0 if dSkip2 is None else dSkip2.ld, y.ptr(), y.ld, _p(y.scale), _p(y.shift),
+         _p(save_mean), _p(save_invstd), _p(_f32c(coef)), dY.ptr(), dY.ld, y.B, y.H, y.W, y.C, y.dt, _stream())
 
 
 def bn_bwd_finalize(bn_ws, count, dgamma, dbeta, coef):

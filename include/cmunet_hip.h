@@ -179,6 +179,13 @@ int cmu_maxpool_bwd2(const void* dP, int64_t ldp, const void* dSkip, int64_t lds
                      int64_t ldy, const float* scale, const float* shift, void* dA, int64_t lda,
                      const float* save_mean, const float* save_invstd, void* bn_ws,
                      int B, int H, int W, int C, int dt, void* stream);
+/* Round 3 -- the pooled gradient never stored.  cmu_maxpool_bwd2 with dA == NULL (bn_ws required) leaves only the BatchNorm-backward
+ * sums; after cmu_bn_bwd_finalize, cmu_maxpool_bwd_apply recomputes dA = unpool(dP) + dSkip (+ dSkip2), rounds it to the storage type
+ * as the stored form would have been, and writes dY = scale * (gate * dA - coef[0] - xhat * coef[1]) -- bit-identical to
+ * cmu_maxpool_bwd2 + cmu_bn_bwd_apply (the BatchNorm2d + ReLU + MaxPool2d backward of model.py:20-25,42-45), one tensor pass less. */
+int cmu_maxpool_bwd_apply(const void* dP, int64_t ldp, const void* dSkip, int64_t lds, const void* dSkip2, int64_t lds2, const void* y,
+                          int64_t ldy, const float* scale, const float* shift, const float* save_mean, const float* save_invstd,
+                          const float* coef, void* dY, int64_t ldo, int B, int H, int W, int C, int dt, void* stream);
 
 /* ConvTranspose2d 2x2 s2 backward.  data: dX (B,H,W,Cin) from dOut (B,2H,2W,ldd) (GEMM K = 4*Cout).
  * weight: dW (Cin,Cout,2,2) and dbias (Cout) fp32, overwritten.                                    */

@@ -175,6 +175,44 @@ def test_maxpool_bwd(ops, dt, with_skip):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("skips", [0, 1, 2])
+def test_maxpool_bwd_apply_never_stores_the_pooled_gradient(ops, dt, skips):
+    """Round 3: ``maxpool_bwd(dA=None)`` (BatchNorm-backward sums only) + ``bn_bwd_finalize`` + ``maxpool_bwd_apply`` against the stored
+    form ``maxpool_bwd`` + ``bn_bwd_finalize`` + ``bn_bwd_apply``: the same sums bit for bit (they are taken on the gradient rounded as it
+    would have been stored) and the same dY bit for bit, with zero, one and two skip gradients, strided operands."""
+    from cmunet_amd import _lib
+    B, C, H, W = 2, 32, 8, 12
+    g = torch.Generator().manual_seed(25 + skips)
+    y = q(torch.randn(B, C, H, W, generator=g), dt, ops)
+    sc, sh = torch.randn(C, generator=g), torch.randn(C, generator=g) * 0.2
+    dP = to_act(q(torch.randn(B, C, H // 2, W // 2, generator=g), dt, ops), dt, ops)
+    s1 = to_act(q(torch.randn(B, C, H, W, generator=g), dt, ops), dt, ops, ld=2 * C, coff=C) if skips >= 1 else None
+    s2 = to_act(q(torch.randn(B, C, H, W, generator=g), dt, ops), dt, ops, ld=3 * C, coff=2 * C) if skips >= 2 else None
+    ya = to_act(y, dt, ops).with_transform(sc.cuda(), sh.cuda(), 0)
+    mean, invstd = (torch.randn(C, generator=g) * 0.1).cuda(), (torch.rand(C, generator=g) + 0.5).cuda()
+    n = _lib.lib().cmu_bn_bwd_ws_bytes(C)
+    ws_a, ws_b = ws_bytes(n), ws_bytes(n)
+    # stored form
+    dA = ops.new_act(B, H, W, C, dt, "cuda")
+    ops.maxpool_bwd(dP, s1, ya, dA, mean, invstd, ws_a, dSkip2=s2)
+    coef_a, dg_a, db_a = torch.empty(2, C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ops.bn_bwd_finalize(ws_a, B * H * W, dg_a, db_a, coef_a)
+    dY_a = ops.new_act(B, H, W, C, dt, "cuda")
+    ops.bn_bwd_apply(dA, ya, mean, invstd, coef_a, dY_a)
+    # never-stored form
+    ops.maxpool_bwd(dP, s1, ya, None, mean, invstd, ws_b, dSkip2=s2)
+    coef_b, dg_b, db_b = torch.empty(2, C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ops.bn_bwd_finalize(ws_b, B * H * W, dg_b, db_b, coef_b)
+    assert torch.equal(coef_a, coef_b) and torch.equal(dg_a, dg_b) and torch.equal(db_a, db_b)
+    dY_b = ops.Act(torch.full((B, H, W, 2 * C), 7.0, device="cuda").to(ops.TORCH_DT[ops.dt_code(dt)]), C, C)     # strided destination
+    ops.maxpool_bwd_apply(dP, s1, ya, mean, invstd, coef_b, dY_b, dSkip2=s2)
+    assert torch.equal(dY_b.buf[..., C:].contiguous().view(torch.uint8), dY_a.buf.view(torch.uint8))
+    assert bool((dY_b.buf[..., :C] == 7.0).all())                                   # the other half of the buffer is untouched
+    with pytest.raises(_lib.CmuError):
+        ops.maxpool_bwd(dP, s1, ya, None)                                           # dA may only be missing in the sums-only form
+
+
+@pytest.mark.parametrize("dt", DTS)
 def test_maxpool_bwd_two_skip_gradients(ops, dt):
     """cmu_maxpool_bwd2: two gradients of the same skip tensor (CM_UNet's pixel and feature decoders hang on one encoder,
     cmunet.py:121-124 of the reference; autograd sums them) added in fp32 inside the pass, with different strides / channel offsets;

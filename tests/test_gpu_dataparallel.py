@@ -274,7 +274,9 @@ def test_neck_syncbn_two_ranks_vs_reference_fixture(cuda):
         assert rel(two[rk]["running_mean"], torch.from_numpy(f["running_mean"])) <= 1e-5
         assert rel(two[rk]["running_var"], torch.from_numpy(f["running_var"])) <= 1e-5
     tot = {n: two[0]["grads"][n] + two[1]["grads"][n] for n in two[0]["grads"]}
-    assert rel(tot["fc0.bias"], torch.from_numpy(f["dfc0_bias"])) <= 2e-4
+    # (fc0's bias is followed by a training-mode BatchNorm: its gradient is a rounding remainder of sums that cancel, ~1e-8 in the
+    # reference's run as well -- held to an absolute bar on the scale of the BatchNorm bias gradient)
+    assert (tot["fc0.bias"] - torch.from_numpy(f["dfc0_bias"])).abs().max().item() <= 1e-5 * float(np.abs(f["dbn0_bias"]).max())
     assert rel(tot["bn0.weight"], torch.from_numpy(f["dbn0_weight"])) <= 2e-4
     assert rel(tot["bn0.bias"], torch.from_numpy(f["dbn0_bias"])) <= 2e-4
     assert rel(tot["fc1.weight"][:16], torch.from_numpy(f["dfc1_weight_rows"])) <= 2e-4

@@ -335,9 +335,18 @@ def test_cmunet_joint_step_16bit_vs_reference_fixture(cuda, golden_dir, dt):
     ref = torch.from_numpy(f["grad_norms"]).double()
     got = torch.stack([named[k].grad.double().norm().cpu() for k in trainable]) / scale
     noise = torch.tensor([k.endswith((".0.bias", ".3.bias", "fc0.bias")) or k == "feature_decoder.conv_last.bias" for k in trainable])
-    relerr = ((got - ref).abs() / ref.clamp_min(1e-30))[~noise]
+    # (a ConvTranspose bias feeds a conv + training-mode BatchNorm: its gradient is the border remainder of sums that cancel, ~1e-3
+    # of its layer's weight gradient -- measured on that scale, as in test_spark_step_vs_reference_fixture)
+    denom = ref.clone()
+    for i, k in enumerate(trainable):
+        if k.endswith("up_sample.bias"):
+            denom[i] = ref[trainable.index(k[:-len("bias")] + "weight")]
+    relerr = ((got - ref).abs() / denom.clamp_min(1e-30))[~noise]
     worst = sorted(zip(relerr.tolist(), [k for k, n in zip(trainable, noise) if not n]))[-3:]
     print("  worst:", [(f"{e:.2e}", k) for e, k in worst])
+    _parity_record(f"CM_UNet joint step {dt} vs the reference's fp32 fixture (224x224, bs 4): loss_rc {e_rc:.2e}, loss_ct {e_ct:.2e} relative; "
+                   f"per-tensor gradient-norm error worst {float(relerr.max()):.2e}, median {float(relerr.median()):.2e}; worst three "
+                   + "; ".join(f"{k}: {e:.2e}" for e, k in worst))
     print(f"CM_UNet {dt} vs the reference's fp32 run: loss_rc {e_rc:.2e}, loss_ct {e_ct:.2e} relative; gradient norms worst {float(relerr.max()):.2e}, "
           f"median {float(relerr.median()):.2e}")
     # measured: f16 loss_rc 1e-5, loss_ct 5e-3, gradient norms median 7e-3; bf16 (8 significand bits against 11) 1e-4, 2.5e-2, 9e-2 --
@@ -557,9 +566,9 @@ def test_spark_step_vs_reference_fixture(cuda, golden_dir, dt, fixture):
     Pretraining/Spark imported behind stubs): ``spark_unet`` = 64 px at mask ratio 0.6, ``spark_unet_m75`` = 128 px at BASELINE
     config 5's ratio 0.75 (16 of 64 patches kept per image; the tile-skipping conv path has whole tiles to skip there).
     ``spark_unet_m75_b8`` = the same configuration at batch 8 (round-2 review): 128 active positions per channel in the
-    bottleneck's sparse BatchNorm instead of 32 -- well conditioned, so here every tensor's gradient norm is held to the stated
-    bar itself (f16 10 %, bf16 15 %, f32 2e-3) with no slack; on the two small fixtures (6 - 32 positions per channel: the
-    reference's own f32 gradients sit 3e-3 from its float64 run) the per-tensor bar keeps its factor of 5.
+    bottleneck's sparse BatchNorm instead of 32.  On all three, every tensor's gradient norm is held to the stated bar itself
+    (f32 2e-3, f16 10 %, bf16 15 %; measured worst 9e-4 / 4.2e-2 / 8.2e-2, profiles/r03_parity.txt) -- the factor of 5 round 2
+    allowed was only ever needed by the ConvTranspose biases, whose gradient is a cancellation remainder (see below).
     f32: max-norm 2e-3; f16 / bf16: loss 1.5e-2 / 3e-2 (storage rounding through 18 sparse BatchNorms)."""
     d = np.load(f"{golden_dir}/{fixture}.npz")
     x, active = torch.from_numpy(d["x"]), torch.from_numpy(d["active"]).bool()
@@ -569,20 +578,33 @@ def test_spark_step_vs_reference_fixture(cuda, golden_dir, dt, fixture):
     else:
         assert model.fmap_h == 8 and model.len_keep == 16 and model.mask_ratio == 0.75
         assert x.shape[0] == (8 if fixture.endswith("_b8") else 2)
-    slack = 1.0 if fixture.endswith("_b8") else 5.0
+    slack = 1.0        # (round 2 allowed 5x the per-tensor bar on the two small fixtures; with the ConvTranspose biases measured on
+    #                    their layer's scale -- see below -- every fixture meets the stated bar itself: profiles/r03_parity.txt)
     loss = model(x.to(cuda), active_b1ff=active.to(cuda))
     loss.backward()
     ltol, gtol = {"f32": (2e-4, 2e-3), "f16": (1.5e-2, 0.10), "bf16": (3e-2, 0.15)}[dt]
     assert abs(float(loss) - float(d["loss"])) <= ltol * max(1.0, abs(float(d["loss"]))), (float(loss), float(d["loss"]))
     named = dict(model.named_parameters())
-    worst = 0.0
-    for k, n in zip(d["grad_norm_keys"], d["grad_norms"]):
-        k = str(k)
-        if ".0.bias" in k or ".3.bias" in k or float(n) < 1e-7:
+    worst, errs = 0.0, []
+    ref_norm = {str(k): float(n) for k, n in zip(d["grad_norm_keys"], d["grad_norms"])}
+    for k, n in ref_norm.items():
+        if ".0.bias" in k or ".3.bias" in k or n < 1e-7:
             continue
-        e = abs(named[k].grad.norm().item() - float(n)) / float(n)
+        got = named[k].grad.norm().item()
+        if k.endswith("up_sample.bias"):
+            # A ConvTranspose bias feeds a conv + training-mode BatchNorm, which is invariant to a constant shift of its input
+            # except through the zero padding at the image border: the true gradient is a small remainder of sums that cancel
+            # (norm ~1e-3 against ~1 for the layer's weight), so its RELATIVE error only measures the cancellation.  It is held
+            # to the bar relative to the gradient norm of the same layer's weight instead.
+            scale = ref_norm[k[:-len("bias")] + "weight"]
+            e = abs(got - n) / scale
+        else:
+            e = abs(got - n) / n
+        errs.append((e, k, got, n))
         worst = max(worst, e)
-        assert e <= gtol * slack, f"|d{k}| {named[k].grad.norm().item():.4e} vs {float(n):.4e} ({e:.3e})"
+    errs.sort(reverse=True)
+    top = "; ".join(f"{k}: {e:.2e}" for e, k, _, _ in errs[:4])
+    assert errs[0][0] <= gtol * slack, f"worst per-tensor gradient-norm errors: {top}"
     tg = torch.cat([p.grad.flatten() for p in model.mask_tokens]).cpu()
     # Sparse BatchNorm here normalises as few as 6 active positions per channel, so the reference's OWN f32 gradients sit
     # ~3e-3 from its float64 run (fixture keys *64).  The f32 bar is therefore stated against the float64 truth:
@@ -603,7 +625,7 @@ def test_spark_step_vs_reference_fixture(cuda, golden_dir, dt, fixture):
         assert rel(tg, tg64) <= 0.3
     print(f"[spark {dt} {fixture}] loss {float(loss):.5f} vs {float(d['loss']):.5f}, worst grad-norm err {worst:.2e}")
     _parity_record(f"spark step vs reference fixture {fixture} {dt}: loss {float(loss):.6f} vs {float(d['loss']):.6f}, "
-                   f"worst per-tensor gradient-norm error {worst:.3e} (bar {gtol * slack:.2g})")
+                   f"worst per-tensor gradient-norm errors {top} (bar {gtol * slack:.2g})")
 
 
 def test_spark_sync_batchnorm_two_ranks(cuda):
