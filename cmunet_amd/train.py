@@ -121,8 +121,9 @@ def train(model, train_loader, test_loader, train_epoch, test_epoch, TRAINING, E
             print("valid_logs : ", valid_logs)
             if best_dice_score > valid_logs['dice_loss']:
                 best_dice_score = valid_logs['dice_loss']
-                torch.save(model, name)
-                print('Model saved!')
+                if name is not None:                      # (None: measurement runs that keep no checkpoint)
+                    torch.save(model, name)
+                    print('Model saved!')
     return train_logs_list, valid_logs_list
 
 
@@ -306,7 +307,7 @@ def main_finetuning(args, loss, metrics, DEVICE, select_class_values, X_finetuni
                     if save_best:
                         os.makedirs(work_dir, exist_ok=True)
                     train_logs_list, valid_logs_list = train(model, train_loader, test_loader, train_epoch, test_epoch, True, EPOCH,
-                                                             name if save_best else os.devnull)
+                                                             name if save_best else None)
                     runtime = time.time() - start_time
                     cv_results.append(find_best_epochs(valid_logs_list, EPOCH, LR, BATCH, runtime)["dice_loss"])
                     result.append({"epochs": EPOCH, "lr": LR, "batch_size": BATCH, "runtime": runtime, "fold": fold + 1,

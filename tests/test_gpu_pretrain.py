@@ -351,7 +351,9 @@ def test_cmunet_joint_step_16bit_vs_reference_fixture(cuda, golden_dir, dt):
           f"median {float(relerr.median()):.2e}")
     # measured: f16 loss_rc 1e-5, loss_ct 5e-3, gradient norms median 7e-3; bf16 (8 significand bits against 11) 1e-4, 2.5e-2, 9e-2 --
     # the contrastive gradient goes through a BatchNorm over bs 4 rows and a softmax at temperature 0.07, which amplify operand rounding
-    bar_l, bar_g, bar_m = (5e-3, 1e-1, 2e-2) if dt == "f16" else (3e-2, 3.5e-1, 1.5e-1)
+    # round 3: with the ConvTranspose biases on their layer's scale the f16 worst per-tensor error is 2.8e-2 (median 4.9e-3), bf16 0.26
+    # (median 8.9e-2) -- profiles/r03_parity.txt; the f16 bars are halved accordingly (worst 10 % -> 5 %, median 2 % -> 1 %)
+    bar_l, bar_g, bar_m = (5e-3, 5e-2, 1e-2) if dt == "f16" else (3e-2, 3.5e-1, 1.5e-1)
     assert e_rc <= bar_l and e_ct <= 10 * bar_l, (e_rc, e_ct)
     assert float(relerr.max()) <= bar_g and float(relerr.median()) <= bar_m
 
