@@ -200,8 +200,25 @@ class ArenaTrainer:
         self._bucket_of = {n: b for b in self._buckets for n in b["names"]}
         self._ov_active = False
         self._works = []
-        for n, p in self.flat.params.items():
-            p.register_post_accumulate_grad_hook(lambda _p, n=n: self._on_grad(n))
+        # (hooks hold the trainer weakly: a model that outlives its trainer keeps no arena alive, and a dead trainer's hooks are no-ops)
+        import weakref
+        me = weakref.ref(self)
+
+        def hook(name):
+            def fire(_p):
+                t = me()
+                if t is not None:
+                    t._on_grad(name)
+            return fire
+        self._hook_handles = [p.register_post_accumulate_grad_hook(hook(n)) for n, p in self.flat.params.items()]
+
+    def close(self):
+        """Detach from the model: remove the gradient hooks (a second trainer on the same model starts clean)."""
+        for h in getattr(self, "_hook_handles", []):
+            h.remove()
+        self._hook_handles = []
+        if getattr(self.model, "_grads_ready", None) is not None and getattr(self.model._grads_ready, "__self__", None) is self:
+            object.__setattr__(self.model, "_grads_ready", None)
 
     # ---- overlapped exchange ----------------------------------------------------------------------------------------------
     def _begin_overlap(self):

@@ -144,3 +144,31 @@ def test_lr_schedules_vs_reference(golden_dir):
         assert abs(moco_cosine_lr(0.03, ep, 7) - opt.param_groups[0]["lr"]) < 1e-12, ep
         opt.step()
         sch.step()
+
+
+def test_kfold_indices_are_sklearns_split():
+    """train.kfold_indices == sklearn.model_selection.KFold(n_splits=3, shuffle=True, random_state=42).split (Finetuning/train.py:326,330:
+    the folds of main_finetuning), for the 18-image split of BASELINE config 4 and for sizes that do not divide by three."""
+    sk = pytest.importorskip("sklearn.model_selection")
+    from cmunet_amd import train as T
+    for n in (18, 20, 7, 3):
+        ours = T.kfold_indices(n, 3, 42)
+        ref = list(sk.KFold(n_splits=3, shuffle=True, random_state=42).split(list(range(n))))
+        assert len(ours) == 3
+        for (a_tr, a_te), (b_tr, b_te) in zip(ours, ref):
+            assert np.array_equal(a_tr, b_tr) and np.array_equal(a_te, b_te), n
+    assert sorted(int(i) for _, te in T.kfold_indices(18) for i in te) == list(range(18))
+
+
+def test_find_best_epochs_contract():
+    """utils.py:4-60: the best epoch by the training criterion, hyper-parameters attached; the first epoch may be the best one (the
+    reference leaves ``best_result`` unbound there and raises UnboundLocalError)."""
+    from cmunet_amd import train as T
+    logs = [{"dice_loss + cross_entropy_loss": 1.0, "dice_loss": 0.6, "iou_loss": 0.7},
+            {"dice_loss + cross_entropy_loss": 0.8, "dice_loss": 0.7, "iou_loss": 0.6},
+            {"dice_loss + cross_entropy_loss": 0.9, "dice_loss": 0.5, "iou_loss": 0.5}]
+    r = T.find_best_epochs(logs, 3, 1e-3, 6, 12.5)
+    assert (r["epochs"], r["lr"], r["batch_size"], r["runtime"]) == (3, 1e-3, 6, 12.5)
+    assert r["dice_loss"] == 0.7 and r["iou_loss"] == 0.6                       # epoch 1: smallest criterion
+    assert T.find_best_epochs(logs[:1], 1, 1e-3, 6, 1.0)["dice_loss"] == 0.6    # a single / first epoch is fine
+    assert T.find_best_epochs([{"dice_loss": 0.4}, {"dice_loss": 0.3}], 2, 1e-2, 2, 0.0)["dice_loss"] == 0.3   # falls back to dice_loss

@@ -1,6 +1,6 @@
 """Diagnostic: which host-side torch calls issue the __amd_rocclr_copyBuffer launches of a step (torch.profiler, with stacks)."""
 import os, sys, collections
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from torch.profiler import profile, ProfilerActivity
