@@ -78,6 +78,8 @@ _SIGS = {
     "cmu_maxpool_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cmu_maxpool_bwd2": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cmu_maxpool_bwd_apply": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "cmu_bnrelu_maxpool_fwd_masked": (_I, [_P, _L, _P, _P, _P, _I, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "cmu_maxpool_bwd_masked": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _I, _P, _L, _I, _I, _I, _I, _I, _P]),
     "cmu_bn_bwd_finalize": (_I, [_P, _L, _P, _P, _P, _I, _P]),
     "cmu_convT2x2_dgrad": (_I, [_P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
     "cmu_convT2x2_dgrad_bn": (_I, [_P, _L, _P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -335,7 +335,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
                                                          unsigned char* __restrict__ dA, int64_t lda, int B, int H, int W, int C,
                                                          int cpb, int ppb, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, float* __restrict__ bn_ws,
-                                                         const float* __restrict__ coef) {
+                                                         const float* __restrict__ coef, const uint8_t* __restrict__ amask = nullptr,
+                                                         int mf = 0, int msbits = 0) {
     constexpr int EPC = TR::EPC;
     constexpr int ES = (int)sizeof(typename TR::elem_t);
     __shared__ float red[256];
@@ -362,6 +363,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
         for (int64_t pp = (int64_t)blockIdx.x * ppb + prow; pp < npool; pp += (int64_t)gridDim.x * ppb) {
             int xo, yo, b;
             cmu_pixel_coords(pp, Wo, Ho, npool <= 0x7fffffffll, b, yo, xo);
+            // SparK's sparse encoder: a masked window (see bnrelu_maxpool_kernel) has no gradient -- its dA is left unwritten (the
+            // masked BatchNorm-backward passes that follow never read masked positions and write zeros there)
+            if (amask != nullptr && !sp_active(amask, mf, msbits, b, 2 * yo, 2 * xo, 0)) continue;
             float best[EPC], g[EPC], f[4][EPC];
             int arg[EPC];
             TR::unpack(ld_global16_nt(dP + (pp * ldp + ch * EPC) * ES), g);
@@ -433,7 +437,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
 template <class TR>
 static int maxpool_bwd_t(const void* dP, int64_t ldp, const void* dS, int64_t lds, const void* dS2, int64_t lds2, const void* y, int64_t ldy, const float* scale,
                          const float* shift, void* dA, int64_t lda, int B, int H, int W, int C, const float* mean, const float* invstd,
-                         void* bn_ws, hipStream_t st, const float* coef = nullptr) {
+                         void* bn_ws, hipStream_t st, const float* coef = nullptr, const uint8_t* amask = nullptr, int mf = 0) {
     int cpb, ppb, gy;
     chunk_geometry(C / TR::EPC, &cpb, &ppb, &gy);
     const int64_t npool = (int64_t)B * (H / 2) * (W / 2);
@@ -442,7 +446,7 @@ static int maxpool_bwd_t(const void* dP, int64_t ldp, const void* dS, int64_t ld
 #define CMU_POOLB_LAUNCH(MODE_)                                                                                                            \
     hipLaunchKernelGGL((maxpool_bwd_kernel<TR, MODE_>), dim3(gx, gy), dim3(256), 0, st, (const unsigned char*)dP, ldp, (const unsigned char*)dS, lds, \
                        (const unsigned char*)dS2, lds2, (const unsigned char*)y, ldy, scale, shift, (unsigned char*)dA, lda, B, H, W, C, cpb, ppb, \
-                       mean, invstd, (float*)bn_ws, coef)
+                       mean, invstd, (float*)bn_ws, coef, amask, mf, amask ? sp_shift_bits(H, mf) : 0)
     if (coef != nullptr) CMU_POOLB_LAUNCH(2);
     else if (dA == nullptr) CMU_POOLB_LAUNCH(1);
     else CMU_POOLB_LAUNCH(0);
@@ -464,6 +468,20 @@ extern "C" int cmu_maxpool_bwd2(const void* dP, int64_t ldp, const void* dSkip, 
     CMU_CHECK_ARG(scale && shift && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "cmu_maxpool_bwd: bad dims (%d,%d)", H, W);
     CMU_DISPATCH_DT(dt, maxpool_bwd_t, dP, ldp, dSkip, lds, dSkip2, lds2, y, ldy, scale, shift, dA, lda, B, H, W, C, save_mean, save_invstd,
                     bn_ws, (hipStream_t)stream);
+}
+extern "C" int cmu_maxpool_bwd_masked(const void* dP, int64_t ldp, const void* dSkip, int64_t lds, const void* y, int64_t ldy, const float* scale,
+                                      const float* shift, const uint8_t* active, int f, void* dA, int64_t lda, int B, int H, int W, int C, int dt,
+                                      void* stream) {
+    CMU_CHECK_ARG(active && f > 0 && dA && scale && shift, "cmu_maxpool_bwd_masked: null argument");
+    int rc;
+    if ((rc = check_pair("cmu_maxpool_bwd_masked(dP,y)", dP, ldp, y, ldy, C, dt))) return rc;
+    if ((rc = check_pair("cmu_maxpool_bwd_masked(dA,y)", dA, lda, y, ldy, C, dt))) return rc;
+    if (dSkip && (rc = check_pair("cmu_maxpool_bwd_masked(dSkip,y)", dSkip, lds, y, ldy, C, dt))) return rc;
+    CMU_CHECK_ARG(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "cmu_maxpool_bwd_masked: bad dims (%d,%d)", H, W);
+    const int sbits = sp_shift_bits(H, f);
+    CMU_CHECK_ARG(sbits >= 1 && (f << sbits) == W, "cmu_maxpool_bwd_masked: H=%d, W=%d must be f=%d times a power of two >= 2", H, W, f);
+    CMU_DISPATCH_DT(dt, maxpool_bwd_t, dP, ldp, dSkip, lds, nullptr, 0, y, ldy, scale, shift, dA, lda, B, H, W, C, nullptr, nullptr, nullptr,
+                    (hipStream_t)stream, nullptr, active, f);
 }
 extern "C" int cmu_maxpool_bwd_apply(const void* dP, int64_t ldp, const void* dSkip, int64_t lds, const void* dSkip2, int64_t lds2, const void* y,
                                      int64_t ldy, const float* scale, const float* shift, const float* save_mean, const float* save_invstd,

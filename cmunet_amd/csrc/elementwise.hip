@@ -519,7 +519,7 @@ extern "C" int cmu_conv3x3_c1_fwd(const float* x, const uint8_t* mask, int mask_
 template <class TR>
 __global__ void bnrelu_maxpool_kernel(const unsigned char* __restrict__ y, int64_t ldy, const float* __restrict__ scale,
                                       const float* __restrict__ shift, unsigned char* __restrict__ out, int64_t ldo, int B, int H,
-                                      int W, int C, int64_t total) {
+                                      int W, int C, int64_t total, const uint8_t* __restrict__ amask = nullptr, int f = 0, int sbits = 0) {
     constexpr int EPC = TR::EPC;
     constexpr int ES = (int)sizeof(typename TR::elem_t);
     const int nchunk = C / EPC;
@@ -536,6 +536,13 @@ __global__ void bnrelu_maxpool_kernel(const unsigned char* __restrict__ y, int64
             pix = o / nchunk;
         }
         cmu_pixel_coords(pix, Wo, Ho, total <= 0x7fffffffll, b, yo, xo);
+        // SparK's sparse encoder (amask: the patch mask, patches at least 2 px wide at every pooled level, so a window is active or
+        // masked as a whole): a masked window pools to zero without reading anything -- the activated, masked copy of y that the
+        // plain pool would read (cmu_mask_select) is never materialised
+        if (amask != nullptr && !sp_active(amask, f, sbits, b, 2 * yo, 2 * xo, 0)) {
+            st_global16(out + ((((int64_t)b * Ho + yo) * Wo + xo) * ldo + ch * EPC) * ES, u32x4{0u, 0u, 0u, 0u});
+            continue;
+        }
         float sc[EPC], sh[EPC], m[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
@@ -556,14 +563,14 @@ __global__ void bnrelu_maxpool_kernel(const unsigned char* __restrict__ y, int64
 }
 template <class TR>
 static int bnrelu_maxpool_t(const void* y, int64_t ldy, const float* scale, const float* shift, void* out, int64_t ldo, int B, int H,
-                            int W, int C, hipStream_t st) {
+                            int W, int C, hipStream_t st, const uint8_t* amask = nullptr, int f = 0) {
     const int64_t total = (int64_t)B * (H / 2) * (W / 2) * (C / TR::EPC);
 #ifndef CMU_POOLF_CAP
 #define CMU_POOLF_CAP 65536
 #endif
     const int grid = (int)(cmu_div_up64(total, 256) < CMU_POOLF_CAP ? cmu_div_up64(total, 256) : CMU_POOLF_CAP);
     hipLaunchKernelGGL((bnrelu_maxpool_kernel<TR>), dim3(grid), dim3(256), 0, st, (const unsigned char*)y, ldy, scale, shift,
-                       (unsigned char*)out, ldo, B, H, W, C, total);
+                       (unsigned char*)out, ldo, B, H, W, C, total, amask, f, amask ? sp_shift_bits(H, f) : 0);
     CMU_CHECK_LAUNCH("cmu_bnrelu_maxpool_fwd");
     return CMU_OK;
 }
@@ -576,6 +583,18 @@ extern "C" int cmu_bnrelu_maxpool_fwd(const void* y, int64_t ldy, const float* s
     CMU_CHECK_ARG(C % epc == 0 && ldy % epc == 0 && ldo % epc == 0 && ldy >= C && ldo >= C, "cmu_bnrelu_maxpool_fwd: C/ld alignment");
     CMU_CHECK_ARG(cmu_aligned16(y) && cmu_aligned16(out), "cmu_bnrelu_maxpool_fwd: pointer alignment");
     CMU_DISPATCH_DT(dt, bnrelu_maxpool_t, y, ldy, scale, shift, out, ldo, B, H, W, C, (hipStream_t)stream);
+}
+extern "C" int cmu_bnrelu_maxpool_fwd_masked(const void* y, int64_t ldy, const float* scale, const float* shift, const uint8_t* active, int f,
+                                             void* out, int64_t ldo, int B, int H, int W, int C, int dt, void* stream) {
+    const int es = cmu_dtype_size(dt);
+    CMU_CHECK_ARG(es > 0 && y && out && scale && shift && active && f > 0, "cmu_bnrelu_maxpool_fwd_masked: bad args");
+    const int epc = 16 / es;
+    CMU_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && H > 0 && W > 0 && B > 0, "cmu_bnrelu_maxpool_fwd_masked: H,W must be even (got %d,%d)", H, W);
+    CMU_CHECK_ARG(C % epc == 0 && ldy % epc == 0 && ldo % epc == 0 && ldy >= C && ldo >= C, "cmu_bnrelu_maxpool_fwd_masked: C/ld alignment");
+    CMU_CHECK_ARG(cmu_aligned16(y) && cmu_aligned16(out), "cmu_bnrelu_maxpool_fwd_masked: pointer alignment");
+    const int sbits = sp_shift_bits(H, f);
+    CMU_CHECK_ARG(sbits >= 1 && (f << sbits) == W, "cmu_bnrelu_maxpool_fwd_masked: H=%d, W=%d must be f=%d times a power of two >= 2 (a pool window lies in one patch)", H, W, f);
+    CMU_DISPATCH_DT(dt, bnrelu_maxpool_t, y, ldy, scale, shift, out, ldo, B, H, W, C, (hipStream_t)stream, active, f);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -402,6 +402,19 @@ def mask_select(x, active, out, relu=False, invert=False, fill=None, use_transfo
          out.ld, x.B, x.H, x.W, x.C, x.dt, _stream())
 
 
+def bnrelu_maxpool_fwd_masked(y, active, out):
+    """BN + ReLU + 2x2 max of the raw ``y`` with masked windows pooled to zero (no activated / masked copy of y in memory)."""
+    assert y.scale is not None
+    call("cmu_bnrelu_maxpool_fwd_masked", y.ptr(), y.ld, _p(y.scale), _p(y.shift), _p(active), active.shape[-1], out.ptr(), out.ld,
+         y.B, y.H, y.W, y.C, y.dt, _stream())
+
+
+def maxpool_bwd_masked(dP, dSkip, y, dA, active):
+    """``maxpool_bwd`` on the raw ``y`` + transform at active windows only; dA of masked windows is left unwritten."""
+    call("cmu_maxpool_bwd_masked", dP.ptr(), dP.ld, None if dSkip is None else dSkip.ptr(), 0 if dSkip is None else dSkip.ld, y.ptr(), y.ld,
+         _p(y.scale), _p(y.shift), _p(active), active.shape[-1], dA.ptr(), dA.ld, y.B, y.H, y.W, y.C, y.dt, _stream())
+
+
 def bn_bwd_reduce_masked(dA, y, save_mean, save_invstd, dgamma, dbeta, coef, active, count, ws):
     call("cmu_bn_bwd_reduce_masked", dA.ptr(), dA.ld, y.ptr(), y.ld, _p(y.scale), _p(y.shift), _p(save_mean), _p(save_invstd),
          _p(dgamma), _p(dbeta), _p(coef), _p(active), active.shape[-1], int(count), y.B, y.H, y.W, y.C, y.dt, _p(ws), _stream())

@@ -34,6 +34,8 @@ import torch.nn as nn
 
 from . import _lib, ops
 from .engine import BN_EPS, BN_MOMENTUM
+
+_FUSE_POOL = os.environ.get("CMU_SPARK_POOL_FUSE", "1") != "0"     # A/B: "0" = the activated + masked copy of every conv output is stored
 from .model import DoubleConv, DownBlock, UpBlock, _EngineOwner, _named_state, _param_args, _require_cuda
 from .ops import Act
 
@@ -209,7 +211,9 @@ class SparK(_EngineOwner, nn.Module):
             wg["lists"][tile_h] = (ops.TileList(wg["active"], wg["H"], wg["W"], tile_h, 16), share)
         return wg["lists"][tile_h]
 
-    def _sp_convbn_fwd(self, eng, sd, pconv, pbn, x, x_img, inv_pix, active, count, B, H, W, training, sync=False, tiles=None):
+    def _sp_convbn_fwd(self, eng, sd, pconv, pbn, x, x_img, inv_pix, active, count, B, H, W, training, sync=False, tiles=None, need_a=True):
+        """``need_a`` False (a level's SECOND conv, round 3): the activated + masked copy of the output is not materialised -- its
+        consumers (the mask-aware pool, the densify select, the pool backward) work from the raw output + transform + mask."""
         w = sd[pconv + "weight"]
         C = w.shape[0]
         y = eng._new(B, H, W, C)
@@ -241,8 +245,10 @@ class SparK(_EngineOwner, nn.Module):
         if training:
             sd[pbn + "num_batches_tracked"] += 1
         yt = y.with_transform(scale, shift, 0)
-        a = eng._new(B, H, W, C)
-        ops.mask_select(yt, active, a, relu=True)                                  # BN + ReLU, zeros at masked positions
+        a = None
+        if need_a:
+            a = eng._new(B, H, W, C)
+            ops.mask_select(yt, active, a, relu=True)                              # BN + ReLU, zeros at masked positions
         return {"pconv": pconv, "pbn": pbn, "x": x, "x_img": x_img, "mask": inv_pix, "mps": True, "y": yt, "a": a,
                 "mean": mean, "invstd": invstd, "sync": sync, "count_all": count, "tiles": tiles}
 
@@ -314,11 +320,16 @@ class SparK(_EngineOwner, nn.Module):
             tl = self._level_tiles(eng, active, B, h, w_, n_cells)
             s1 = self._sp_convbn_fwd(eng, sd, p + "0.", p + "1.", x, ximg, inv_pix if ximg is not None else None, active, cnt, B, h, w_, training,
                                      tiles=tl)
-            s2 = self._sp_convbn_fwd(eng, sd, p + "3.", p + "4.", s1["a"], None, None, active, cnt, B, h, w_, training, tiles=tl)
-            C = s2["a"].C
-            one, zero = self._ident(eng, C)
+            fuse_pool = _FUSE_POOL and (h // f) >= 2
+            s2 = self._sp_convbn_fwd(eng, sd, p + "3.", p + "4.", s1["a"], None, None, active, cnt, B, h, w_, training, tiles=tl,
+                                     need_a=not fuse_pool)
+            C = s2["y"].C
             pooled = eng._new(B, h // 2, w_ // 2, C)
-            ops.bnrelu_maxpool_fwd(s2["a"].with_transform(one, zero, 0), pooled)   # zeros stay zeros: pool then *= active
+            if fuse_pool:
+                ops.bnrelu_maxpool_fwd_masked(s2["y"], active, pooled)             # masked windows pool to zero; no activated copy of y
+            else:
+                one, zero = self._ident(eng, C)
+                ops.bnrelu_maxpool_fwd(s2["a"].with_transform(one, zero, 0), pooled)   # zeros stay zeros: pool then *= active
             levels.append({"s1": s1, "s2": s2, "cnt": cnt})
             x, ximg, h, w_ = pooled, None, h // 2, w_ // 2
         p = f"{ep}double_conv.double_conv."
@@ -326,23 +337,30 @@ class SparK(_EngineOwner, nn.Module):
         sbn = bool(getattr(self.sparse_encoder, "sbn", False))     # (SparK's own ``sbn`` only concerns the densify norms)
         tlb = self._level_tiles(eng, active, B, h, w_, n_cells) if nd > 0 else None
         b1 = self._sp_convbn_fwd(eng, sd, p + "0.", p + "1.", x, ximg, None, active, cnt_b, B, h, w_, training, sync=sbn, tiles=tlb)
-        b2 = self._sp_convbn_fwd(eng, sd, p + "3.", p + "4.", b1["a"], None, None, active, cnt_b, B, h, w_, training, sync=sbn, tiles=tlb)
+        b2 = self._sp_convbn_fwd(eng, sd, p + "3.", p + "4.", b1["a"], None, None, active, cnt_b, B, h, w_, training, sync=sbn, tiles=tlb,
+                                 need_a=not _FUSE_POOL)
 
         # ---- densify (spark.py:98-111): feature maps from the smallest to the largest, mask_tokens[i] likewise ----
-        feats = [b2["a"]] + [lv["s2"]["a"] for lv in reversed(levels)]
+        # (a feature map is the activated + masked second-conv output of its level: taken from the stored copy, or -- when that copy was
+        # never made -- selected from the raw output + transform in the densify pass itself)
+        feats = [b2] + [lv["s2"] for lv in reversed(levels)]
         # the densified skips are written straight into the right halves of the decoder's concat buffers (no copy at the hand-over)
         cats = eng.decoder_alloc(sd, B, H, W, dp)
         nf = len(feats)
-        into_cats = len(cats) == nf - 1 and all(cats[nf - 1 - i]["Cskip"] == feats[i].C for i in range(1, nf))
+        into_cats = len(cats) == nf - 1 and all(cats[nf - 1 - i]["Cskip"] == feats[i]["y"].C for i in range(1, nf))
         to_dec = []
-        for i, a in enumerate(feats):
+        for i, s in enumerate(feats):
+            a = s["a"] if s["a"] is not None else s["y"]
             tok = self.mask_tokens[i].detach().reshape(-1).contiguous()
             if i > 0 and into_cats:
                 c = cats[nf - 1 - i]                             # feats[i] is the skip of up_conv{nf - i}
                 d = Act(c["buf"], c["Cup"], c["Cskip"])
             else:
                 d = eng._new(a.B, a.H, a.W, a.C)
-            ops.mask_select(a, active, d, relu=False, fill=tok, use_transform=False)
+            if s["a"] is not None:
+                ops.mask_select(a, active, d, relu=False, fill=tok, use_transform=False)
+            else:
+                ops.mask_select(a, active, d, relu=True, fill=tok, use_transform=True)      # BN + ReLU at active positions, the token elsewhere
             to_dec.append(d)
 
         # ---- dense decoder (decoder.py:49-55) + loss (spark.py:112-123) ----
@@ -368,9 +386,13 @@ class SparK(_EngineOwner, nn.Module):
         for i in range(nd, 0, -1):
             lv = levels[i - 1]
             a2 = lv["s2"]["a"]
-            one, zero = self._ident(eng, a2.C)
-            dA2 = eng._new(a2.B, a2.H, a2.W, a2.C)
-            ops.maxpool_bwd(dP, d_feats[nd - i + 1], a2.with_transform(one, zero, 0), dA2)
+            y2 = lv["s2"]["y"]
+            dA2 = eng._new(y2.B, y2.H, y2.W, y2.C)
+            if a2 is None:
+                ops.maxpool_bwd_masked(dP, d_feats[nd - i + 1], y2, dA2, active)   # arg-max from the raw output + transform, active windows only
+            else:
+                one, zero = self._ident(eng, a2.C)
+                ops.maxpool_bwd(dP, d_feats[nd - i + 1], a2.with_transform(one, zero, 0), dA2)
             dA1 = self._sp_convbn_bwd(eng, sd, lv["s2"], dA2, active, lv["cnt"], grads, True)
             dP = self._sp_convbn_bwd(eng, sd, lv["s1"], dA1, active, lv["cnt"], grads, i > 1)
         return loss[0], grads

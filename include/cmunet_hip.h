@@ -187,6 +187,17 @@ int cmu_maxpool_bwd_apply(const void* dP, int64_t ldp, const void* dSkip, int64_
                           int64_t ldy, const float* scale, const float* shift, const float* save_mean, const float* save_invstd,
                           const float* coef, void* dY, int64_t ldo, int B, int H, int W, int C, int dt, void* stream);
 
+/* SparK's sparse encoder (Pretraining/Spark/encoder.py:20-36 + models/custom.py:152-182: conv * mask -> sparse BN -> ReLU -> MaxPool2d):
+ * mask-aware pools, so that the activated + masked copy of a level's second conv output is never materialised.  A pool window lies in
+ * one patch (patch side >= 2 px at every pooled level): cmu_bnrelu_maxpool_fwd_masked writes zero for masked windows without reading
+ * y, cmu_maxpool_bwd_masked leaves their dA unwritten (the masked BatchNorm-backward passes that follow never read masked positions and
+ * write zeros there).  active: (B,f,f) uint8; H = W = f << s, s >= 1.                                                          */
+int cmu_bnrelu_maxpool_fwd_masked(const void* y, int64_t ldy, const float* scale, const float* shift, const uint8_t* active, int f,
+                                  void* out, int64_t ldo, int B, int H, int W, int C, int dt, void* stream);
+int cmu_maxpool_bwd_masked(const void* dP, int64_t ldp, const void* dSkip, int64_t lds, const void* y, int64_t ldy, const float* scale,
+                           const float* shift, const uint8_t* active, int f, void* dA, int64_t lda, int B, int H, int W, int C, int dt,
+                           void* stream);
+
 /* ConvTranspose2d 2x2 s2 backward.  data: dX (B,H,W,Cin) from dOut (B,2H,2W,ldd) (GEMM K = 4*Cout).
  * weight: dW (Cin,Cout,2,2) and dbias (Cout) fp32, overwritten.                                    */
 int cmu_convT2x2_dgrad(const void* dOut, int64_t ldd, const void* wpacked_dgrad, void* dX, int64_t ldx,

@@ -229,6 +229,47 @@ def test_rows_statistics_equal_masked_statistics(ops, dt):
         assert (u - v).abs().max().item() <= 2e-5 * max(v.abs().max().item(), 1e-6)
 
 
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("case", [(2, 4, 16, 32), (3, 8, 16, 64), (1, 8, 32, 16)])     # (B, f, H, C): patch sides 4, 2, 4
+def test_masked_pools_equal_the_materialised_form(ops, dt, case):
+    """Round 3 (SparK): the mask-aware pools work from the raw conv output + transform + patch mask, so the activated + masked copy of a
+    level's second conv output (cmu_mask_select) is never written.  Forward: identical bits to select -> plain pool (rounding is
+    monotonic, so max and rounding commute).  Backward: at f32 identical bits on every active window; at 16 bits the arg-max is taken
+    on the un-rounded activations, so a window whose two largest values ROUND to the same number may route its pooled gradient to the
+    other one -- the window's gradient SUM is identical, and such windows are rare.  Masked windows: zero forward, untouched backward."""
+    B, f, H, C = case
+    W = H
+    tdt = ops.TORCH_DT[ops.dt_code(dt)]
+    g = torch.Generator().manual_seed(B * 100 + f)
+    act = _active(B, f, max(1, f * f // 3), 7).cuda()
+    y = ops.Act(torch.randn(B, H, W, C, generator=g).to(tdt).cuda(), 0, C, (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda(), 0)
+    a = ops.new_act(B, H, W, C, dt, "cuda")
+    ops.mask_select(y, act, a, relu=True)
+    one, zero = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    ref, got = ops.new_act(B, H // 2, W // 2, C, dt, "cuda"), ops.new_act(B, H // 2, W // 2, C, dt, "cuda")
+    ops.bnrelu_maxpool_fwd(a.with_transform(one, zero, 0), ref)
+    ops.bnrelu_maxpool_fwd_masked(y, act, got)
+    assert torch.equal(ref.buf.view(torch.uint8), got.buf.view(torch.uint8))
+    up = act.repeat_interleave(H // f, 1).repeat_interleave(W // f, 2).bool()            # (B,H,W) pixel mask
+    assert bool((got.buf.float()[~up[:, ::2, ::2]] == 0).all())
+    dP = ops.Act(torch.randn(B, H // 2, W // 2, C, generator=g).to(tdt).cuda())
+    dS = ops.Act(torch.randn(B, H, W, 2 * C, generator=g).to(tdt).cuda(), C, C)         # strided skip gradient
+    dA_ref, dA = ops.new_act(B, H, W, C, dt, "cuda"), ops.Act(torch.full((B, H, W, C), 7.0, device="cuda").to(tdt))
+    ops.maxpool_bwd(dP, dS, a.with_transform(one, zero, 0), dA_ref)
+    ops.maxpool_bwd_masked(dP, dS, y, dA, act)
+    assert bool((dA.buf.float()[~up] == 7.0).all())                                      # masked windows are left alone
+    r, q = dA_ref.buf.float()[up], dA.buf.float()[up]
+    if dt == "f32":
+        assert torch.equal(r, q)
+    else:
+        # per 2x2 window and channel the gradient sum agrees; elementwise differences only where the arg-max moved inside a window
+        win = lambda t: t.float().view(B, H // 2, 2, W // 2, 2, C).sum((2, 4))
+        mw = up[:, ::2, ::2]
+        tol = 2e-2 if dt == "f16" else 1e-1
+        assert (win(dA.buf)[mw] - win(dA_ref.buf)[mw]).abs().max().item() <= tol
+        assert (r != q).float().mean().item() <= 2e-2
+
+
 _STEP = r'''
 import sys, torch
 sys.path.insert(0, %r)
@@ -257,6 +298,16 @@ def test_spark_step_with_and_without_tile_skipping(ops, dt, tmp_path):
         env = dict(os.environ, CMU_SPARK_TILES=flag, CMU_SPARK_GATHER=gather)
         subprocess.run([sys.executable, "-c", _STEP % ROOT, dt, o], env=env, check=True, timeout=420)
         outs[flag + gather] = torch.load(o)
+    # round 3: the mask-aware pools (no activated copy of a level's second conv output) against the materialised form, everything else
+    # at its default: the forward is the same arithmetic (identical loss at f32), the backward differs by arg-max ties only
+    o = str(tmp_path / "nofuse.pt")
+    subprocess.run([sys.executable, "-c", _STEP % ROOT, dt, o], env=dict(os.environ, CMU_SPARK_POOL_FUSE="0"), check=True, timeout=420)
+    nofuse = torch.load(o)
+    if dt == "f32":
+        assert float(nofuse["loss"]) == float(outs["11"]["loss"])
+    num = sum((outs["11"]["grads"][k] - g0).double().pow(2).sum().item() for k, g0 in nofuse["grads"].items())
+    den = sum(g0.double().pow(2).sum().item() for g0 in nofuse["grads"].values())
+    assert (num / den) ** 0.5 <= (1e-5 if dt == "f32" else 5e-2), (num / den) ** 0.5
     # tile lists alone: the forward is the same arithmetic on every active pixel
     assert float(outs["10"]["loss"]) == float(outs["00"]["loss"])
     # The gather kernel sums K tap-major, the statistics passes visit the pixels in list order: rounding-level differences, which
