@@ -393,6 +393,55 @@ torch.save({k: v.cpu() for k, v in out.items()}, sys.argv[1])
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("hw", [(32, 64), (16, 16), (28, 28)])
+def test_conv3x3_narrow_channel_blocks_equal_the_wide_ones(ops, dt, hw):
+    """Launches with fewer 128-channel items than half the chip's CUs take 64-channel blocks (conv_igemm3.inc::igemm3_narrow_blocks:
+    small batches, deep levels).  Same MFMA order per accumulator -> the outputs are bit-identical to the 128-channel blocks
+    (CMU_CONV_NARROW=0, read per launch); the per-tile statistics fold the same pixels in another lane order.  Whole-tile shape
+    (persistent kernel), a 16 x 16 image (half-empty tiles, one-tile kernel) and 28 x 28 (partial tiles); forward with pending
+    transform + statistics, plain data gradient, data gradient with fused BN-backward sums."""
+    import os
+    g = torch.Generator().manual_seed(5)
+    B, (H, W), Cin, Cout = 2, hw, 128, 256
+    tdt = ops.TORCH_DT[ops.dt_code(dt)]
+    x = torch.randn(B, H, W, Cin, generator=g).to(tdt).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / 32).cuda()
+    sc, sh = (torch.rand(Cin, generator=g) + 0.5).cuda(), (torch.randn(Cin, generator=g) * 0.3).cuda()
+    xr = torch.randn(B, H, W, Cout, generator=g).to(tdt).cuda()
+    bsc, bsh = (torch.rand(Cout, generator=g) + 0.5).cuda(), (torch.randn(Cout, generator=g) * 0.3).cuda()
+    mu, istd = (torch.randn(Cout, generator=g) * 0.1).cuda(), (torch.rand(Cout, generator=g) + 0.5).cuda()
+    wt = (torch.randn(Cin, Cout, 3, 3, generator=g) / 32).cuda()
+    outs = []
+    old = os.environ.get("CMU_CONV_NARROW")
+    try:
+        for v in ("0", "1"):
+            os.environ["CMU_CONV_NARROW"] = v
+            y = ops.new_act(B, H, W, Cout, dt, "cuda")
+            st = ops.new_stats(B, H, W, Cout, "cuda")
+            ops.conv3x3_fwd(ops.Act(x, 0, Cin, sc, sh, 0), ops.pack_conv3x3(w, dt), y, st)
+            y2 = ops.new_act(B, H, W, Cout, dt, "cuda")
+            ops.conv3x3_fwd(ops.Act(x, 0, Cin), ops.pack_conv3x3(w, dt), y2, None)
+            dX = ops.new_act(B, H, W, Cout, dt, "cuda")
+            slab = ops.new_stats(B, H, W, Cout, "cuda")
+            ops.conv3x3_dgrad_bn(ops.Act(x, 0, Cin), ops.pack_conv3x3(wt, dt, transpose_flip=True), dX, ops.Act(xr, 0, Cout, bsc, bsh, 0), mu, istd, slab)
+            torch.cuda.synchronize()
+            outs.append({"y": y.buf.clone(), "y2": y2.buf.clone(), "dx": dX.buf.clone(), "s": st.clone(), "slab": slab.clone()})
+    finally:
+        if old is None:
+            os.environ.pop("CMU_CONV_NARROW", None)
+        else:
+            os.environ["CMU_CONV_NARROW"] = old
+    for k in ("y", "y2", "dx"):
+        assert torch.equal(outs[0][k].view(torch.uint8), outs[1][k].view(torch.uint8)), k
+    for k in ("s", "slab"):
+        check(outs[1][k].cpu(), outs[0][k].cpu(), 2e-5, f"{k}: narrow vs wide blocks")
+    # and against torch on the same operands (the narrow path is what small shapes now run)
+    xa = torch.relu(x.float() * sc + sh).to(tdt).float()
+    ref = torch.nn.functional.conv2d(xa.permute(0, 3, 1, 2), w.to(tdt).float(), padding=1).permute(0, 2, 3, 1)
+    check(outs[1]["y"].float().cpu(), ref.cpu(), {"f32": 2e-5, "f16": 4e-3, "bf16": 2e-2}[dt], "narrow blocks vs torch")
+
+
+@pytest.mark.parametrize("dt", DTS)
 def test_pack_batch_matches_single_packs(ops, dt):
     """cmu_pack_batch (all packs of a step in one launch) writes exactly what the per-weight entries write."""
     g = torch.Generator().manual_seed(23)

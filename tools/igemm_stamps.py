@@ -24,8 +24,9 @@ import os
 # CMU_SWEEP_DT=1: f16 (default 2: bf16).  CMU_SWEEP_DATA=zero_w | zero_x | zero_both: the same launch on operands that do not
 # toggle the multipliers -- the shader clock under an MFMA load depends on the data (csrc/probe.hip), so the time these take
 # against the normal run separates the power limit from the kernel's own stalls
-DT = int(os.environ.get("CMU_SWEEP_DT", "2"))
-TDT = torch.float16 if DT == 1 else torch.bfloat16
+DT = int(os.environ.get("CMU_SWEEP_DT", "2"))           # 0: f32, 1: f16, 2: bf16
+TDT = {0: torch.float32, 1: torch.float16, 2: torch.bfloat16}[DT]
+B = int(os.environ.get("CMU_SWEEP_B", B))               # batch (small-batch finetuning shapes: tools/small_sweep.sh)
 DATA = os.environ.get("CMU_SWEEP_DATA", "normal")
 torch.manual_seed(0)
 x = torch.randn(B, H, W, Cin, device=dev).to(TDT)
@@ -62,7 +63,7 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 20
 fl = 2.0 * B * H * W * Cin * Cout * 9
-print(f"layer {Cin}->{Cout} @ {H}x{W} B={B}{'' if DATA == 'normal' else ' [' + DATA + ']'}{' f16' if DT == 1 else ''}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TFLOP/s")
+print(f"layer {Cin}->{Cout} @ {H}x{W} B={B}{'' if DATA == 'normal' else ' [' + DATA + ']'}{(' f32', ' f16', '')[DT]}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TFLOP/s")
 
 if not hasattr(lib, "cmu_debug_ig_stamps"):
     sys.exit(0)
