@@ -728,6 +728,52 @@ def gen_moco_2rank(seed=5300):
          bn_k=torch.stack([res[0]["bn_k"], res[1]["bn_k"]]))
 
 
+def gen_finetune_sensitivity(ref, M, seed=6100, runs=4, eps=2.0 ** -22):
+    """tests/golden/finetune_sensitivity.npz: how far the REFERENCE's own two-epoch trajectory of finetune_ref.npz moves when its
+    initial weights are perturbed by rounding-size noise (w * (1 + eps * u), u uniform in [-1, 1], eps = 2^-22: four float32 ulps
+    peak) -- the reference's loop run ``runs`` times on CPU, every log of every epoch stored.  A second implementation of the same
+    arithmetic in another summation order cannot track the fixture closer than this spread: tests/test_gpu_finetune.py takes its
+    trajectory bar from it."""
+    import types
+    from oracle import unet as OU
+    for name in ("cv2", "albumentations"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    if not any(q.rstrip("/").endswith("Finetuning") for q in sys.path):
+        sys.path.insert(0, os.path.join(REF, "Finetuning"))
+    for clash in ("utils", "config", "dataset", "train"):
+        sys.modules.pop(clash, None)
+    import train as ref_train  # noqa
+    base = np.load(os.path.join(OUT, "finetune_ref.npz"))
+    keys = [str(k) for k in base["log_keys"]]
+    sd = OU.make_state_dict(base_ch=64, depth=5, seed=seed)
+    train_loader, valid_loader = OU.finetune_fixture_data(seed + 1)
+    mk = dict(activation="softmax", threshold=0.5, ignore_channels=[0])
+    tls, vls = [], []
+    for r in range(runs):
+        g = torch.Generator().manual_seed(9000 + r)
+        torch.manual_seed(0)
+        model = ref.UNet()
+        model.load_state_dict({k: (v * (1 + eps * (2 * torch.rand(v.shape, generator=g) - 1))).to(v.dtype) if v.is_floating_point() else v.clone()
+                               for k, v in sd.items()})
+        loss = M.DiceLoss(**mk) + M.CrossEntropyLoss()
+        metrics = [M.DiceLoss(**mk), M.CrossEntropyLoss(), M.IoU(**mk), M.soft_cldice(**mk)]
+        opt = torch.optim.Adam([dict(params=model.parameters(), lr=1e-3)])
+        tr = ref_train.TrainEpoch(model, loss=loss, metrics=metrics, optimizer=opt, device="cpu", verbose=False)
+        va = ref_train.ValidEpoch(model, loss=loss, metrics=metrics, device="cpu", verbose=False)
+        tmp = tempfile.mkdtemp(prefix="ft_sens_")
+        tl, vl = ref_train.train(model, train_loader, valid_loader, tr, va, True, 2, name=os.path.join(tmp, "best_model.pth"))
+        tls.append([[float(tl[ep][k]) for k in keys] for ep in range(2)])
+        vls.append([[float(vl[ep][k]) for k in keys] for ep in range(2)])
+    tls, vls = np.array(tls, dtype=np.float64), np.array(vls, dtype=np.float64)
+    dev_t = np.abs(tls - base["train_logs"][None]).max(0)
+    dev_v = np.abs(vls - base["valid_logs"][None]).max(0)
+    for ep in range(2):
+        for i, k in enumerate(keys):
+            print(f"  sensitivity epoch {ep} {k}: train {dev_t[ep, i]:.2e}  valid {dev_v[ep, i]:.2e}")
+    save("finetune_sensitivity", seed=np.array(seed), eps=np.array(eps), runs=np.array(runs), log_keys=np.array(keys),
+         train_logs=tls, valid_logs=vls, train_dev=dev_t, valid_dev=dev_v)
+
+
 def gen_finetune(ref, M, seed=6100):
     """tests/golden/finetune_ref.npz: the reference's OWN training loop -- Finetuning/train.py's TrainEpoch / ValidEpoch / train()
     imported behind empty cv2 / albumentations stand-ins (dataset.py imports them at the top; the Dataset class itself is not used)
@@ -1145,6 +1191,9 @@ def main():
         return
     if "--only-loadmodel" in sys.argv:  # tests/golden/load_model_ref.npz alone (the reference's own load_model on the five layouts)
         gen_load_model()
+        return
+    if "--only-finetune-sensitivity" in sys.argv:   # tests/golden/finetune_sensitivity.npz (needs finetune_ref.npz)
+        gen_finetune_sensitivity(ref, M)
         return
     if "--only-finetune" in sys.argv:   # tests/golden/finetune_ref.npz alone (the reference's own TrainEpoch / ValidEpoch / train())
         gen_finetune(ref, M)

@@ -437,6 +437,22 @@ def test_moco_two_rank_oracle_vs_reference_fixture(golden_dir):
     assert float((f["loss"][0] - f["loss"][1]).abs()) > 1e-4              # the ranks had different images
 
 
+def test_finetune_sensitivity_fixture_is_consistent(golden_dir):
+    """tests/golden/finetune_sensitivity.npz (the reference's loop re-run from initial weights perturbed by four-ulp noise): the stored
+    deviations are those of the stored runs against finetune_ref.npz, epoch 0 barely moves, and the epoch-1 validation Dice -- a
+    thresholded metric after six Adam steps -- moves by more than 1e-3: the spread the GPU trajectory test takes its bar from."""
+    d = np.load(f"{golden_dir}/finetune_ref.npz")
+    s = np.load(f"{golden_dir}/finetune_sensitivity.npz")
+    keys = [str(k) for k in s["log_keys"]]
+    assert keys == [str(k) for k in d["log_keys"]] and int(s["seed"]) == int(d["seed"]) and float(s["eps"]) == 2.0 ** -22
+    assert s["train_logs"].shape == (int(s["runs"]), 2, len(keys))
+    assert np.array_equal(s["train_dev"], np.abs(s["train_logs"] - d["train_logs"][None]).max(0))
+    assert np.array_equal(s["valid_dev"], np.abs(s["valid_logs"] - d["valid_logs"][None]).max(0))
+    i = keys.index("dice_loss")
+    assert s["train_dev"][0, i] < 5e-4 and s["valid_dev"][0, i] < 5e-4
+    assert 1e-3 < s["valid_dev"][1, i] < 1e-2
+
+
 def test_finetune_loop_oracle_vs_reference_fixture(golden_dir):
     """tests/golden/finetune_ref.npz: per-epoch logs of the REFERENCE's own TrainEpoch / ValidEpoch / train() (Finetuning/train.py)
     over two epochs on a synthetic split, reference UNet + DiceLoss + CrossEntropyLoss + Adam.  The oracle loop reproduces the

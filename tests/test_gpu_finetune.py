@@ -136,8 +136,10 @@ def test_finetune_loop_vs_reference_loop_fixture(golden_dir):
     from cmunet_amd import metrics as M, model as Mod, train as T
     from oracle import unet as OU
     d = np.load(f"{golden_dir}/finetune_ref.npz")
+    sens = np.load(f"{golden_dir}/finetune_sensitivity.npz")
     seed = int(d["seed"])
     keys = [str(k) for k in d["log_keys"]]
+    assert [str(k) for k in sens["log_keys"]] == keys and int(sens["seed"]) == seed
     train_loader, valid_loader = OU.finetune_fixture_data(seed + 1)
     net = Mod.UNet(dtype="f32")
     net.load_state_dict(OU.make_state_dict(base_ch=64, depth=5, seed=seed))
@@ -156,9 +158,13 @@ def test_finetune_loop_vs_reference_loop_fixture(golden_dir):
             for k, b in zip(keys, ref):
                 print(f"[finetune vs reference loop] epoch {ep} {what} {k}: {float(logs[k]):.6f} vs reference {float(b):.6f} "
                       f"(delta {abs(float(logs[k]) - float(b)):.2e})")
-                # (two training trajectories; soft-clDice compares skeletons of THRESHOLDED masks: a few flipped pixels move it most)
-                bar = 1e-2 if k == "soft_clDice" else 3e-3
-                assert abs(float(logs[k]) - float(b)) <= bar * max(1.0, abs(float(b))), (ep, what, k, float(logs[k]), float(b))
+                # (two training trajectories; soft-clDice compares skeletons of THRESHOLDED masks: a few flipped pixels move it most.
+                # Where the REFERENCE's own loop moves by more than a third of the fixed bar under four-ulp noise on its initial
+                # weights -- tests/golden/finetune_sensitivity.npz, oracle/gen_golden.py::gen_finetune_sensitivity: epoch-1 validation
+                # Dice 1.9e-3, loss 2.6e-3, clDice 5e-3 over four runs -- the bar is three times that spread)
+                dev = float(sens[what + "_dev"][ep][keys.index(k)])
+                bar = max(1e-2 if k == "soft_clDice" else 3e-3, 3.0 * dev)
+                assert abs(float(logs[k]) - float(b)) <= bar * max(1.0, abs(float(b))), (ep, what, k, float(logs[k]), float(b), bar)
     named = dict(net.named_parameters())
     pk = [str(k) for k in d["param_keys"]]
     norms = torch.stack([named[k].detach().double().norm().cpu() for k in pk])

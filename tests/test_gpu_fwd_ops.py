@@ -442,6 +442,57 @@ def test_conv3x3_narrow_channel_blocks_equal_the_wide_ones(ops, dt, hw):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("bhw", [(2, 16, 16), (3, 14, 14), (2, 9, 7), (22, 48, 48)])
+def test_conv3x3_slim_tiles_equal_the_32_pixel_ones(ops, dt, bhw):
+    """Images with an odd number of 16-pixel columns run on 16 x 16 pixel tiles (conv_igemm3.inc::igemm3_slim_tiles: one-column
+    images at every dtype; f32 up to 7 columns once the 32-pixel tiles fill the chip) instead of leaving half of a 16 x 32 tile
+    empty.  Same MFMA order per accumulator -> bit-identical outputs against CMU_CONV_SLIM=0 (read per launch); statistics in
+    another fold order.  Forward with pending transform + statistics, data gradient with fused BN-backward sums."""
+    import os
+    B, H, W = bhw
+    if B > 8 and dt != "f32":
+        pytest.skip("the wide-image form is f32-only")
+    g = torch.Generator().manual_seed(9)
+    Cin, Cout = 64, 256
+    tdt = ops.TORCH_DT[ops.dt_code(dt)]
+    x = torch.randn(B, H, W, Cin, generator=g).to(tdt).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / 24).cuda()
+    sc, sh = (torch.rand(Cin, generator=g) + 0.5).cuda(), (torch.randn(Cin, generator=g) * 0.3).cuda()
+    xr = torch.randn(B, H, W, Cout, generator=g).to(tdt).cuda()
+    bsc, bsh = (torch.rand(Cout, generator=g) + 0.5).cuda(), (torch.randn(Cout, generator=g) * 0.3).cuda()
+    mu, istd = (torch.randn(Cout, generator=g) * 0.1).cuda(), (torch.rand(Cout, generator=g) + 0.5).cuda()
+    wt = (torch.randn(Cin, Cout, 3, 3, generator=g) / 24).cuda()
+    outs = []
+    old = os.environ.get("CMU_CONV_SLIM")
+    try:
+        for v in ("0", "1"):
+            os.environ["CMU_CONV_SLIM"] = v
+            y = ops.new_act(B, H, W, Cout, dt, "cuda")
+            st = ops.new_stats(B, H, W, Cout, "cuda")
+            ops.conv3x3_fwd(ops.Act(x, 0, Cin, sc, sh, 0), ops.pack_conv3x3(w, dt), y, st)
+            dX = ops.new_act(B, H, W, Cout, dt, "cuda")
+            slab = ops.new_stats(B, H, W, Cout, "cuda")
+            ops.conv3x3_dgrad_bn(ops.Act(x, 0, Cin), ops.pack_conv3x3(wt, dt, transpose_flip=True), dX, ops.Act(xr, 0, Cout, bsc, bsh, 0), mu, istd, slab)
+            torch.cuda.synchronize()
+            outs.append({"y": y.buf.clone(), "dx": dX.buf.clone(), "s": st.clone(), "slab": slab.clone()})
+    finally:
+        if old is None:
+            os.environ.pop("CMU_CONV_SLIM", None)
+        else:
+            os.environ["CMU_CONV_SLIM"] = old
+    for k in ("y", "dx"):
+        assert torch.equal(outs[0][k].view(torch.uint8), outs[1][k].view(torch.uint8)), k
+    for k in ("s", "slab"):
+        check(outs[1][k].sum(0).cpu(), outs[0][k].sum(0).cpu(), 2e-5, f"{k}: 16-pixel vs 32-pixel tiles")
+    xa = torch.relu(x.float() * sc + sh).to(tdt).float()
+    ref = torch.nn.functional.conv2d(xa.permute(0, 3, 1, 2), w.to(tdt).float(), padding=1).permute(0, 2, 3, 1)
+    check(outs[1]["y"].float().cpu(), ref.cpu(), {"f32": 2e-5, "f16": 4e-3, "bf16": 2e-2}[dt], "16-pixel tiles vs torch")
+    ssum = outs[1]["s"].sum(0).cpu()          # per-channel (sum, sum of squares) over all tiles == the stored output's
+    yf = outs[1]["y"].float().cpu().reshape(-1, Cout)
+    check(ssum[0], ref.cpu().reshape(-1, Cout).sum(0), {"f32": 2e-4, "f16": 5e-3, "bf16": 2e-2}[dt], "statistics: sum")
+
+
+@pytest.mark.parametrize("dt", DTS)
 def test_pack_batch_matches_single_packs(ops, dt):
     """cmu_pack_batch (all packs of a step in one launch) writes exactly what the per-weight entries write."""
     g = torch.Generator().manual_seed(23)
