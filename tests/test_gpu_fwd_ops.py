@@ -338,10 +338,12 @@ torch.save({"y": y.buf.float().cpu(), "s": st.sum(0).cpu()}, sys.argv[1])
 
 
 @pytest.mark.parametrize("chans,hw", [((64, 128), (48, 96)), ((128, 64), (48, 96)), ((64, 64), (48, 96)),
-                                      ((128, 64), (64, 96)), ((64, 64), (96, 64))])
+                                      ((128, 64), (64, 96)), ((64, 64), (96, 64)),
+                                      ((64, 128), (56, 56)), ((128, 64), (40, 80)), ((64, 64), (28, 28)), ((128, 128), (24, 48))])
 def test_conv3x3_persistent_kernel_is_bit_identical(chans, hw):
     """The persistent wide kernel (conv_igemm3p.inc: one workgroup walks a list of tiles) against the one-tile-per-workgroup
-    kernel (CMU_CONV_PERSIST=0) on a whole-tile shape, with 13 workgroups forced so that every workgroup streams several
+    kernel (CMU_CONV_PERSIST=0) on whole-tile shapes and on shapes whose tiles overhang the image (the PART instantiation:
+    predicated stores / statistics; 56, 40 x 80, 28, 24 x 48), with 13 workgroups forced so that every workgroup streams several
     tiles and the per-XCD item ranges are uneven: same MFMA order per accumulator, same statistics folding order ->
     identical bits, for the forward (pending transform + BN statistics), the plain data gradient and the data gradient
     with fused BN-backward sums."""
