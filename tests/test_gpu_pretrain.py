@@ -749,10 +749,33 @@ def test_cmunet_joint_step_reference_geometry(cuda):
     (ref['loss_ct'] + ref['loss_rc']).backward()
     assert abs(float(losses['loss_rc']) - float(ref['loss_rc'])) <= 2e-4 * max(1, abs(float(ref['loss_rc'])))
     assert abs(float(losses['loss_ct']) - float(ref['loss_ct'])) <= 2e-3 * max(1, abs(float(ref['loss_ct'])))
+    # How far can two correct fp32 implementations be apart here?  The online encoder sees an image that is 65 % zeros: inside the
+    # masked patches every pixel of a level has the same value in exact arithmetic, so max-pool windows tie and the LAST BIT decides
+    # where a pooled gradient goes.  Measured: the oracle's own gradients move by 3 ... 5e-3 (encoder, deepest ConvTranspose) when its
+    # weights are perturbed by four ulps, and by as much between fp32 and fp64 -- while head / projector / the last convs move by
+    # 1e-7 ... 4e-5.  So the oracle runs a second time from weights * (1 + 2^-22 u) and every tensor's bar is three times ITS spread
+    # (floor 1e-4; 1e-3 inside the conv chain): 50 x tighter than the flat 5e-3 this test used for the well-conditioned tensors, honest for
+    # the others.
+    gp = torch.Generator().manual_seed(5)
+    psd = {k: ((v * (1 + 2.0 ** -22 * (2 * torch.rand(v.shape, generator=gp) - 1))).requires_grad_(True)
+               if v.is_floating_point() and "running" not in k and not k.startswith("target_") else v.clone()) for k, v in sd.items()}
+    pref = OC.forward_train(img, img_t, mask.numpy(), rw, rb, psd, temperature=0.07, ct_weight=1.0, rc_weight=1.0)
+    (pref['loss_ct'] + pref['loss_rc']).backward()
     params = dict(model.named_parameters())
+    errs, sens = {}, {}
     for k in ("head.predictor.fc1.weight", "head.predictor.bn0.weight", "projector.fc1.weight", "projector.fc0.weight", "projector.bn0.bias",
               "feature_decoder.conv_last.weight", "pixel_decoder.conv_last.weight", "pixel_decoder.up_conv4.up_sample.weight",
               "feature_decoder.up_conv1.double_conv.double_conv.3.weight", "backbone.double_conv.double_conv.3.weight",
               "backbone.down_conv1.double_conv.double_conv.0.weight", "backbone.down_conv3.double_conv.double_conv.1.weight"):
         e = (params[k].grad.detach().double().cpu() - osd[k].grad.double()).norm().item() / max(osd[k].grad.double().norm().item(), 1e-12)
-        assert e <= 5e-3, f"d{k}: relative L2 error {e:.2e}"          # (f32 oracle against f32 kernels: rounding on both sides)
+        errs[k] = e
+        sens[k] = (psd[k].grad.double() - osd[k].grad.double()).norm().item() / max(osd[k].grad.double().norm().item(), 1e-12)
+    line = ", ".join(f"{k}: {errs[k]:.2e} (oracle under 4-ulp weight noise: {sens[k]:.2e})" for k in errs)
+    print("[joint step @ 224, f32 vs oracle] relative L2 error of the gradients: " + line)
+    _parity_record("CM_UNet joint step f32 at the reference geometry (224x224, bs 4, base 32) vs the fp32 oracle, relative L2 error per gradient "
+                   "(in brackets: how far the oracle's own gradient moves under four-ulp weight noise): " + line)
+    for k, e in errs.items():
+        # (one perturbed run is one sample of a spread made of discrete flips: tensors inside the conv chain get a floor of 1e-3 --
+        # feature_decoder.up_conv1 moved by 7e-5 ... 6e-4 over seeds and is 5.8e-4 apart between the fp32 and fp64 oracle)
+        floor = 1e-3 if ("backbone." in k or "up_conv" in k) else 1e-4
+        assert e <= max(floor, 3.0 * sens[k]), f"d{k}: relative L2 error {e:.2e} against a spread of {sens[k]:.2e}"
