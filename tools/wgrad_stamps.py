@@ -5,8 +5,11 @@ import sys
 import numpy as np
 import torch
 
+import os
 LIB = sys.argv[1]
-B = 32
+B = int(os.environ.get("CMU_SWEEP_B", "32"))
+DT = int(os.environ.get("CMU_SWEEP_DT", "2"))           # 0: f32, 1: f16, 2: bf16
+TDT = {0: torch.float32, 1: torch.float16, 2: torch.bfloat16}[DT]
 H = W = int(sys.argv[2]); Cin = int(sys.argv[3]); Cout = int(sys.argv[4])
 dev = torch.device("cuda:0")
 lib = ctypes.CDLL(LIB)
@@ -14,17 +17,17 @@ lib.cmu_conv3x3_wgrad_ws_bytes.restype = ctypes.c_int64
 lib.cmu_last_error.restype = ctypes.c_char_p
 vp, i64 = ctypes.c_void_p, ctypes.c_int64
 torch.manual_seed(0)
-x = torch.randn(B, H, W, Cin, device=dev).to(torch.bfloat16)
-dy = torch.randn(B, H, W, Cout, device=dev).to(torch.bfloat16)
+x = torch.randn(B, H, W, Cin, device=dev).to(TDT)
+dy = torch.randn(B, H, W, Cout, device=dev).to(TDT)
 sc = torch.rand(Cin, device=dev) + 0.5
 sh = torch.randn(Cin, device=dev) * 0.1
 dW = torch.empty(Cout, Cin, 3, 3, device=dev)
-ws = torch.empty(lib.cmu_conv3x3_wgrad_ws_bytes(B, H, W, Cin, Cout, 2), dtype=torch.uint8, device=dev)
+ws = torch.empty(lib.cmu_conv3x3_wgrad_ws_bytes(B, H, W, Cin, Cout, DT), dtype=torch.uint8, device=dev)
 
 
 def run():
     rc = lib.cmu_conv3x3_wgrad(vp(x.data_ptr()), i64(Cin), vp(sc.data_ptr()), vp(sh.data_ptr()), 0, vp(dy.data_ptr()), i64(Cout),
-                               vp(dW.data_ptr()), B, H, W, Cin, Cout, 2, vp(ws.data_ptr()), vp(0))
+                               vp(dW.data_ptr()), B, H, W, Cin, Cout, DT, vp(ws.data_ptr()), vp(0))
     assert rc == 0, lib.cmu_last_error()
 
 
@@ -38,13 +41,13 @@ for _ in range(20):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 20
-print(f"wgrad {Cin}->{Cout} @ {H}x{W} B={B}: {ms:.3f} ms  {2.0 * B * H * W * Cin * Cout * 9 / ms / 1e9:.0f} TFLOP/s (incl. reduce)")
+print(f"wgrad {Cin}->{Cout} @ {H}x{W} B={B}{(' f32', ' f16', '')[DT]}: {ms:.3f} ms  {2.0 * B * H * W * Cin * Cout * 9 / ms / 1e9:.0f} TFLOP/s (incl. reduce)")
 if not hasattr(lib, "cmu_debug_wg_stamps"):
     sys.exit(0)
 buf = np.zeros(64 * 16 * 8, dtype=np.uint64)
 assert lib.cmu_debug_wg_stamps(buf.ctypes.data_as(vp)) == 0
 names = sys.argv[5].split(",") if len(sys.argv) > 5 else ["mfma", "barrierA", "stage", "barrierB"]
-if Cout % 128 == 0 and Cin % 64 == 0:      # wide kernel: waves 0 and 4 of 32 workgroups stamp through LDS
+if DT != 0 and Cout % 128 == 0 and Cin % 64 == 0:      # wide kernel (16-bit dtypes): waves 0 and 4 of 32 workgroups stamp through LDS
     st2 = buf.reshape(32, 2, 16, 8).astype(np.int64)
     for grp in range(2):
         stg = st2[:, grp]
