@@ -330,6 +330,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WGParams p) {
 }
 
 #include "conv_wgrad2.inc"
+#include "conv_wgrad2s.inc"
 #include "conv_wgrad2f.inc"
 
 // partial slabs -> parameter-gradient layout, summed in split order
@@ -624,6 +625,51 @@ static int wgrad3_wide_t(WGParams p, float* dW, hipStream_t st) {
     return CMU_OK;
 }
 
+// 64 n x 64 c form for the 16-bit dtypes (conv_wgrad2s.inc): whole 64-blocks on both sides where neither form above applies (the
+// 64 -> 64 layers).  CMU_WGRAD_SQUARE=0 keeps them on the first kernel (A/B switch, read per launch).
+static bool wg2s_shape_ok(int CA, int CB, int dt) {
+    static const bool wide = []() { const char* e = getenv("CMU_WGRAD_WIDE"); return !(e && e[0] == '0'); }();
+    const char* e = getenv("CMU_WGRAD_SQUARE");
+    return wide && !(e && e[0] == '0') && cmu_dtype_size(dt) == 2 && CA % 64 == 0 && CB % 64 == 0 && !wg2_shape_ok(CA, CB, dt) &&
+           !wg2_swap_ok(CA, CB, dt);
+}
+static void wg2s_geometry(int B, int H, int W, int CA, int CB, WGParams& p) {
+    p.tilesX = cmu_div_up(W, 16);
+    p.tilesY = cmu_div_up(H, 8);
+    p.ntiles = B * p.tilesX * p.tilesY;
+    p.nAB = CA / 64;
+    p.nBB = CB / 64;
+    p.CApad = CA;
+    p.CBpad = CB;
+    p.splitk = wg_splitk(p.nAB * p.nBB, p.ntiles, 1, cmu_wg_wide_target());
+}
+template <class TR>
+static int wgrad3_square_t(WGParams p, float* dW, hipStream_t st) {
+    typedef WG2SCfg<TR> C;
+    static CmuPerDevice attr_set;   // hipFuncSetAttribute is per device
+    if (!attr_set.done()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad2s_kernel<TR>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           C::LDS_BYTES);
+        if (e != hipSuccess) {
+            cmu_set_error("cmu_conv3x3_wgrad(64 x 64): hipFuncSetAttribute(%d B LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
+            return CMU_ERR_LAUNCH;
+        }
+        attr_set.mark();
+    }
+    WG2Params pp;
+    pp.g = p;
+    pp.dtx = p.splitk % p.tilesX;
+    pp.dty = (p.splitk / p.tilesX) % p.tilesY;
+    pp.dtb = p.splitk / (p.tilesX * p.tilesY);
+    hipLaunchKernelGGL((conv_wgrad2s_kernel<TR>), dim3(p.nAB * p.nBB * p.splitk), dim3(512), C::LDS_BYTES, st, pp);
+    cmu_set_kernel_tag("conv_wgrad2s_kernel");
+    CMU_CHECK_LAUNCH("cmu_conv3x3_wgrad(64 x 64)");
+    // (the wave halves wrote separate slabs: 2 x splitk partial sums, summed in slab order)
+    launch_wgrad_reduce((const float*)p.ws, p.splitk * 2, 9, p.CA, p.CB, p.CA, p.CB, dW, (int)MODE_W3, st);
+    CMU_CHECK_LAUNCH("cmu_conv3x3_wgrad(reduce)");
+    return CMU_OK;
+}
+
 // fp32 wide kernel (conv_wgrad2f.inc): Cout and Cin in whole 64-blocks (128 n x 64 c blocks when Cout allows, else 64 x 64 with two
 // k-parts).  CMU_WGRAD_WIDE_F32=0 keeps fp32 on the first kernel (A/B switch, read per launch for the tests).
 static bool wg2f_shape_ok(int CA, int CB, int dt) {
@@ -734,6 +780,12 @@ extern "C" int64_t cmu_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int 
         const int64_t w = (int64_t)q.splitk * 9 * q.CApad * q.CBpad * (int64_t)sizeof(float);
         if (w > need) need = w;
     }
+    if (cmu_dtype_size(dt) == 2 && Cout % 64 == 0 && Cin % 64 == 0) {   // the 64 x 64 form: two slabs per split
+        WGParams q = {};
+        wg2s_geometry(B, H, W, Cout, Cin, q);
+        const int64_t w = (int64_t)q.splitk * 2 * 9 * q.CApad * q.CBpad * (int64_t)sizeof(float);
+        if (w > need) need = w;
+    }
     if (dt == CMU_F32 && Cout % 64 == 0 && Cin % 64 == 0) {   // the fp32 wide kernel (two slabs per split for 64 x 64 blocks)
         WGParams q = {};
         wg2f_geometry(B, H, W, Cout, Cin, q);
@@ -766,6 +818,12 @@ extern "C" int cmu_conv3x3_wgrad(const void* x, int64_t ldx, const float* in_sca
         wg2_geometry(B, H, W, Cout, Cin, p, true);
         if (dt == CMU_F16) return wgrad3_wide_t<F16Traits, true>(p, dW, (hipStream_t)stream);
         return wgrad3_wide_t<BF16Traits, true>(p, dW, (hipStream_t)stream);
+    }
+    if (wg2s_shape_ok(Cout, Cin, dt) && (px * ldd + Cout) * 2 < 0x7fff0000ll && ((px + W + 1) * ldx + Cin) * 2 < 0x7fff0000ll &&
+        (in_scale == nullptr || ((reinterpret_cast<uintptr_t>(in_scale) | reinterpret_cast<uintptr_t>(in_shift)) & 3) == 0)) {
+        wg2s_geometry(B, H, W, Cout, Cin, p);
+        if (dt == CMU_F16) return wgrad3_square_t<F16Traits>(p, dW, (hipStream_t)stream);
+        return wgrad3_square_t<BF16Traits>(p, dW, (hipStream_t)stream);
     }
     if (wg2f_shape_ok(Cout, Cin, dt) && (px * ldd + Cout) * 4 < 0x7fff0000ll && ((px + W + 1) * ldx + Cin) * 4 < 0x7fff0000ll &&
         (in_scale == nullptr || ((reinterpret_cast<uintptr_t>(in_scale) | reinterpret_cast<uintptr_t>(in_shift)) & 3) == 0)) {

@@ -67,7 +67,11 @@ WG_CASES = [(2, 20, 24, 32, 64, True), (1, 16, 16, 16, 16, False), (2, 7, 9, 8, 
             (1, 5, 3, 64, 128, True),
             # Cout == 64 and Cin % 128 == 0 -> the same kernel with the operands' roles swapped (halo on dY, transform on the
             # plain images, taps flipped at the store); (3, 16, 32, 128, 64) above is one more
-            (2, 20, 24, 128, 64, True), (1, 7, 37, 256, 64, True), (1, 5, 3, 128, 64, False), (2, 33, 16, 128, 64, True)]
+            (2, 20, 24, 128, 64, True), (1, 7, 37, 256, 64, True), (1, 5, 3, 128, 64, False), (2, 33, 16, 128, 64, True),
+            # whole 64-blocks on both sides where neither form applies -> 64 n x 64 c blocks with the wave halves as k-parts
+            # (conv_wgrad2s.inc, 16-bit); at f32 all of the above with Cout % 64 == Cin % 64 == 0 run on conv_wgrad2f.inc
+            (2, 20, 24, 64, 64, True), (1, 7, 37, 64, 64, False), (3, 33, 16, 64, 192, True), (1, 5, 3, 64, 64, True),
+            (2, 40, 24, 192, 64, True), (4, 8, 16, 64, 64, True)]
 
 
 @pytest.mark.parametrize("dt", DTS)
