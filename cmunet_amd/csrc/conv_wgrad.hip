@@ -760,6 +760,54 @@ static int wgradT_t(WGParams p, float* dW, float* dbias, float* ws_sum, hipStrea
     return CMU_OK;
 }
 
+// fp32 wide ConvTranspose weight gradient (conv_wgrad2f.inc): 128 c x 64 n blocks.  Follows CMU_WGRAD_WIDE_F32.
+static bool wgT2f_shape_ok(int CA, int CB, int dt) { return wg2f_shape_ok(64, 64, dt) && CA % 64 == 0 && CB % 128 == 0; }
+static void wgT2f_geometry(int B, int H, int W, int CA, int CB, WGParams& p) {
+    p.tilesX = cmu_div_up(W, 16);
+    p.tilesY = cmu_div_up(H, 2);
+    p.ntiles = B * p.tilesX * p.tilesY;
+    p.nAB = CA / 64;
+    p.nBB = CB / 128;
+    p.CApad = CA;
+    p.CBpad = CB;
+    p.splitk = wg_splitk(p.nAB * p.nBB, p.ntiles, 1, cmu_wg_wide_target());
+}
+static int wgradT_wide_f32(WGParams p, float* dW, float* dbias, float* ws_sum, hipStream_t st) {
+    typedef WGT2FCfg C;
+    static CmuPerDevice attr_set;   // hipFuncSetAttribute is per device
+    if (!attr_set.done()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgradT2f_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           C::LDS_BYTES);
+        if (e != hipSuccess) {
+            cmu_set_error("cmu_convT2x2_wgrad(wide, fp32): hipFuncSetAttribute(%d B LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
+            return CMU_ERR_LAUNCH;
+        }
+        attr_set.mark();
+    }
+    WG2Params pp;
+    pp.g = p;
+    pp.dtx = p.splitk % p.tilesX;
+    pp.dty = (p.splitk / p.tilesX) % p.tilesY;
+    pp.dtb = p.splitk / (p.tilesX * p.tilesY);
+    hipLaunchKernelGGL(conv_wgradT2f_kernel, dim3(p.nAB * p.nBB * p.splitk), dim3(512), C::LDS_BYTES, st, pp);
+    cmu_set_kernel_tag("conv_wgradT2f_kernel");
+    CMU_CHECK_LAUNCH("cmu_convT2x2_wgrad(wide, fp32)");
+    launch_wgrad_reduce((const float*)p.ws, p.splitk, 4, p.CApad, p.CBpad, p.CA, p.CB, dW, 2, st);
+    CMU_CHECK_LAUNCH("cmu_convT2x2_wgrad(reduce)");
+    // bias gradient: sum of dOut over all (B,2H,2W) pixels (the first path's channel-sum kernels)
+    typedef F32Traits TR;
+    const int nchunk = p.CA / TR::EPC;
+    const int cpb = nchunk < 256 ? nchunk : 256, ppb = 256 / cpb, gy = cmu_div_up(nchunk, cpb);
+    const int64_t npix = (int64_t)p.B * 4 * p.H * p.W;
+    int gx = (int)(cmu_div_up64(npix, ppb * 4) < CSUM_BLOCKS ? cmu_div_up64(npix, ppb * 4) : CSUM_BLOCKS);
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL((channel_sum_kernel<TR>), dim3(gx, gy), dim3(256), 0, st, (const unsigned char*)p.a, p.lda, ws_sum, npix, p.CA, cpb, ppb);
+    CMU_CHECK_LAUNCH("cmu_convT2x2_wgrad(bias)");
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cmu_div_up(p.CA, 16)), dim3(256), 0, st, (const float*)ws_sum, gx, p.CA, dbias);
+    CMU_CHECK_LAUNCH("cmu_convT2x2_wgrad(bias final)");
+    return CMU_OK;
+}
+
 static int wg_check(const char* name, const void* t, int64_t ld, int C, int dt) {
     const int es = cmu_dtype_size(dt);
     CMU_CHECK_ARG(es > 0, "%s: bad dtype %d", name, dt);
@@ -883,6 +931,12 @@ extern "C" int64_t cmu_convT2x2_wgrad_ws_bytes(int B, int H, int W, int Cin, int
         const int64_t w = (int64_t)q.splitk * ((int64_t)4 * Cout * Cin + Cout) * (int64_t)sizeof(float);
         if (w > need) need = w;
     }
+    if (dt == CMU_F32 && Cout % 64 == 0 && Cin % 128 == 0) {   // the fp32 wide form
+        WGParams q = {};
+        wgT2f_geometry(B, H, W, Cout, Cin, q);
+        const int64_t w = ((int64_t)q.splitk * 4 * Cout * Cin + (int64_t)CSUM_BLOCKS * Cout) * (int64_t)sizeof(float);
+        if (w > need) need = w;
+    }
     return need;
 }
 extern "C" int cmu_convT2x2_wgrad(const void* x, int64_t ldx, const float* in_scale, const float* in_shift, int relu_from, const void* dOut,
@@ -902,6 +956,11 @@ extern "C" int cmu_convT2x2_wgrad(const void* x, int64_t ldx, const float* in_sc
         wgT2_geometry(B, H, W, Cout, Cin, p);
         if (dt == CMU_F16) return wgradT_wide_t<F16Traits>(p, dW, dbias, (hipStream_t)stream);
         return wgradT_wide_t<BF16Traits>(p, dW, dbias, (hipStream_t)stream);
+    }
+    if (wgT2f_shape_ok(Cout, Cin, dt) && (4 * px * ldd + Cout) * 4 < 0x7fff0000ll && (px * ldx + Cin) * 4 < 0x7fff0000ll &&
+        (in_scale == nullptr || ((reinterpret_cast<uintptr_t>(in_scale) | reinterpret_cast<uintptr_t>(in_shift)) & 3) == 0)) {
+        wgT2f_geometry(B, H, W, Cout, Cin, p);
+        return wgradT_wide_f32(p, dW, dbias, (float*)ws + (int64_t)p.splitk * 4 * Cout * Cin, (hipStream_t)stream);
     }
     wg_geometry(B, H, W, Cout, Cin, dt, 4, p);
     float* ws_sum = (float*)ws + (int64_t)p.splitk * 4 * p.CApad * p.CBpad;
