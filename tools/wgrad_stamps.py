@@ -20,6 +20,8 @@ torch.manual_seed(0)
 x = torch.randn(B, H, W, Cin, device=dev).to(TDT)
 dy = torch.randn(B, H, W, Cout, device=dev).to(TDT)
 sc = torch.rand(Cin, device=dev) + 0.5
+if os.environ.get("CMU_SWEEP_DATA", "") == "zero_both":      # operands that do not toggle the multipliers (power limit vs schedule)
+    x.zero_(); dy.zero_()
 sh = torch.randn(Cin, device=dev) * 0.1
 dW = torch.empty(Cout, Cin, 3, 3, device=dev)
 ws = torch.empty(lib.cmu_conv3x3_wgrad_ws_bytes(B, H, W, Cin, Cout, DT), dtype=torch.uint8, device=dev)
@@ -47,7 +49,7 @@ if not hasattr(lib, "cmu_debug_wg_stamps"):
 buf = np.zeros(64 * 16 * 8, dtype=np.uint64)
 assert lib.cmu_debug_wg_stamps(buf.ctypes.data_as(vp)) == 0
 names = sys.argv[5].split(",") if len(sys.argv) > 5 else ["mfma", "barrierA", "stage", "barrierB"]
-if DT != 0 and Cout % 128 == 0 and Cin % 64 == 0:      # wide kernel (16-bit dtypes): waves 0 and 4 of 32 workgroups stamp through LDS
+if (DT != 0 and Cout % 128 == 0 and Cin % 64 == 0) or (DT == 0 and Cout % 64 == 0 and Cin % 64 == 0):      # wide kernels (conv_wgrad2.inc / conv_wgrad2f.inc): waves 0 and 4 of 32 workgroups stamp through LDS
     st2 = buf.reshape(32, 2, 16, 8).astype(np.int64)
     for grp in range(2):
         stg = st2[:, grp]
@@ -58,6 +60,11 @@ if DT != 0 and Cout % 128 == 0 and Cin % 64 == 0:      # wide kernel (16-bit dty
             d = stg[:, 1:nst - 1, k + 1] - stg[:, 1:nst - 1, k]
             print(f"  {nm:11s} avg {d.mean():8.0f} cyc (min {d.min()}, max {d.max()})")
         print(f"  per-tile total {(stg[:, 2:nst - 1, 0] - stg[:, 1:nst - 2, 0]).mean():.0f} cyc")
+    clk = st2[:, 0, 15]                      # slot 15 of wave 0: (memtime, memrealtime) before and after the loop
+    clk = clk[clk[:, 0] > 0]
+    if clk.shape[0]:
+        mhz = (clk[:, 2] - clk[:, 0]) / np.maximum(clk[:, 3] - clk[:, 1], 1) * 100.0
+        print(f"  shader clock over the loop: {mhz.mean():.0f} MHz (s_memtime / s_memrealtime at 100 MHz)")
     sys.exit(0)
 st = buf.reshape(64, 16, 8).astype(np.int64)
 st = st[st[:, 0, 0] > 0]
