@@ -889,9 +889,13 @@ static bool wg2_list_ok(int B, int H, int W, int64_t ldx, int64_t ldd, int Cin, 
     const int64_t px = (int64_t)H * W;
     return wg2_shape_ok(Cout, Cin, dt) && (px * ldd + Cout) * 2 < 0x7fff0000ll && ((px + W + 1) * ldx + Cin) * 2 < 0x7fff0000ll;
 }
+static bool wg2s_list_ok(int B, int H, int W, int64_t ldx, int64_t ldd, int Cin, int Cout, int dt) {
+    const int64_t px = (int64_t)H * W;
+    return wg2s_shape_ok(Cout, Cin, dt) && (px * ldd + Cout) * 2 < 0x7fff0000ll && ((px + W + 1) * ldx + Cin) * 2 < 0x7fff0000ll;
+}
 extern "C" int cmu_conv3x3_wgrad_tile_h(int B, int H, int W, int Cin, int Cout, int dt) {
     if (cmu_dtype_size(dt) == 0 || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return -1;
-    return wg2_list_ok(B, H, W, Cin, Cout, Cin, Cout, dt) ? 8 : 16;   // (dense NHWC tensors: ld = C)
+    return (wg2_list_ok(B, H, W, Cin, Cout, Cin, Cout, dt) || wg2s_list_ok(B, H, W, Cin, Cout, Cin, Cout, dt)) ? 8 : 16;   // (dense NHWC tensors: ld = C)
 }
 extern "C" int cmu_conv3x3_wgrad_tiles(const void* x, int64_t ldx, const float* in_scale, const float* in_shift, int relu_from,
                                        const void* dY, int64_t ldd, float* dW, const int* tile_list, const int* tile_count, int tile_h,
@@ -907,6 +911,12 @@ extern "C" int cmu_conv3x3_wgrad_tiles(const void* x, int64_t ldx, const float* 
     p.a = dY; p.lda = ldd; p.b = x; p.ldb = ldx; p.b_scale = in_scale; p.b_shift = in_shift; p.relu_from = relu_from;
     p.ws = (float*)ws; p.B = B; p.H = H; p.W = W; p.CA = Cout; p.CB = Cin;
     p.tile_list = tile_list; p.tile_count = tile_count;
+    if (tile_h == 8 && wg2s_list_ok(B, H, W, ldx, ldd, Cin, Cout, dt) &&
+        (in_scale == nullptr || ((reinterpret_cast<uintptr_t>(in_scale) | reinterpret_cast<uintptr_t>(in_shift)) & 3) == 0)) {
+        wg2s_geometry(B, H, W, Cout, Cin, p);   // (the 64 x 64 form walks the same 8 x 16 lists)
+        if (dt == CMU_F16) return wgrad3_square_t<F16Traits>(p, dW, (hipStream_t)stream);
+        return wgrad3_square_t<BF16Traits>(p, dW, (hipStream_t)stream);
+    }
     if (tile_h == 8) {
         CMU_CHECK_ARG(wg2_list_ok(B, H, W, ldx, ldd, Cin, Cout, dt) &&
                           (in_scale == nullptr || ((reinterpret_cast<uintptr_t>(in_scale) | reinterpret_cast<uintptr_t>(in_shift)) & 3) == 0),

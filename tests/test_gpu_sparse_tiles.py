@@ -107,14 +107,16 @@ def test_wgrad_tiles_equals_dense_when_dy_is_masked(ops, dt, shape):
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
-@pytest.mark.parametrize("shape", [(2, 64, 64, 128, 8), (3, 96, 128, 128, 12), (2, 128, 64, 256, 16), (1, 32, 128, 128, 2)])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 128, 8), (3, 96, 128, 128, 12), (2, 128, 64, 256, 16), (1, 32, 128, 128, 2),
+                                   # 64 -> 64 (SparK level 1): the 64 n x 64 c form (conv_wgrad2s.inc) walks the same 8 x 16 lists
+                                   (2, 128, 64, 64, 8), (3, 64, 64, 64, 4)])
 def test_wgrad_tiles_wide_kernel_8x16_list(ops, dt, shape):
     """The wide weight-gradient kernel over a list of 8 x 16 pixel tiles (its K tile; SparK level 2: one tile = two 8 x 8 patches):
     equal to the dense launch when dY vanishes outside the active patches, and to float64.  Lists longer and shorter than the
     split count, a batch of three, 8-pixel and larger patches; ``conv3x3_wgrad_tile_h`` names the list a shape wants."""
     from cmunet_amd import _lib
     B, S, Cin, Cout, f = shape
-    assert ops.conv3x3_wgrad_tile_h(B, S, S, Cin, Cout, dt) == 8 and ops.conv3x3_wgrad_tile_h(B, S, S, 64, 64, dt) == 16
+    assert ops.conv3x3_wgrad_tile_h(B, S, S, Cin, Cout, dt) == 8 and ops.conv3x3_wgrad_tile_h(B, S, S, 32, 64, dt) == 16
     assert ops.conv3x3_wgrad_tile_h(B, S, S, Cin, Cout, "f32") == 16
     tdt = ops.TORCH_DT[ops.dt_code(dt)]
     g = torch.Generator(device="cuda").manual_seed(4)
@@ -139,7 +141,7 @@ def test_wgrad_tiles_wide_kernel_8x16_list(ops, dt, shape):
     assert (dWt.double().cpu() - ref).abs().max().item() <= (2e-3 if dt == "f16" else 1.6e-2) * ref.abs().max().item()
     # a 16 x 16 list is refused for nothing: it runs the first kernel; an 8 x 16 list on a shape of the first kernel is refused
     with pytest.raises(Exception, match="8 x 16 tile list needs"):
-        ops.conv3x3_wgrad_tiles(ops.Act(x[..., :64].contiguous()), ops.Act(dy[..., :64].contiguous()), torch.empty(64, 64, 3, 3, device="cuda"), ws, tl)
+        ops.conv3x3_wgrad_tiles(ops.Act(x[..., :32].contiguous()), ops.Act(dy[..., :64].contiguous()), torch.empty(64, 32, 3, 3, device="cuda"), ws, tl)
 
 
 @pytest.mark.parametrize("case", [(2, 4, 32, 4), (3, 8, 32, 16), (2, 8, 8, 64), (1, 4, 64, 5), (2, 16, 16, 0)])
