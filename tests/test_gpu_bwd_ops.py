@@ -1,5 +1,6 @@
 """GPU parity of the backward / loss / optimiser C-ABI entry points against the oracle's arithmetic
 (torch CPU fp64 autograd on the same dtype-quantised operands)."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -96,6 +97,38 @@ def test_conv3x3_wgrad(ops, dt, case):
     ops.conv3x3_wgrad(xa, to_act(dy, dt, ops), dW, ws)
     ref = torch.nn.grad.conv2d_weight(ref_in, (Cout, Cin, 3, 3), dy.double(), padding=1)
     check(dW.cpu(), ref, 1e-4 if dt == "f32" else 2e-3, "dW 3x3")
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("seed", range(10))
+def test_conv3x3_wgrad_random_shapes_of_the_wide_kernels(ops, dt, seed):
+    """Seeded random shapes with whole 64-channel blocks on both sides -- what the wide weight-gradient kernels serve (16-bit:
+    conv_wgrad2.inc, its swapped form and conv_wgrad2s.inc; fp32: conv_wgrad2f.inc) -- against float64: heights and widths that do
+    not divide into K tiles (down to one pixel), batches of 1-4, channel-sliced buffers, pending transform with the ReLU starting
+    at a random 16-byte chunk."""
+    from cmunet_amd import _lib
+    rs = np.random.RandomState(1000 + seed)
+    B, H, W = int(rs.randint(1, 5)), int(rs.randint(1, 41)), int(rs.randint(1, 41))
+    Cin, Cout = 64 * int(rs.randint(1, 4)), 64 * int(rs.randint(1, 4))
+    tf = bool(rs.randint(0, 2))
+    g = torch.Generator().manual_seed(seed)
+    x = q(torch.randn(B, Cin, H, W, generator=g), dt, ops)
+    dy = q(torch.randn(B, Cout, H, W, generator=g), dt, ops)
+    ex, ed = 16 * int(rs.randint(0, 3)), 16 * int(rs.randint(0, 3))
+    xa = to_act(x, dt, ops, ld=Cin + ex, coff=ex)
+    ref_in = x.double()
+    if tf:
+        sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+        rf = 8 * int(rs.randint(0, Cin // 8 + 1))
+        xa = xa.with_transform(sc.cuda(), sh.cuda(), rf)
+        t = x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+        t[:, rf:] = t[:, rf:].clamp_min(0)
+        ref_in = q(t.float(), dt, ops).double()
+    dW = torch.full((Cout, Cin, 3, 3), 9.0, device="cuda")
+    ws = ws_bytes(_lib.lib().cmu_conv3x3_wgrad_ws_bytes(B, H, W, Cin, Cout, ops.dt_code(dt)))
+    ops.conv3x3_wgrad(xa, to_act(dy, dt, ops, ld=Cout + ed, coff=ed), dW, ws)
+    ref = torch.nn.grad.conv2d_weight(ref_in, (Cout, Cin, 3, 3), dy.double(), padding=1)
+    check(dW.cpu(), ref, 1e-4 if dt == "f32" else 2e-3, f"dW 3x3 {(B, H, W, Cin, Cout, tf, ex, ed)}")
 
 
 @pytest.mark.parametrize("dt", DTS)
