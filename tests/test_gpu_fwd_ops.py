@@ -108,6 +108,46 @@ def test_conv3x3_fwd(ops, dt, case):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("seed", range(12))
+def test_conv3x3_fwd_random_shapes_of_the_wide_kernels(ops, dt, seed):
+    """Seeded random shapes with whole 64 / 128-channel blocks -- the shapes the small-shape dispatch of the wide kernels decides on
+    (64-channel blocks for under-filled launches, 16 x 16 pixel tiles for an odd number of 16-pixel columns, partial tiles on the
+    persistent kernel): batches of 1-6, 1-70 pixels per side, channel-sliced buffers, a pending transform whose ReLU starts at a
+    random 16-byte chunk -- against float64, outputs and BatchNorm statistics."""
+    import numpy as np
+    rs = np.random.RandomState(2000 + seed)
+    B, H, W = int(rs.randint(1, 7)), int(rs.randint(1, 71)), int(rs.randint(1, 71))
+    Cin, Cout = 64 * int(rs.randint(1, 5)), 64 * int(rs.choice([1, 2, 4, 6]))
+    tf = bool(rs.randint(0, 2))
+    ex, ey = 16 * int(rs.randint(0, 3)), 16 * int(rs.randint(0, 3))
+    g = torch.Generator().manual_seed(seed)
+    x = q(torch.randn(B, Cin, H, W, generator=g), dt, ops)
+    w = q(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5, dt, ops)
+    xa = to_act(x, dt, ops, ld=Cin + ex, coff=ex)
+    ref_in = x.double()
+    if tf:
+        sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+        rf = 8 * int(rs.randint(0, Cin // 8 + 1))
+        xa = xa.with_transform(sc.cuda(), sh.cuda(), rf)
+        t = x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+        t[:, rf:] = t[:, rf:].clamp_min(0)
+        ref_in = q(t.float(), dt, ops).double()
+    ybuf = torch.full((B, H, W, Cout + ey), -3.0, dtype=ops.TORCH_DT[ops.dt_code(dt)], device="cuda")
+    ya = ops.Act(ybuf, ey, Cout)
+    stats = ops.new_stats(B, H, W, Cout, "cuda")
+    ops.conv3x3_fwd(xa, ops.pack_conv3x3(w.cuda(), dt), ya, stats)
+    torch.cuda.synchronize()
+    ref = F.conv2d(ref_in, w.double(), padding=1)
+    what = f"{(B, H, W, Cin, Cout, tf, ex, ey)}"
+    check(from_act(ya), ref, TOL[dt] * (2.0 if tf else 1.0), "conv3x3 y " + what)
+    if ey:
+        assert (ybuf[..., :ey] == -3.0).all(), "conv wrote outside its channel slice " + what
+    sm = stats.double().sum(0).cpu()
+    check(sm[0], ref.sum((0, 2, 3)), 1e-3 if dt != "f32" else 1e-4, "stats sum " + what)
+    check(sm[1], (ref * ref).sum((0, 2, 3)), 1e-3 if dt != "f32" else 1e-4, "stats sumsq " + what)
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("shape", [(2, 18, 21, 24, 40), (1, 18, 37, 128, 64), (2, 16, 32, 64, 128)])
 def test_conv3x3_dgrad_via_flipped_pack(ops, dt, shape):
     B, H, W, Cin, Cout = shape
