@@ -308,6 +308,37 @@ def test_convT2x2_wgrad(ops, dt, case):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("seed", range(8))
+def test_convT2x2_wgrad_random_shapes_of_the_wide_kernels(ops, dt, seed):
+    """Seeded random shapes with Cin % 128 == 0 and Cout % 64 == 0 (16-bit: conv_wgradT2_kernel; fp32: conv_wgradT2f_kernel): 1-3 images
+    of 1-23 low-res pixels per side, channel-sliced dOut, with and without the pending transform -- weight and bias gradient vs float64."""
+    from cmunet_amd import _lib
+    rs = np.random.RandomState(3000 + seed)
+    B, H, W = int(rs.randint(1, 4)), int(rs.randint(1, 24)), int(rs.randint(1, 24))
+    Cin, Cout = 128 * int(rs.randint(1, 3)), 64 * int(rs.randint(1, 4))
+    tf = bool(rs.randint(0, 2))
+    ed = 16 * int(rs.randint(0, 3))
+    g = torch.Generator().manual_seed(seed)
+    x = q(torch.randn(B, Cin, H, W, generator=g), dt, ops)
+    dout = q(torch.randn(B, Cout, 2 * H, 2 * W, generator=g), dt, ops)
+    xa = to_act(x, dt, ops)
+    ref_in = x.double()
+    if tf:
+        sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+        xa = xa.with_transform(sc.cuda(), sh.cuda(), 0)
+        ref_in = q(F.relu(x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).float(), dt, ops).double()
+    w = torch.zeros(Cin, Cout, 2, 2, dtype=torch.float64, requires_grad=True)
+    bias = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    (F.conv_transpose2d(ref_in, w, bias, stride=2) * dout.double()).sum().backward()
+    dW, db = torch.empty(Cin, Cout, 2, 2, device="cuda"), torch.empty(Cout, device="cuda")
+    ws = ws_bytes(_lib.lib().cmu_convT2x2_wgrad_ws_bytes(B, H, W, Cin, Cout, ops.dt_code(dt)))
+    ops.convT2x2_wgrad(xa, to_act(dout, dt, ops, ld=Cout + ed, coff=ed), dW, db, ws)
+    what = f"{(B, H, W, Cin, Cout, tf, ed)}"
+    check(dW.cpu(), w.grad, 1e-4 if dt == "f32" else 2e-3, "dW convT " + what)
+    check(db.cpu(), bias.grad, 1e-4, "dbias convT " + what)
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("C", [16, 64])
 def test_conv1x1_head_bwd(ops, dt, C):
     from cmunet_amd import _lib
