@@ -25,6 +25,7 @@ _SIGS = {
     "cmu_last_kernel": (ctypes.c_char_p, []),
     "cmu_softmax2_threshold": (_I, [_P, _F, _P, _I, _I, _I, _P]),
     "cmu_conv3x3_c1_wgrad_bn": (_I, [_P, _P, _I, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "cmu_conv3x3_c1_wgrad_bn_w": (_I, [_P, _P, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "cmu_soft_skeleton_ws_bytes": (_L, [_L]),
     "cmu_soft_skeleton": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "cmu_cldice_sums_ws_bytes": (_L, []),

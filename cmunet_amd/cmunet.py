@@ -224,8 +224,8 @@ class MUNetPretrainDecoder(_EngineOwner, nn.Module):
 
 
 class _SkinnyLinearFn(torch.autograd.Function):
-    """nn.Linear on <= 32 rows through the weight-streaming kernels (csrc/skinny.hip, necks.hip): one pass over the weights
-    for the forward, one for the input gradient, one write of the weight gradient.  ``compute_dt`` None: exact fp32 products
+    """nn.Linear on <= 256 rows through the weight-streaming kernels (csrc/skinny.hip, necks.hip): per group of 32 rows one pass
+    over the weights for the forward and one for the input gradient; one write of the weight gradient.  ``compute_dt`` None: exact fp32 products
     everywhere; 'f16' / 'bf16' (the AMP configuration): the 16-bit-operand kernel where it is the faster one -- measured at
     K = 262,144, N = 1,536 (tools/skinny_bench.py, profiles/r02_workloads.txt): weight gradient 0.37 ms against 0.55 ms exact;
     the exact forward stages its operands through LDS as contiguous runs (0.41 ms; the 16-bit-operand form still reads 32 rows
@@ -254,11 +254,13 @@ class _SkinnyLinearFn(torch.autograd.Function):
 
 
 def neck_linear(fc, x, compute_dt=None):
-    """``fc(x)`` for the necks' Linear layers (nonlinear_neck.py:63-66, 95-101): skinny kernels for <= 32 fp32 rows, else the
-    library GEMM (rocBLAS through torch) that a plain tall product is."""
+    """``fc(x)`` for the necks' Linear layers (nonlinear_neck.py:63-66, 95-101) on the weight-streaming kernels: up to
+    ``ops.SKINNY_MAX_ROWS`` = 256 fp32 rows per GPU (the reference's own batch size, cmunet_config.py:55), in_features a multiple
+    of 8.  There is no library GEMM behind this (round 4): anything else raises."""
     if ops.skinny_eligible(x, fc.weight):
         return _SkinnyLinearFn.apply(x, fc.weight, fc.bias, compute_dt)
-    return fc(x)
+    raise RuntimeError(f"neck_linear: needs a CUDA fp32 (rows <= {ops.SKINNY_MAX_ROWS}, in_features % 8 == 0) input, got "
+                       f"{tuple(x.shape)} {x.dtype} on {x.device} (the HIP path has no library / CPU fallback)")
 
 
 class _BN1dFn(torch.autograd.Function):
@@ -428,6 +430,8 @@ class _CMUNetFn(torch.autograd.Function):
         latent_t = ops.conv1x1_nchw_fwd(tctx["latent"], reduce_w.detach().float(), None if reduce_b is None else reduce_b.detach().float())
         ctx.module, ctx.names, ctx.eng = module, names, eng
         ctx.saved = (ectx, pctx, fctx)
+        if getattr(module, "keep_ctx", False):      # tests: the engine's saved state of this forward (raw conv outputs + pending transforms)
+            module.last_ctx = (ectx, pctx, fctx)
         return pctx["logits"], fctx["logits"], latent_t
 
     @staticmethod

@@ -9,7 +9,17 @@
 constexpr int RED_MAX_BLOCKS = 2048;     // rows of the partial-sum slabs (workspace sizes)
 // measured on the bench step: the max-pool backward is fastest with 2048 workgroups (1.22 ms; 1.34 at 1024, 1.38 at 8192), the
 // head backward with 1024 (0.47 ms; 0.54 at 2048, 0.76 at 8192) -- each workgroup ends with a cross-wave fold of its sums
-constexpr int POOLB_MAX_BLOCKS = 2048, HEADB_MAX_BLOCKS = 1024;
+// (round 4: with the per-workgroup fold inside the waves -- fold_rows -- the A/B was repeated, see the macros' defaults)
+#ifndef CMU_POOLB_BLOCKS
+#define CMU_POOLB_BLOCKS 2048
+#endif
+#ifndef CMU_HEADB_BLOCKS
+#define CMU_HEADB_BLOCKS 768
+#endif
+#ifndef CMU_POOLA_PPT
+#define CMU_POOLA_PPT 0      // > 0: the apply form (MODE 2, no sums) on an uncapped grid with that many pooled pixels per thread -- measured SLOWER than the capped grid-stride form (4 levels of the bench step: 1.15 ms capped, 1.24 at 4, 1.48 at 2, 2.12 at 1)
+#endif
+constexpr int POOLB_MAX_BLOCKS = CMU_POOLB_BLOCKS, HEADB_MAX_BLOCKS = CMU_HEADB_BLOCKS;
 // BN-backward partial-sum slab ("bn_ws"): int32 header word 0 = number of rows written by the producer kernel
 // (device side, no host sync), then float rows [row][2][C] from byte 16 on.  Producers: cmu_bn_bwd_reduce,
 // cmu_maxpool_bwd, cmu_conv1x1_head_bwd (fused); consumer: bn_bwd_final_kernel.
@@ -27,6 +37,51 @@ __device__ static inline float sum_over_rows(float v, float* red, int tid, int c
     return a;
 }
 
+// The same for NV values at once (round 4): threads that share a channel chunk sit cpb lanes apart, so for cpb <= 64 (a power of
+// two) the fold runs inside the wave first (xor shuffles in a fixed order) and only the four waves' partial sums cross LDS --
+// one barrier pair per group of FOLD_G values instead of one pair per value and a serial ppb-term sum by cpb threads (the head
+// backward folded 34 values per workgroup through 68 barriers: a tenth of its time).  cpb > 64 (cpb = 128 / 256: ppb = 2 / 1):
+// the rows meet in LDS only.  red: LDS float[FOLD_G * 256].  Results valid for tid < cpb.  All 256 threads must call; needs
+// prow < ppb for every thread (256 % cpb == 0), which the callers' chunk geometry gives for every power-of-two chunk count.
+constexpr int FOLD_G = 8;
+template <int NV>
+__device__ static inline void fold_rows(float (&v)[NV], float* red, int tid, int cpb, int ppb) {
+    const int lane = tid & 63, wv = tid >> 6;
+    if (cpb <= 64) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            for (int o = cpb; o < 64; o <<= 1) v[i] += __shfl_xor(v[i], o, 64);
+    }
+#pragma unroll
+    for (int g0 = 0; g0 < NV; g0 += FOLD_G) {
+        __syncthreads();
+        if (cpb <= 64) {
+            if (lane < cpb) {
+#pragma unroll
+                for (int i = g0; i < g0 + FOLD_G && i < NV; ++i) red[((i - g0) * 4 + wv) * 64 + lane] = v[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = g0; i < g0 + FOLD_G && i < NV; ++i) red[(i - g0) * 256 + tid] = v[i];
+        }
+        __syncthreads();
+        if (tid < cpb) {
+#pragma unroll
+            for (int i = g0; i < g0 + FOLD_G && i < NV; ++i) {
+                float a = 0.f;
+                if (cpb <= 64) {
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) a += red[((i - g0) * 4 + w) * 64 + tid];
+                } else {
+                    for (int k = 0; k < ppb; ++k) a += red[(i - g0) * 256 + k * cpb + tid];
+                }
+                v[i] = a;
+            }
+        }
+    }
+}
+__device__ static inline bool fold_ok(int cpb) { return (cpb & (cpb - 1)) == 0; }
+
 // ---------------------------------------------------------------------------------------------
 // BatchNorm2d + ReLU backward (autograd of model.py:18-19, 21-22)
 // ---------------------------------------------------------------------------------------------
@@ -40,7 +95,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const unsigned char*
                                                            const int* __restrict__ rows, const int* __restrict__ n_rows) {
     constexpr int EPC = TR::EPC;
     constexpr int ES = (int)sizeof(typename TR::elem_t);
-    __shared__ float red[256];
+    __shared__ float red[FOLD_G * 256];
     const int tid = threadIdx.x;
     if (rows != nullptr) npix = *n_rows;      // sparse form: the loop runs over the list of active pixels only
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *reinterpret_cast<int*>(ws) = (int)gridDim.x;
@@ -77,6 +132,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const unsigned char*
                 s2[e] = fmaf(dz, (v[e] - mu[e]) * is[e], s2[e]);
             }
         }
+    if (fold_ok(cpb)) {
+        float t[2 * EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { t[e] = s1[e]; t[EPC + e] = s2[e]; }
+        fold_rows<2 * EPC>(t, red, tid, cpb, ppb);
+        if (tid < cpb && blockIdx.y * cpb + tid < nchunk) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const int c = (blockIdx.y * cpb + tid) * EPC + e;
+                ws[((int64_t)blockIdx.x * 2 + 0) * C + c] = t[e];
+                ws[((int64_t)blockIdx.x * 2 + 1) * C + c] = t[EPC + e];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
         const float a = sum_over_rows(s1[e], red, tid, cpb, ppb);
@@ -339,7 +409,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
                                                          int mf = 0, int msbits = 0) {
     constexpr int EPC = TR::EPC;
     constexpr int ES = (int)sizeof(typename TR::elem_t);
-    __shared__ float red[256];
+    __shared__ float red[MODE == 2 ? 1 : FOLD_G * 256];
     const int tid = threadIdx.x;
     const int nchunk = C / EPC;
     const int ch = blockIdx.y * cpb + tid % cpb;
@@ -359,8 +429,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
         c2[e] = MODE == 2 ? coef[C + c] : 0.f;
         s1[e] = s2[e] = 0.f;
     }
+    // MODE 2 (no sums, uncapped grid): a workgroup's pooled pixels are one contiguous range (cmu_bn_bwd_apply's finding)
+    constexpr int PPT = (MODE == 2 && CMU_POOLA_PPT > 0) ? CMU_POOLA_PPT : 0;
+    const int64_t span = PPT > 0 ? (int64_t)ppb * PPT : (int64_t)gridDim.x * ppb;          // distance between a thread's ranges
     if (active)
-        for (int64_t pp = (int64_t)blockIdx.x * ppb + prow; pp < npool; pp += (int64_t)gridDim.x * ppb) {
+        for (int64_t rng = (int64_t)blockIdx.x * (PPT > 0 ? span : ppb); rng < npool; rng += (PPT > 0 ? (int64_t)gridDim.x * span : npool))
+        for (int64_t pp = rng + prow; pp < npool && (PPT == 0 || pp < rng + span); pp += (PPT > 0 ? ppb : span)) {
             int xo, yo, b;
             cmu_pixel_coords(pp, Wo, Ho, npool <= 0x7fffffffll, b, yo, xo);
             // SparK's sparse encoder: a masked window (see bnrelu_maxpool_kernel) has no gradient -- its dA is left unwritten (the
@@ -423,6 +497,21 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
     if (MODE == 2 || bn_ws == nullptr) return;
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *reinterpret_cast<int*>(bn_ws) = (int)gridDim.x;
     float* ws = bn_ws + BNWS_HDR / 4;
+    if (fold_ok(cpb)) {
+        float t[2 * EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { t[e] = s1[e]; t[EPC + e] = s2[e]; }
+        fold_rows<2 * EPC>(t, red, tid, cpb, ppb);
+        if (tid < cpb && blockIdx.y * cpb + tid < nchunk) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const int c = (blockIdx.y * cpb + tid) * EPC + e;
+                ws[((int64_t)blockIdx.x * 2 + 0) * C + c] = t[e];
+                ws[((int64_t)blockIdx.x * 2 + 1) * C + c] = t[EPC + e];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
         const float a = sum_over_rows(s1[e], red, tid, cpb, ppb);
@@ -442,6 +531,10 @@ static int maxpool_bwd_t(const void* dP, int64_t ldp, const void* dS, int64_t ld
     chunk_geometry(C / TR::EPC, &cpb, &ppb, &gy);
     const int64_t npool = (int64_t)B * (H / 2) * (W / 2);
     int gx = (int)(cmu_div_up64(npool, ppb * 2) < POOLB_MAX_BLOCKS ? cmu_div_up64(npool, ppb * 2) : POOLB_MAX_BLOCKS);
+    if (coef != nullptr && CMU_POOLA_PPT > 0) {
+        const int64_t nb = cmu_div_up64(npool, (int64_t)ppb * (CMU_POOLA_PPT > 0 ? CMU_POOLA_PPT : 1));
+        gx = (int)(nb < (1 << 20) ? nb : (1 << 20));
+    }
     if (gx < 1) gx = 1;
 #define CMU_POOLB_LAUNCH(MODE_)                                                                                                            \
     hipLaunchKernelGGL((maxpool_bwd_kernel<TR, MODE_>), dim3(gx, gy), dim3(256), 0, st, (const unsigned char*)dP, ldp, (const unsigned char*)dS, lds, \
@@ -518,7 +611,7 @@ __global__ __launch_bounds__(256) void conv1x1_head_bwd_kernel(const float* __re
                                                               float* __restrict__ bn_ws) {
     constexpr int EPC = TR::EPC;
     constexpr int ES = (int)sizeof(typename TR::elem_t);
-    __shared__ float red[256];
+    __shared__ float red[FOLD_G * 256];
     const int tid = threadIdx.x;
     const int nchunk = C / EPC;  // power of two <= 64
     const int ch = tid % nchunk;
@@ -543,71 +636,101 @@ __global__ __launch_bounds__(256) void conv1x1_head_bwd_kernel(const float* __re
         }
     }
     const int64_t HW = (int64_t)H * W;
-    // (image, pixel-in-image) carried along the grid-stride loop instead of a 64-bit division per pixel and thread
-    const int64_t stride = (int64_t)gridDim.x * ppb;
+    // Round 4: four pixels per thread and trip, their 16-byte loads and dlogits reads issued together (one load in flight per
+    // thread left this pass latency-bound at 2.6 TB/s), and the workgroup's sums folded inside the waves (fold_rows).
+    // (image, pixel-in-image) of the trip's first pixel is carried along the grid-stride loop instead of a 64-bit division per
+    // pixel and thread; the other three follow by increments.
+    constexpr int U = 4;
+    const int64_t stride = (int64_t)gridDim.x * ppb * U;
     const int64_t sb = stride / HW, sr = stride % HW;
-    int64_t pix = (int64_t)blockIdx.x * ppb + prow;
-    int64_t b = pix / HW, r = pix % HW;
-    for (; pix < npix; pix += stride, b += sb, r += sr) {
-        if (r >= HW) { r -= HW; ++b; }
-        float f[EPC], o[EPC], dl[KT];
-        TR::unpack(ld_global16(x + (pix * ldx + ch * EPC) * ES), f);
+    int64_t pix0 = (int64_t)blockIdx.x * ppb * U + prow;
+    int64_t b0 = pix0 / HW, r0 = pix0 % HW;
+    for (; pix0 < npix; pix0 += stride, b0 += sb, r0 += sr) {
+        if (r0 >= HW) { r0 -= HW; ++b0; }
+        u32x4 q[U];
+        float dlv[U][KT];
+        bool ok[U];
 #pragma unroll
-        for (int k = 0; k < KT; ++k) dl[k] = (k < K) ? dlogits[(b * K + k) * HW + r] : 0.f;
+        for (int u = 0; u < U; ++u) {
+            const int64_t pix = pix0 + (int64_t)u * ppb;
+            ok[u] = pix < npix;
+            int64_t b = b0, r = r0 + (int64_t)u * ppb;
+            while (r >= HW) { r -= HW; ++b; }
+            q[u] = ok[u] ? ld_global16(x + (pix * ldx + ch * EPC) * ES) : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            float a = fmaf(f[e], sc[e], sh[e]);
-            if (scale) a = fmaxf(a, 0.f);
-            float d = 0.f;
-#pragma unroll
-            for (int k = 0; k < KT; ++k) {
-                d = fmaf(dl[k], wk[k][e], d);
-                dw[k][e] = fmaf(dl[k], a, dw[k][e]);
-            }
-            o[e] = d;
+            for (int k = 0; k < KT; ++k) dlv[u][k] = (ok[u] && k < K) ? dlogits[(b * K + k) * HW + r] : 0.f;
         }
-        if (ch == 0) {
 #pragma unroll
-            for (int k = 0; k < KT; ++k) db[k] += dl[k];
-        }
-        const u32x4 packed = TR::pack(o);
-        if (dX) st_global16(dX + (pix * ldo + ch * EPC) * ES, packed);
-        if (bn_ws) {   // BN+ReLU backward statistics of the producing layer, on dX as stored
-            float dr[EPC];
-            TR::unpack(packed, dr);
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            const int64_t pix = pix0 + (int64_t)u * ppb;
+            float f[EPC], o[EPC];
+            TR::unpack(q[u], f);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
-                const float dz = fmaf(f[e], sc[e], sh[e]) > 0.f ? dr[e] : 0.f;
-                s1[e] += dz;
-                s2[e] = fmaf(dz, (f[e] - mu[e]) * is[e], s2[e]);
+                float a = fmaf(f[e], sc[e], sh[e]);
+                if (scale) a = fmaxf(a, 0.f);
+                float d = 0.f;
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    d = fmaf(dlv[u][k], wk[k][e], d);
+                    dw[k][e] = fmaf(dlv[u][k], a, dw[k][e]);
+                }
+                o[e] = d;
+            }
+            if (ch == 0) {
+#pragma unroll
+                for (int k = 0; k < KT; ++k) db[k] += dlv[u][k];
+            }
+            const u32x4 packed = TR::pack(o);
+            if (dX) st_global16(dX + (pix * ldo + ch * EPC) * ES, packed);
+            if (bn_ws) {   // BN+ReLU backward statistics of the producing layer, on dX as stored
+                float dr[EPC];
+                TR::unpack(packed, dr);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float dz = fmaf(f[e], sc[e], sh[e]) > 0.f ? dr[e] : 0.f;
+                    s1[e] += dz;
+                    s2[e] = fmaf(dz, (f[e] - mu[e]) * is[e], s2[e]);
+                }
             }
         }
     }
+    // nchunk is a power of two <= 64 (host check): every sum of the workgroup goes through fold_rows
     if (bn_ws) {
         if (blockIdx.x == 0 && tid == 0) *reinterpret_cast<int*>(bn_ws) = (int)gridDim.x;
         float* bws = bn_ws + BNWS_HDR / 4;
+        float t[2 * EPC];
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            const float a = sum_over_rows(s1[e], red, tid, nchunk, ppb);
-            const float bsum = sum_over_rows(s2[e], red, tid, nchunk, ppb);
-            if (tid < nchunk) {
-                bws[((int64_t)blockIdx.x * 2 + 0) * C + tid * EPC + e] = a;
-                bws[((int64_t)blockIdx.x * 2 + 1) * C + tid * EPC + e] = bsum;
+        for (int e = 0; e < EPC; ++e) { t[e] = s1[e]; t[EPC + e] = s2[e]; }
+        fold_rows<2 * EPC>(t, red, tid, nchunk, ppb);
+        if (tid < nchunk) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                bws[((int64_t)blockIdx.x * 2 + 0) * C + tid * EPC + e] = t[e];
+                bws[((int64_t)blockIdx.x * 2 + 1) * C + tid * EPC + e] = t[EPC + e];
             }
         }
     }
     float* out = ws + (int64_t)blockIdx.x * (K * C + K);
+    {
+        float t[KT * EPC + KT];
 #pragma unroll
-    for (int k = 0; k < KT; ++k) {
-        if (k >= K) break;   // K is uniform; indices stay compile-time constants after unrolling
+        for (int k = 0; k < KT; ++k) {
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            const float a = sum_over_rows(dw[k][e], red, tid, nchunk, ppb);
-            if (tid < nchunk) out[k * C + tid * EPC + e] = a;
+            for (int e = 0; e < EPC; ++e) t[k * EPC + e] = dw[k][e];
+            t[KT * EPC + k] = db[k];     // bias: only ch == 0 threads carry data (tid % nchunk == 0)
         }
-        // bias: only ch == 0 threads carry data (tid % nchunk == 0)
-        const float bsum = sum_over_rows(db[k], red, tid, nchunk, ppb);
-        if (tid == 0) out[K * C + k] = bsum;
+        fold_rows<KT * EPC + KT>(t, red, tid, nchunk, ppb);
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            if (k >= K) break;   // K is uniform; indices stay compile-time constants after unrolling
+            if (tid < nchunk) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) out[k * C + tid * EPC + e] = t[k * EPC + e];
+            }
+            if (tid == 0) out[K * C + k] = t[KT * EPC + k];
+        }
     }
 }
 __global__ __launch_bounds__(256) void sum_slab_kernel(const float* __restrict__ ws, int nblocks, int64_t n, float* __restrict__ out0,
@@ -778,54 +901,87 @@ extern "C" int cmu_conv1x1_head_bn_apply(const float* dlogits, const void* x, in
 #ifndef CMU_C1W_BLOCKS
 #define CMU_C1W_BLOCKS 512
 #endif
+#ifndef CMU_C1W_RECOMP
+#define CMU_C1W_RECOMP 1     // 1: the fused-BN form recomputes the layer's raw output from the image instead of reading it (below)
+#endif
 constexpr int C1W_MAX_BLOCKS = CMU_C1W_BLOCKS;
-template <class TR>
-__global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask,
+// Round 4.  (i) The next tile's halo is loaded into registers before the current tile's pixels are walked and stored to the other
+// LDS buffer behind them: one barrier per tile and no exposed round trip (was: barrier, load, barrier per 16 x 16 tile).
+// (ii) The workgroup's 72 sums per thread are folded inside the waves (fold_rows): 9 barrier pairs instead of 144, which is what
+// had capped the grid at 512 workgroups.  (iii) RECOMP (the fused-BN form, DESIGN section 8 item 0 on its cheapest consumer): the
+// raw output y1 of this layer is 9 FMAs per element away from the halo the pass holds in LDS anyway, so it is recomputed -- in the
+// forward kernel's order (conv3x3_c1_fwd_kernel: a = fmaf(in[t], w[t], a), t = 0..8, from 0) and rounded through the storage type, i.e.
+// the very bits the forward stored -- instead of read: 1.07 GB of the pass's 2.28 GB at 32 x 512 x 512 never leave HBM.
+template <class TR, bool RECOMP>
+__global__ __launch_bounds__(256, 2) void conv3x3_c1_wgrad_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask,
                                                               int mask_per_sample, const unsigned char* __restrict__ dY, int64_t ldd,
                                                               float* __restrict__ ws, int B, int H, int W, int Cout, int tilesX,
                                                               int tilesY, int ntiles, const unsigned char* __restrict__ yraw, int64_t ldy,
                                                               const float* __restrict__ bsc, const float* __restrict__ bsh,
                                                               const float* __restrict__ bmu, const float* __restrict__ bis,
-                                                              const float* __restrict__ coef) {
+                                                              const float* __restrict__ coef, const float* __restrict__ wfwd) {
     constexpr int EPC = TR::EPC;
     constexpr int ES = (int)sizeof(typename TR::elem_t);
-    __shared__ float halo[18 * 18];
-    __shared__ float red[256];
+    __shared__ float halo[2][18 * 18];
+    __shared__ float red[FOLD_G * 256];
     const int tid = threadIdx.x;
     const int nchunk = Cout / EPC;
     const int ppi = 256 / nchunk;
     const int chunk = tid % nchunk, prow = tid / nchunk;
     const bool active = prow < ppi;
+    const bool bn = RECOMP || yraw != nullptr;
     float acc[EPC][9];
 #pragma unroll
     for (int e = 0; e < EPC; ++e)
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[e][t] = 0.f;
-    // yraw != NULL: ``dY`` holds dA (gradient w.r.t. the activated output) and the BatchNorm+ReLU backward of this layer is
+    // bn: ``dY`` holds dA (gradient w.r.t. the activated output) and the BatchNorm+ReLU backward of this layer is
     // applied on the fly (cmu_conv3x3_c1_wgrad_bn) -- the first layer has no data gradient, so dY is never materialised
     float sc[EPC], sh[EPC], mu[EPC], is[EPC], c1[EPC], c2[EPC];
-    if (yraw != nullptr) {
+    if (bn) {
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             const int c = active ? chunk * EPC + e : 0;
             sc[e] = bsc[c]; sh[e] = bsh[c]; mu[e] = bmu[c]; is[e] = bis[c]; c1[e] = coef[c]; c2[e] = coef[Cout + c];
         }
     }
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int tx = tile % tilesX, ty = (tile / tilesX) % tilesY, b = tile / (tilesX * tilesY);
-        const int ty0 = ty * 16, tx0 = tx * 16;
-        __syncthreads();
-        for (int i = tid; i < 18 * 18; i += 256) {
-            const int gy = ty0 - 1 + i / 18, gx = tx0 - 1 + i % 18;
+    float wr[RECOMP ? EPC : 1][9];
+    if (RECOMP) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) wr[e][t] = active ? wfwd[(chunk * EPC + e) * 9 + t] : 0.f;
+    }
+    const int tpi = tilesX * tilesY;
+    float hv[2];
+    auto halo_load = [&](int tile) {
+        const int tx = tile % tilesX, ty = (tile / tilesX) % tilesY, b = tile / tpi;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid + k * 256;
+            const int gy = ty * 16 - 1 + i / 18, gx = tx * 16 - 1 + i % 18;
             float v = 0.f;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            if (i < 18 * 18 && gy >= 0 && gy < H && gx >= 0 && gx < W) {
                 v = x[((int64_t)b * H + gy) * W + gx];
                 if (mask) v *= (float)(1 - (int)mask[((int64_t)(mask_per_sample ? b : 0) * H + gy) * W + gx]);
             }
-            halo[i] = v;
+            hv[k] = v;
         }
-        __syncthreads();
-        // four pixels per trip: their 16-byte loads (dY, and the raw output when the BN backward is fused) go out together --
+    };
+    auto halo_store = [&](float* buf) {
+        buf[tid] = hv[0];
+        if (tid + 256 < 18 * 18) buf[tid + 256] = hv[1];
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) { halo_load(tile); halo_store(halo[0]); }
+    __syncthreads();
+    for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
+        const int tx = tile % tilesX, ty = (tile / tilesX) % tilesY, b = tile / tpi;
+        const int ty0 = ty * 16, tx0 = tx * 16;
+        const float* hb = halo[it & 1];
+        const bool more = tile + (int)gridDim.x < ntiles;
+        if (more) halo_load(tile + gridDim.x);
+        // four pixels per trip: their 16-byte loads (dY, and the raw output when it is read) go out together --
         // one or two loads in flight per wave left this pass latency-bound at ~2.6 TB/s
         constexpr int U = 4;
         if (active)
@@ -840,7 +996,7 @@ __global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __re
                     gq[u] = vq[u] = u32x4{0u, 0u, 0u, 0u};
                     if (ok[u]) {
                         gq[u] = ld_global16_nt(dY + ((((int64_t)b * H + gy) * W + gx) * ldd + chunk * EPC) * ES);
-                        if (yraw != nullptr) vq[u] = ld_global16_nt(yraw + ((((int64_t)b * H + gy) * W + gx) * ldy + chunk * EPC) * ES);
+                        if (!RECOMP && yraw != nullptr) vq[u] = ld_global16_nt(yraw + ((((int64_t)b * H + gy) * W + gx) * ldy + chunk * EPC) * ES);
                     }
                 }
 #pragma unroll
@@ -848,11 +1004,25 @@ __global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __re
                     if (!ok[u]) continue;
                     const int pix = pix0 + u * ppi;
                     const int py = pix >> 4, px = pix & 15;
-                    float g[EPC];
+                    float g[EPC], in[9];
                     TR::unpack(gq[u], g);
-                    if (yraw != nullptr) {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) in[t] = hb[(py + t / 3) * 18 + px + t % 3];
+                    if (bn) {
                         float v[EPC];
-                        TR::unpack(vq[u], v);
+                        if (RECOMP) {
+                            float o[EPC];
+#pragma unroll
+                            for (int e = 0; e < EPC; ++e) {
+                                float a = 0.f;
+#pragma unroll
+                                for (int t = 0; t < 9; ++t) a = fmaf(in[t], wr[e][t], a);
+                                o[e] = a;
+                            }
+                            TR::unpack(TR::pack(o), v);
+                        } else {
+                            TR::unpack(vq[u], v);
+                        }
 #pragma unroll
                         for (int e = 0; e < EPC; ++e) {
                             const float dz = fmaf(v[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
@@ -861,14 +1031,28 @@ __global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __re
                     }
 #pragma unroll
                     for (int t = 0; t < 9; ++t) {
-                        const float xv = halo[(py + t / 3) * 18 + px + t % 3];
 #pragma unroll
-                        for (int e = 0; e < EPC; ++e) acc[e][t] = fmaf(g[e], xv, acc[e][t]);
+                        for (int e = 0; e < EPC; ++e) acc[e][t] = fmaf(g[e], in[t], acc[e][t]);
                     }
                 }
             }
+        if (more) halo_store(halo[(it + 1) & 1]);
+        __syncthreads();
     }
     float* out = ws + (int64_t)blockIdx.x * Cout * 9;
+    if (fold_ok(nchunk) && nchunk <= 256) {
+        float t9[EPC * 9];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) t9[e * 9 + t] = active ? acc[e][t] : 0.f;
+        fold_rows<EPC * 9>(t9, red, tid, nchunk, ppi);
+        if (tid < nchunk) {
+#pragma unroll
+            for (int q = 0; q < EPC * 9; ++q) out[tid * EPC * 9 + q] = t9[q];
+        }
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < EPC; ++e)
 #pragma unroll
@@ -881,12 +1065,16 @@ template <class TR>
 static int conv3x3_c1_wgrad_t(const float* x, const uint8_t* mask, int mps, const void* dY, int64_t ldd, float* dW, int B, int H, int W,
                               int Cout, void* ws, hipStream_t st, const void* yraw = nullptr, int64_t ldy = 0, const float* bsc = nullptr,
                               const float* bsh = nullptr, const float* bmu = nullptr, const float* bis = nullptr,
-                              const float* coef = nullptr) {
+                              const float* coef = nullptr, const float* wfwd = nullptr) {
     const int tilesX = cmu_div_up(W, 16), tilesY = cmu_div_up(H, 16);
     const int ntiles = B * tilesX * tilesY;
     const int grid = ntiles < C1W_MAX_BLOCKS ? ntiles : C1W_MAX_BLOCKS;
-    hipLaunchKernelGGL((conv3x3_c1_wgrad_kernel<TR>), dim3(grid), dim3(256), 0, st, x, mask, mps, (const unsigned char*)dY, ldd, (float*)ws,
-                       B, H, W, Cout, tilesX, tilesY, ntiles, (const unsigned char*)yraw, ldy, bsc, bsh, bmu, bis, coef);
+    if (wfwd != nullptr)
+        hipLaunchKernelGGL((conv3x3_c1_wgrad_kernel<TR, true>), dim3(grid), dim3(256), 0, st, x, mask, mps, (const unsigned char*)dY, ldd, (float*)ws,
+                           B, H, W, Cout, tilesX, tilesY, ntiles, (const unsigned char*)yraw, ldy, bsc, bsh, bmu, bis, coef, wfwd);
+    else
+        hipLaunchKernelGGL((conv3x3_c1_wgrad_kernel<TR, false>), dim3(grid), dim3(256), 0, st, x, mask, mps, (const unsigned char*)dY, ldd, (float*)ws,
+                           B, H, W, Cout, tilesX, tilesY, ntiles, (const unsigned char*)yraw, ldy, bsc, bsh, bmu, bis, coef, wfwd);
     CMU_CHECK_LAUNCH("cmu_conv3x3_c1_wgrad");
     const int64_t n = (int64_t)Cout * 9;
     hipLaunchKernelGGL(sum_slab_kernel, dim3((unsigned)cmu_div_up64(n, 16)), dim3(256), 0, st, (const float*)ws, grid, n, dW, n, (float*)nullptr);
@@ -918,4 +1106,20 @@ extern "C" int cmu_conv3x3_c1_wgrad_bn(const float* x, const uint8_t* mask, int 
                   "cmu_conv3x3_c1_wgrad_bn: alignment / stride");
     CMU_DISPATCH_DT(dt, conv3x3_c1_wgrad_t, x, mask, mask_per_sample, dA, ldd, dW, B, H, W, Cout, ws, (hipStream_t)stream, yraw, ldy, scale,
                     shift, save_mean, save_invstd, coef);
+}
+// The same with the raw output RECOMPUTED from the image and the layer's forward weights ``w`` (Cout,1,3,3) instead of read
+// (conv3x3_c1_wgrad_kernel<., true>): bit-identical to cmu_conv3x3_c1_wgrad_bn on the tensor cmu_conv3x3_c1_fwd stored, at half
+// the HBM traffic.  ``w`` must be the weights (and x / mask the inputs) that forward pass used.
+extern "C" int cmu_conv3x3_c1_wgrad_bn_w(const float* x, const uint8_t* mask, int mask_per_sample, const void* dA, int64_t ldd,
+                                         const float* w, const float* scale, const float* shift, const float* save_mean,
+                                         const float* save_invstd, const float* coef, float* dW, int B, int H, int W, int Cout, int dt,
+                                         void* ws, void* stream) {
+    const int es = cmu_dtype_size(dt);
+    CMU_CHECK_ARG(es > 0 && x && dA && w && scale && shift && save_mean && save_invstd && coef && dW && ws && B > 0 && H > 0 && W > 0,
+                  "cmu_conv3x3_c1_wgrad_bn_w: bad args");
+    const int epc = 16 / es;
+    CMU_CHECK_ARG(Cout > 0 && Cout % epc == 0 && Cout / epc <= 256, "cmu_conv3x3_c1_wgrad_bn_w: Cout=%d unsupported", Cout);
+    CMU_CHECK_ARG(cmu_aligned16(dA) && ldd % epc == 0 && ldd >= Cout, "cmu_conv3x3_c1_wgrad_bn_w: alignment / stride");
+    CMU_DISPATCH_DT(dt, conv3x3_c1_wgrad_t, x, mask, mask_per_sample, dA, ldd, dW, B, H, W, Cout, ws, (hipStream_t)stream, nullptr, 0, scale,
+                    shift, save_mean, save_invstd, coef, w);
 }

@@ -379,13 +379,21 @@ extern "C" int cmu_bn_bwd_finalize_tiles(const float* bstats, int ntiles, int64_
 // ---------------------------------------------------------------------------------------------
 // first layer: Conv2d(1, Cout, 3, p=1) direct, optional patch-mask multiply fused into the load
 // ---------------------------------------------------------------------------------------------
+#ifndef CMU_C1F_WAVES
+#define CMU_C1F_WAVES 4      // waves per SIMD the register allocation is held to (132 registers unconstrained: one wave per SIMD less)
+#endif
+// Round 4: (i) the next tile's halo is loaded into registers before the current tile's pixels are walked and stored to the other
+// LDS buffer behind them (one barrier per tile, no exposed round trip); (ii) the batch statistics are summed per THREAD over all
+// tiles of the workgroup and folded once at its end (inside the waves, then across them) -- the per-tile fold (48 shuffles, a
+// barrier, a 4-way LDS sum) was a sixth of the pass.  The slab keeps one row per tile: the workgroup's sums go to the row of its
+// first tile, zeros to the rows of its other tiles (consumers sum the rows).
 template <class TR>
-__global__ __launch_bounds__(256) void conv3x3_c1_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask,
+__global__ __launch_bounds__(256, CMU_C1F_WAVES) void conv3x3_c1_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask,
                                                             int mask_per_sample, const float* __restrict__ w,
                                                             typename TR::elem_t* __restrict__ y, int64_t ldy, float* stats, int B,
                                                             int H, int W, int Cout, int tilesX, int tilesY) {
     constexpr int EPC = TR::EPC;
-    __shared__ float halo[18 * 18];
+    __shared__ float halo[2][18 * 18];
     __shared__ float red[2][256];
     const int tid = threadIdx.x;
     const int nchunk = Cout / EPC;
@@ -398,49 +406,70 @@ __global__ __launch_bounds__(256) void conv3x3_c1_fwd_kernel(const float* __rest
 #pragma unroll
         for (int t = 0; t < 9; ++t) wr[e][t] = active ? w[(chunk * EPC + e) * 9 + t] : 0.f;
     const int ntile = B * tilesX * tilesY;
-    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-    const int tx = tile % tilesX, ty = (tile / tilesX) % tilesY, b = tile / (tilesX * tilesY);
-    const int ty0 = ty * 16, tx0 = tx * 16;
-    __syncthreads();   // the previous tile's halo / reduction buffers are free
-    for (int i = tid; i < 18 * 18; i += 256) {
-        const int gy = ty0 - 1 + i / 18, gx = tx0 - 1 + i % 18;
-        float v = 0.f;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            v = x[((int64_t)b * H + gy) * W + gx];
-            if (mask) v *= (float)(1 - (int)mask[((int64_t)(mask_per_sample ? b : 0) * H + gy) * W + gx]);
+    const int tpi = tilesX * tilesY;
+    float hv[2];
+    auto halo_load = [&](int tile) {
+        const int tx = tile % tilesX, ty = (tile / tilesX) % tilesY, b = tile / tpi;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid + k * 256;
+            const int gy = ty * 16 - 1 + i / 18, gx = tx * 16 - 1 + i % 18;
+            float v = 0.f;
+            if (i < 18 * 18 && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                v = x[((int64_t)b * H + gy) * W + gx];
+                if (mask) v *= (float)(1 - (int)mask[((int64_t)(mask_per_sample ? b : 0) * H + gy) * W + gx]);
+            }
+            hv[k] = v;
         }
-        halo[i] = v;
-    }
-    __syncthreads();
+    };
+    auto halo_store = [&](float* buf) {
+        buf[tid] = hv[0];
+        if (tid + 256 < 18 * 18) buf[tid + 256] = hv[1];
+    };
     float s1[EPC], s2[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
-    if (active)
-        for (int pix = prow; pix < 256; pix += ppi) {
-            const int py = pix >> 4, px = pix & 15;
-            const int gy = ty0 + py, gx = tx0 + px;
-            if (gy >= H || gx >= W) continue;
-            float in[9];
+    int tile = blockIdx.x;
+    if (tile < ntile) { halo_load(tile); halo_store(halo[0]); }
+    __syncthreads();
+    for (int it = 0; tile < ntile; tile += gridDim.x, ++it) {
+        const int tx = tile % tilesX, ty = (tile / tilesX) % tilesY, b = tile / tpi;
+        const int ty0 = ty * 16, tx0 = tx * 16;
+        const float* hb = halo[it & 1];
+        const bool more = tile + (int)gridDim.x < ntile;
+        if (more) halo_load(tile + gridDim.x);
+        if (active)
+            for (int pix = prow; pix < 256; pix += ppi) {
+                const int py = pix >> 4, px = pix & 15;
+                const int gy = ty0 + py, gx = tx0 + px;
+                if (gy >= H || gx >= W) continue;
+                float in[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) in[t] = halo[(py + t / 3) * 18 + px + t % 3];
-            float o[EPC];
+                for (int t = 0; t < 9; ++t) in[t] = hb[(py + t / 3) * 18 + px + t % 3];
+                float o[EPC];
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                float a = 0.f;
+                for (int e = 0; e < EPC; ++e) {
+                    float a = 0.f;
 #pragma unroll
-                for (int t = 0; t < 9; ++t) a = fmaf(in[t], wr[e][t], a);
-                o[e] = a;
-                s1[e] += a;
-                s2[e] = fmaf(a, a, s2[e]);
+                    for (int t = 0; t < 9; ++t) a = fmaf(in[t], wr[e][t], a);
+                    o[e] = a;
+                    s1[e] += a;
+                    s2[e] = fmaf(a, a, s2[e]);
+                }
+                st_global16_nt(reinterpret_cast<unsigned char*>(y) + ((((int64_t)b * H + gy) * W + gx) * ldy + chunk * EPC) * sizeof(typename TR::elem_t),
+                            TR::pack(o));
             }
-            st_global16_nt(reinterpret_cast<unsigned char*>(y) + ((((int64_t)b * H + gy) * W + gx) * ldy + chunk * EPC) * sizeof(typename TR::elem_t),
-                        TR::pack(o));
-        }
-    if (stats == nullptr) continue;
-    if ((nchunk & (nchunk - 1)) == 0 && nchunk <= 32) {
+        if (stats != nullptr && it > 0)      // rows of the workgroup's later tiles: zero (its sums go to its first tile's row)
+            for (int c = tid; c < 2 * Cout; c += 256) stats[(int64_t)tile * 2 * Cout + c] = 0.f;
+        if (more) halo_store(halo[(it + 1) & 1]);
+        __syncthreads();
+    }
+    if (stats == nullptr || (int)blockIdx.x >= ntile) return;
+    tile = blockIdx.x;
+    if ((nchunk & (nchunk - 1)) == 0 && nchunk <= 32 && nchunk * EPC <= 64) {
         // threads sharing a channel chunk sit nchunk lanes apart: fold inside the wave (fixed xor order), then the four
-        // waves through LDS -- one barrier instead of sixteen and no serial 32-term sums by eight threads
-        float* wred = &red[0][0];   // [4 waves][Cout <= 128][2]
+        // waves through LDS
+        float* wred = &red[0][0];   // [4 waves][Cout <= 64][2]
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             float a = s1[e], q = s2[e];
@@ -448,32 +477,30 @@ __global__ __launch_bounds__(256) void conv3x3_c1_fwd_kernel(const float* __rest
                 a += __shfl_xor(a, o, 64);
                 q += __shfl_xor(q, o, 64);
             }
-            if ((tid & 63) < nchunk && nchunk * EPC <= 64) {
+            if ((tid & 63) < nchunk) {
                 wred[((tid >> 6) * 64 + (tid & 63) * EPC + e) * 2 + 0] = a;
                 wred[((tid >> 6) * 64 + (tid & 63) * EPC + e) * 2 + 1] = q;
             }
         }
-        if (nchunk * EPC <= 64) {
-            __syncthreads();
-            if (tid < Cout) {
-                float a = 0.f, q = 0.f;
+        __syncthreads();
+        if (tid < Cout) {
+            float a = 0.f, q = 0.f;
 #pragma unroll
-                for (int wv = 0; wv < 4; ++wv) {
-                    a += wred[(wv * 64 + tid) * 2 + 0];
-                    q += wred[(wv * 64 + tid) * 2 + 1];
-                }
-                stats[((int64_t)tile * 2 + 0) * Cout + tid] = a;
-                stats[((int64_t)tile * 2 + 1) * Cout + tid] = q;
+            for (int wv = 0; wv < 4; ++wv) {
+                a += wred[(wv * 64 + tid) * 2 + 0];
+                q += wred[(wv * 64 + tid) * 2 + 1];
             }
-            continue;
+            stats[((int64_t)tile * 2 + 0) * Cout + tid] = a;
+            stats[((int64_t)tile * 2 + 1) * Cout + tid] = q;
         }
+        return;
     }
     // general shapes: combine the threads that share a channel chunk (same tid % nchunk): fixed-order tree over prow
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
         __syncthreads();
-        red[0][tid] = s1[e];
-        red[1][tid] = s2[e];
+        red[0][tid] = active ? s1[e] : 0.f;
+        red[1][tid] = active ? s2[e] : 0.f;
         __syncthreads();
         if (tid < nchunk) {
             float a = 0.f, q = 0.f;
@@ -485,7 +512,6 @@ __global__ __launch_bounds__(256) void conv3x3_c1_fwd_kernel(const float* __rest
             stats[((int64_t)tile * 2 + 1) * Cout + tid * EPC + e] = q;
         }
     }
-    }   // tiles
 }
 
 template <class TR>
@@ -494,7 +520,7 @@ static int conv3x3_c1_fwd_t(const float* x, const uint8_t* mask, int mps, const 
     const int tilesX = cmu_div_up(W, 16), tilesY = cmu_div_up(H, 16);
     const int ntile = B * tilesX * tilesY;
 #ifndef CMU_C1F_CAP
-#define CMU_C1F_CAP 4096
+#define CMU_C1F_CAP 2048
 #endif
     hipLaunchKernelGGL((conv3x3_c1_fwd_kernel<TR>), dim3(ntile < CMU_C1F_CAP ? ntile : CMU_C1F_CAP), dim3(256), 0, st, x, mask, mps, w,
                        (typename TR::elem_t*)y, ldy, stats, B, H, W, Cout, tilesX, tilesY);

@@ -256,6 +256,7 @@ __device__ static inline u32x4 sk16_pack8(const f32x4s& a, const f32x4s& b) {
     float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     return TR::pack(f);
 }
+constexpr int SK16_MAX_M = 256;    // rows per call, in groups of 32 (skinny.hip: SK_MAX_M)
 __device__ static inline f32x4s sk16_ld4(const float* p, bool ok) {
     return ok ? *reinterpret_cast<const f32x4s*>(p) : f32x4s{0.f, 0.f, 0.f, 0.f};
 }
@@ -317,23 +318,26 @@ static int sk16_splits(int N, int64_t K, int64_t* kchunk) {
 }
 extern "C" int64_t cmu_skinny16_gemm_ws_bytes(int M, int N, int64_t K) {
     int64_t kc;
-    return (int64_t)sk16_splits(N, K, &kc) * M * N * (int64_t)sizeof(float);
+    return (int64_t)sk16_splits(N, K, &kc) * (M < 32 ? M : 32) * N * (int64_t)sizeof(float);     // one slab, reused by every 32-row group
 }
 template <class TR>
 static int skinny16_fwd_t(const float* x, const float* w, const float* bias, float* y, int M, int N, int64_t K, void* ws, hipStream_t st) {
     int64_t kc;
     const int splits = sk16_splits(N, K, &kc);
-    hipLaunchKernelGGL((skinny16_fwd_kernel<TR>), dim3(cmu_div_up(N, 128), splits), dim3(256), 0, st, x, w, (float*)ws, M, N, K, kc);
-    CMU_CHECK_LAUNCH("cmu_skinny16_gemm_fwd");
-    hipLaunchKernelGGL(skinny16_fwd_reduce_kernel, dim3((unsigned)cmu_div_up64((int64_t)M * N, 256)), dim3(256), 0, st, (const float*)ws, bias, y,
-                       M, N, splits);
-    CMU_CHECK_LAUNCH("cmu_skinny16_gemm_fwd(reduce)");
+    for (int m0 = 0; m0 < M; m0 += 32) {      // row groups of 32 over one slab (same stream)
+        const int Mg = M - m0 < 32 ? M - m0 : 32;
+        hipLaunchKernelGGL((skinny16_fwd_kernel<TR>), dim3(cmu_div_up(N, 128), splits), dim3(256), 0, st, x + (int64_t)m0 * K, w, (float*)ws, Mg, N, K, kc);
+        CMU_CHECK_LAUNCH("cmu_skinny16_gemm_fwd");
+        hipLaunchKernelGGL(skinny16_fwd_reduce_kernel, dim3((unsigned)cmu_div_up64((int64_t)Mg * N, 256)), dim3(256), 0, st, (const float*)ws, bias,
+                           y + (int64_t)m0 * N, Mg, N, splits);
+        CMU_CHECK_LAUNCH("cmu_skinny16_gemm_fwd(reduce)");
+    }
     return CMU_OK;
 }
 extern "C" int cmu_skinny16_gemm_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int64_t K, int dt, void* ws,
                                      void* stream) {
-    CMU_CHECK_ARG(x && w && y && ws && M >= 1 && M <= 32 && N >= 1 && K >= 16 && K % 16 == 0 && (dt == CMU_F16 || dt == CMU_BF16),
-                  "cmu_skinny16_gemm_fwd: needs 1 <= M <= 32, K %% 16 == 0, dt f16 / bf16 (M=%d, K=%lld, dt=%d)", M, (long long)K, dt);
+    CMU_CHECK_ARG(x && w && y && ws && M >= 1 && M <= SK16_MAX_M && N >= 1 && K >= 16 && K % 16 == 0 && (dt == CMU_F16 || dt == CMU_BF16),
+                  "cmu_skinny16_gemm_fwd: needs 1 <= M <= 256, K %% 16 == 0, dt f16 / bf16 (M=%d, K=%lld, dt=%d)", M, (long long)K, dt);
     CMU_CHECK_ARG(cmu_aligned16(x) && cmu_aligned16(w), "cmu_skinny16_gemm_fwd: x / w must be 16-byte aligned");
     if (dt == CMU_F16) return skinny16_fwd_t<F16Traits>(x, w, bias, y, M, N, K, ws, (hipStream_t)stream);
     return skinny16_fwd_t<BF16Traits>(x, w, bias, y, M, N, K, ws, (hipStream_t)stream);
@@ -393,20 +397,26 @@ __global__ __launch_bounds__(256) void skinny16_dgrad_kernel(const float* __rest
     }
 }
 extern "C" int cmu_skinny16_gemm_dgrad(const float* dy, const float* w, float* dx, int M, int N, int64_t K, int dt, void* stream) {
-    CMU_CHECK_ARG(dy && w && dx && M >= 1 && M <= 32 && N >= 1 && K >= 4 && K % 4 == 0 && (dt == CMU_F16 || dt == CMU_BF16),
-                  "cmu_skinny16_gemm_dgrad: needs 1 <= M <= 32, K %% 4 == 0, dt f16 / bf16 (M=%d, K=%lld, dt=%d)", M, (long long)K, dt);
+    CMU_CHECK_ARG(dy && w && dx && M >= 1 && M <= SK16_MAX_M && N >= 1 && K >= 4 && K % 4 == 0 && (dt == CMU_F16 || dt == CMU_BF16),
+                  "cmu_skinny16_gemm_dgrad: needs 1 <= M <= 256, K %% 4 == 0, dt f16 / bf16 (M=%d, K=%lld, dt=%d)", M, (long long)K, dt);
     CMU_CHECK_ARG(cmu_aligned16(w) && cmu_aligned16(dx), "cmu_skinny16_gemm_dgrad: w / dx must be 16-byte aligned");
     const dim3 grid((unsigned)cmu_div_up64(K, 128));
-    if (dt == CMU_F16) hipLaunchKernelGGL((skinny16_dgrad_kernel<F16Traits>), grid, dim3(256), 0, (hipStream_t)stream, dy, w, dx, M, N, K);
-    else hipLaunchKernelGGL((skinny16_dgrad_kernel<BF16Traits>), grid, dim3(256), 0, (hipStream_t)stream, dy, w, dx, M, N, K);
-    CMU_CHECK_LAUNCH("cmu_skinny16_gemm_dgrad");
+    for (int m0 = 0; m0 < M; m0 += 32) {      // row groups of 32: one pass over the weights each
+        const int Mg = M - m0 < 32 ? M - m0 : 32;
+        const float* dyg = dy + (int64_t)m0 * N;
+        float* dxg = dx + (int64_t)m0 * K;
+        if (dt == CMU_F16) hipLaunchKernelGGL((skinny16_dgrad_kernel<F16Traits>), grid, dim3(256), 0, (hipStream_t)stream, dyg, w, dxg, Mg, N, K);
+        else hipLaunchKernelGGL((skinny16_dgrad_kernel<BF16Traits>), grid, dim3(256), 0, (hipStream_t)stream, dyg, w, dxg, Mg, N, K);
+        CMU_CHECK_LAUNCH("cmu_skinny16_gemm_dgrad");
+    }
     return CMU_OK;
 }
 
 // ---- weight gradient: dw (N,K) = dy^T (N,M) . x (M,K): wave = 32 * NT rows n x 128 columns k, contraction over the M <= 32 rows in
 // two 16-row MFMAs.  B operand of tile j, MFMA s: x[m = 16 s + 8 h + i][4c + j]; A operand: dy[m = 16 s + 8 h + i][n0 + r].
 constexpr int SK16W_NT = 2;
-template <class TR>
+// MULTI (round 4, M > 32): row groups of 32 with both n tiles' accumulators live; the one-group form keeps one tile's at a time
+template <class TR, bool MULTI>
 __global__ __launch_bounds__(256) void skinny16_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw,
                                                             int M, int N, int64_t K) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -414,50 +424,104 @@ __global__ __launch_bounds__(256) void skinny16_wgrad_kernel(const float* __rest
     const int64_t kcol = ((int64_t)blockIdx.x * 4 + wave) * 128 + 4 * c;
     const bool kok = kcol < K;
     const int nbase = blockIdx.y * 32 * SK16W_NT;
-    u32x4 xb[2][4];     // [MFMA s][tile j]
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        f32x4s xv[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int m = 16 * s + 8 * h + i;
-            xv[i] = sk16_ld4(x + (int64_t)(m < M ? m : 0) * K + kcol, kok && m < M);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float bf[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) bf[i] = xv[i][j];
-            xb[s][j] = TR::pack(bf);
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < SK16W_NT; ++t) {
-        const int n = nbase + 32 * t + c;
-        f32x16 acc[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    if (!MULTI) {
+        u32x4 xb[2][4];     // [MFMA s][tile j]
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            float af[8];
+            f32x4s xv[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int m = 16 * s + 8 * h + i;
-                af[i] = (n < N && m < M) ? dy[(int64_t)m * N + n] : 0.f;
+                xv[i] = sk16_ld4(x + (int64_t)(m < M ? m : 0) * K + kcol, kok && m < M);
             }
-            const u32x4 a = TR::pack(af);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) TR::mma16(a, xb[s][j], acc[j]);
+            for (int j = 0; j < 4; ++j) {
+                float bf[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) bf[i] = xv[i][j];
+                xb[s][j] = TR::pack(bf);
+            }
         }
-        if (kok) {
+#pragma unroll
+        for (int t = 0; t < SK16W_NT; ++t) {
+            const int n = nbase + 32 * t + c;
+            f32x16 acc1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc1[j][e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float af[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int m = 16 * s + 8 * h + i;
+                    af[i] = (n < N && m < M) ? dy[(int64_t)m * N + n] : 0.f;
+                }
+                const u32x4 a = TR::pack(af);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) TR::mma16(a, xb[s][j], acc1[j]);
+            }
+            if (kok) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int nr = nbase + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (nr < N) __builtin_nontemporal_store(f32x4s{acc1[0][e], acc1[1][e], acc1[2][e], acc1[3][e]}, reinterpret_cast<f32x4s*>(dw + (int64_t)nr * K + kcol));
+                }
+            }
+        }
+        return;
+    }
+    f32x16 acc[SK16W_NT][4];
+#pragma unroll
+    for (int t = 0; t < SK16W_NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][j][e] = 0.f;
+    for (int m0 = 0; m0 < M; m0 += 32) {      // row groups of 32 (one trip for the <= 32 rows the kernel was written for)
+        u32x4 xb[2][4];     // [MFMA s][tile j]
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f32x4s xv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = m0 + 16 * s + 8 * h + i;
+                xv[i] = sk16_ld4(x + (int64_t)(m < M ? m : 0) * K + kcol, kok && m < M);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float bf[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) bf[i] = xv[i][j];
+                xb[s][j] = TR::pack(bf);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < SK16W_NT; ++t) {
+            const int n = nbase + 32 * t + c;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float af[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int m = m0 + 16 * s + 8 * h + i;
+                    af[i] = (n < N && m < M) ? dy[(int64_t)m * N + n] : 0.f;
+                }
+                const u32x4 a = TR::pack(af);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) TR::mma16(a, xb[s][j], acc[t][j]);
+            }
+        }
+    }
+    if (kok) {
+#pragma unroll
+        for (int t = 0; t < SK16W_NT; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int nr = nbase + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (nr < N) __builtin_nontemporal_store(f32x4s{acc[0][e], acc[1][e], acc[2][e], acc[3][e]}, reinterpret_cast<f32x4s*>(dw + (int64_t)nr * K + kcol));
+                if (nr < N) __builtin_nontemporal_store(f32x4s{acc[t][0][e], acc[t][1][e], acc[t][2][e], acc[t][3][e]}, reinterpret_cast<f32x4s*>(dw + (int64_t)nr * K + kcol));
             }
-        }
     }
 }
 __global__ void skinny16_colsum_kernel(const float* __restrict__ dy, float* __restrict__ dbias, int M, int N) {
@@ -468,12 +532,17 @@ __global__ void skinny16_colsum_kernel(const float* __restrict__ dy, float* __re
     dbias[n] = s;
 }
 extern "C" int cmu_skinny16_gemm_wgrad(const float* dy, const float* x, float* dw, float* dbias, int M, int N, int64_t K, int dt, void* stream) {
-    CMU_CHECK_ARG(dy && x && dw && M >= 1 && M <= 32 && N >= 1 && K >= 4 && K % 4 == 0 && (dt == CMU_F16 || dt == CMU_BF16),
-                  "cmu_skinny16_gemm_wgrad: needs 1 <= M <= 32, K %% 4 == 0, dt f16 / bf16 (M=%d, K=%lld, dt=%d)", M, (long long)K, dt);
+    CMU_CHECK_ARG(dy && x && dw && M >= 1 && M <= SK16_MAX_M && N >= 1 && K >= 4 && K % 4 == 0 && (dt == CMU_F16 || dt == CMU_BF16),
+                  "cmu_skinny16_gemm_wgrad: needs 1 <= M <= 256, K %% 4 == 0, dt f16 / bf16 (M=%d, K=%lld, dt=%d)", M, (long long)K, dt);
     CMU_CHECK_ARG(cmu_aligned16(x) && cmu_aligned16(dw), "cmu_skinny16_gemm_wgrad: x / dw must be 16-byte aligned");
     const dim3 grid((unsigned)cmu_div_up64(K, 512), cmu_div_up(N, 32 * SK16W_NT));
-    if (dt == CMU_F16) hipLaunchKernelGGL((skinny16_wgrad_kernel<F16Traits>), grid, dim3(256), 0, (hipStream_t)stream, dy, x, dw, M, N, K);
-    else hipLaunchKernelGGL((skinny16_wgrad_kernel<BF16Traits>), grid, dim3(256), 0, (hipStream_t)stream, dy, x, dw, M, N, K);
+    if (dt == CMU_F16) {
+        if (M <= 32) hipLaunchKernelGGL((skinny16_wgrad_kernel<F16Traits, false>), grid, dim3(256), 0, (hipStream_t)stream, dy, x, dw, M, N, K);
+        else hipLaunchKernelGGL((skinny16_wgrad_kernel<F16Traits, true>), grid, dim3(256), 0, (hipStream_t)stream, dy, x, dw, M, N, K);
+    } else {
+        if (M <= 32) hipLaunchKernelGGL((skinny16_wgrad_kernel<BF16Traits, false>), grid, dim3(256), 0, (hipStream_t)stream, dy, x, dw, M, N, K);
+        else hipLaunchKernelGGL((skinny16_wgrad_kernel<BF16Traits, true>), grid, dim3(256), 0, (hipStream_t)stream, dy, x, dw, M, N, K);
+    }
     CMU_CHECK_LAUNCH("cmu_skinny16_gemm_wgrad");
     if (dbias != nullptr) {
         hipLaunchKernelGGL(skinny16_colsum_kernel, dim3(cmu_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, dy, dbias, M, N);

@@ -6,7 +6,10 @@
 //   fwd    y  (M,N) = x (M,K) . w (N,K)^T (+ bias)     [nn.Linear]
 //   dgrad  dx (M,K) = dy (M,N) . w (N,K)
 //   wgrad  dw (N,K) = dy^T (N,M) . x (M,K),  dbias (N) = sum_m dy
-// for M <= 32 rows (one 32-row MFMA tile; more rows are a plain library GEMM and stay with rocBLAS on the host side).
+// for M <= 32 rows in one 32-row MFMA tile; up to SK_MAX_M = 256 rows (the reference's own batch size per GPU, cmunet_config.py:55,
+// moco2_module.py:91) as row groups of 32 (round 4: nothing on the neck path dispatches into a library any more) -- forward and
+// input gradient take one pass over the weights per group, the weight gradient contracts over all groups inside one launch.  At
+// M = 256, K = 50,176, N = 1,536 that is 8 x 0.3 GB per product, ~0.5 ms: 1 % of the joint step at that batch size.
 // fp32 in, fp32 out on `v_mfma_f32_32x32x2_f32` (exact f32 products, f32 accumulation -- the reference computes these layers
 // in fp32): per wave 16-byte loads straight from HBM into the MFMA operand registers (lane l: row or column l & 31, four
 // consecutive k of half l >> 5, so MFMA j of a step contracts k = kb + j and kb + 4 + j), no LDS.  Each wave streams its own
@@ -16,6 +19,7 @@
 #include <stdlib.h>
 
 typedef float f32x4s __attribute__((ext_vector_type(4)));
+constexpr int SK_MAX_M = 256;      // rows per call (groups of 32)
 
 __device__ static inline f32x4s sk_ld4(const float* p, bool ok) {
     return ok ? *reinterpret_cast<const f32x4s*>(p) : f32x4s{0.f, 0.f, 0.f, 0.f};
@@ -124,11 +128,11 @@ static int skf_splits(int N, int64_t K, int64_t* kchunk) {
 }
 extern "C" int64_t cmu_skinny_gemm_ws_bytes(int M, int N, int64_t K) {
     int64_t kc;
-    return (int64_t)skf_splits(N, K, &kc) * M * N * (int64_t)sizeof(float);
+    return (int64_t)skf_splits(N, K, &kc) * (M < 32 ? M : 32) * N * (int64_t)sizeof(float);     // one slab, reused by every 32-row group
 }
 extern "C" int cmu_skinny_gemm_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int64_t K, void* ws, void* stream) {
-    CMU_CHECK_ARG(x && w && y && ws && M >= 1 && M <= 32 && N >= 1 && K >= 8 && K % 8 == 0, "cmu_skinny_gemm_fwd: needs 1 <= M <= 32, K %% 8 == 0 (M=%d, K=%lld)",
-                  M, (long long)K);
+    CMU_CHECK_ARG(x && w && y && ws && M >= 1 && M <= SK_MAX_M && N >= 1 && K >= 8 && K % 8 == 0, "cmu_skinny_gemm_fwd: needs 1 <= M <= %d, K %% 8 == 0 (M=%d, K=%lld)",
+                  SK_MAX_M, M, (long long)K);
     CMU_CHECK_ARG(cmu_aligned16(x) && cmu_aligned16(w), "cmu_skinny_gemm_fwd: x / w must be 16-byte aligned");
     int64_t kc;
     const int splits = skf_splits(N, K, &kc);
@@ -141,11 +145,15 @@ extern "C" int cmu_skinny_gemm_fwd(const float* x, const float* w, const float* 
         }
         attr_set.mark();
     }
-    hipLaunchKernelGGL(skinny_fwd_kernel, dim3(cmu_div_up(N, 128), splits), dim3(256), SKF_LDS_BYTES, (hipStream_t)stream, x, w, (float*)ws, M, N, K, kc);
-    CMU_CHECK_LAUNCH("cmu_skinny_gemm_fwd");
-    hipLaunchKernelGGL(skinny_fwd_reduce_kernel, dim3((unsigned)cmu_div_up64((int64_t)M * N, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)ws, bias, y, M, N, splits);
-    CMU_CHECK_LAUNCH("cmu_skinny_gemm_fwd(reduce)");
+    for (int m0 = 0; m0 < M; m0 += 32) {      // row groups of 32: the slab is reused (same stream: the group's reduce precedes the next kernel)
+        const int Mg = M - m0 < 32 ? M - m0 : 32;
+        hipLaunchKernelGGL(skinny_fwd_kernel, dim3(cmu_div_up(N, 128), splits), dim3(256), SKF_LDS_BYTES, (hipStream_t)stream, x + (int64_t)m0 * K, w,
+                           (float*)ws, Mg, N, K, kc);
+        CMU_CHECK_LAUNCH("cmu_skinny_gemm_fwd");
+        hipLaunchKernelGGL(skinny_fwd_reduce_kernel, dim3((unsigned)cmu_div_up64((int64_t)Mg * N, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)ws, bias, y + (int64_t)m0 * N, Mg, N, splits);
+        CMU_CHECK_LAUNCH("cmu_skinny_gemm_fwd(reduce)");
+    }
     return CMU_OK;
 }
 
@@ -202,21 +210,29 @@ __global__ void skinny_transpose_kernel(const float* __restrict__ a, float* __re
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < (int64_t)M * N) at[(i % N) * M + i / N] = a[i];
 }
-extern "C" int64_t cmu_skinny_gemm_bwd_ws_bytes(int M, int N) { return (int64_t)M * N * (int64_t)sizeof(float); }
+extern "C" int64_t cmu_skinny_gemm_bwd_ws_bytes(int M, int N) { return (int64_t)(M < 32 ? M : 32) * N * (int64_t)sizeof(float); }
 extern "C" int cmu_skinny_gemm_dgrad(const float* dy, const float* w, float* dx, int M, int N, int64_t K, void* ws, void* stream) {
-    CMU_CHECK_ARG(dy && w && dx && ws && M >= 1 && M <= 32 && N >= 1 && K >= 4 && K % 4 == 0, "cmu_skinny_gemm_dgrad: needs 1 <= M <= 32, K %% 4 == 0 (M=%d, K=%lld)",
-                  M, (long long)K);
+    CMU_CHECK_ARG(dy && w && dx && ws && M >= 1 && M <= SK_MAX_M && N >= 1 && K >= 4 && K % 4 == 0, "cmu_skinny_gemm_dgrad: needs 1 <= M <= %d, K %% 4 == 0 (M=%d, K=%lld)",
+                  SK_MAX_M, M, (long long)K);
     CMU_CHECK_ARG(cmu_aligned16(w) && cmu_aligned16(dx), "cmu_skinny_gemm_dgrad: w / dx must be 16-byte aligned");
-    hipLaunchKernelGGL(skinny_transpose_kernel, dim3((unsigned)cmu_div_up64((int64_t)M * N, 256)), dim3(256), 0, (hipStream_t)stream, dy, (float*)ws, M, N);
-    CMU_CHECK_LAUNCH("cmu_skinny_gemm_dgrad(transpose)");
-    hipLaunchKernelGGL(skinny_dgrad_kernel, dim3((unsigned)cmu_div_up64(K, 128)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, w, dx, M, N, K);
-    CMU_CHECK_LAUNCH("cmu_skinny_gemm_dgrad");
+    for (int m0 = 0; m0 < M; m0 += 32) {
+        const int Mg = M - m0 < 32 ? M - m0 : 32;
+        hipLaunchKernelGGL(skinny_transpose_kernel, dim3((unsigned)cmu_div_up64((int64_t)Mg * N, 256)), dim3(256), 0, (hipStream_t)stream, dy + (int64_t)m0 * N,
+                           (float*)ws, Mg, N);
+        CMU_CHECK_LAUNCH("cmu_skinny_gemm_dgrad(transpose)");
+        hipLaunchKernelGGL(skinny_dgrad_kernel, dim3((unsigned)cmu_div_up64(K, 128)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, w,
+                           dx + (int64_t)m0 * K, Mg, N, K);
+        CMU_CHECK_LAUNCH("cmu_skinny_gemm_dgrad");
+    }
     return CMU_OK;
 }
 
 // ---- weight gradient: wave = 32 rows n x 128 columns k; contraction over the M <= 32 rows (16 MFMA k-pairs) -----------------------
 // A operand: lane r holds dy[m = 2p + h][n0 + r] for the 16 pairs p (contiguous 128-byte reads of dy rows); B: x[m][4c .. 4c+3]
 constexpr int SKW_NT = 2;        // 32-row n tiles per wave and x fragment (halves the passes over x)
+// MULTI (round 4, M > 32): the contraction runs over row groups of 32 with both n tiles' accumulators live; the one-group form
+// keeps one tile's accumulators at a time (the shape the kernel was tuned for: the looped form measured 0.54 -> 1.00 ms on it)
+template <bool MULTI>
 __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw,
                                                           int M, int N, int64_t K) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -224,32 +240,68 @@ __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const float* __restri
     const int64_t kcol = ((int64_t)blockIdx.x * 4 + wave) * 128 + 4 * c;
     const bool kok = kcol < K;
     const int nbase = blockIdx.y * 32 * SKW_NT;
-    f32x4s xv[16];
-#pragma unroll
-    for (int p = 0; p < 16; ++p) {
-        const int m = 2 * p + h;
-        xv[p] = sk_ld4(x + (int64_t)(m < M ? m : 0) * K + kcol, kok && m < M);
-    }
-#pragma unroll
-    for (int t = 0; t < SKW_NT; ++t) {
-        const int n = nbase + 32 * t + c;       // A operand row of this lane
-        f32x16 acc[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = sk_zero();
+    if (!MULTI) {
+        f32x4s xv[16];
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             const int m = 2 * p + h;
-            const float a = (n < N && m < M) ? dy[(int64_t)m * N + n] : 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xv[p][j], acc[j], 0, 0, 0);
+            xv[p] = sk_ld4(x + (int64_t)(m < M ? m : 0) * K + kcol, kok && m < M);
         }
-        if (kok) {
+#pragma unroll
+        for (int t = 0; t < SKW_NT; ++t) {
+            const int n = nbase + 32 * t + c;       // A operand row of this lane
+            f32x16 acc1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc1[j] = sk_zero();
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const int m = 2 * p + h;
+                const float a = (n < N && m < M) ? dy[(int64_t)m * N + n] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xv[p][j], acc1[j], 0, 0, 0);
+            }
+            if (kok) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int nr = nbase + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;      // output row (D row = A row)
+                    if (nr < N) *reinterpret_cast<f32x4s*>(dw + (int64_t)nr * K + kcol) = f32x4s{acc1[0][e], acc1[1][e], acc1[2][e], acc1[3][e]};
+                }
+            }
+        }
+        return;
+    }
+    f32x16 acc[SKW_NT][4];
+#pragma unroll
+    for (int t = 0; t < SKW_NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = sk_zero();
+    for (int m0 = 0; m0 < M; m0 += 32) {      // row groups of 32 (one trip for the <= 32 rows the kernel was written for)
+        f32x4s xv[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int m = m0 + 2 * p + h;
+            xv[p] = sk_ld4(x + (int64_t)(m < M ? m : 0) * K + kcol, kok && m < M);
+        }
+#pragma unroll
+        for (int t = 0; t < SKW_NT; ++t) {
+            const int n = nbase + 32 * t + c;       // A operand row of this lane
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const int m = m0 + 2 * p + h;
+                const float a = (n < N && m < M) ? dy[(int64_t)m * N + n] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xv[p][j], acc[t][j], 0, 0, 0);
+            }
+        }
+    }
+    if (kok) {
+#pragma unroll
+        for (int t = 0; t < SKW_NT; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int nr = nbase + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;      // output row (D row = A row)
-                if (nr < N) *reinterpret_cast<f32x4s*>(dw + (int64_t)nr * K + kcol) = f32x4s{acc[0][e], acc[1][e], acc[2][e], acc[3][e]};
+                if (nr < N) *reinterpret_cast<f32x4s*>(dw + (int64_t)nr * K + kcol) = f32x4s{acc[t][0][e], acc[t][1][e], acc[t][2][e], acc[t][3][e]};
             }
-        }
     }
 }
 __global__ void skinny_colsum_kernel(const float* __restrict__ dy, float* __restrict__ dbias, int M, int N) {
@@ -260,11 +312,12 @@ __global__ void skinny_colsum_kernel(const float* __restrict__ dy, float* __rest
     dbias[n] = s;
 }
 extern "C" int cmu_skinny_gemm_wgrad(const float* dy, const float* x, float* dw, float* dbias, int M, int N, int64_t K, void* stream) {
-    CMU_CHECK_ARG(dy && x && dw && M >= 1 && M <= 32 && N >= 1 && K >= 4 && K % 4 == 0, "cmu_skinny_gemm_wgrad: needs 1 <= M <= 32, K %% 4 == 0 (M=%d, K=%lld)",
-                  M, (long long)K);
+    CMU_CHECK_ARG(dy && x && dw && M >= 1 && M <= SK_MAX_M && N >= 1 && K >= 4 && K % 4 == 0, "cmu_skinny_gemm_wgrad: needs 1 <= M <= %d, K %% 4 == 0 (M=%d, K=%lld)",
+                  SK_MAX_M, M, (long long)K);
     CMU_CHECK_ARG(cmu_aligned16(x) && cmu_aligned16(dw), "cmu_skinny_gemm_wgrad: x / dw must be 16-byte aligned");
-    hipLaunchKernelGGL(skinny_wgrad_kernel, dim3((unsigned)cmu_div_up64(K, 512), cmu_div_up(N, 32 * SKW_NT)), dim3(256), 0, (hipStream_t)stream, dy, x, dw,
-                       M, N, K);
+    const dim3 grid((unsigned)cmu_div_up64(K, 512), cmu_div_up(N, 32 * SKW_NT));
+    if (M <= 32) hipLaunchKernelGGL(skinny_wgrad_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dy, x, dw, M, N, K);
+    else hipLaunchKernelGGL(skinny_wgrad_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dy, x, dw, M, N, K);
     CMU_CHECK_LAUNCH("cmu_skinny_gemm_wgrad");
     if (dbias != nullptr) {
         hipLaunchKernelGGL(skinny_colsum_kernel, dim3(cmu_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, dy, dbias, M, N);

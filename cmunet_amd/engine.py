@@ -32,6 +32,7 @@ BN_MOMENTUM = 0.1
 _FUSE_HEAD = os.environ.get("CMU_HEAD_FUSE", "1") != "0"   # A/B: "0" = the head's input gradient is stored and re-read by cmu_bn_bwd_apply
 _FUSE_DGRAD_BN = os.environ.get("CMU_DGRAD_BN", "1")    # A/B: "0" = BN-backward sums as a separate pass, "64"/"128" = fused up to C
 _FUSE_POOL = os.environ.get("CMU_POOL_FUSE", "1") != "0"   # A/B: "0" = the pool's input gradient is stored and re-read by cmu_bn_bwd_apply
+_C1W_RECOMP = os.environ.get("CMU_C1W_RECOMP", "1") != "0"  # A/B: "0" = the first layer's weight gradient reads the raw output instead of recomputing it
 
 
 class _Scratch:
@@ -179,7 +180,8 @@ class UNetEngine:
         if training and (pbn + "num_batches_tracked") in sd:
             self._nbt.append(sd[pbn + "num_batches_tracked"])
         return {"pconv": pconv, "pbn": pbn, "x": x, "x_img": x_img, "mask": mask, "mps": mask_per_sample,
-                "y": out.with_transform(scale, shift, 0), "mean": mean, "invstd": invstd}
+                "y": out.with_transform(scale, shift, 0), "mean": mean, "invstd": invstd,
+                "w_ver": (w._version, w.data_ptr()) if x_img is not None else None}
 
     def _double_conv_fwd(self, sd, prefix, x, out2, training, x_img=None, mask=None, mask_per_sample=False, affine_out2=None):
         """DoubleConv (model.py:16-26).  ``out2``: where the second conv writes its raw output."""
@@ -248,7 +250,12 @@ class UNetEngine:
         dW = self._gbuf(s["pconv"] + "weight", w)
         if s["x_img"] is not None:
             wsb = self.scratch.get("wg", self.lib.cmu_conv3x3_c1_wgrad_ws_bytes(B, H, W, C))
-            ops.conv3x3_c1_wgrad_bn(s["x_img"], dA, y, y.scale, y.shift, s["mean"], s["invstd"], coef, dW, wsb, s["mask"], s["mps"])
+            # the raw output is recomputed from the image when the weights are still the ones the forward used (same bits, half
+            # the traffic of the pass); a parameter rewritten between forward and backward falls back to the stored tensor
+            same_w = (_C1W_RECOMP and s.get("w_ver") == (w._version, w.data_ptr())
+                      and getattr(self.lib, "cmu_conv3x3_c1_wgrad_bn_w", None) is not None)    # (older builds under CMU_LIB_PATH: A/B runs)
+            ops.conv3x3_c1_wgrad_bn(s["x_img"], dA, y, y.scale, y.shift, s["mean"], s["invstd"], coef, dW, wsb, s["mask"], s["mps"],
+                                    w=w.detach() if same_w else None)
         else:
             Cin = w.shape[1]
             wsb = self.scratch.get("wg", self.lib.cmu_conv3x3_wgrad_ws_bytes(B, H, W, Cin, C, self.dt))

@@ -69,7 +69,7 @@ class UNet_encoder(_MaskEncoder):
 
 
 class _QueueLogitsFn(torch.autograd.Function):
-    """l_neg = q @ queue (moco2_module.py:262, ``einsum("nc,ck->nk")``) for <= 32 query rows on the weight-streaming skinny
+    """l_neg = q @ queue (moco2_module.py:262, ``einsum("nc,ck->nk")``) for <= 256 query rows on the weight-streaming skinny
     kernels: the queue (D, K) is the matrix whose rows are contiguous in k -- the "input gradient" shape forward, the "forward"
     shape backward (dq = dl @ queue^T); exact fp32 products."""
 
@@ -85,10 +85,13 @@ class _QueueLogitsFn(torch.autograd.Function):
 
 
 def queue_logits(q, queue):
-    if q.is_cuda and q.dtype == torch.float32 and queue.dtype == torch.float32 and 1 <= q.shape[0] <= 32 and queue.is_contiguous() \
-            and queue.shape[1] % 8 == 0:
+    """``einsum("nc,ck->nk", [q, queue])`` of the non-fused ``Moco_v2.forward`` on the skinny kernels: up to
+    ``ops.SKINNY_MAX_ROWS`` = 256 query rows per GPU (the reference's batch size, moco2_module.py:91); no library GEMM behind it."""
+    if q.is_cuda and q.dtype == torch.float32 and queue.dtype == torch.float32 and 1 <= q.shape[0] <= ops.SKINNY_MAX_ROWS \
+            and queue.is_contiguous() and queue.shape[1] % 8 == 0:
         return _QueueLogitsFn.apply(q, queue)
-    return torch.einsum("nc,ck->nk", [q, queue])          # more than 32 rows: a plain library GEMM
+    raise RuntimeError(f"queue_logits: needs CUDA fp32 q (rows <= {ops.SKINNY_MAX_ROWS}) and a contiguous (D, K) queue with K % 8 == 0, "
+                       f"got q {tuple(q.shape)} {q.dtype} on {q.device}, queue {tuple(queue.shape)} (no library / CPU fallback)")
 
 
 class Moco_v2(nn.Module):

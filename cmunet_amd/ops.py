@@ -254,10 +254,15 @@ def conv3x3_c1_wgrad(x_bhw, dY, dW, ws, mask=None, mask_per_sample=False):
          B, H, W, dW.shape[0], dY.dt, _p(ws), _stream())
 
 
-def conv3x3_c1_wgrad_bn(x_bhw, dA, yraw, scale, shift, save_mean, save_invstd, coef, dW, ws, mask=None, mask_per_sample=False):
-    """First-layer weight gradient with the layer's BatchNorm+ReLU backward applied in registers (no dY in memory)."""
+def conv3x3_c1_wgrad_bn(x_bhw, dA, yraw, scale, shift, save_mean, save_invstd, coef, dW, ws, mask=None, mask_per_sample=False, w=None):
+    """First-layer weight gradient with the layer's BatchNorm+ReLU backward applied in registers (no dY in memory).  ``w``: the
+    layer's forward weights -- the raw output is then recomputed from the image instead of read from ``yraw`` (same bits)."""
     B, H, W = x_bhw.shape
     assert dA.dt == yraw.dt
+    if w is not None:
+        call("cmu_conv3x3_c1_wgrad_bn_w", _p(_f32c(x_bhw)), _p(mask), int(mask_per_sample), dA.ptr(), dA.ld, _p(_f32c(w)), _p(scale), _p(shift),
+             _p(save_mean), _p(save_invstd), _p(coef), _p(_f32c(dW)), B, H, W, dW.shape[0], dA.dt, _p(ws), _stream())
+        return
     call("cmu_conv3x3_c1_wgrad_bn", _p(_f32c(x_bhw)), _p(mask), int(mask_per_sample), dA.ptr(), dA.ld, yraw.ptr(), yraw.ld,
          _p(scale), _p(shift), _p(save_mean), _p(save_invstd), _p(coef), _p(_f32c(dW)), B, H, W, dW.shape[0], dA.dt, _p(ws),
          _stream())
@@ -669,10 +674,14 @@ def philox_normal(n, offset=0, seed=0, device="cuda"):
 
 
 # ---- skinny GEMMs of the necks ----------------------------------------------------------------------------------
+SKINNY_MAX_ROWS = 256      # csrc/skinny.hip SK_MAX_M: the reference's own batch size per GPU (cmunet_config.py:55, moco2_module.py:91)
+
+
 def skinny_eligible(x, weight):
-    """nn.Linear on <= 32 fp32 rows with K % 8 == 0: the weight-streaming kernels; anything else is a plain library GEMM."""
-    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2 and 1 <= x.shape[0] <= 32
-            and x.shape[1] % 8 == 0 and x.shape[1] >= 8)
+    """nn.Linear on <= SKINNY_MAX_ROWS fp32 rows with K % 8 == 0: what the weight-streaming kernels take (the product path has
+    no other GEMM: callers raise on anything else)."""
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2
+            and 1 <= x.shape[0] <= SKINNY_MAX_ROWS and x.shape[1] % 8 == 0 and x.shape[1] >= 8)
 
 
 def _mm16(compute_dt, K, need):

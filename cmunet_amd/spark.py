@@ -130,6 +130,7 @@ class SparK(_EngineOwner, nn.Module):
         # static loss scale of the fused step (set by pretrain.SparKPretrainer for f16 storage: a per-pixel loss gradient is
         # ~3e-7 at bs 32 x 512 x 512, below f16's normal range); the parameter gradients come out multiplied by it
         self.grad_scale = 1.0
+        self.keep_rec, self.last_rec = False, None      # keep_rec: the step leaves its decoder output (B,1,H,W) fp32 in last_rec (vis, tests)
         self.densify_projs = nn.ModuleList()
         self.mask_tokens = nn.ParameterList()
         e_widths, d_width = list(sparse_encoder.enc_feat_map_chs), dense_decoder.width
@@ -152,13 +153,40 @@ class SparK(_EngineOwner, nn.Module):
 
     def forward(self, inp_bchw, active_b1ff=None, vis=False):
         _require_cuda(inp_bchw, "SparK")
-        if vis:
-            raise NotImplementedError("vis=True (visualisation tensors) is not part of the training hot path")
         if active_b1ff is None:
             active_b1ff = self.mask(inp_bchw.shape[0], inp_bchw.device)
+        if vis:
+            # spark.py:124-128: (input, masked input, reconstruction pasted into the masked patches) -- a forward of the HIP path that
+            # keeps its decoder output, then the reference's own de-normalisation as element-wise glue (not a training path)
+            keep, self.keep_rec = self.keep_rec, True
+            try:
+                with torch.no_grad():
+                    self._step(inp_bchw, active_b1ff, need_grads=False)
+                rec = self.last_rec
+            finally:
+                self.keep_rec, self.last_rec = keep, None
+            r = self.downsample_raito
+            active_b1hw = active_b1ff.repeat_interleave(r, 2).repeat_interleave(r, 3)
+            inp = self.patchify(inp_bchw.float())
+            mean = inp.mean(dim=-1, keepdim=True)
+            var = (inp.var(dim=-1, keepdim=True) + 1e-6) ** .5
+            rec_bchw = self.unpatchify(self.patchify(rec) * var + mean)
+            return inp_bchw, inp_bchw * active_b1hw, torch.where(active_b1hw, inp_bchw.float(), rec_bchw)
         names, params = _param_args(self)
         need_grads = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         return _SparKFn.apply(self, inp_bchw, active_b1ff, need_grads, names, *params)
+
+    def patchify(self, bchw):
+        """spark.py:133-139: (B, C, H, W) -> (B, f*f, C*p*p)."""
+        p, h, w = self.downsample_raito, self.fmap_h, self.fmap_w
+        B, C = bchw.shape[:2]
+        return torch.einsum('bchpwq->bhwpqc', bchw.reshape(B, C, h, p, w, p)).reshape(B, h * w, C * p * p)
+
+    def unpatchify(self, bln):
+        """spark.py:141-148: the inverse of ``patchify``."""
+        p, h, w = self.downsample_raito, self.fmap_h, self.fmap_w
+        B, C = bln.shape[0], bln.shape[-1] // p ** 2
+        return torch.einsum('bhwpqc->bchpwq', bln.reshape(B, h, w, p, p, C)).reshape(B, C, h * p, w * p)
 
     # ---------------------------------------------------------------------------------------------
     def _ident(self, eng, C):
@@ -367,6 +395,8 @@ class SparK(_EngineOwner, nn.Module):
         skips = list(reversed(to_dec[1:]))                       # skips[i-1] belongs to up_conv{i}
         dctx = eng.decoder_forward(sd, to_dec[0], skips, training, dp, cats if into_cats else None, True)
         rec = dctx["logits"]                                     # (B,1,H,W)
+        if self.keep_rec:
+            self.last_rec = rec
         loss = torch.empty(1, dtype=torch.float32, device=eng.device)
         drec = torch.empty_like(rec) if need_grads else None
         ws = eng.scratch.get("sploss", eng.lib.cmu_spark_loss_ws_bytes(B, f))

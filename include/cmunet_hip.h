@@ -163,6 +163,12 @@ int cmu_conv3x3_c1_wgrad_bn(const float* x, const uint8_t* mask, int mask_per_sa
                             const void* yraw, int64_t ldy, const float* scale, const float* shift, const float* save_mean,
                             const float* save_invstd, const float* coef, float* dW, int B, int H, int W, int Cout, int dt,
                             void* ws, void* stream);
+/* Same, with the raw output recomputed from the image and the layer's forward weights w (Cout,1,3,3) instead of read: the bits
+ * cmu_conv3x3_c1_fwd stored (same FMA order, rounded through the storage type), half the HBM traffic of the pass.           */
+int cmu_conv3x3_c1_wgrad_bn_w(const float* x, const uint8_t* mask, int mask_per_sample, const void* dA, int64_t ldd,
+                              const float* w, const float* scale, const float* shift, const float* save_mean,
+                              const float* save_invstd, const float* coef, float* dW, int B, int H, int W, int Cout, int dt,
+                              void* ws, void* stream);
 
 /* MaxPool2d(2) backward fused with the skip-branch add: dA = unpool(dP) + dSkip (dSkip may be NULL).
  * The arg-max is recomputed from the raw output + transform (first max in row-major 2x2 order, as ATen). */
@@ -448,11 +454,14 @@ int cmu_philox_normal(double* out, int64_t n, uint64_t offset, uint64_t seed, vo
 int cmu_random_patch_mask(uint8_t* mask, int B, int H, int W, int patch, int n_mask, uint64_t seed, uint64_t offset, void* stream);
 
 /* ---- skinny (weight-streaming) GEMMs of the projector / predictor necks (nonlinear_neck.py:63-66, 95-101 with
- * cmunet_config.py:18-38: Linear(H*W -> 1536) on <= 32 rows per GPU) -- nn.Linear and its autograd, fp32, M <= 32:
+ * cmunet_config.py:18-38: Linear(H*W -> 1536)) -- nn.Linear and its autograd, fp32, M <= 256 rows per GPU (the reference's batch
+ * size, cmunet_config.py:55; moco2_module.py:91,262 for the queue logits), taken in groups of 32 rows (one 32-row MFMA tile):
  *   fwd    y (M,N) = x (M,K) . w (N,K)^T + bias (or NULL)      K % 8 == 0; ws: cmu_skinny_gemm_ws_bytes (split-K slab)
  *   dgrad  dx (M,K) = dy (M,N) . w (N,K)                        K % 4 == 0; ws: cmu_skinny_gemm_bwd_ws_bytes (dy transposed)
  *   wgrad  dw (N,K) = dy^T . x, dbias (N) = sum_m dy (or NULL)  K % 4 == 0
- * x, w, dx, dw 16-byte aligned, rows contiguous.  One pass over the weights each; v_mfma_f32_32x32x2_f32.                  */
+ * x, w, dx, dw 16-byte aligned, rows contiguous.  fwd / dgrad: one pass over the weights per group of 32 rows; wgrad: one
+ * launch contracting over all rows; v_mfma_f32_32x32x2_f32.  M > 256 is an argument error (there is no library GEMM behind
+ * these entries: the host side raises).                                                                                   */
 int64_t cmu_skinny_gemm_ws_bytes(int M, int N, int64_t K);
 int cmu_skinny_gemm_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int64_t K, void* ws, void* stream);
 int64_t cmu_skinny_gemm_bwd_ws_bytes(int M, int N);

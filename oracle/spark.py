@@ -98,10 +98,16 @@ def forward(inp_b1hw, active_b1ff, sd, mask_tokens, enc_prefix="sparse_encoder.s
     for k in range(n_up):
         x = U.up_block(x, to_dec[k + 1], sd, f"{dec_prefix}up_conv{n_up - k}.", "conv_transpose", training)
     rec = F.conv2d(x, sd[dec_prefix + "conv_last.weight"], sd[dec_prefix + "conv_last.bias"])
-    inp, recp = patchify(inp_b1hw, ratio), patchify(rec, ratio)
+    return recon_loss(inp_b1hw, rec, active_b1ff), rec
+
+
+def recon_loss(inp_b1hw, rec_b1hw, active_b1ff):
+    """spark.py:112-123: per-patch normalised L2 between the reconstruction and the input, averaged over the NON-active patches."""
+    ratio = inp_b1hw.shape[-1] // active_b1ff.shape[-1]
+    inp, recp = patchify(inp_b1hw, ratio), patchify(rec_b1hw, ratio)
     mean = inp.mean(dim=-1, keepdim=True)
     var = (inp.var(dim=-1, keepdim=True) + 1e-6) ** .5
     inp = (inp - mean) / var
     l2 = ((recp - inp) ** 2).mean(dim=2)
     non_active = active_b1ff.logical_not().int().view(active_b1ff.shape[0], -1)
-    return (l2 * non_active).sum() / (non_active.sum() + 1e-8), rec
+    return (l2 * non_active).sum() / (non_active.sum() + 1e-8)

@@ -22,6 +22,14 @@ import torch.nn.functional as F
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
+# Optional forward taps (tests only; None = the plain restatement).  An object with
+#   conv(key, y) -> y     called on every 3x3 conv's raw output (key = the conv's state-dict prefix, e.g. 'backbone.down_conv1.
+#                         double_conv.double_conv.0.'),
+#   act(key, z) -> a      called INSTEAD of relu(z) on that layer's BatchNorm output.
+# tests/test_gpu_pretrain.py::test_cmunet_joint_step_gate_forced_backward uses it to run the oracle's backward pass on the HIP
+# path's own forward values and ReLU gates (the gradient of a ReLU network is discontinuous in its weights: see that test).
+TAP = None
+
 
 def _bn(x, sd, p, training):
     rm, rv = sd[p + "running_mean"], sd[p + "running_var"]
@@ -35,8 +43,10 @@ def double_conv(x, sd, prefix, training=True):
     """model.py:16-26. ``prefix`` ends with 'double_conv.' (the nn.Sequential)."""
     for conv, bn in ((0, 1), (3, 4)):
         x = F.conv2d(x, sd[f"{prefix}{conv}.weight"], sd[f"{prefix}{conv}.bias"], padding=1)
+        if TAP is not None:
+            x = TAP.conv(f"{prefix}{conv}.", x)
         x = _bn(x, sd, f"{prefix}{bn}.", training)
-        x = F.relu(x)
+        x = F.relu(x) if TAP is None else TAP.act(f"{prefix}{conv}.", x)
     return x
 
 

@@ -180,6 +180,35 @@ def test_conv3x3_c1_wgrad_bn(ops, dt, masked):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", [(2, 20, 37, 32, 0), (1, 48, 64, 64, 1), (3, 33, 16, 64, 2), (2, 16, 16, 8, 0)])
+def test_conv3x3_c1_wgrad_bn_recomputed_output_is_bit_identical(ops, dt, case):
+    """cmu_conv3x3_c1_wgrad_bn_w (round 4): the layer's raw output recomputed from the image and the forward weights instead of
+    read -- the bits cmu_conv3x3_c1_fwd stored, so the weight gradient equals the reading form's bit for bit (partial tiles, several
+    tiles per workgroup, batch mask / per-sample mask)."""
+    from cmunet_amd import _lib
+    B, H, W, Cout, masked = case
+    g = torch.Generator().manual_seed(11 + Cout)
+    x = torch.randn(B, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, 1, 3, 3, generator=g) / 3).cuda()
+    dA = to_act(q(torch.randn(B, Cout, H, W, generator=g), dt, ops), dt, ops)
+    sc, sh = (torch.rand(Cout, generator=g) + 0.5).cuda(), (torch.randn(Cout, generator=g) * 0.3).cuda()
+    mu, istd = (torch.randn(Cout, generator=g) * 0.1).cuda(), (torch.rand(Cout, generator=g) + 0.5).cuda()
+    coef = (torch.randn(2, Cout, generator=g) * 0.1).cuda()
+    mask = None
+    if masked:
+        m = (torch.rand(B, H, W, generator=g) > 0.5).to(torch.uint8)
+        mask = (m[:1] if masked == 1 else m).contiguous().cuda()
+    y = ops.new_act(B, H, W, Cout, dt, "cuda")
+    ops.conv3x3_c1_fwd(x, w, y, None, mask, masked == 2)
+    ws = ws_bytes(_lib.lib().cmu_conv3x3_c1_wgrad_ws_bytes(B, H, W, Cout))
+    dW_read, dW_rec = torch.empty(Cout, 1, 3, 3, device="cuda"), torch.empty(Cout, 1, 3, 3, device="cuda")
+    ops.conv3x3_c1_wgrad_bn(x, dA, y, sc, sh, mu, istd, coef, dW_read, ws, mask, masked == 2)
+    ops.conv3x3_c1_wgrad_bn(x, dA, y, sc, sh, mu, istd, coef, dW_rec, ws, mask, masked == 2, w=w)
+    assert torch.equal(dW_read, dW_rec)
+    assert float(dW_read.abs().max()) > 0
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("with_skip", [True, False])
 def test_maxpool_bwd(ops, dt, with_skip):
     B, C, H, W = 2, 32, 8, 12

@@ -293,37 +293,130 @@ def test_training_step_reproducible_and_consistent(dt):
         assert (good, skipped) == (3, 0) and sc == 65536.0, (sc, good, skipped)
 
 
+def _spark_active(Bn, f, keep, seed):
+    g = torch.Generator().manual_seed(seed)
+    a = torch.zeros(Bn, f * f, dtype=torch.uint8)
+    for b in range(Bn):
+        a[b, torch.randperm(f * f, generator=g)[:keep]] = 1
+    return a.view(Bn, f, f)
+
+
+def _active_windows(pix, n, gen, win=8):
+    """(b, y0, x0) of win x win windows that contain active pixels: origins on active pixels shifted so that windows straddle patch
+    borders (where the gather / the tile list meets masked neighbours) and image borders."""
+    S = pix.shape[1]
+    idx = pix.nonzero()
+    out = []
+    while len(out) < n:
+        b, y, x = (int(v) for v in idx[int(torch.randint(0, idx.shape[0], (1,), generator=gen))])
+        y0 = min(max(y - int(torch.randint(0, win, (1,), generator=gen)), 0), S - win)
+        x0 = min(max(x - int(torch.randint(0, win, (1,), generator=gen)), 0), S - win)
+        out.append((b, y0, x0))
+    return out
+
+
+# SparK's sparse encoder at 512 x 512, mask 0.75 (f = 32: 256 of 1,024 patches active per image): the level shapes of config 5
+SPARK_LEVELS = [(64, 64, 512), (64, 128, 256), (128, 128, 256), (128, 256, 128), (256, 256, 128), (256, 512, 64), (512, 512, 64),
+                (512, 1024, 32), (1024, 1024, 32)]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("layer", SPARK_LEVELS)
+def test_spark_sparse_conv_kernels_sampled_windows_fp64(ops, layer, dt):
+    """Config 5's sparse 3x3 convolutions at the size its number is quoted on (bs 32, 512 x 512, 25 % of the patches active;
+    Spark/encoder.py:20-23: dense op, then ``*= active``): the kernel each level runs in ``SparK._step`` -- the persistent kernel
+    over the 16 x 32 tile list where the shape supports it (levels 1-2) and the gather-GEMM over the active-pixel list (levels 2-5)
+    -- forward and, with the flipped pack, data gradient, against float64 on sampled windows that contain active pixels (patch
+    and image borders included); pixels the kernels must not touch keep a sentinel."""
+    Cin, Cout, S = layer
+    f = 32
+    tdt = ops.TORCH_DT[ops.dt_code(dt)]
+    g = torch.Generator(device="cuda").manual_seed(31)
+    act = _spark_active(B, f, 256, seed=S + Cin).cuda()
+    pix = act.bool().repeat_interleave(S // f, 1).repeat_interleave(S // f, 2)
+    x = (torch.randn(B, S, S, Cin, generator=g, device="cuda") * pix.unsqueeze(-1)).to(tdt)        # masked input, as in SparK
+    dy = (torch.randn(B, S, S, Cout, generator=g, device="cuda") * pix.unsqueeze(-1)).to(tdt)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g, device="cuda") / (3 * Cin ** 0.5)
+    wq = w.to(tdt).double().cpu()
+    wq_t = wq.permute(1, 0, 2, 3).flip(2, 3).contiguous()
+    win = 8
+    n = int(max(6, min(48, 4e9 / (2.0 * win * win * 9 * Cin * Cout * 2))))
+    wins = _active_windows(pix.cpu(), n, torch.Generator().manual_seed(7), win)
+    ran = []
+    for kind in ("tiles", "rows"):
+        for flip in (False, True):
+            ci, co = (Cout, Cin) if flip else (Cin, Cout)
+            xin, wref = (dy, wq_t) if flip else (x, wq)
+            sup = ops.conv3x3_tiles_supported if kind == "tiles" else ops.conv3x3_rows_supported
+            if not sup(B, S, S, ci, co, dt):
+                continue
+            wp = ops.pack_conv3x3(w, dt, transpose_flip=flip)
+            out = ops.Act(torch.full((B, S, S, co), 7.0, dtype=tdt, device="cuda"))
+            if kind == "tiles":
+                tl = ops.TileList(act, S, S, 16, 32)
+                ops.conv3x3_fwd_tiles(ops.Act(xin), wp, out, tl)
+                on = pix.view(B, S // 16, 16, S // 32, 32).any(4).any(2)                       # listed tiles
+                cover = on.repeat_interleave(16, 1).repeat_interleave(32, 2)
+            else:
+                pl = ops.PixelList(act, S, S, max_rows=int(act.sum()) * (S // f) ** 2)
+                ops.conv3x3_fwd_rows(ops.Act(xin), wp, out, pl)
+                cover = pix
+            assert bool((out.buf[~cover] == 7.0).all()), (kind, flip, "a pixel outside the list was written")
+            worst = 0.0
+            for (b, y0, x0) in wins:
+                ref = F.conv2d(_halo(xin, b, y0, x0, win, S), wref)[0].permute(1, 2, 0)
+                got = out.buf[b, y0:y0 + win, x0:x0 + win].double().cpu()
+                m = cover[b, y0:y0 + win, x0:x0 + win].cpu()
+                assert bool(m.any())
+                e = (got - ref)[m].abs().max().item() / max(ref[m].abs().max().item(), 1e-6)
+                assert e <= TOL[dt], f"{kind} flip={flip} {layer} {dt}: window (b={b}, y={y0}, x={x0}) err {e:.3e}"
+                worst = max(worst, e)
+            ran.append(f"{kind}{'/dgrad' if flip else ''} {worst:.1e}")
+    assert ran, f"no sparse kernel serves {layer} at {dt}"
+    print(f"[fullsize spark {dt} {Cin}->{Cout}@{S}] {n} windows: " + ", ".join(ran) + f" (tol {TOL[dt]})")
+
+
 def test_spark_full_size_step_f16_mask075():
-    """BASELINE config 5 as stated: SparK sparse UNet at 512 x 512, mask ratio 0.75 (256 of 1,024 patches kept), fp16.  One
-    step at bs 8 with a static loss scale: finite, bitwise reproducible, a loss of the order of 1 (targets are patch-normalised)
-    and gradients of a sane size.  (Parity of the same configuration against the reference: the 128-pixel fixture
-    ``spark_unet_m75`` in tests/test_gpu_pretrain.py.)"""
+    """BASELINE config 5 as stated (Spark/spark.py:88-131 on the sparse UNet): bs 32, 512 x 512, mask ratio 0.75 (256 of 1,024 patches
+    kept), f16 storage, one fused SparKPretrainer step (LAMB) with the bench's static loss scale.  The loss equals the oracle's
+    patch-normalised masked L2 (oracle/spark.py::recon_loss = spark.py:112-123) evaluated on the HIP path's OWN decoder output and
+    active mask; two runs from the same seed agree bit for bit (loss, gradient arena, updated parameters); the gradients are finite
+    and of a sane size; the mask keeps exactly 256 patches per image."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    from cmunet_amd import spark as S
+    from cmunet_amd import pretrain as P, spark as S
+    from oracle import spark as OS
     dev = torch.device("cuda:0")
-    torch.manual_seed(0)
-    enc = S.build_sparse_encoder("unet_sparse", input_size=512, dtype="f16")
-    model = S.SparK(enc, S.UnetDecoder(dtype="f16"), mask_ratio=0.75, densify_norm="", dtype="f16").to(dev).train()
-    assert model.fmap_h == 32 and model.len_keep == 256
     g = torch.Generator().manual_seed(3)
-    x = torch.randn(8, 1, 512, 512, generator=g).to(dev)
-    active = model.mask(8, dev, g)
-    assert active.view(8, -1).sum(1).tolist() == [256] * 8
+    x = torch.randn(B, 1, 512, 512, generator=g).to(dev)
 
     def run():
-        model.zero_grad()
-        model.grad_scale = 4096.0
-        loss = model(x, active_b1ff=active)
-        loss.backward()
-        return float(loss), torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None])
-    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
-    l1, g1 = run()
-    model.load_state_dict(sd0)
-    l2, g2 = run()
-    assert l1 == l2 and torch.equal(g1, g2) and torch.isfinite(g1).all() and 0.3 < l1 < 3.0, (l1, l2)
-    gn = float(g1.norm()) / 4096.0
-    assert 1e-3 < gn < 1e3, gn
+        torch.manual_seed(0)
+        enc = S.build_sparse_encoder("unet_sparse", input_size=512, dtype="f16")
+        model = S.SparK(enc, S.UnetDecoder(dtype="f16"), mask_ratio=0.75, densify_norm="", dtype="f16").to(dev).train()
+        assert model.fmap_h == 32 and model.len_keep == 256
+        active = model.mask(B, dev, torch.Generator().manual_seed(5))
+        tr = P.SparKPretrainer(model, lr=2e-4)
+        model.keep_rec = True
+        loss = float(tr.step(x, active_b1ff=active, loss_scale=4096.0))
+        return model, tr, active, loss, model.last_rec.detach().clone()
+
+    model, tr, active, loss, rec = run()
+    assert active.view(B, -1).sum(1).tolist() == [256] * B
+    ref = float(OS.recon_loss(x.float().cpu(), rec.float().cpu(), active.cpu()))
+    assert abs(loss - ref) <= 2e-4 * max(1.0, abs(ref)), (loss, ref)
+    assert 0.3 < loss < 3.0, loss
+    gn = float(tr.flat.grad.norm()) / 4096.0
+    assert bool(torch.isfinite(tr.flat.grad).all()) and 1e-3 < gn < 1e3, gn
+    model2, tr2, active2, loss2, rec2 = run()
+    assert torch.equal(active2, active) and loss2 == loss and torch.equal(rec2, rec)
+    assert torch.equal(tr2.flat.grad, tr.flat.grad) and torch.equal(tr2.flat.arena, tr.flat.arena)
+    # vis=True (spark.py:124-128): input, masked input, reconstruction pasted into the masked patches -- from the same decoder output
+    model.eval()
+    inp, masked, rec_or_inp = model(x[:2], active_b1ff=active[:2], vis=True)
+    a_hw = active[:2].repeat_interleave(16, 2).repeat_interleave(16, 3)
+    assert torch.equal(masked, x[:2] * a_hw) and torch.equal(rec_or_inp[a_hw], x[:2][a_hw]) and bool(torch.isfinite(rec_or_inp).all())
+    print(f"[fullsize spark step f16 bs {B}] loss {loss:.6f} vs oracle recon_loss on the HIP path's decoder output {ref:.6f}")
 
 
 # ---------------------------------------------------------------------------------------------------------------------

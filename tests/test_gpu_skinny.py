@@ -1,5 +1,5 @@
 """Weight-streaming GEMMs of the projector / predictor necks (csrc/skinny.hip) against torch float64:
-y = x.w^T + b, dx = dy.w, dw = dy^T.x, db = sum dy for <= 32 rows.  fp32 MFMA products with fp32 accumulation: tolerance
+y = x.w^T + b, dx = dy.w, dw = dy^T.x, db = sum dy for <= 256 rows (groups of 32).  fp32 MFMA products with fp32 accumulation: tolerance
 1e-5 relative to the result's scale times sqrt(K) growth (written below)."""
 import pytest
 import torch
@@ -22,7 +22,10 @@ def _close(got, ref, K, what):
 
 
 @pytest.mark.parametrize("M,K,N,bias", [(32, 50176, 1536, True), (32, 1536, 256, False), (5, 104, 70, True), (1, 8, 1, False),
-                                        (17, 4096, 33, True), (32, 40, 128, False)])
+                                        (17, 4096, 33, True), (32, 40, 128, False),
+                                        # round 4: more than one 32-row group (the reference's batch sizes: 64 and 256 per GPU)
+                                        (33, 3136, 96, True), (64, 50176, 1536, True), (256, 12544, 1536, False), (256, 1536, 256, True),
+                                        (100, 104, 70, True), (256, 4096, 1024, False)])
 def test_skinny_gemm_three_products(ops, M, K, N, bias):
     g = torch.Generator().manual_seed(M * 7 + N)
     x = torch.randn(M, K, generator=g)
@@ -41,38 +44,60 @@ def test_skinny_gemm_three_products(ops, M, K, N, bias):
     assert torch.equal(y, y2)                                   # fixed-order split-K: bitwise reproducible
 
 
-def test_neck_linear_autograd_matches_library_gemm(ops):
-    """The necks' Linear through the skinny kernels (<= 32 rows) and through the library GEMM (more rows) agree with
-    torch.nn.functional.linear in value and in all three gradients."""
+def test_neck_linear_autograd_vs_float64(ops):
+    """The necks' Linear through the skinny kernels as an autograd node, one to eight 32-row groups: value and all three
+    gradients against float64 products on the CPU (round 4: there is no library GEMM in the product to compare with or to fall
+    back to -- more than ops.SKINNY_MAX_ROWS rows, or a K that is not a multiple of 8, raises)."""
     from cmunet_amd.cmunet import neck_linear
     torch.manual_seed(3)
     fc = torch.nn.Linear(3136, 96, bias=True).cuda()
-    for rows in (8, 32, 48):
+    w64, b64 = fc.weight.detach().double().cpu(), fc.bias.detach().double().cpu()
+    for rows in (8, 32, 33, 48, 64, 256):
         x = torch.randn(rows, 3136, device="cuda", requires_grad=True)
         go = torch.randn(rows, 96, device="cuda")
         fc.zero_grad()
         y = neck_linear(fc, x)
         y.backward(go)
-        got = (y.detach().clone(), x.grad.clone(), fc.weight.grad.clone(), fc.bias.grad.clone())
-        x2 = x.detach().clone().requires_grad_(True)
-        fc.zero_grad()
-        y2 = torch.nn.functional.linear(x2, fc.weight, fc.bias)
-        y2.backward(go)
-        for a, b_, what in zip(got, (y2.detach(), x2.grad, fc.weight.grad, fc.bias.grad), ("y", "dx", "dw", "db")):
-            assert (a - b_).abs().max().item() <= 2e-5 * max(1.0, b_.abs().max().item()), (rows, what)
+        xd, gd = x.detach().double().cpu(), go.double().cpu()
+        refs = (xd @ w64.t() + b64, gd @ w64, gd.t() @ xd, gd.sum(0))
+        for a, b_, what in zip((y.detach(), x.grad, fc.weight.grad, fc.bias.grad), refs, ("y", "dx", "dw", "db")):
+            assert (a.double().cpu() - b_).abs().max().item() <= 2e-5 * max(1.0, b_.abs().max().item()), (rows, what)
+    with pytest.raises(RuntimeError, match="no library"):
+        neck_linear(fc, torch.randn(ops.SKINNY_MAX_ROWS + 1, 3136, device="cuda"))
+    with pytest.raises(RuntimeError, match="no library"):
+        neck_linear(torch.nn.Linear(20, 8).cuda(), torch.randn(4, 20, device="cuda"))
+
+
+def test_queue_logits_rows_beyond_one_group_vs_float64(ops):
+    """Moco_v2.forward's l_neg = q @ queue (moco2_module.py:262) at the reference's batch size (256 rows per GPU) on the skinny
+    kernels, value and dq against float64; more rows raise (no einsum behind it)."""
+    from cmunet_amd.moco import queue_logits
+    g = torch.Generator().manual_seed(9)
+    queue = torch.nn.functional.normalize(torch.randn(128, 4096, generator=g), dim=0).cuda()
+    for rows in (32, 40, 256):
+        q = torch.nn.functional.normalize(torch.randn(rows, 128, generator=g), dim=1).cuda().requires_grad_(True)
+        go = torch.randn(rows, 4096, generator=g).cuda()
+        l = queue_logits(q, queue)
+        l.backward(go)
+        ref = q.detach().double().cpu() @ queue.double().cpu()
+        refd = go.double().cpu() @ queue.double().cpu().t()
+        assert (l.double().cpu() - ref).abs().max().item() <= 2e-6 and (q.grad.double().cpu() - refd).abs().max().item() <= 2e-5 * refd.abs().max().item()
+    with pytest.raises(RuntimeError, match="no library"):
+        queue_logits(torch.randn(257, 128, device="cuda"), queue)
 
 
 def test_skinny_rejects_what_it_cannot_do(ops):
     from cmunet_amd._lib import CmuError
     with pytest.raises(CmuError):
-        ops.skinny_gemm_fwd(torch.randn(33, 64, device="cuda"), torch.randn(8, 64, device="cuda"))
+        ops.skinny_gemm_fwd(torch.randn(257, 64, device="cuda"), torch.randn(8, 64, device="cuda"))
     with pytest.raises(CmuError):
         ops.skinny_gemm_fwd(torch.randn(4, 20, device="cuda"), torch.randn(8, 20, device="cuda"))
 
 
 @pytest.mark.parametrize("cdt", ["f16", "bf16"])
 @pytest.mark.parametrize("M,K,N,bias", [(32, 50176, 1536, True), (32, 1536, 256, False), (5, 112, 70, True), (1, 16, 1, False),
-                                        (17, 4096, 33, True), (32, 48, 128, False)])
+                                        (17, 4096, 33, True), (32, 48, 128, False),
+                                        (33, 3136, 96, True), (64, 50176, 1536, True), (256, 12544, 1536, False), (100, 112, 70, True)])
 def test_skinny16_gemm_three_products(ops, M, K, N, bias, cdt):
     """16-bit-operand variants (csrc/necks.hip; the AMP arithmetic of cmunet_config.py:76-78): the operands are rounded to
     f16 / bf16 in registers and multiplied into fp32 -- against float64 products of the SAME rounded operands the error is
