@@ -332,6 +332,61 @@ def build_workload(name, args, dev, rank, world):
     raise SystemExit(f"unknown workload {name}")
 
 
+def rank_plan(args, env):
+    """What this rank will do, derived from the launcher's environment alone (no GPU, no process group): the torch.distributed
+    coordinates, the device it binds, and the workload's data-parallel invariants -- per-GPU batch fixed (weak scaling), the
+    reference's learning-rate rule lr * batch * gpus / 256 (cmunet_config.py:70-73, arg_util.py:133), and for MoCo the queue length a
+    multiple of the gathered key batch (moco2_module.py:169: ``assert self.hparams.num_negatives % batch_size == 0`` on B * world keys)."""
+    world = int(env.get("WORLD_SIZE", "1"))
+    rank = int(env.get("RANK", "0"))
+    local_rank = int(env.get("LOCAL_RANK", "0"))
+    # rehearsal knobs (one-GPU box): CMU_DIST_BACKEND=gloo CMU_SINGLE_DEVICE=1 run all ranks on cuda:0 over gloo
+    backend = env.get("CMU_DIST_BACKEND", "nccl")
+    single_dev = env.get("CMU_SINGLE_DEVICE", "0") == "1"
+    dev_index = 0 if (world == 1 or single_dev) else local_rank
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not (0 <= rank < world and 0 <= local_rank < world):
+        raise SystemExit(f"RANK={rank} / LOCAL_RANK={local_rank} outside WORLD_SIZE={world}")
+    plan = {"world": world, "rank": rank, "local_rank": local_rank, "backend": backend, "dev_index": dev_index,
+            "master": f"{env.get('MASTER_ADDR', '')}:{env.get('MASTER_PORT', '')}", "workload": args.workload,
+            "batch_per_gpu": args.batch, "global_batch": args.batch * world, "lr_rule": args.batch * world / 256.0,
+            "data_seed": 1234 + rank, "ipc_mode_legacy": env.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+    if args.workload == "moco":
+        K = 4096
+        plan["queue"] = {"K": K, "gathered_keys": args.batch * world, "divides": K % (args.batch * world) == 0}
+        if not plan["queue"]["divides"]:
+            raise SystemExit(f"MoCo queue of {K} is not a multiple of the gathered key batch {args.batch} x {world} (moco2_module.py:169)")
+    return plan
+
+
+def dry_run_env(plan, dist, torch):
+    """--dry-run-env: the ranks meet in a gloo group on the CPU (the launcher's own MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE),
+    prove the rendezvous with an all-reduce of ones, gather their plans on rank 0 and check them against each other: one device per
+    rank (LOCAL_RANK -> device index, all distinct), one rendezvous address, one workload and batch, distinct data seeds.  Returns
+    the exit status; rank 0 prints one JSON line."""
+    world, rank = plan["world"], plan["rank"]
+    if world > 1 or "MASTER_PORT" in os.environ:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        ones = torch.ones(1)
+        dist.all_reduce(ones)
+        plans = [None] * world
+        dist.all_gather_object(plans, plan)
+        seen = int(ones.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        plans, seen = [plan], 1
+    if rank != 0:
+        return 0
+    ok = (seen == world and sorted(p["rank"] for p in plans) == list(range(world))
+          and len({p["master"] for p in plans}) == 1 and len({(p["workload"], p["batch_per_gpu"], p["global_batch"], p["lr_rule"]) for p in plans}) == 1
+          and len({p["data_seed"] for p in plans}) == world
+          and (world == 1 or os.environ.get("CMU_SINGLE_DEVICE", "0") == "1" or sorted(p["dev_index"] for p in plans) == list(range(world))))
+    print(json.dumps({"dry_run_env": True, "ok": bool(ok), "ranks_seen": seen, "plans": plans}), flush=True)
+    return 0 if ok else 3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -350,6 +405,10 @@ def main():
     ap.add_argument("--gemm-events-only", action="store_true", help="(default behaviour; kept for scripts)")
     ap.add_argument("--graph", action="store_true", help="capture the step of each pre-staged batch in a hipGraph and replay it "
                     "(experiment: removes the host's ~230 launches per step; implies --no-kernel-events)")
+    ap.add_argument("--dry-run-env", action="store_true",
+                    help="rehearse the launch up to the first GPU call: every rank derives its plan from the environment (device index, "
+                         "batch, learning-rate rule, queue divisibility), the ranks meet in a CPU (gloo) group, compare their plans and "
+                         "rank 0 prints them as one JSON line -- no GPU is touched (tests/test_cpu_distributed.py runs --gpus 8 this way)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -357,17 +416,12 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from cmunet_amd import _lib
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # rehearsal knobs (one-GPU box): CMU_DIST_BACKEND=gloo CMU_SINGLE_DEVICE=1 run all ranks on cuda:0 over gloo
-    backend = os.environ.get("CMU_DIST_BACKEND", "nccl")
-    single_dev = os.environ.get("CMU_SINGLE_DEVICE", "0") == "1"
-    dev_index = 0 if (world == 1 or single_dev) else local_rank
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    plan = rank_plan(args, os.environ)
+    world, rank, local_rank, backend, dev_index = plan["world"], plan["rank"], plan["local_rank"], plan["backend"], plan["dev_index"]
+    if args.dry_run_env:
+        sys.exit(dry_run_env(plan, dist, torch))
+    from cmunet_amd import _lib
     # CMU_DP_REHEARSE=1 under a launcher with one rank: the RCCL group is built and every collective of the step runs on it
     use_dist = world > 1 or (os.environ.get("CMU_DP_REHEARSE", "0") == "1" and "WORLD_SIZE" in os.environ)
     if use_dist:
@@ -422,10 +476,19 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     _lib.PROFILER = None
+    rccl = None
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # proof that the collective library saw N ranks (not just WORLD_SIZE in the environment): an all-reduce of ones, the group's
+        # own world size and backend, and what the last step's gradient exchange looked like (buckets started inside the backward)
+        ones = torch.ones(1, dtype=torch.float32, device=dev)
+        dist.all_reduce(ones)
+        rccl = {"world": dist.get_world_size(), "ranks_seen": int(round(float(ones.item()))), "backend": str(dist.get_backend()),
+                "exchange": getattr(tr, "last_exchange", None)}
+        if rccl["world"] != world or rccl["ranks_seen"] != world:
+            raise SystemExit(f"process group saw {rccl['ranks_seen']} of {rccl['world']} ranks, WORLD_SIZE={world}")
     loss_val = float(loss.reshape(-1)[0].item())
 
     metric = {"recon": "pretrain images/sec/node at 512x512 (CM-UNet masked-reconstruction step)",
@@ -442,7 +505,7 @@ def main():
         "metric": metric,
         "value": round(B * world * args.steps / elapsed, 3),
         "unit": "images/sec",
-        "n_gpus": world,
+        "n_gpus": rccl["world"] if rccl is not None else world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(1000.0 * elapsed / args.steps, 3),
@@ -453,6 +516,8 @@ def main():
         "data": "synthetic (seeded randn images, random 16x16 patch masks; random-init weights)",
         "config": cfg,
     }
+    if rccl is not None:
+        out["rccl"] = rccl
     if rank == 0 and prof is not None:
         summ = prof.summary()
         tot_ms = sum(v["ms"] for v in summ.values())

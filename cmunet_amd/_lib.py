@@ -52,6 +52,7 @@ _SIGS = {
     "cmu_pack_desc_blocks": (_L, [_I, _I, _I, _I, _I]),
     "cmu_pack_batch": (_I, [_P, _I, _L, _I, _P]),
     "cmu_version": (_I, []),
+    "cmu_set_dispatch_override": (_I, [ctypes.c_char_p, _I]),
     "cmu_mfma_sustained_rate": (_I, [_I, _I, _I, _I, _P, _P, _P, _P]),
     "cmu_dtype_size": (_I, [_I]),
     "cmu_pack_conv3x3_elems": (_L, [_I, _I, _I, _I]),

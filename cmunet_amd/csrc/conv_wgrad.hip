@@ -626,11 +626,10 @@ static int wgrad3_wide_t(WGParams p, float* dW, hipStream_t st) {
 }
 
 // 64 n x 64 c form for the 16-bit dtypes (conv_wgrad2s.inc): whole 64-blocks on both sides where neither form above applies (the
-// 64 -> 64 layers).  CMU_WGRAD_SQUARE=0 keeps them on the first kernel (A/B switch, read per launch).
+// 64 -> 64 layers).  CMU_WGRAD_SQUARE=0 keeps them on the first kernel (A/B switch: environment read once, cmu_set_dispatch_override in tests).
 static bool wg2s_shape_ok(int CA, int CB, int dt) {
     static const bool wide = []() { const char* e = getenv("CMU_WGRAD_WIDE"); return !(e && e[0] == '0'); }();
-    const char* e = getenv("CMU_WGRAD_SQUARE");
-    return wide && !(e && e[0] == '0') && cmu_dtype_size(dt) == 2 && CA % 64 == 0 && CB % 64 == 0 && !wg2_shape_ok(CA, CB, dt) &&
+    return wide && cmu_switch_on(CMU_SW_WGRAD_SQUARE) && cmu_dtype_size(dt) == 2 && CA % 64 == 0 && CB % 64 == 0 && !wg2_shape_ok(CA, CB, dt) &&
            !wg2_swap_ok(CA, CB, dt);
 }
 static void wg2s_geometry(int B, int H, int W, int CA, int CB, WGParams& p) {
@@ -671,11 +670,10 @@ static int wgrad3_square_t(WGParams p, float* dW, hipStream_t st) {
 }
 
 // fp32 wide kernel (conv_wgrad2f.inc): Cout and Cin in whole 64-blocks (128 n x 64 c blocks when Cout allows, else 64 x 64 with two
-// k-parts).  CMU_WGRAD_WIDE_F32=0 keeps fp32 on the first kernel (A/B switch, read per launch for the tests).
+// k-parts).  CMU_WGRAD_WIDE_F32=0 keeps fp32 on the first kernel (A/B switch: environment read once, cmu_set_dispatch_override in tests).
 static bool wg2f_shape_ok(int CA, int CB, int dt) {
     static const bool wide = []() { const char* e = getenv("CMU_WGRAD_WIDE"); return !(e && e[0] == '0'); }();
-    const char* e = getenv("CMU_WGRAD_WIDE_F32");
-    return wide && !(e && e[0] == '0') && dt == CMU_F32 && CA % 64 == 0 && CB % 64 == 0;
+    return wide && cmu_switch_on(CMU_SW_WGRAD_WIDE_F32) && dt == CMU_F32 && CA % 64 == 0 && CB % 64 == 0;
 }
 static void wg2f_geometry(int B, int H, int W, int CA, int CB, WGParams& p) {
     p.tilesX = cmu_div_up(W, 16);

@@ -24,6 +24,33 @@ static thread_local const char* g_kernel_tag = "";
 void cmu_set_kernel_tag(const char* tag) { g_kernel_tag = tag; }
 extern "C" const char* cmu_last_kernel(void) { return g_kernel_tag; }
 extern "C" int cmu_version(void) { return 100; }
+
+// ---- dispatch switches (common.h: CmuSwitch) -----------------------------------------------------------------------------------
+static const char* const g_switch_names[CMU_SW_COUNT] = {"CMU_CONV_NARROW", "CMU_CONV_SLIM", "CMU_CONV_PERSIST_PART", "CMU_WGRAD_SQUARE",
+                                                         "CMU_WGRAD_WIDE_F32"};
+static int g_switch_env[CMU_SW_COUNT] = {-1, -1, -1, -1, -1};        // -1: environment not read yet; 0 / 1 afterwards
+static int g_switch_override[CMU_SW_COUNT] = {-1, -1, -1, -1, -1};   // -1: no override
+bool cmu_switch_on(int id) {
+    const int ov = __atomic_load_n(&g_switch_override[id], __ATOMIC_RELAXED);
+    if (ov >= 0) return ov != 0;
+    int v = __atomic_load_n(&g_switch_env[id], __ATOMIC_RELAXED);
+    if (v < 0) {
+        const char* e = getenv(g_switch_names[id]);
+        v = (e && e[0] == '0') ? 0 : 1;
+        __atomic_store_n(&g_switch_env[id], v, __ATOMIC_RELAXED);
+    }
+    return v != 0;
+}
+extern "C" int cmu_set_dispatch_override(const char* name, int value) {
+    CMU_CHECK_ARG(name != nullptr && value >= -1 && value <= 1, "cmu_set_dispatch_override: value must be -1 (environment), 0 or 1");
+    for (int i = 0; i < CMU_SW_COUNT; ++i)
+        if (strcmp(name, g_switch_names[i]) == 0) {
+            __atomic_store_n(&g_switch_override[i], value, __ATOMIC_RELAXED);
+            return CMU_OK;
+        }
+    cmu_set_error("cmu_set_dispatch_override: unknown switch '%s'", name);
+    return CMU_ERR_ARG;
+}
 extern "C" int cmu_dtype_size(int dt) { return dt == CMU_F32 ? 4 : (dt == CMU_F16 || dt == CMU_BF16) ? 2 : 0; }
 
 // ---------------------------------------------------------------------------------------------

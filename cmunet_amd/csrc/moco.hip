@@ -49,7 +49,9 @@ struct MocoParams {
 // narrower than the CU count (tools/cu_partition.py's masked streams) or beside another resident kernel that holds the CUs it needs
 // (an RCCL kernel on the process-group stream, several ranks sharing one card): do not run this entry concurrently with other
 // kernels.  So that such a misuse fails instead of hanging the GPU, the spin is BOUNDED (~2 s of s_sleep polls): on expiry the
-// workgroup raises bar[7], leaves the barrier, and the launch ends with loss = NaN (the trainers' inf / nan checks see it).
+// workgroup raises bar[7] and leaves the barrier; every workgroup reads that flag behind the last barrier and the launch then
+// ends with loss = NaN, dq = 0 (nothing computed on incomplete data reaches the optimiser), and the queue and its pointer
+// UNTOUCHED (advisor, round 3: they used to take the garbage keys).  pretrain.MocoPretrainer raises on the NaN loss.
 __device__ static inline void moco_grid_barrier(unsigned* counter, unsigned target, unsigned* timeout_flag) {
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -243,6 +245,15 @@ __global__ __launch_bounds__(256) void moco_fused_kernel(const MocoParams p) {
     moco_grid_barrier(p.bar + 3, G, p.bar + 7);
 
     // ---- P4: dq = (I - qn qn^T) (gpos kn + G) / |q|;  enqueue;  pointer;  loss ------------------------------------------------------
+    // (a barrier that timed out anywhere in the grid: every workgroup sees the flag here -- it is raised before the workgroup that
+    // gave up arrives at the counters the others wait on, and a waiting workgroup leaves its spin as soon as it is raised)
+    const bool timed_out = __hip_atomic_load(p.bar + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    if (timed_out) {
+        if (p.dq != nullptr)
+            for (int64_t o = (int64_t)blockIdx.x * 256 + tid; o < (int64_t)B * D; o += (int64_t)G * 256) p.dq[o] = 0.f;
+        if (blockIdx.x == 0 && tid == 0) p.loss[0] = __builtin_nanf("");
+        return;
+    }
     if (p.dq != nullptr) {
         for (int b = blockIdx.x; b < B; b += G) {
             const float qnorm = p.rowst[b * 4 + 0], gpos = p.rowst[b * 4 + 2];
@@ -274,8 +285,7 @@ __global__ __launch_bounds__(256) void moco_fused_kernel(const MocoParams p) {
     if (blockIdx.x == 0 && tid == 0) {
         double tot = 0.0;
         for (int r = 0; r < B; ++r) tot += (double)p.rowst[r * 4 + 3];
-        const bool timed_out = __hip_atomic_load(p.bar + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-        p.loss[0] = timed_out ? __builtin_nanf("") : (float)tot;
+        p.loss[0] = (float)tot;
         p.queue_ptr[0] = (int64_t)((ptr0 + p.Nk) % K);
     }
 }

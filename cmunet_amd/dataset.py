@@ -6,7 +6,9 @@ the reference, plus the synthetic generators used by bench.py and the tests (the
       (any callable with albumentations' ``aug(image=, mask=) -> {'image','mask'}`` protocol; the library itself
       is out of scope) -> PIL resize to 256x256 (bicubic / nearest) -> one-hot float64 mask.
       item = (image (256,256) float32, mask (n_cls,256,256) float64).
-  CMUNetDataset-style two-view items {'img','img_t'} (cmunet_dataset.py:60-88): ``two_view_item``.
+  CMUNetDataset(data_root, data_ann, pipeline, pixel=31, test=False)   cmae/datasets/cmunet_dataset.py:16-88: directory of ``.npy``
+      images, the reference's two train_test_split calls, items {'img','img_t'} built by ``two_view_item``.
+  MoCoDataset(data_path, tau_g)                                         moco/moco_data_set.py:11-37: item ((crop_0, crop_1), 0).
 """
 import numpy as np
 import torch
@@ -92,6 +94,115 @@ def two_view_item(img256, rng, pixel=31, out=224):
     b = shift_pixel_crop(img256, pixel, out, rng).astype(np.float32)
     b = b + rng.standard_normal(b.shape).astype(np.float32) * (float(b.max()) / 10.0)
     return {'img': a, 'img_t': b.astype(np.float32)}
+
+
+def train_test_split_indices(n, test_size, random_state):
+    """Index form of sklearn.model_selection.train_test_split(shuffle=True) for a float ``test_size`` (what
+    cmunet_dataset.py:30-31 calls twice): n_test = ceil(test_size * n), one permutation of a RandomState(random_state), the first
+    n_test indices are the test set, the rest the training set.  -> (train indices, test indices); checked against sklearn in
+    tests/test_cpu_surface.py."""
+    n_test = int(np.ceil(test_size * n))
+    n_train = n - n_test
+    if n_train <= 0:
+        raise ValueError(f"With n_samples={n} and test_size={test_size} the resulting train set will be empty")
+    perm = np.random.RandomState(random_state).permutation(n)
+    return perm[n_test:n_test + n_train], perm[:n_test]
+
+
+class _RandomResizedCropFlip:
+    """The two base transforms of configs/cmunet_config.py:48-51 on a 'img' results dict: RandomResizedCrop(scale 256,
+    crop_ratio_range (0.2, 1), pillow bicubic) + RandomFlip(0.5, horizontal).  (mmcv's transform classes are a third-party
+    dependency absent here; the crop law is ``random_resized_crop_params``, the resampling is Pillow's, as the config asks.)"""
+
+    def __init__(self, scale=256, crop_ratio_range=(0.2, 1.0), flip_prob=0.5, rng=None):
+        self.scale, self.crop_ratio_range, self.flip_prob = scale, crop_ratio_range, flip_prob
+        self.rng = rng if rng is not None else np.random
+
+    def __call__(self, results):
+        from PIL import Image
+        img = np.asarray(results['img'])
+        h, w = img.shape[:2]
+        x0, y0, cw, ch = random_resized_crop_params(h, w, self.rng, self.crop_ratio_range)
+        out = Image.fromarray(img).resize((self.scale, self.scale), resample=Image.BICUBIC, box=(x0, y0, x0 + cw, y0 + ch))
+        out = np.asarray(out)
+        if self.rng.uniform() < self.flip_prob:
+            out = out[:, ::-1]
+        return {'img': np.ascontiguousarray(out)}
+
+
+class CMUNetDataset(Dataset):
+    """cmae/datasets/cmunet_dataset.py:16-88, same constructor and item contract: ``data_root`` is a directory of ``.npy`` float
+    images; the file list is sorted, split 80 / 20 (random_state 42) and the training part once more 98.75 / 1.25 -- ``image_paths``
+    is that inner training part, ``test`` the 20 % (``test=`` itself is accepted and unused, as in the reference).
+    ``__getitem__`` -> {'img', 'img_t'}: np.load -> PIL bicubic resize to 256 x 256 -> base pipeline (first two entries:
+    RandomResizedCrop + RandomFlip) -> 'img' = ShiftPixel(0) crop, 'img_t' = ShiftPixel(<= pixel) crop + GaussNoise (always applied,
+    sigma = max / 10: SURVEY A-11) -> final pipeline (the entries after the first two).
+
+    ``pipeline``: None = the shipped configuration (cmunet_config.py:48-53) with tensors out; or a list whose entries are callables on
+    a results dict (mmengine-style config dicts need mmcv / mmengine, which are not part of this build: a dict entry raises).  The
+    whole-batch form that keeps the pixels in HBM is ``DeviceTwoViewPipeline``."""
+
+    def __init__(self, data_root, data_ann=None, pipeline=None, pixel=31, test=False, out=224, seed=None):
+        import os
+        self.data_root = data_root
+        paths = [os.path.join(data_root, f) for f in sorted(os.listdir(data_root))]
+        tr, te = train_test_split_indices(len(paths), 0.2, 42)
+        inner, _ = train_test_split_indices(len(tr), 0.0125, 42)
+        self.image_paths = [paths[tr[i]] for i in inner]
+        self.test = [paths[i] for i in te]
+        self.pixel, self.out = pixel, out
+        self.rng = np.random.RandomState(seed) if seed is not None else np.random
+        if pipeline is None:
+            base, final = [_RandomResizedCropFlip(256, (0.2, 1.0), 0.5, self.rng)], [lambda r: {'img': torch.from_numpy(np.ascontiguousarray(r['img']))}]
+        else:
+            for t in pipeline:
+                if not callable(t):
+                    raise TypeError("CMUNetDataset: pipeline entries must be callables on a results dict (config dicts need mmcv / mmengine)")
+            base, final = list(pipeline[:2]), list(pipeline[2:])
+        self.pipeline_base, self.pipeline_final = base, final
+
+    def __len__(self):
+        return len(self.image_paths)
+
+    @staticmethod
+    def _run(transforms, results):
+        for t in transforms:
+            results = t(results)
+        return results
+
+    def __getitem__(self, idx):
+        from PIL import Image
+        image = np.load(self.image_paths[idx])
+        image = np.asarray(Image.fromarray(image).resize((256, 256), resample=Image.BICUBIC))
+        src = self._run(self.pipeline_base, {'img': image})['img']
+        views = two_view_item(np.asarray(src, dtype=np.float32), self.rng, self.pixel, self.out)
+        patch = self._run(self.pipeline_final, {'img': views['img']})
+        img_t = self._run(self.pipeline_final, {'img': views['img_t']})
+        return {'img': patch['img'], 'img_t': img_t['img']}
+
+
+class MoCoDataset(Dataset):
+    """pl_bolts/models/self_supervised/moco/moco_data_set.py:11-37, same constructor and item contract: ``data_path`` is a LIST of
+    ``.npy`` paths, ``tau_g`` a list of (two) global transforms on a (1, 256, 256) tensor; item = ((crop_0, crop_1), 0) after
+    np.load -> PIL bicubic resize to 256 x 256."""
+
+    def __init__(self, data_path, tau_g):
+        self.tau_g = tau_g
+        self.data_path = data_path
+
+    def __len__(self):
+        return len(self.data_path)
+
+    def __str__(self):
+        return f"LoGoDataset with {self.__len__()} images"
+
+    def __getitem__(self, idx):
+        from PIL import Image
+        image = np.load(self.data_path[idx])
+        image = np.array(Image.fromarray(image).resize((256, 256), resample=Image.BICUBIC))
+        image = torch.from_numpy(image[np.newaxis, :])
+        crops = [t(image) for t in self.tau_g]
+        return (crops[0], crops[1]), 0
 
 
 class SyntheticTwoViewDataset(Dataset):

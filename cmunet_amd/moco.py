@@ -154,8 +154,11 @@ class Moco_v2(nn.Module):
         if K % n_keys != 0:
             raise AssertionError(f"num_negatives={K} must be a multiple of the enqueued batch {n_keys} (moco2_module.py:169)")
         sh = self.__dict__.get("_ptr_shadow")
-        if sh is None or sh[1] != n_keys or sh[2] != self.queue_ptr.data_ptr():
-            sh = [int(self.queue_ptr.item()), n_keys, self.queue_ptr.data_ptr()]
+        # (the fused kernel advances the pointer through its raw address: no version bump; an in-place edit by torch -- a non-fused
+        # _dequeue_and_enqueue on the training queue, queue_ptr.zero_() -- bumps it, and the shadow is re-read from the buffer)
+        ver = self.queue_ptr._version
+        if sh is None or sh[1] != n_keys or sh[2] != self.queue_ptr.data_ptr() or sh[3] != ver:
+            sh = [int(self.queue_ptr.item()), n_keys, self.queue_ptr.data_ptr(), ver]
         if sh[0] % n_keys != 0:
             raise RuntimeError(f"queue pointer {sh[0]} is not a multiple of the enqueued batch {n_keys}: the reference's "
                                "queue[:, ptr:ptr + bs] = keys.T (moco2_module.py:172) fails here too")
@@ -221,6 +224,45 @@ class Moco_v2(nn.Module):
         k_raw = self._encode_keys(img_k)
         return _MocoLossFn.apply(q_raw, k_raw, self.queue, self.queue_ptr, self.hparams["softmax_temperature"])
 
+
+    def _compute_l_s(self, output, target, keys, queue=None):
+        """moco2_module.py:272-285 (the non-fused form of the loss, kept for callers of the reference's API): enqueue ``keys`` into the
+        TRAINING queue -- the reference ignores its ``queue`` argument and always uses self.queue / self.queue_ptr -- then the
+        InfoNCE cross entropy of ``output`` (the logits of ``forward``) against ``target``."""
+        self._dequeue_and_enqueue(keys, queue=self.queue, queue_ptr=self.queue_ptr)
+        self.__dict__.pop("_ptr_shadow", None)       # the pointer moved outside the fused step: its host-side shadow is re-read
+        return F.cross_entropy(output.float(), target.long())
+
+    def configure_optimizers(self, max_epochs=None):
+        """moco2_module.py:338-349: SGD(lr, momentum, weight_decay) over the trainable parameters + cosine annealing over
+        ``max_epochs`` (the reference reads ``self.trainer.max_epochs``; without a Lightning trainer pass it here).  Returns
+        ([optimizer], [scheduler]) like the reference -- the optimiser is the fused one-launch SGD over a flat arena
+        (optim.FusedSGD, csrc/optim.hip), the scheduler an object with ``step()`` / ``get_last_lr()`` that follows
+        torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, max_epochs) (closed form, pretrain.moco_cosine_lr)."""
+        from .optim import FlatParams, FusedSGD
+        from .pretrain import moco_cosine_lr
+        if max_epochs is None:
+            tr = getattr(self, "trainer", None)
+            max_epochs = getattr(tr, "max_epochs", None)
+        if max_epochs is None:
+            raise ValueError("configure_optimizers: max_epochs is needed for the cosine schedule (moco2_module.py:346-348)")
+        want = {n for n, p in self.named_parameters() if p.requires_grad}
+        flat = FlatParams(self, names=lambda n: n in want)
+        hp = self.hparams
+        opt = FusedSGD(flat, lr=hp["learning_rate"], momentum=hp["momentum"], weight_decay=hp["weight_decay"])
+        opt.auto_gather = True          # loss.backward(); optimizer.step() as with torch.optim.SGD
+
+        class _Cosine:
+            def __init__(sched):
+                sched.base_lr, sched.epoch = hp["learning_rate"], 0
+
+            def step(sched):
+                sched.epoch += 1
+                opt.lr = moco_cosine_lr(sched.base_lr, sched.epoch, max_epochs)
+
+            def get_last_lr(sched):
+                return [opt.lr]
+        return [opt], [_Cosine()]
 
     @torch.no_grad()
     def validation_step(self, batch, batch_idx=0):

@@ -52,6 +52,22 @@ def mfma_sustained_rate(dt="f16", pattern=0, lds_fed=False, iters=60000, device=
     return tf.value, clk.value
 
 
+class dispatch_override:
+    """``with ops.dispatch_override("CMU_CONV_NARROW", 0): ...`` -- force one of the library's A/B dispatch switches for the
+    launches inside the block (cmu_set_dispatch_override; the switches' environment variables are read once, not per launch)."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name.encode(), int(value)
+
+    def __enter__(self):
+        call("cmu_set_dispatch_override", self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        call("cmu_set_dispatch_override", self.name, -1)
+        return False
+
+
 def _f32c(t):
     assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
     return t

@@ -152,8 +152,12 @@ class FlatParams:
         complete in a backward pass) apart from its down blocks."""
         if key is None:
             def key(n):
-                top, _, rest = n.partition(".")
-                return top + (".double_conv" if rest.startswith("double_conv.") else "")
+                top = n.partition(".")[0]
+                # the bottleneck is ``<prefix>double_conv.double_conv.*`` with no down / up block in front (backbone.double_conv...,
+                # sparse_encoder.sp_cnn.double_conv...): the down blocks are ``<prefix>down_convK.double_conv.double_conv.*``
+                i = n.find("double_conv.double_conv.")
+                bott = i >= 0 and "down_conv" not in n[:i] and "up_conv" not in n[:i]
+                return top + (".double_conv" if bott else "")
         out, cur = [], None
         for n in self.names:
             k = key(n)
@@ -288,6 +292,8 @@ class FusedSGD:
             p.grad = None
 
     def step(self, grad_scale=1.0):
+        if getattr(self, "auto_gather", False):      # used like a torch optimiser (Moco_v2.configure_optimizers): p.grad -> arena first
+            self.flat.gather_autograd_grads()
         self.step_count += 1
         ops.sgd_step(self.flat.arena, self.flat.grad, self.buf, self.wd_mask, self.lr, self.momentum, self.dampening,
                      self.weight_decay, self.nesterov, self.step_count, grad_scale)

@@ -56,6 +56,16 @@ def random_patch_mask_device(batch_size, H, W, patch_size=16, mask_ratio=0.65, g
     return m.repeat_interleave(patch_size, 1).repeat_interleave(patch_size, 2).contiguous()
 
 
+def default_amp(model, amp):
+    """``amp=None`` resolves by the model's storage type: f16 activations need the loss scaler (a masked-MSE gradient is ~1e-7 per
+    pixel at bs 32 x 512 x 512, below f16's smallest normal: without scaling it is flushed, silently), so the default for an
+    f16 model is the reference's own AmpOptimWrapper(loss_scale='dynamic') (cmunet_config.py:76-78); f32 / bf16 models default to no
+    scaler.  ``amp=False`` switches it off explicitly (advisor, round 3: the defaults did not compose)."""
+    if amp is None:
+        return ops.dt_code(getattr(model, "dtype", "f32")) == ops.F16
+    return amp
+
+
 class MaskedReconPretrainer:
     """One object = model + flat arenas + fused AdamW + (optional) data-parallel group."""
 
@@ -63,7 +73,8 @@ class MaskedReconPretrainer:
                  ref_compat=True, pred_channel=1, process_group=None, loss_scale=1.0, amp=None):
         """``amp``: True (or an ``ops.AmpScaler``) turns on the dynamic loss scaling of the reference's AmpOptimWrapper
         (cmunet_config.py:76-78; needed with f16 activations: a masked-MSE gradient is ~1e-7 per pixel at bs 32 x 512 x 512,
-        below f16's smallest normal) -- state and decisions stay on the device."""
+        below f16's smallest normal) -- state and decisions stay on the device.  None (default): on for an f16 model, off
+        otherwise (``default_amp``); False: off."""
         assert next(model.parameters()).is_cuda, "move the model to the GPU first"
         self.model = model.train()
         self.device = next(model.parameters()).device
@@ -76,6 +87,7 @@ class MaskedReconPretrainer:
         self.rc_weight, self.ref_compat, self.pred_channel = rc_weight, ref_compat, pred_channel
         self.group = process_group
         self.loss_scale = loss_scale
+        amp = default_amp(model, amp)
         self.amp = ops.AmpScaler(self.device) if amp is True else (amp or None)
         self.opt.amp = self.amp
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
@@ -123,14 +135,25 @@ class MaskedReconPretrainer:
                                self.rc_weight * self.loss_scale, self._ws, self.amp)
         eng.grad_target, eng.grad_prefix = self.flat.grad_views, ""
         self._pending = []
+        exch = dp_exchanges(self.group)
+        # what the exchange of this step looked like (bench.py prints it next to the RCCL world size): buckets, how many of them
+        # were started from inside the backward pass, bytes left for after it
+        self.last_exchange = {"buckets": 1 + (self._dec_off is not None) + (self._bott is not None), "early": 0, "in_backward": 0,
+                              "flushed": 0, "exposed_bytes": 4 * int(self.flat.grad.numel())}
 
         def decoder_done():
             if self._dec_off is not None:
                 self._pending.append(self.flat.all_reduce_range_async(self._dec_off, self.flat.grad.numel(), self.group))
+                if exch:
+                    self.last_exchange["early"] += 1
+                    self.last_exchange["exposed_bytes"] -= 4 * int(self.flat.grad.numel() - self._dec_off)
 
         def bottleneck_done():
             if self._bott is not None:
                 self._pending.append(self.flat.all_reduce_range_async(self._bott[0], self._bott[1], self.group))
+                if exch:
+                    self.last_exchange["early"] += 1
+                    self.last_exchange["exposed_bytes"] -= 4 * int(self._bott[1] - self._bott[0])
 
         try:
             eng.unet_backward(self.sd, ctx, self._dlogits, after_decoder=decoder_done, after_bottleneck=bottleneck_done)
@@ -226,7 +249,7 @@ class ArenaTrainer:
             b["pending"], b["launched"] = len(b["names"]), False
         self._works = []
         self._ov_active = True
-        self.last_exchange = {"buckets": len(self._buckets), "early": 0, "in_backward": 0, "flushed": 0}
+        self.last_exchange = {"buckets": len(self._buckets), "early": 0, "in_backward": 0, "flushed": 0, "exposed_bytes": 0}
 
     def _launch(self, b):
         """Gradients of bucket ``b`` are final: bring stragglers into the arena, start its all-reduce (async, on the group's stream)."""
@@ -273,6 +296,7 @@ class ArenaTrainer:
         for b in self._buckets:
             if not b["launched"]:
                 self.last_exchange["flushed"] += 1
+                self.last_exchange["exposed_bytes"] += 4 * int(b["hi"] - b["lo"])
                 self._launch(b)
         from .optim import _SINKS_CLAIMED
         _SINKS_CLAIMED.difference_update(id(p) for p in self.flat.params.values())
@@ -302,8 +326,10 @@ class ArenaTrainer:
             if b.is_floating_point():
                 dist.broadcast(b, src=src, group=self.group)
 
-    def backward_and_step(self, loss, loss_scale=1.0, amp=None, ema=None):
+    def backward_and_step(self, loss, loss_scale=1.0, amp=None, ema=None, overlap_begun=False):
         """``loss``: scalar tensor from the model's forward (already multiplied by ``loss_scale`` if one is used).
+        ``overlap_begun``: the caller opened the overlapped exchange before the FORWARD (SparK: its fused node produces the gradients
+        there) -- buckets may already be in flight.
         ``ema``: (segments, momentum) handed to the optimiser kernel (``FusedAdam.step``): the momentum networks' EMA in the same pass.
         ``amp``: an ``ops.AmpScaler`` -- dynamic loss scaling as mmengine's AmpOptimWrapper does it (cmunet_config.py:76-78): the loss
         is multiplied by the scale held ON THE DEVICE (no host read), the inf / nan check runs on the exchanged gradients, the
@@ -314,7 +340,8 @@ class ArenaTrainer:
             loss = loss * amp.state[:4].view(torch.float32)          # the current scale, a one-element device tensor
         scale = 1.0
         if self._overlap and dp_exchanges(self.group):
-            self._begin_overlap()
+            if not overlap_begun:
+                self._begin_overlap()
             try:
                 loss.backward()
             finally:
@@ -347,11 +374,13 @@ class JointPretrainer(ArenaTrainer):
 
     def __init__(self, model, lr=1.5e-4, betas=(0.9, 0.95), weight_decay=0.05, eps=1e-8, process_group=None, amp=None):
         """``amp``: True (or an ``ops.AmpScaler``): the dynamic loss scaling of the reference's AmpOptimWrapper (cmunet_config.py:76-78);
-        wanted with f16 activations (the masked-MSE gradient per pixel is far below f16's normals)."""
+        needed with f16 activations (the masked-MSE gradient per pixel is far below f16's normals).  None (default): on for an f16
+        model -- what ``cmunet_config()`` / ``CM_UNet`` default to --, off otherwise (``default_amp``); False: off."""
         model.train()
         flat = self.trainable(model)
         opt = FusedAdam(flat, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decoupled=True, decay_filter=no_decay_bias_norm)
         super().__init__(model, opt, process_group)
+        amp = default_amp(model, amp)
         self.amp = ops.AmpScaler(self.device) if amp is True else (amp or None)
         self.opt.amp = self.amp
         tnames = {n for n, _ in model.named_parameters() if n.startswith(("target_backbone.", "target_projector."))}
@@ -423,9 +452,18 @@ class MocoPretrainer(ArenaTrainer):
     def step(self, img_q, img_k, loss_scale=1.0):
         """``loss_scale``: static scale on the loss before backward (16-bit activations store their gradients in the model's dtype:
         the InfoNCE gradient reaches the first layers at ~1e-6 per element), divided out again by the SGD kernel."""
+        # the PREVIOUS step's loss is checked here (its kernels have finished long before the host gets back: no stall of the launch
+        # queue): the fused InfoNCE kernel ends with a NaN loss, a zero query gradient and an untouched queue when one of its
+        # grid barriers timed out (csrc/moco.hip) -- SGD has no inf / nan skip of its own, so that must not pass silently
+        prev = getattr(self, "_prev_loss", None)
+        if prev is not None and not bool(torch.isfinite(prev)):
+            self._prev_loss = None
+            raise RuntimeError("MocoPretrainer: the previous step's loss is not finite (a timed-out grid barrier of "
+                               "cmu_moco_infonce_enqueue -- was another kernel resident beside it? -- or an overflow)")
         loss = self.model.training_step((img_q, img_k))
         self.backward_and_step(loss * float(loss_scale) if loss_scale != 1.0 else loss, loss_scale)
-        return loss.detach()
+        self._prev_loss = loss.detach()
+        return self._prev_loss
 
 
 class SparKPretrainer(ArenaTrainer):
@@ -440,6 +478,10 @@ class SparKPretrainer(ArenaTrainer):
         opt = FusedLAMB(flat, lr=lr, betas=betas, weight_decay=weight_decay, max_grad_norm=clip,
                         decay_filter=lambda n, p: not (p.dim() == 1 or n.endswith(".bias") or any(k in n for k in nowd)))
         super().__init__(model, opt, process_group)
+        # round 4: SparK's fused node computes its gradients inside its FORWARD (spark._SparKFn) -- it announces the decoder, the
+        # bottleneck and each encoder level as their gradients land in the arena, so their all-reduces run under the rest of the
+        # step instead of back to back behind it (137 MB were exposed; now the down blocks' 19 MB + the mask tokens, as in the other trainers)
+        object.__setattr__(model, "_grads_ready", self.notify_ready)
 
     def anneal(self, peak_lr, wd, wd_end, cur_it, wp_it, max_it):
         """main.py:192: set this iteration's learning rate and weight decay (``spark_lr_wd``); returns them."""
@@ -451,11 +493,20 @@ class SparKPretrainer(ArenaTrainer):
         """``loss_scale``: static scale applied to the loss gradient INSIDE the fused step (the activations' gradients are
         stored in the model's dtype) and divided out again by the optimiser kernel."""
         self.model.grad_scale = float(loss_scale)
+        begun = self._overlap and dp_exchanges(self.group)
         try:
+            if begun:
+                for p in self.flat.params.values():
+                    p.grad = None
+                self._begin_overlap()                      # before the forward: that is where this model's gradients are produced
+                self.model._unit_backward = True           # loss.backward() below hands the node a gradient of exactly 1: no in-place
+                #                                            rescale of gradients whose all-reduce may be in flight
             loss = self.model(inp_bchw, active_b1ff=active_b1ff)
-            self.backward_and_step(loss, loss_scale)
+            self.backward_and_step(loss, loss_scale, overlap_begun=begun)
         finally:
             self.model.grad_scale = 1.0
+            self.model._unit_backward = False
+            self._ov_active = False
         return loss.detach()
 
 

@@ -95,7 +95,7 @@ class _SparKFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, inp, active, need_grads, names, *params):
         loss, grads = module._step(inp, active, need_grads=need_grads)     # (grad mode is off inside Function.forward)
-        ctx.names, ctx.grads = names, grads
+        ctx.names, ctx.grads, ctx.module = names, grads, module
         return loss
 
     @staticmethod
@@ -104,7 +104,9 @@ class _SparKFn(torch.autograd.Function):
         # scaled in place by the incoming gradient in a few multi-tensor launches (one multiply per parameter was 86 launches a step);
         # the tensors are the engine's: fresh ones, or aliases of the trainer's gradient arena that autograd adopts as they are
         have = [grads[n] for n in ctx.names if grads.get(n) is not None]
-        if have:
+        # (``_unit_backward``: set by pretrain.SparKPretrainer, whose loss.backward() passes exactly 1 -- the gradients may already be
+        # in an all-reduce started from inside the forward, so they are not touched again)
+        if have and not getattr(ctx.module, "_unit_backward", False):
             torch._foreach_mul_(have, g.reshape(()).to(have[0].dtype))
         out = [grads.get(n) for n in ctx.names]
         ctx.grads = None
@@ -406,13 +408,20 @@ class SparK(_EngineOwner, nn.Module):
 
         # ---- backward ----
         grads = {}
+        # a data-parallel trainer is told as soon as a sub-network's gradients are final (pretrain.ArenaTrainer.notify_ready)
+        ready = getattr(self, "_grads_ready", None)
         d_lat, d_skips = eng.decoder_backward(sd, dctx, drec, grads, True)
+        if ready is not None:
+            ready("dense_decoder.", grads)
         d_feats = [d_lat] + list(reversed(d_skips))              # same order as feats / mask_tokens
         for i, d in enumerate(d_feats):
             slab = ops.masked_channel_stats(Act(d.buf, d.coff, d.C), active, invert=True)     # sum over NON-active pixels
             grads[f"mask_tokens.{i}"] = slab[:, 0, :].sum(0).view_as(self.mask_tokens[i])
         dA = self._sp_convbn_bwd(eng, sd, b2, d_feats[0], active, cnt_b, grads, True)
         dP = self._sp_convbn_bwd(eng, sd, b1, dA, active, cnt_b, grads, nd > 0)
+        if ready is not None:
+            eng.flush_zero_bias()
+            ready("sparse_encoder.sp_cnn.double_conv.", grads)
         for i in range(nd, 0, -1):
             lv = levels[i - 1]
             a2 = lv["s2"]["a"]

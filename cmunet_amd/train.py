@@ -271,13 +271,20 @@ def find_best_epochs(valid_logs_list, EPOCH, LR, BATCH, runtime, metric='dice_lo
 
 
 def main_finetuning(args, loss, metrics, DEVICE, select_class_values, X_finetuning, y_finetuning, make_loaders=None,
-                    work_dir="./work_dir", save_best=True):
+                    work_dir="./work_dir", save_best=True, train_augmentation=None, keep_models=False):
     """train.py:311-378, same loop order and the same quirk (A-6): ONE ``load_model(args)`` per (LR, EPOCH, BATCH) whose weights
     are trained on through all three folds; KFold(3, shuffle, random_state 42); a fresh Adam per fold; ``train()`` keeps the
     checkpoint with the best validation dice_loss.  ``make_loaders(train_idx, val_idx, BATCH) -> (train_loader, test_loader)``
     replaces the reference's SegmentationDataset + albumentations + DataLoader construction (file-based, train.py:333-349) for
     in-memory / synthetic data; without it the drop-in ``dataset.SegmentationDataset`` is used on the given path lists.
-    Returns (best [lr, batch_size, epochs], result list) -- the reference pickles ``result`` and returns the first."""
+    ``train_augmentation``: the callable the TRAINING dataset applies (``aug(image=, mask=) -> {'image', 'mask'}``): the reference
+    passes ``get_training_augmentation()`` (Finetuning/dataset.py:134-165, an albumentations pipeline: random 475-pixel crop, noise,
+    blur, brightness, downscale, flips / rotations) -- albumentations is third-party and its augmentation zoo out of this build's
+    scope, so on the file-based path a caller who wants the reference's trajectories hands that object in; without it
+    the training images are NOT augmented and a warning says so (advisor, round 3).
+    Returns (best [lr, batch_size, epochs], result list) -- the reference pickles ``result`` and returns the first.  The result
+    entries hold what the reference's do (train.py:372), plus the fold number; ``keep_models=True`` adds the live model under
+    'model' (tools/chain_config4.py reads the finetuned weights from it)."""
     import os
     import time
     from torch.utils.data import DataLoader
@@ -294,8 +301,14 @@ def main_finetuning(args, loss, metrics, DEVICE, select_class_values, X_finetuni
                         train_loader, test_loader = make_loaders(train_idx, val_idx, BATCH)
                     else:
                         from .dataset import SegmentationDataset
+                        if train_augmentation is None and not getattr(main_finetuning, "_warned_no_aug", False):
+                            import warnings
+                            warnings.warn("main_finetuning: no train_augmentation given -- the reference trains on "
+                                          "get_training_augmentation() (albumentations, Finetuning/dataset.py:134-165, train.py:337); "
+                                          "fold trajectories and Dice on file-based data will differ from it", stacklevel=2)
+                            main_finetuning._warned_no_aug = True
                         tr_ds = SegmentationDataset([X_finetuning[i] for i in train_idx], [y_finetuning[i] for i in train_idx],
-                                                    class_values=select_class_values)
+                                                    class_values=select_class_values, augmentation=train_augmentation)
                         va_ds = SegmentationDataset([X_finetuning[i] for i in val_idx], [y_finetuning[i] for i in val_idx],
                                                     class_values=select_class_values)
                         train_loader = DataLoader(tr_ds, batch_size=BATCH, shuffle=True, num_workers=0)
@@ -310,8 +323,11 @@ def main_finetuning(args, loss, metrics, DEVICE, select_class_values, X_finetuni
                                                              name if save_best else None)
                     runtime = time.time() - start_time
                     cv_results.append(find_best_epochs(valid_logs_list, EPOCH, LR, BATCH, runtime)["dice_loss"])
-                    result.append({"epochs": EPOCH, "lr": LR, "batch_size": BATCH, "runtime": runtime, "fold": fold + 1,
-                                   "train_logs_list": train_logs_list, "valid_logs_list": valid_logs_list, "model": model})
+                    entry = {"epochs": EPOCH, "lr": LR, "batch_size": BATCH, "runtime": runtime, "fold": fold + 1,
+                             "train_logs_list": train_logs_list, "valid_logs_list": valid_logs_list}
+                    if keep_models:
+                        entry["model"] = model
+                    result.append(entry)
                 score.append({"epochs": EPOCH, "lr": LR, "batch_size": BATCH, "dice_loss": float(np.mean(cv_results))})
     best = min(score, key=lambda x: x["dice_loss"])
     return [best[key] for key in ["lr", "batch_size", "epochs"]], result

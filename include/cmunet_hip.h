@@ -41,6 +41,10 @@ const char* cmu_last_error(void);
 /* name of the compute kernel the calling thread's last GEMM-shaped entry launched ("" if none): for profilers */
 const char* cmu_last_kernel(void);
 int cmu_version(void);
+/* Test entry: force one of the dispatch switches that A/B two kernel forms with bit-identical results -- "CMU_CONV_NARROW",
+ * "CMU_CONV_SLIM", "CMU_CONV_PERSIST_PART", "CMU_WGRAD_SQUARE", "CMU_WGRAD_WIDE_F32" -- to 0 / 1, or back to the environment
+ * variable of the same name (value -1; the environment is read once, never on the launch path).  Unknown name: CMU_ERR_ARG. */
+int cmu_set_dispatch_override(const char* name, int value);
 /* element size in bytes of a cmu_dtype */
 int cmu_dtype_size(int dt);
 

@@ -129,3 +129,41 @@ def test_one_rank_group_and_the_rehearsal_knob():
     res = q.get(timeout=180)
     p.join(timeout=60)
     assert res == "ok", res
+
+
+@pytest.mark.parametrize("workload", ["recon", "moco", "joint", "spark"])
+def test_bench_self_launcher_eight_rank_environment(workload):
+    """``python bench.py --gpus 8 --workload X`` up to the first GPU call (the driver's 8-GPU run is the first time RCCL
+    sees more than one rank): the parent spawns eight children with the torch.distributed environment, every child derives its plan
+    (LOCAL_RANK -> device index, per-GPU batch, lr rule batch * gpus / 256, MoCo's K % (B * world)), the children rendezvous on
+    127.0.0.1 over gloo, all-reduce ones and compare their plans; no GPU and no HIP library is touched (``--dry-run-env``)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--workload", workload, "--dry-run-env"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["ok"] and d["ranks_seen"] == 8 and len(d["plans"]) == 8
+    plans = sorted(d["plans"], key=lambda p: p["rank"])
+    assert [p["dev_index"] for p in plans] == list(range(8)) and [p["local_rank"] for p in plans] == list(range(8))
+    assert all(p["world"] == 8 and p["backend"] == "nccl" and p["global_batch"] == 256 and p["lr_rule"] == 1.0 for p in plans)
+    assert len({p["master"] for p in plans}) == 1 and plans[0]["master"].startswith("127.0.0.1:")
+    assert all(p["ipc_mode_legacy"] == "0" for p in plans)          # dmabuf IPC: RCCL across processes needs it on this image
+    if workload == "moco":
+        assert all(p["queue"] == {"K": 4096, "gathered_keys": 256, "divides": True} for p in plans)
+
+
+def test_bench_refuses_a_queue_the_gathered_keys_do_not_divide():
+    """MoCo's ``assert num_negatives % batch_size == 0`` (moco2_module.py:169) on the gathered key batch: 48 x 8 keys into K = 4096."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="8", RANK="3", LOCAL_RANK="3", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--workload", "moco", "--batch", "48", "--dry-run-env"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode != 0 and "not a multiple of the gathered key batch" in (res.stdout + res.stderr)

@@ -172,3 +172,60 @@ def test_find_best_epochs_contract():
     assert r["dice_loss"] == 0.7 and r["iou_loss"] == 0.6                       # epoch 1: smallest criterion
     assert T.find_best_epochs(logs[:1], 1, 1e-3, 6, 1.0)["dice_loss"] == 0.6    # a single / first epoch is fine
     assert T.find_best_epochs([{"dice_loss": 0.4}, {"dice_loss": 0.3}], 2, 1e-2, 2, 0.0)["dice_loss"] == 0.3   # falls back to dice_loss
+
+
+def test_train_test_split_indices_are_sklearns():
+    """dataset.train_test_split_indices == sklearn.model_selection.train_test_split (what cmunet_dataset.py:30-31 calls)."""
+    from sklearn.model_selection import train_test_split
+    from cmunet_amd.dataset import train_test_split_indices
+    for n, ts, rs in ((50, 0.2, 42), (40, 0.0125, 42), (7, 0.2, 1), (1001, 0.33, 7)):
+        tr, te = train_test_split_indices(n, ts, rs)
+        a, b = train_test_split(list(range(n)), test_size=ts, random_state=rs)
+        assert list(tr) == a and list(te) == b, (n, ts, rs)
+
+
+def test_cmunet_dataset_surface(tmp_path):
+    """CMUNetDataset(data_root, data_ann, pipeline, pixel, test) on a directory of .npy images: the reference's two
+    train_test_split calls (cmunet_dataset.py:28-35), the {'img','img_t'} item contract (:60-88), GaussNoise always applied (A-11),
+    and a custom pipeline of callables; a config-dict pipeline (mmcv / mmengine) raises."""
+    from sklearn.model_selection import train_test_split
+    from cmunet_amd.dataset import CMUNetDataset
+    rng = np.random.RandomState(0)
+    for i in range(30):
+        np.save(tmp_path / f"im_{i:03d}.npy", rng.standard_normal((300, 280)).astype(np.float32))
+    ds = CMUNetDataset(str(tmp_path), "unused.json", None, pixel=31, seed=5)
+    paths = [str(tmp_path / f) for f in sorted(p.name for p in tmp_path.iterdir())]
+    X_train, X_test, y_train, _ = train_test_split(paths, paths.copy(), test_size=0.2, random_state=42)
+    inner, _, _, _ = train_test_split(X_train, y_train, test_size=0.0125, random_state=42)
+    assert ds.image_paths == inner and ds.test == X_test and len(ds) == len(inner) == 23
+    it = ds[0]
+    assert set(it) == {"img", "img_t"} and it["img"].shape == (224, 224) and it["img_t"].shape == (224, 224)
+    assert it["img"].dtype == torch.float32 and it["img_t"].dtype == torch.float32
+    assert not torch.equal(it["img"], it["img_t"]) and bool(torch.isfinite(it["img_t"]).all())
+    # the base pipeline is the first two entries, the final one the rest -- both views go through the final one
+    seen = []
+    base = [lambda r: {"img": np.asarray(r["img"], dtype=np.float32) * 0 + 2.0}, lambda r: r]
+    final = [lambda r: (seen.append(r["img"].shape), {"img": r["img"] + 1})[1]]
+    ds2 = CMUNetDataset(str(tmp_path), None, base + final, pixel=0, seed=1)
+    it2 = ds2[3]
+    assert seen == [(224, 224), (224, 224)] and float(it2["img"].min()) == 3.0 and it2["img"].max() == 3.0
+    assert abs(float(it2["img_t"].mean()) - 3.0) < 0.05 and float(it2["img_t"].std()) > 0.1      # 2 + N(0, (2 / 10)^2) + 1
+    with pytest.raises(TypeError):
+        CMUNetDataset(str(tmp_path), None, [dict(type="RandomResizedCrop", scale=256)])
+
+
+def test_moco_dataset_surface(tmp_path):
+    """MoCoDataset(data_path, tau_g): list of .npy paths, two global transforms on a (1, 256, 256) tensor, item ((c0, c1), 0)
+    (moco_data_set.py:11-37)."""
+    from PIL import Image
+    from cmunet_amd.dataset import MoCoDataset
+    rng = np.random.RandomState(1)
+    paths = []
+    for i in range(3):
+        paths.append(str(tmp_path / f"m{i}.npy"))
+        np.save(paths[-1], rng.standard_normal((180, 200)).astype(np.float32))
+    ds = MoCoDataset(paths, [lambda t: t[:, :224, :224], lambda t: t.flip(-1)[:, 16:240, 16:240]])
+    assert len(ds) == 3 and str(ds) == "LoGoDataset with 3 images"
+    (c0, c1), label = ds[1]
+    ref = torch.from_numpy(np.array(Image.fromarray(np.load(paths[1])).resize((256, 256), resample=Image.BICUBIC)))[None]
+    assert label == 0 and torch.equal(c0, ref[:, :224, :224]) and torch.equal(c1, ref.flip(-1)[:, 16:240, 16:240])

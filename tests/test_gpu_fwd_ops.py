@@ -439,7 +439,7 @@ torch.save({k: v.cpu() for k, v in out.items()}, sys.argv[1])
 def test_conv3x3_narrow_channel_blocks_equal_the_wide_ones(ops, dt, hw):
     """Launches with fewer 128-channel items than half the chip's CUs take 64-channel blocks (conv_igemm3.inc::igemm3_narrow_blocks:
     small batches, deep levels).  Same MFMA order per accumulator -> the outputs are bit-identical to the 128-channel blocks
-    (CMU_CONV_NARROW=0, read per launch); the per-tile statistics fold the same pixels in another lane order.  Whole-tile shape
+    (CMU_CONV_NARROW forced off through cmu_set_dispatch_override); the per-tile statistics fold the same pixels in another lane order.  Whole-tile shape
     (persistent kernel), a 16 x 16 image (half-empty tiles, one-tile kernel) and 28 x 28 (partial tiles); forward with pending
     transform + statistics, plain data gradient, data gradient with fused BN-backward sums."""
     import os
@@ -454,10 +454,8 @@ def test_conv3x3_narrow_channel_blocks_equal_the_wide_ones(ops, dt, hw):
     mu, istd = (torch.randn(Cout, generator=g) * 0.1).cuda(), (torch.rand(Cout, generator=g) + 0.5).cuda()
     wt = (torch.randn(Cin, Cout, 3, 3, generator=g) / 32).cuda()
     outs = []
-    old = os.environ.get("CMU_CONV_NARROW")
-    try:
-        for v in ("0", "1"):
-            os.environ["CMU_CONV_NARROW"] = v
+    for v in (0, 1):
+        with ops.dispatch_override("CMU_CONV_NARROW", v):
             y = ops.new_act(B, H, W, Cout, dt, "cuda")
             st = ops.new_stats(B, H, W, Cout, "cuda")
             ops.conv3x3_fwd(ops.Act(x, 0, Cin, sc, sh, 0), ops.pack_conv3x3(w, dt), y, st)
@@ -468,11 +466,6 @@ def test_conv3x3_narrow_channel_blocks_equal_the_wide_ones(ops, dt, hw):
             ops.conv3x3_dgrad_bn(ops.Act(x, 0, Cin), ops.pack_conv3x3(wt, dt, transpose_flip=True), dX, ops.Act(xr, 0, Cout, bsc, bsh, 0), mu, istd, slab)
             torch.cuda.synchronize()
             outs.append({"y": y.buf.clone(), "y2": y2.buf.clone(), "dx": dX.buf.clone(), "s": st.clone(), "slab": slab.clone()})
-    finally:
-        if old is None:
-            os.environ.pop("CMU_CONV_NARROW", None)
-        else:
-            os.environ["CMU_CONV_NARROW"] = old
     for k in ("y", "y2", "dx"):
         assert torch.equal(outs[0][k].view(torch.uint8), outs[1][k].view(torch.uint8)), k
     for k in ("s", "slab"):
@@ -484,11 +477,34 @@ def test_conv3x3_narrow_channel_blocks_equal_the_wide_ones(ops, dt, hw):
 
 
 @pytest.mark.parametrize("dt", DTS)
+def test_conv3x3_short_last_batch_takes_another_kernel_same_outputs(ops, dt):
+    """Advisor (round 3): the kernel form depends on the batch size (64-channel blocks while 2 x items <= CUs) -- the short last
+    batch of an epoch runs another form than the full ones.  Its outputs for the images both batches hold are the same bits (same
+    MFMA order per accumulator); only the statistics' fold order differs.  128 -> 256 @ 32 x 64 on a 256-CU chip:
+    16 images = 128 items (narrow blocks), 17 images = 136 items (128-channel blocks)."""
+    g = torch.Generator().manual_seed(6)
+    Cin, Cout, H, W = 128, 256, 32, 64
+    tdt = ops.TORCH_DT[ops.dt_code(dt)]
+    x = torch.randn(17, H, W, Cin, generator=g).to(tdt).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / 32).cuda()
+    sc, sh = (torch.rand(Cin, generator=g) + 0.5).cuda(), (torch.randn(Cin, generator=g) * 0.3).cuda()
+    outs, stats = [], []
+    for B in (17, 16):
+        y, st = ops.new_act(B, H, W, Cout, dt, "cuda"), ops.new_stats(B, H, W, Cout, "cuda")
+        ops.conv3x3_fwd(ops.Act(x[:B].contiguous(), 0, Cin, sc, sh, 0), ops.pack_conv3x3(w, dt), y, st)
+        outs.append(y.buf)
+        stats.append(st)
+    assert torch.equal(outs[0][:16].view(torch.uint8), outs[1].view(torch.uint8))
+    rows = stats[1].shape[0]
+    check(stats[1].sum(0).cpu(), stats[0][:rows].sum(0).cpu(), 2e-5, "statistics of the 16 shared images, two fold orders")
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("bhw", [(2, 16, 16), (3, 14, 14), (2, 9, 7), (22, 48, 48)])
 def test_conv3x3_slim_tiles_equal_the_32_pixel_ones(ops, dt, bhw):
     """Images with an odd number of 16-pixel columns run on 16 x 16 pixel tiles (conv_igemm3.inc::igemm3_slim_tiles: one-column
     images at every dtype; f32 up to 7 columns once the 32-pixel tiles fill the chip) instead of leaving half of a 16 x 32 tile
-    empty.  Same MFMA order per accumulator -> bit-identical outputs against CMU_CONV_SLIM=0 (read per launch); statistics in
+    empty.  Same MFMA order per accumulator -> bit-identical outputs against CMU_CONV_SLIM forced off (cmu_set_dispatch_override); statistics in
     another fold order.  Forward with pending transform + statistics, data gradient with fused BN-backward sums."""
     import os
     B, H, W = bhw
@@ -505,10 +521,8 @@ def test_conv3x3_slim_tiles_equal_the_32_pixel_ones(ops, dt, bhw):
     mu, istd = (torch.randn(Cout, generator=g) * 0.1).cuda(), (torch.rand(Cout, generator=g) + 0.5).cuda()
     wt = (torch.randn(Cin, Cout, 3, 3, generator=g) / 24).cuda()
     outs = []
-    old = os.environ.get("CMU_CONV_SLIM")
-    try:
-        for v in ("0", "1"):
-            os.environ["CMU_CONV_SLIM"] = v
+    for v in (0, 1):
+        with ops.dispatch_override("CMU_CONV_SLIM", v):
             y = ops.new_act(B, H, W, Cout, dt, "cuda")
             st = ops.new_stats(B, H, W, Cout, "cuda")
             ops.conv3x3_fwd(ops.Act(x, 0, Cin, sc, sh, 0), ops.pack_conv3x3(w, dt), y, st)
@@ -517,11 +531,6 @@ def test_conv3x3_slim_tiles_equal_the_32_pixel_ones(ops, dt, bhw):
             ops.conv3x3_dgrad_bn(ops.Act(x, 0, Cin), ops.pack_conv3x3(wt, dt, transpose_flip=True), dX, ops.Act(xr, 0, Cout, bsc, bsh, 0), mu, istd, slab)
             torch.cuda.synchronize()
             outs.append({"y": y.buf.clone(), "dx": dX.buf.clone(), "s": st.clone(), "slab": slab.clone()})
-    finally:
-        if old is None:
-            os.environ.pop("CMU_CONV_SLIM", None)
-        else:
-            os.environ["CMU_CONV_SLIM"] = old
     for k in ("y", "dx"):
         assert torch.equal(outs[0][k].view(torch.uint8), outs[1][k].view(torch.uint8)), k
     for k in ("s", "slab"):

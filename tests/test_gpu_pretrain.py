@@ -240,6 +240,47 @@ def test_joint_trainer_dynamic_loss_scale(cuda):
     assert not torch.equal(tr.flat.arena, before)
 
 
+def test_default_constructed_trainers_scale_the_loss_at_f16(cuda):
+    """Advisor (round 3): ``cmunet_config()`` / ``CM_UNet`` default to f16 storage, so ``JointPretrainer(model)`` and
+    ``MaskedReconPretrainer(model)`` with NO amp argument must come up with the reference's dynamic loss scaler
+    (cmunet_config.py:76-78) -- their first step equals the ``amp=True`` one bit for bit and moves the encoder --, f32 models come up
+    without one, and ``amp=False`` switches it off."""
+    from cmunet_amd import cmunet as C, model as M
+    from cmunet_amd.pretrain import JointPretrainer, MaskedReconPretrainer, create_random_patch_mask
+    B, S = 4, 32
+    g = torch.Generator().manual_seed(3)
+    img, img_t = torch.randn(B, S, S, generator=g).to(cuda), torch.randn(B, S, S, generator=g).to(cuda)
+    mask = torch.from_numpy(create_random_patch_mask(B, S, 16, 0.65, np.random.RandomState(4))).to(cuda)
+
+    def joint(**kw):
+        torch.manual_seed(0)
+        cfg = C.cmunet_config(img_size=S, base_ch=16, depth=3)
+        model = C.build_model(cfg).to(cuda).train()
+        assert model.dtype == "f16"
+        tr = JointPretrainer(model, lr=1e-3, **kw)
+        w0 = tr.flat.arena.clone()
+        tr.step(img, img_t, mask)
+        enc = tr.flat.prefix_range("backbone.")
+        return tr, w0, enc
+    tr_def, w0, enc = joint()
+    tr_amp, _, _ = joint(amp=True)
+    assert tr_def.amp is not None and tr_def.amp.read()[3] == 1                       # one good (unskipped) update
+    assert torch.equal(tr_def.flat.arena, tr_amp.flat.arena) and torch.equal(tr_def.flat.grad, tr_amp.flat.grad)
+    assert not torch.equal(tr_def.flat.arena[enc[0]:enc[1]], w0[enc[0]:enc[1]]) and float(tr_def.flat.grad[enc[0]:enc[1]].abs().max()) > 0
+    tr_off, _, _ = joint(amp=False)
+    assert tr_off.amp is None
+
+    def recon(dt, **kw):
+        torch.manual_seed(0)
+        net = M.UNet(out_classes=2, dtype=dt, base_ch=16, depth=3).to(cuda)
+        tr = MaskedReconPretrainer(net, lr=1e-3, **kw)
+        tr.step(img, mask)
+        return tr
+    r_def, r_amp = recon("f16"), recon("f16", amp=True)
+    assert r_def.amp is not None and torch.equal(r_def.flat.arena, r_amp.flat.arena)
+    assert recon("f32").amp is None and recon("bf16").amp is None and recon("f16", amp=False).amp is None
+
+
 def test_cmunet_modules_standalone(cuda):
     """UNet_encoder / MUNetPretrainDecoder used on their own keep the reference's tensor contract."""
     from cmunet_amd import cmunet as C
@@ -487,6 +528,52 @@ def test_moco_forward_enqueue_backward_order_and_batch_size_change(cuda):
     assert torch.equal(qv[:, 8:40], qd[:, 8:40]) and int(pd) == (40 + 16) % 48 and bool(torch.isfinite(loss).all())
 
 
+def test_moco_compute_l_s_and_configure_optimizers(cuda):
+    """The reference's non-fused call sequence (moco2_module.py:287-309: forward -> _compute_l_s -> backward -> optimizer.step with
+    the objects of configure_optimizers): same loss and queue as the fused training_step, and the fused SGD + cosine schedule
+    returned by ``configure_optimizers`` follow torch.optim.SGD + CosineAnnealingLR on a copy of the model."""
+    from cmunet_amd import moco as MO
+
+    def make():
+        torch.manual_seed(0)
+        return MO.Moco_v2(emb_dim=64, num_negatives=64, softmax_temperature=0.2, encoder_momentum=0.99, learning_rate=0.05, momentum=0.9,
+                          weight_decay=1e-4, dtype="f32", base_ch=16, depth=3).to(cuda).train()
+    g = torch.Generator().manual_seed(8)
+    xq, xk = torch.randn(8, 1, 32, 32, generator=g).to(cuda), torch.randn(8, 1, 32, 32, generator=g).to(cuda)
+    a, b = make(), make()
+    # (a) the reference's sequence on the API-faithful methods; (b) the fused step
+    a._momentum_update_key_encoder()
+    output, target, keys, _ = a(img_q=xq, img_k=xk, queue=a.queue)
+    loss_a = a._compute_l_s(output, target, keys, a.queue)
+    loss_b = b.training_step((xq, xk))
+    assert abs(float(loss_a) - float(loss_b)) <= 1e-5 * max(1.0, abs(float(loss_b)))
+    assert int(a.queue_ptr) == int(b.queue_ptr) == 8 and (a.queue - b.queue).abs().max().item() <= 1e-6
+    (opt,), (sched,) = a.configure_optimizers(max_epochs=10)
+    ref_params = [p for p in b.parameters() if p.requires_grad]
+    ref_opt = torch.optim.SGD(ref_params, 0.05, momentum=0.9, weight_decay=1e-4)
+    ref_sched = torch.optim.lr_scheduler.CosineAnnealingLR(ref_opt, 10)
+    for step in range(2):
+        if step:
+            output, target, keys, _ = a(img_q=xq, img_k=xk, queue=a.queue)
+            loss_a = a._compute_l_s(output, target, keys, a.queue)
+            loss_b = b.training_step((xq, xk))
+        opt.zero_grad()
+        ref_opt.zero_grad()
+        loss_a.backward()
+        loss_b.backward()
+        opt.step()
+        ref_opt.step()
+        sched.step()
+        ref_sched.step()
+        assert abs(sched.get_last_lr()[0] - ref_sched.get_last_lr()[0]) <= 1e-12
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    for n, p in pb.items():
+        if p.requires_grad:
+            assert (pa[n].detach() - p.detach()).abs().max().item() <= 2e-4 * max(1.0, float(p.detach().abs().max())), n
+    with pytest.raises(ValueError):
+        a.configure_optimizers()                     # no Lightning trainer, no max_epochs
+
+
 def test_moco_trainer_static_loss_scale_is_transparent(cuda):
     """MocoPretrainer.step(loss_scale=s): the scale multiplies the loss before backward and is divided out by the SGD kernel -- at f32
     the update equals the unscaled one (a power of two: to rounding of the momentum buffer only)."""
@@ -729,7 +816,7 @@ def _joint224_hip_vs_oracle(cuda, mode):
     ref_losses, ref = J.oracle_step(sd, (img, img_t, mask, rw, rb))
     params = dict(model.named_parameters())
     errs = {k: J.rel_l2(params[k].grad.detach().cpu(), ref[k]) for k in J.KEYS}
-    return J, sd, errs, {k: float(v) for k, v in losses.items()}, ref_losses
+    return J, sd, errs, {k: float(v.detach()) for k, v in losses.items()}, ref_losses
 
 
 def _joint224_spread(J, sd, mode):
@@ -793,8 +880,9 @@ def test_cmunet_joint_step_gate_forced_backward(cuda, mode):
     every gate and every activated value of the online encoder and both decoders are taken from the engine's saved state
     (oracle.unet.TAP), the max-pools then pick the same elements, and what is left between the two gradients is the arithmetic of the
     HIP backward kernels alone (data / weight gradients of the partial-tile, narrow and slim dispatch of this geometry, BatchNorm
-    backward, pool backward with two skip gradients, ConvTranspose, the necks' skinny GEMMs).  Flat bars at f32: 1e-4 on the
-    head / projector tensors, 1e-3 on every tensor of the conv chain -- the deepest ConvTranspose and the first encoder layer included."""
+    backward, pool backward with two skip gradients, ConvTranspose, the necks' skinny GEMMs).  ONE flat bar at f32 for every tensor
+    -- head, projector, both decoders, the deepest ConvTranspose, the first encoder layer: 1e-4 (measured: 1e-8 ... 1.9e-5; the
+    review asked for 1e-4 on head / projector and 1e-3 on the conv chain)."""
     import joint224_case as J
     from oracle import unet as OU
     model, sd, (img, img_t, mask, rw, rb) = J.build(mode)
@@ -814,17 +902,16 @@ def test_cmunet_joint_step_gate_forced_backward(cuda, mode):
     finally:
         OU.TAP = None
     assert taps.seen == set(layers), "a layer of the oracle ran without the HIP path's forward"
-    assert abs(float(losses['loss_rc']) - ref_losses['loss_rc']) <= 2e-5 * max(1, abs(ref_losses['loss_rc']))
-    assert abs(float(losses['loss_ct']) - ref_losses['loss_ct']) <= 2e-4 * max(1, abs(ref_losses['loss_ct']))
+    assert abs(float(losses['loss_rc'].detach()) - ref_losses['loss_rc']) <= 2e-5 * max(1, abs(ref_losses['loss_rc']))
+    assert abs(float(losses['loss_ct'].detach()) - ref_losses['loss_ct']) <= 2e-4 * max(1, abs(ref_losses['loss_ct']))
     params = dict(model.named_parameters())
     errs = {k: J.rel_l2(params[k].grad.detach().cpu(), ref[k]) for k in J.KEYS}
     line = ", ".join(f"{k}: {e:.2e}" for k, e in errs.items())
     print(f"[joint step @ 224 {mode}, f32, oracle backward on the HIP forward] relative L2 error of the gradients: " + line)
     _parity_record(f"CM_UNet joint step f32 at the reference geometry (224x224, bs 4, base 32; input mask '{mode}'), float64 oracle backward on the HIP "
-                   "path's own forward values and ReLU gates (flat bars 1e-4 head / projector, 1e-3 conv chain): " + line)
+                   "path's own forward values and ReLU gates (one flat bar, 1e-4, on every tensor): " + line)
     for k, e in errs.items():
-        bar = 1e-3 if J.in_conv_chain(k) else 1e-4
-        assert e <= bar, f"d{k}: relative L2 error {e:.2e} with the gates forced (bar {bar:.0e})"
+        assert e <= 1e-4, f"d{k}: relative L2 error {e:.2e} with the gates forced (bar 1e-4)"
 
 
 @pytest.mark.parametrize("mode", ["random65", "tie_free"])

@@ -92,7 +92,7 @@ def run_chain(pre_steps=20, pre_size=512, pre_batch=32, ft_images=18, ft_size=25
     t0 = time.perf_counter()
     with (contextlib.nullcontext() if verbose else contextlib.redirect_stdout(sink)):
         best, result = T.main_finetuning(args, crit, mets, str(dev), None, list(range(ft_images)), list(range(ft_images)),
-                                         make_loaders=make_loaders, work_dir=tmp, save_best=False)
+                                         make_loaders=make_loaders, work_dir=tmp, save_best=False, keep_models=True)
     torch.cuda.synchronize()
     dt_ft = time.perf_counter() - t0
     n_train, n_val = 2 * ft_images // 3, ft_images // 3
