@@ -291,7 +291,7 @@ __global__ void bn_bwd_apply_kernel(const unsigned char* __restrict__ dA, int64_
                                     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ coef,
                                     unsigned char* __restrict__ dY, int64_t ldo, int64_t npix, int C, int cpb, int ppb,
                                     const uint8_t* __restrict__ amask, int f, int sbits, int H, int W,
-                                    const float* __restrict__ hd_dlogits = nullptr, const float* __restrict__ hd_w = nullptr) {
+                                    const float* __restrict__ hd_dlogits = nullptr, const float* __restrict__ hd_w = nullptr, int hd_K = 2) {
     constexpr int EPC = TR::EPC;
     constexpr int ES = (int)sizeof(typename TR::elem_t);
     const int tid = threadIdx.x;
@@ -306,12 +306,13 @@ __global__ void bn_bwd_apply_kernel(const unsigned char* __restrict__ dA, int64_
         sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; is[e] = invstd[c];
         c1[e] = coef[c]; c2[e] = coef[C + c];
     }
-    // head mode (hd_dlogits != NULL, two classes): dA is not in memory -- it is the rank-2 product dlogits[p][0..1] * w[0..1][c]
-    // of the 1x1 head this layer feeds, recomputed here and rounded as the head backward would have stored it
+    // head mode (hd_dlogits != NULL, one or two classes): dA is not in memory -- it is the rank-K product dlogits[p][0..K) * w[0..K)[c]
+    // of the 1x1 head this layer feeds, recomputed here and rounded as the head backward would have stored it (K = 1: SparK's
+    // one-channel reconstruction head, decoder.py:47 -- it ran on the generic kernel at half this one's rate until round 4)
     float w0[EPC], w1[EPC];
     if (hd_dlogits != nullptr) {
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) { w0[e] = hd_w[ch * EPC + e]; w1[e] = hd_w[C + ch * EPC + e]; }
+        for (int e = 0; e < EPC; ++e) { w0[e] = hd_w[ch * EPC + e]; w1[e] = hd_K > 1 ? hd_w[C + ch * EPC + e] : 0.f; }
     }
     const unsigned HWu = (unsigned)H * (unsigned)W;
     // a workgroup's CMU_APPLY_PPT chunks per thread are ADJACENT pixel groups (one contiguous range per workgroup) rather than one group
@@ -330,7 +331,7 @@ __global__ void bn_bwd_apply_kernel(const unsigned char* __restrict__ dA, int64_
         float g[EPC], v[EPC], o[EPC];
         if (hd_dlogits != nullptr) {
             const unsigned bq = (unsigned)p / HWu, r = (unsigned)p - bq * HWu;      // (the launcher keeps npix below 2^31 here)
-            const float d0 = hd_dlogits[(int64_t)(2 * bq) * HWu + r], d1 = hd_dlogits[(int64_t)(2 * bq + 1) * HWu + r];
+            const float d0 = hd_dlogits[(int64_t)(hd_K * bq) * HWu + r], d1 = hd_K > 1 ? hd_dlogits[(int64_t)(2 * bq + 1) * HWu + r] : 0.f;
 #pragma unroll
             for (int e = 0; e < EPC; ++e) o[e] = fmaf(d1, w1[e], fmaf(d0, w0[e], 0.f));
             TR::unpack(TR::pack(o), g);
@@ -351,7 +352,7 @@ template <class TR>
 static int bn_bwd_apply_t(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift,
                           const float* mean, const float* invstd, const float* coef, void* dY, int64_t ldo, int B, int H, int W,
                           int C, const uint8_t* active, int f, hipStream_t st, const float* hd_dlogits = nullptr,
-                          const float* hd_w = nullptr) {
+                          const float* hd_w = nullptr, int hd_K = 2) {
     int cpb, ppb, gy;
     chunk_geometry(C / TR::EPC, &cpb, &ppb, &gy);
     const int64_t npix = (int64_t)B * H * W;
@@ -362,7 +363,7 @@ static int bn_bwd_apply_t(const void* dA, int64_t ldd, const void* y, int64_t ld
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL((bn_bwd_apply_kernel<TR>), dim3(gx, gy), dim3(256), 0, st, (const unsigned char*)dA, ldd,
                        (const unsigned char*)y, ldy, scale, shift, mean, invstd, coef, (unsigned char*)dY, ldo, npix, C, cpb, ppb, active, f,
-                       sbits, H, W, hd_dlogits, hd_w);
+                       sbits, H, W, hd_dlogits, hd_w, hd_K);
     CMU_CHECK_LAUNCH("cmu_bn_bwd_apply");
     return CMU_OK;
 }
@@ -885,11 +886,12 @@ extern "C" int cmu_conv1x1_head_bn_apply(const float* dlogits, const void* x, in
     CMU_CHECK_ARG(C % epc == 0 && nchunk > 0 && (nchunk & (nchunk - 1)) == 0 && nchunk <= 64, "cmu_conv1x1_head_bn_apply: C=%d unsupported", C);
     CMU_CHECK_ARG(cmu_aligned16(x) && ldx % epc == 0 && ldx >= C && cmu_aligned16(dY) && ldo % epc == 0 && ldo >= C,
                   "cmu_conv1x1_head_bn_apply: alignment / stride");
-    if (K == 2 && (int64_t)B * H * W < (1ll << 31)) {
-        // two classes (every head of the reference): the BatchNorm-backward apply kernel itself, with dA recomputed from dlogits
-        // in its load slot (same grid, same loop: it runs at the HBM rate; the generic kernel below measured 1.07 ms against 0.56)
+    if (K <= 2 && (int64_t)B * H * W < (1ll << 31)) {
+        // one or two classes (every head of the reference: two for the UNet / CM-UNet decoders, one for SparK's): the BatchNorm-backward
+        // apply kernel itself, with dA recomputed from dlogits in its load slot (same grid, same loop: it runs at the HBM rate; the
+        // generic kernel below measured 1.07 ms against 0.56)
         CMU_DISPATCH_DT(dt, bn_bwd_apply_t, nullptr, ldx, x, ldx, in_scale, in_shift, save_mean, save_invstd, coef, dY, ldo, B, H, W, C,
-                        (const uint8_t*)nullptr, 0, (hipStream_t)stream, dlogits, w);
+                        (const uint8_t*)nullptr, 0, (hipStream_t)stream, dlogits, w, K);
     }
     CMU_DISPATCH_DT(dt, conv1x1_head_bn_apply_t, dlogits, x, ldx, in_scale, in_shift, w, save_mean, save_invstd, coef, dY, ldo, B, H, W, C, K,
                     (hipStream_t)stream);

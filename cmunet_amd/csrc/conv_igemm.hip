@@ -792,36 +792,60 @@ extern "C" int cmu_sparse_pixel_list(const uint8_t* active, int f, int B, int H,
 
 // Active-tile list of a (B, H, W) level for the patch map `active` (B, f, f): tile (b, ty, tx) of th x tw pixels is listed
 // iff one of the patches it overlaps is active.  One workgroup, ascending tile order (deterministic), count in count[0].
+// Round 4: two phases per trip of up to 65,536 tiles.  (1) The 1,024 threads stride over the tiles -- independent, coalesced mask
+// loads, many in flight -- and each wave's ballot goes into a bitmap in LDS; (2) every thread takes a run of up to 64 CONSECUTIVE
+// tiles out of the bitmap (one 64-bit mask), the workgroup scans the runs' counts once (wave prefix by shuffles + the 16 wave
+// totals) and each thread writes its listed tiles behind its offset.  Five barriers per trip where the tile-per-thread loop took
+// three per 1,024 tiles with one dependent mask load each (45 us per list, nine lists per SparK step).  Same ascending order.
 __global__ __launch_bounds__(1024) void sparse_tile_list_kernel(const uint8_t* __restrict__ active, int f, int sbits, int B, int tilesY,
                                                                int tilesX, int th, int tw, int* __restrict__ list, int* __restrict__ count) {
+    __shared__ unsigned long long bits[1024];
     __shared__ int wsum[16];
     __shared__ int base;
     const int total = B * tilesY * tilesX;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) base = 0;
     __syncthreads();
-    for (int t0 = 0; t0 < total; t0 += 1024) {
-        const int t = t0 + (int)threadIdx.x;
-        bool on = false;
-        if (t < total) {
-            const int tx = t % tilesX, ty = (t / tilesX) % tilesY, b = t / (tilesX * tilesY);
-            const int py0 = (ty * th) >> sbits, py1 = (ty * th + th - 1) >> sbits;
-            const int px0 = (tx * tw) >> sbits, px1 = (tx * tw + tw - 1) >> sbits;
-            for (int py = py0; py <= py1 && py < f; ++py)
-                for (int px = px0; px <= px1 && px < f; ++px) on |= active[((int64_t)b * f + py) * f + px] != 0;
+    const int want = total / 1024 + (total % 1024 != 0);
+    const int per = want < 64 ? want : 64;                     // tiles per thread and trip
+    for (int t0 = 0; t0 < total; t0 += 1024 * per) {
+        for (int b0 = 0; b0 < 1024 * per; b0 += 1024) {
+            const int t = t0 + b0 + (int)threadIdx.x;
+            bool on = false;
+            if (t < total) {
+                const int tx = t % tilesX, ty = (t / tilesX) % tilesY, b = t / (tilesX * tilesY);
+                const int py0 = (ty * th) >> sbits, py1 = (ty * th + th - 1) >> sbits;
+                const int px0 = (tx * tw) >> sbits, px1 = (tx * tw + tw - 1) >> sbits;
+                for (int py = py0; py <= py1 && py < f; ++py)
+                    for (int px = px0; px <= px1 && px < f; ++px) on |= active[((int64_t)b * f + py) * f + px] != 0;
+            }
+            const unsigned long long m64 = __ballot(on);
+            if (lane == 0) bits[(b0 >> 6) + wave] = m64;
         }
-        const unsigned long long m = __ballot(on);
-        const int before = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wsum[wave] = __popcll(m);
         __syncthreads();
-        int off = base;
+        const int start = (int)threadIdx.x * per, w0 = start >> 6, sh = start & 63;
+        unsigned long long m = bits[w0] >> sh;
+        if (sh != 0 && w0 + 1 < 1024) m |= bits[w0 + 1] << (64 - sh);
+        if (per < 64) m &= (1ull << per) - 1ull;
+        const int first = t0 + start;
+        const int mine = __popcll(m);
+        int incl = mine;                                   // inclusive prefix over the wave (fixed shuffle order)
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int off = base + incl - mine;
         for (int w = 0; w < wave; ++w) off += wsum[w];
-        if (on) list[off + before] = t;
+        for (int k = 0; k < per; ++k)
+            if ((m >> k) & 1ull) list[off++] = first + k;
         __syncthreads();
         if (threadIdx.x == 0) {
-            int s = 0;
-            for (int w = 0; w < 16; ++w) s += wsum[w];
-            base += s;
+            int sum = 0;
+            for (int w = 0; w < 16; ++w) sum += wsum[w];
+            base += sum;
         }
         __syncthreads();
     }

@@ -384,10 +384,13 @@ class UNetEngine:
                 if sk.scale.data_ptr() != cat["scale"][Cup:].data_ptr():
                     cat["scale"][Cup:].copy_(sk.scale)
                     cat["shift"][Cup:].copy_(sk.shift)
+                    cat["ident"] = False
                 relu_from = Cup
             else:                      # already-activated skip handed over at a module boundary: identity, no ReLU
-                cat["scale"][Cup:].fill_(1.0)
-                cat["shift"][Cup:].zero_()
+                if not cat.get("ident", False):      # (buffers reused from step to step keep the identity: two fills per level saved)
+                    cat["scale"][Cup:].fill_(1.0)
+                    cat["shift"][Cup:].zero_()
+                    cat["ident"] = True
                 relu_from = Cup + Cs
             wt = sd[p + "up_sample.weight"]
             left = Act(cat["buf"], 0, Cup)

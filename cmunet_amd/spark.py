@@ -151,7 +151,9 @@ class SparK(_EngineOwner, nn.Module):
     def mask(self, B, device, generator=None):
         h, w = self.fmap_h, self.fmap_w
         idx = torch.rand(B, h * w, generator=generator).argsort(dim=1)[:, :self.len_keep].to(device)
-        return torch.zeros(B, h * w, dtype=torch.bool, device=device).scatter_(dim=1, index=idx, value=True).view(B, 1, h, w)
+        active = torch.zeros(B, h * w, dtype=torch.bool, device=device).scatter_(dim=1, index=idx, value=True).view(B, 1, h, w)
+        active._cmu_n_active = B * self.len_keep      # known by construction: the step needs it on the host and would read it back otherwise
+        return active
 
     def forward(self, inp_bchw, active_b1ff=None, vis=False):
         _require_cuda(inp_bchw, "SparK")
@@ -335,7 +337,20 @@ class SparK(_EngineOwner, nn.Module):
         f, r = active_b1ff.shape[-1], self.downsample_raito
         assert H == f * r and W == f * r, "input size must be fmap * downsample ratio"
         active = active_b1ff.reshape(B, f, f).to(torch.uint8).contiguous()
-        n_cells = int(active.sum().item())                        # once per step; the random mask keeps len_keep per sample
+        # number of active patches, needed on the host (statistics counts, list capacities): carried by masks from ``mask()``,
+        # remembered per mask tensor otherwise -- a read-back per step stalls the launch queue behind the previous step
+        n_cells = getattr(active_b1ff, "_cmu_n_active", None)
+        if n_cells is None:
+            import weakref
+            cache = self.__dict__.setdefault("_n_active_cache", {})
+            hit = cache.get(id(active_b1ff))
+            if hit is not None and hit[0]() is active_b1ff and hit[1] == active_b1ff._version:     # the same live tensor, unmodified
+                n_cells = hit[2]
+            else:
+                if len(cache) > 64:
+                    cache.clear()
+                n_cells = int(active.sum().item())
+                cache[id(active_b1ff)] = (weakref.ref(active_b1ff), active_b1ff._version, n_cells)
         x_img = inp_bchw.detach().float().reshape(B, H, W).contiguous()
         inv_pix = (1 - active).repeat_interleave(r, 1).repeat_interleave(r, 2).contiguous()
         ep, dp = "sparse_encoder.sp_cnn.", "dense_decoder."
@@ -375,7 +390,14 @@ class SparK(_EngineOwner, nn.Module):
         # never made -- selected from the raw output + transform in the densify pass itself)
         feats = [b2] + [lv["s2"] for lv in reversed(levels)]
         # the densified skips are written straight into the right halves of the decoder's concat buffers (no copy at the hand-over)
-        cats = eng.decoder_alloc(sd, B, H, W, dp)
+        # (concat buffers + affine arrays of the last shape are reused from step to step: the fused step runs forward and backward in
+        # one call, so nothing of the previous step is alive -- 16 fills and four allocations per step otherwise)
+        ck = (B, H, W, eng.tdt)
+        cc = self.__dict__.get("_cats_cache")
+        if cc is None or cc[0] != ck or cc[1] is not eng:
+            cc = (ck, eng, eng.decoder_alloc(sd, B, H, W, dp))
+            self.__dict__["_cats_cache"] = cc
+        cats = cc[2]
         nf = len(feats)
         into_cats = len(cats) == nf - 1 and all(cats[nf - 1 - i]["Cskip"] == feats[i]["y"].C for i in range(1, nf))
         to_dec = []
