@@ -249,7 +249,10 @@ class ArenaTrainer:
             b["pending"], b["launched"] = len(b["names"]), False
         self._works = []
         self._ov_active = True
-        self.last_exchange = {"buckets": len(self._buckets), "early": 0, "in_backward": 0, "flushed": 0, "exposed_bytes": 0}
+        # per step: how many buckets started from inside a fused node ("early"), from autograd's hooks ("in_backward") or only after
+        # the backward pass ("flushed"), with their bytes; "exposed_bytes" = the flushed ones (nothing left to hide them under)
+        self.last_exchange = {"buckets": len(self._buckets), "early": 0, "in_backward": 0, "flushed": 0, "bytes_early": 0,
+                              "bytes_in_backward": 0, "exposed_bytes": 0}
 
     def _launch(self, b):
         """Gradients of bucket ``b`` are final: bring stragglers into the arena, start its all-reduce (async, on the group's stream)."""
@@ -266,6 +269,7 @@ class ArenaTrainer:
         b["pending"] -= 1
         if b["pending"] == 0 and not b["launched"]:
             self.last_exchange["in_backward"] += 1
+            self.last_exchange["bytes_in_backward"] += 4 * int(b["hi"] - b["lo"])
             self._launch(b)
 
     def notify_ready(self, prefix, grads):
@@ -285,6 +289,7 @@ class ArenaTrainer:
             if ok:
                 b["launched"] = True          # (their hooks fire when the node returns: nothing left to do then)
                 self.last_exchange["early"] += 1
+                self.last_exchange["bytes_early"] += 4 * int(b["hi"] - b["lo"])
                 w = self.flat.all_reduce_range_async(b["lo"], b["hi"], self.group)
                 if w is not None:
                     self._works.append(w)

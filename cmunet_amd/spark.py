@@ -288,7 +288,10 @@ class SparK(_EngineOwner, nn.Module):
         y = s["y"]
         B, H, W, C = y.B, y.H, y.W, y.C
         w = sd[s["pconv"] + "weight"]
-        dgamma, dbeta, coef = eng._f32(C), eng._f32(C), eng._f32(2, C)
+        # parameter gradients go straight into the arena of the trainer that holds the parameter, if any (engine._gbuf): no copies at
+        # the end of the step, and the data-parallel trainer can start a bucket's exchange the moment its last gradient has landed
+        dgamma, dbeta = eng._gbuf(s["pbn"] + "weight", sd[s["pbn"] + "weight"]), eng._gbuf(s["pbn"] + "bias", sd[s["pbn"] + "bias"])
+        coef = eng._f32(2, C)
         tiles = s.get("tiles")
         if tiles is not None and tiles["pix"] is not None:
             ops.bn_bwd_reduce_rows(dA, y, s["mean"], s["invstd"], dgamma, dbeta, coef, tiles["pix"], count, eng._bn_ws(C))
@@ -304,8 +307,10 @@ class SparK(_EngineOwner, nn.Module):
         dY = Act(dA.buf, dA.coff, dA.C)
         ops.bn_bwd_apply_masked(dA, y, s["mean"], s["invstd"], coef, dY, active)
         grads[s["pbn"] + "weight"], grads[s["pbn"] + "bias"] = dgamma, dbeta
-        grads[s["pconv"] + "bias"] = torch.zeros(C, dtype=torch.float32, device=eng.device)
-        dW = torch.empty_like(w, dtype=torch.float32)
+        gb = eng._gbuf(s["pconv"] + "bias", sd[s["pconv"] + "bias"])     # identically zero in front of a training-mode BatchNorm
+        eng._zero_pending.append(gb)
+        grads[s["pconv"] + "bias"] = gb
+        dW = eng._gbuf(s["pconv"] + "weight", w)
         if s["x_img"] is not None:
             ops.conv3x3_c1_wgrad(s["x_img"], dY, dW, eng.scratch.get("wg", eng.lib.cmu_conv3x3_c1_wgrad_ws_bytes(B, H, W, C)), s["mask"], True)
         else:
@@ -456,4 +461,7 @@ class SparK(_EngineOwner, nn.Module):
                 ops.maxpool_bwd(dP, d_feats[nd - i + 1], a2.with_transform(one, zero, 0), dA2)
             dA1 = self._sp_convbn_bwd(eng, sd, lv["s2"], dA2, active, lv["cnt"], grads, True)
             dP = self._sp_convbn_bwd(eng, sd, lv["s1"], dA1, active, lv["cnt"], grads, i > 1)
+        eng.flush_zero_bias()
+        if ready is not None:
+            ready("sparse_encoder.sp_cnn.down_conv", grads)
         return loss[0], grads
