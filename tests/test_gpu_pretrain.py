@@ -872,6 +872,113 @@ def _collect_hip_layers(last_ctx):
     return out
 
 
+@pytest.mark.parametrize("dt", ["f32", "f16"])
+def test_masked_recon_step_gate_forced_backward(cuda, dt):
+    """The HEADLINE step (BASELINE config 2: masked reconstruction through ``MaskedReconPretrainer``'s engine path -- mask fused into the
+    first conv, skips written into the concat buffers, head / pool fusions, first-layer weight gradient with the recomputed raw
+    output) at 224 x 224 (partial tiles: 112 / 56 / 28 / 14-pixel levels), base 32, depth 5, bs 4, with the oracle's float64 backward
+    pass on the HIP path's OWN forward (every conv output, ReLU gate and activated value taken from the engine's saved state, see
+    test_cmunet_joint_step_gate_forced_backward).  EVERY parameter gradient of the network is compared: f32 storage within 1e-4
+    relative L2 (what is left is the backward kernels' summation order); f16 storage -- weights rounded to f16 on both sides, the
+    HIP path storing every activation gradient in f16 -- within 1e-2 (measured 2.8e-3)."""
+    import joint224_case as J
+    from cmunet_amd import model as M, ops
+    from cmunet_amd.pretrain import MaskedReconPretrainer, create_random_patch_mask
+    from oracle import cmunet as OC, unet as OU
+    torch.manual_seed(0)
+    B, S = 4, 224
+    net = M.UNet(out_classes=2, dtype=dt, base_ch=32, depth=5).train()
+    gw = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if p.dim() == 1 and (".1." in n or ".4." in n):
+                p.add_(0.2 * torch.randn(p.shape, generator=gw))
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(1)
+    img = torch.randn(B, S, S, generator=g)
+    mask = torch.from_numpy(create_random_patch_mask(B, S, 16, 0.6, np.random.RandomState(2)))
+    net = net.to(cuda)
+    scale = 1.0 if dt == "f32" else 1024.0
+    tr = MaskedReconPretrainer(net, lr=1e-3, amp=False, loss_scale=scale)
+    eng = tr.engine
+    eng.prepack(tr.sd)
+    x, m = img.to(cuda), mask.to(cuda)
+    logits, ctx = eng.unet_forward(tr.sd, x, True, m, mask_per_sample=False)
+    loss, dlogits = torch.zeros(1, device=cuda), torch.empty_like(logits)
+    ws = torch.empty(ops._lib.lib().cmu_masked_mse_ws_bytes(B, S), dtype=torch.uint8, device=cuda)
+    ops.masked_mse_fwd_bwd(logits, 1, x, m, loss, dlogits, scale, ws, None)
+    tdt = ops.TORCH_DT[ops.dt_code(dt)]
+    layers = {}
+
+    def add(st):
+        y = st["y"]
+        raw = y.buf[..., y.coff:y.coff + y.C].float()
+        z = (raw.double() * y.scale.double() + y.shift.double()).float()            # = fmaf(y, scale, shift)
+        # (the consumers round this to the storage type while staging; the oracle keeps the unrounded value so that its max-pools pick
+        # the element the HIP pool picks -- it compares the fp32 values -- instead of tying on equal 16-bit roundings)
+        act = torch.clamp_min(z, 0)
+        layers[st["pconv"]] = (raw.permute(0, 3, 1, 2).contiguous().cpu(), act.permute(0, 3, 1, 2).contiguous().cpu(),
+                               (z > 0).permute(0, 3, 1, 2).contiguous().cpu())
+    for lv in ctx["enc"]["levels"]:
+        add(lv["s1"]); add(lv["s2"])
+    add(ctx["enc"]["bott"]["s1"]); add(ctx["enc"]["bott"]["s2"])
+    for lv in ctx["dec"]["levels"]:
+        add(lv["s1"]); add(lv["s2"])
+    assert len(layers) == 18
+    eng.grad_target, eng.grad_prefix = tr.flat.grad_views, ""
+    try:
+        eng.unet_backward(tr.sd, ctx, dlogits)
+    finally:
+        eng.grad_target = None
+
+    class Taps:
+        seen = set()
+
+        def conv(self, key, y):
+            self.seen.add(key)
+            return y + (layers[key][0].to(y.dtype) - y).detach()
+
+        def act(self, key, z):
+            a = z * layers[key][2].to(z.dtype)
+            return a + (layers[key][1].to(z.dtype) - a).detach()
+    taps = Taps()
+    # the oracle in float64 on the weights the kernels multiply with (16-bit storage: the packed copies hold the rounded weights)
+    def wq(k, v):
+        if not v.is_floating_point():
+            return v.clone()
+        v = v.to(tdt).double() if (v.dim() == 4 and dt != "f32" and "conv_last" not in k) else v.double()
+        return v.requires_grad_(True) if "running" not in k else v
+    osd = {k: wq(k, v) for k, v in sd.items()}
+    OU.TAP = taps
+    try:
+        out = OU.unet_forward(img.double() * (1 - mask[0]).double(), osd, training=True)
+        ref_loss = OC.masked_mse(out[:, 1], img.double(), mask)
+        ref_loss.backward()
+    finally:
+        OU.TAP = None
+    assert taps.seen == set(layers)
+    assert abs(float(loss) - float(ref_loss.detach())) <= (2e-5 if dt == "f32" else 2e-3) * max(1.0, abs(float(ref_loss.detach())))
+    bar = 1e-4 if dt == "f32" else 1e-2
+    worst, n = ("", 0.0), 0
+    for k, v in osd.items():
+        if not (torch.is_tensor(v) and v.requires_grad) or k.endswith(("0.bias", "3.bias")):     # (conv biases in front of BN: identically zero)
+            continue
+        got = tr.flat.grad_views[k].detach().double().cpu() / scale
+        e = J.rel_l2(got, v.grad)
+        if k.endswith("up_sample.bias"):
+            # a bias in front of conv + training-mode BatchNorm: its gradient is the border remainder of sums that cancel (norm ~1e-3
+            # of its layer's weight gradient) -- held to the bar on the layer's scale
+            wg = osd[k[:-len("bias")] + "weight"].grad
+            e = (got - v.grad).norm().item() / max(v.grad.norm().item(), 1e-2 * wg.norm().item())
+        n += 1
+        if e > worst[1]:
+            worst = (k, e)
+        assert e <= bar, f"d{k}: relative L2 error {e:.2e} with the gates forced (bar {bar:.0e}, {dt})"
+    print(f"[masked-recon step @ 224 {dt}, oracle backward on the HIP forward] {n} parameter gradients, worst {worst[0]}: {worst[1]:.2e} (bar {bar:.0e})")
+    _parity_record(f"masked-reconstruction step (engine path of MaskedReconPretrainer) {dt} at 224x224, bs 4, base 32, depth 5, float64 oracle backward on the HIP "
+                   f"path's own forward values and ReLU gates: {n} parameter gradients, worst relative L2 error {worst[1]:.2e} ({worst[0]}), bar {bar:.0e}")
+
+
 @pytest.mark.parametrize("mode", ["random65", "tie_free"])
 def test_cmunet_joint_step_gate_forced_backward(cuda, mode):
     """The twin of test_cmunet_joint_step_reference_geometry that CAN fail on the conv chain.  Two fp32 implementations of this step
