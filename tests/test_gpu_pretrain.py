@@ -872,22 +872,24 @@ def _collect_hip_layers(last_ctx):
     return out
 
 
-@pytest.mark.parametrize("dt", ["f32", "f16"])
-def test_masked_recon_step_gate_forced_backward(cuda, dt):
+@pytest.mark.parametrize("case", [("f32", 224, 4, 32), ("f16", 224, 4, 32), ("f16", 512, 2, 64)])
+def test_masked_recon_step_gate_forced_backward(cuda, case):
     """The HEADLINE step (BASELINE config 2: masked reconstruction through ``MaskedReconPretrainer``'s engine path -- mask fused into the
     first conv, skips written into the concat buffers, head / pool fusions, first-layer weight gradient with the recomputed raw
     output) at 224 x 224 (partial tiles: 112 / 56 / 28 / 14-pixel levels), base 32, depth 5, bs 4, with the oracle's float64 backward
     pass on the HIP path's OWN forward (every conv output, ReLU gate and activated value taken from the engine's saved state, see
     test_cmunet_joint_step_gate_forced_backward).  EVERY parameter gradient of the network is compared: f32 storage within 1e-4
     relative L2 (what is left is the backward kernels' summation order); f16 storage -- weights rounded to f16 on both sides, the
-    HIP path storing every activation gradient in f16 -- within 1e-2 (measured 2.8e-3)."""
+    HIP path storing every activation gradient in f16 -- within 1e-2 (measured 2.8e-3).  Third case: the REFERENCE network (base 64,
+    depth 5, 31 M parameters) at the bench's 512 x 512 geometry and arithmetic (f16; whole tiles: the weight-resident 64-channel
+    tile and the NB = 128 persistent forms the bench runs), bs 2 so that the float64 oracle finishes in about a minute."""
     import joint224_case as J
+    dt, S, B, base = case
     from cmunet_amd import model as M, ops
     from cmunet_amd.pretrain import MaskedReconPretrainer, create_random_patch_mask
     from oracle import cmunet as OC, unet as OU
     torch.manual_seed(0)
-    B, S = 4, 224
-    net = M.UNet(out_classes=2, dtype=dt, base_ch=32, depth=5).train()
+    net = M.UNet(out_classes=2, dtype=dt, base_ch=base, depth=5).train()
     gw = torch.Generator().manual_seed(7)
     with torch.no_grad():
         for n, p in net.named_parameters():
@@ -974,8 +976,8 @@ def test_masked_recon_step_gate_forced_backward(cuda, dt):
         if e > worst[1]:
             worst = (k, e)
         assert e <= bar, f"d{k}: relative L2 error {e:.2e} with the gates forced (bar {bar:.0e}, {dt})"
-    print(f"[masked-recon step @ 224 {dt}, oracle backward on the HIP forward] {n} parameter gradients, worst {worst[0]}: {worst[1]:.2e} (bar {bar:.0e})")
-    _parity_record(f"masked-reconstruction step (engine path of MaskedReconPretrainer) {dt} at 224x224, bs 4, base 32, depth 5, float64 oracle backward on the HIP "
+    print(f"[masked-recon step @ {S} {dt} bs {B} base {base}, oracle backward on the HIP forward] {n} parameter gradients, worst {worst[0]}: {worst[1]:.2e} (bar {bar:.0e})")
+    _parity_record(f"masked-reconstruction step (engine path of MaskedReconPretrainer) {dt} at {S}x{S}, bs {B}, base {base}, depth 5, float64 oracle backward on the HIP "
                    f"path's own forward values and ReLU gates: {n} parameter gradients, worst relative L2 error {worst[1]:.2e} ({worst[0]}), bar {bar:.0e}")
 
 
