@@ -109,6 +109,18 @@ _SIGS = {
     "cmu_conv3x3_tiles_supported": (_I, [_I, _I, _I, _I, _I, _I]),
     "cmu_rows_channel_stats": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cmu_bn_bwd_reduce_rows": (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _P, _P]),
+    "cmu_sparse_tile_lists_max": (_I, []),
+    "cmu_sparse_tile_lists": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "cmu_sparse_pixel_lists": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "cmu_conv3x3_c1_fwd_tiles_rows": (_I, [_L]),
+    "cmu_conv3x3_c1_fwd_tiles": (_I, [_P, _P, _I, _P, _P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "cmu_conv3x3_c1_wgrad_bn_tiles": (_I, [_P, _P, _I, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "cmu_cells_supported": (_I, [_I, _I, _I, _I, _I, _I]),
+    "cmu_bn_bwd_apply_cells": (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "cmu_mask_select_cells": (_I, [_P, _L, _P, _P, _I, _P, _I, _I, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "cmu_maxpool_bwd_cells": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _I, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "cmu_cells_channel_sum_ws_bytes": (_L, [_I]),
+    "cmu_cells_channel_sum": (_I, [_P, _L, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cmu_sparse_pixel_list_ws_bytes": (_L, [_I, _I]),
     "cmu_sparse_pixel_list": (_I, [_P, _I, _I, _I, _I, _P, _L, _P, _P, _P]),
     "cmu_conv3x3_rows_supported": (_I, [_I, _I, _I, _I, _I, _I]),

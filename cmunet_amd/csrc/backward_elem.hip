@@ -921,7 +921,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c1_wgrad_kernel(const float* _
                                                               int tilesY, int ntiles, const unsigned char* __restrict__ yraw, int64_t ldy,
                                                               const float* __restrict__ bsc, const float* __restrict__ bsh,
                                                               const float* __restrict__ bmu, const float* __restrict__ bis,
-                                                              const float* __restrict__ coef, const float* __restrict__ wfwd) {
+                                                              const float* __restrict__ coef, const float* __restrict__ wfwd,
+                                                              const int* __restrict__ tlist = nullptr, const int* __restrict__ tcount = nullptr) {
+    // tlist (SparK's sparse encoder, cmu_conv3x3_c1_wgrad_bn_tiles): the contraction runs over the listed 16 x 16 tiles only (the
+    // gradient is zero elsewhere), round-robin over the workgroups
     constexpr int EPC = TR::EPC;
     constexpr int ES = (int)sizeof(typename TR::elem_t);
     __shared__ float halo[2][18 * 18];
@@ -974,15 +977,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c1_wgrad_kernel(const float* _
         buf[tid] = hv[0];
         if (tid + 256 < 18 * 18) buf[tid + 256] = hv[1];
     };
-    int tile = blockIdx.x;
-    if (tile < ntiles) { halo_load(tile); halo_store(halo[0]); }
+    const int nwork = tlist != nullptr ? tcount[0] : ntiles;
+    int wi = blockIdx.x;
+    if (wi < nwork) { halo_load(tlist != nullptr ? tlist[wi] : wi); halo_store(halo[0]); }
     __syncthreads();
-    for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
+    for (int it = 0; wi < nwork; wi += gridDim.x, ++it) {
+        const int tile = tlist != nullptr ? tlist[wi] : wi;
         const int tx = tile % tilesX, ty = (tile / tilesX) % tilesY, b = tile / tpi;
         const int ty0 = ty * 16, tx0 = tx * 16;
         const float* hb = halo[it & 1];
-        const bool more = tile + (int)gridDim.x < ntiles;
-        if (more) halo_load(tile + gridDim.x);
+        const bool more = wi + (int)gridDim.x < nwork;
+        if (more) halo_load(tlist != nullptr ? tlist[wi + gridDim.x] : wi + (int)gridDim.x);
         // four pixels per trip: their 16-byte loads (dY, and the raw output when it is read) go out together --
         // one or two loads in flight per wave left this pass latency-bound at ~2.6 TB/s
         constexpr int U = 4;
@@ -1067,16 +1072,18 @@ template <class TR>
 static int conv3x3_c1_wgrad_t(const float* x, const uint8_t* mask, int mps, const void* dY, int64_t ldd, float* dW, int B, int H, int W,
                               int Cout, void* ws, hipStream_t st, const void* yraw = nullptr, int64_t ldy = 0, const float* bsc = nullptr,
                               const float* bsh = nullptr, const float* bmu = nullptr, const float* bis = nullptr,
-                              const float* coef = nullptr, const float* wfwd = nullptr) {
+                              const float* coef = nullptr, const float* wfwd = nullptr, const int* tlist = nullptr,
+                              const int* tcount = nullptr, int64_t max_tiles = 0) {
     const int tilesX = cmu_div_up(W, 16), tilesY = cmu_div_up(H, 16);
     const int ntiles = B * tilesX * tilesY;
-    const int grid = ntiles < C1W_MAX_BLOCKS ? ntiles : C1W_MAX_BLOCKS;
+    const int64_t nwork = tlist != nullptr ? (max_tiles < 1 ? 1 : max_tiles) : ntiles;
+    const int grid = (int)(nwork < C1W_MAX_BLOCKS ? nwork : C1W_MAX_BLOCKS);
     if (wfwd != nullptr)
         hipLaunchKernelGGL((conv3x3_c1_wgrad_kernel<TR, true>), dim3(grid), dim3(256), 0, st, x, mask, mps, (const unsigned char*)dY, ldd, (float*)ws,
-                           B, H, W, Cout, tilesX, tilesY, ntiles, (const unsigned char*)yraw, ldy, bsc, bsh, bmu, bis, coef, wfwd);
+                           B, H, W, Cout, tilesX, tilesY, ntiles, (const unsigned char*)yraw, ldy, bsc, bsh, bmu, bis, coef, wfwd, tlist, tcount);
     else
         hipLaunchKernelGGL((conv3x3_c1_wgrad_kernel<TR, false>), dim3(grid), dim3(256), 0, st, x, mask, mps, (const unsigned char*)dY, ldd, (float*)ws,
-                           B, H, W, Cout, tilesX, tilesY, ntiles, (const unsigned char*)yraw, ldy, bsc, bsh, bmu, bis, coef, wfwd);
+                           B, H, W, Cout, tilesX, tilesY, ntiles, (const unsigned char*)yraw, ldy, bsc, bsh, bmu, bis, coef, wfwd, tlist, tcount);
     CMU_CHECK_LAUNCH("cmu_conv3x3_c1_wgrad");
     const int64_t n = (int64_t)Cout * 9;
     hipLaunchKernelGGL(sum_slab_kernel, dim3((unsigned)cmu_div_up64(n, 16)), dim3(256), 0, st, (const float*)ws, grid, n, dW, n, (float*)nullptr);
@@ -1108,6 +1115,25 @@ extern "C" int cmu_conv3x3_c1_wgrad_bn(const float* x, const uint8_t* mask, int 
                   "cmu_conv3x3_c1_wgrad_bn: alignment / stride");
     CMU_DISPATCH_DT(dt, conv3x3_c1_wgrad_t, x, mask, mask_per_sample, dA, ldd, dW, B, H, W, Cout, ws, (hipStream_t)stream, yraw, ldy, scale,
                     shift, save_mean, save_invstd, coef);
+}
+// cmu_conv3x3_c1_wgrad_bn / cmu_conv3x3_c1_wgrad_bn_w over a list of 16 x 16 tiles (cmu_sparse_tile_list numbering): SparK's sparse first
+// layer (Spark/encoder.py:20-36) -- dA, and the BatchNorm backward applied on the fly, only exist inside active patches, so neither the
+// masked apply pass nor its dY tensor is needed.  Exactly one of yraw (read) / w (recomputed from the image) is given.
+extern "C" int cmu_conv3x3_c1_wgrad_bn_tiles(const float* x, const uint8_t* mask, int mask_per_sample, const void* dA, int64_t ldd,
+                                             const void* yraw, int64_t ldy, const float* w, const float* scale, const float* shift,
+                                             const float* save_mean, const float* save_invstd, const float* coef, const int* tile_list,
+                                             const int* tile_count, int64_t max_tiles, float* dW, int B, int H, int W, int Cout, int dt,
+                                             void* ws, void* stream) {
+    const int es = cmu_dtype_size(dt);
+    CMU_CHECK_ARG(es > 0 && x && dA && scale && shift && save_mean && save_invstd && coef && dW && ws && tile_list && tile_count && B > 0 && H > 0 &&
+                      W > 0 && ((yraw != nullptr) != (w != nullptr)),
+                  "cmu_conv3x3_c1_wgrad_bn_tiles: bad args (exactly one of yraw / w)");
+    const int epc = 16 / es;
+    CMU_CHECK_ARG(Cout > 0 && Cout % epc == 0 && Cout / epc <= 256, "cmu_conv3x3_c1_wgrad_bn_tiles: Cout=%d unsupported", Cout);
+    CMU_CHECK_ARG(cmu_aligned16(dA) && ldd % epc == 0 && ldd >= Cout && (yraw == nullptr || (cmu_aligned16(yraw) && ldy % epc == 0 && ldy >= Cout)),
+                  "cmu_conv3x3_c1_wgrad_bn_tiles: alignment / stride");
+    CMU_DISPATCH_DT(dt, conv3x3_c1_wgrad_t, x, mask, mask_per_sample, dA, ldd, dW, B, H, W, Cout, ws, (hipStream_t)stream, yraw, ldy, scale, shift,
+                    save_mean, save_invstd, coef, w, tile_list, tile_count, max_tiles);
 }
 // The same with the raw output RECOMPUTED from the image and the layer's forward weights ``w`` (Cout,1,3,3) instead of read
 // (conv3x3_c1_wgrad_kernel<., true>): bit-identical to cmu_conv3x3_c1_wgrad_bn on the tensor cmu_conv3x3_c1_fwd stored, at half

@@ -797,11 +797,9 @@ extern "C" int cmu_sparse_pixel_list(const uint8_t* active, int f, int B, int H,
 // tiles out of the bitmap (one 64-bit mask), the workgroup scans the runs' counts once (wave prefix by shuffles + the 16 wave
 // totals) and each thread writes its listed tiles behind its offset.  Five barriers per trip where the tile-per-thread loop took
 // three per 1,024 tiles with one dependent mask load each (45 us per list, nine lists per SparK step).  Same ascending order.
-__global__ __launch_bounds__(1024) void sparse_tile_list_kernel(const uint8_t* __restrict__ active, int f, int sbits, int B, int tilesY,
-                                                               int tilesX, int th, int tw, int* __restrict__ list, int* __restrict__ count) {
-    __shared__ unsigned long long bits[1024];
-    __shared__ int wsum[16];
-    __shared__ int base;
+__device__ static inline void sparse_tile_list_body(const uint8_t* __restrict__ active, int f, int sbits, int B, int tilesY, int tilesX, int th,
+                                                   int tw, int* __restrict__ list, int* __restrict__ count, unsigned long long* bits, int* wsum,
+                                                   int& base) {
     const int total = B * tilesY * tilesX;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) base = 0;
@@ -850,6 +848,97 @@ __global__ __launch_bounds__(1024) void sparse_tile_list_kernel(const uint8_t* _
         __syncthreads();
     }
     if (threadIdx.x == 0) count[0] = base;
+}
+__global__ __launch_bounds__(1024) void sparse_tile_list_kernel(const uint8_t* __restrict__ active, int f, int sbits, int B, int tilesY,
+                                                               int tilesX, int th, int tw, int* __restrict__ list, int* __restrict__ count) {
+    __shared__ unsigned long long bits[1024];
+    __shared__ int wsum[16];
+    __shared__ int base;
+    sparse_tile_list_body(active, f, sbits, B, tilesY, tilesX, th, tw, list, count, bits, wsum, base);
+}
+// every list of a step in ONE launch, one workgroup per list (round 4: nine single-workgroup launches of 11 ... 72 us sat on a SparK
+// step's critical path -- the mask is known before the step starts); same lists as cmu_sparse_tile_list, element for element.
+constexpr int SP_MAX_LISTS = 12;
+struct SpListBatch {
+    int f, B;
+    int sbits[SP_MAX_LISTS], tilesY[SP_MAX_LISTS], tilesX[SP_MAX_LISTS], th[SP_MAX_LISTS], tw[SP_MAX_LISTS];
+    int* list[SP_MAX_LISTS];
+    int* count[SP_MAX_LISTS];
+};
+__global__ __launch_bounds__(1024) void sparse_tile_lists_kernel(const uint8_t* __restrict__ active, SpListBatch q) {
+    __shared__ unsigned long long bits[1024];
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int i = blockIdx.x;
+    sparse_tile_list_body(active, q.f, q.sbits[i], q.B, q.tilesY[i], q.tilesX[i], q.th[i], q.tw[i], q.list[i], q.count[i], bits, wsum, base);
+}
+extern "C" int cmu_sparse_tile_lists_max(void) { return SP_MAX_LISTS; }
+extern "C" int cmu_sparse_tile_lists(const uint8_t* active, int f, int B, int n, const int* H, const int* tile_h, const int* tile_w, int* const* lists,
+                                     int* const* counts, void* stream) {
+    CMU_CHECK_ARG(active && f > 0 && B > 0 && n > 0 && n <= SP_MAX_LISTS && H && tile_h && tile_w && lists && counts,
+                  "cmu_sparse_tile_lists: bad args (at most %d lists per call)", SP_MAX_LISTS);
+    SpListBatch q = {};
+    q.f = f; q.B = B;
+    for (int i = 0; i < n; ++i) {
+        CMU_CHECK_ARG(lists[i] && counts[i] && H[i] > 0 && tile_h[i] > 0 && tile_w[i] > 0, "cmu_sparse_tile_lists: null list / bad tile (entry %d)", i);
+        const int sb = sp_shift_bits(H[i], f);
+        CMU_CHECK_ARG(sb >= 0, "cmu_sparse_tile_lists: H must be f << s (entry %d: H=%d, f=%d)", i, H[i], f);
+        q.sbits[i] = sb;
+        q.tilesY[i] = cmu_div_up(H[i], tile_h[i]);
+        q.tilesX[i] = cmu_div_up(H[i], tile_w[i]);
+        q.th[i] = tile_h[i]; q.tw[i] = tile_w[i];
+        CMU_CHECK_ARG((int64_t)B * q.tilesY[i] * q.tilesX[i] < (1ll << 30), "cmu_sparse_tile_lists: too many tiles (entry %d)", i);
+        q.list[i] = lists[i]; q.count[i] = counts[i];
+    }
+    hipLaunchKernelGGL(sparse_tile_lists_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream, active, q);
+    CMU_CHECK_LAUNCH("cmu_sparse_tile_lists");
+    return CMU_OK;
+}
+// the pixel lists of several levels from ONE patch list (cmu_sparse_tile_list with tiles of one patch, e.g. H = f and 1 x 1 tiles:
+// entries (b*f + fy)*f + fx) in one launch: level i (side H[i] = f << s) gets rows[i][0 .. capacity[i]) and counts[i][0], exactly
+// as cmu_sparse_pixel_list writes them
+struct SpRowsBatch {
+    int f;
+    int s[SP_MAX_LISTS], H[SP_MAX_LISTS];
+    int* rows[SP_MAX_LISTS];
+    int* count[SP_MAX_LISTS];
+    long long cap[SP_MAX_LISTS];
+};
+__global__ void sparse_pixel_rows_multi_kernel(const int* __restrict__ plist, const int* __restrict__ pcount, SpRowsBatch q) {
+    const int i = blockIdx.y;
+    const int np = pcount[0], s = q.s[i], H = q.H[i], f = q.f;
+    const long long n = (long long)np * s * s, cap = q.cap[i];
+    int* __restrict__ rows = q.rows[i];
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < cap; r += (long long)gridDim.x * blockDim.x) {
+        int v = -1;
+        if (r < n) {
+            const int pi = (int)(r / (s * s)), in = (int)(r % (s * s));
+            const int t = plist[pi];
+            const int fx = t % f, fy = (t / f) % f, b = t / (f * f);
+            v = (b * H + fy * s + in / s) * H + fx * s + in % s;
+        }
+        rows[r] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) q.count[i][0] = (int)n;
+}
+extern "C" int cmu_sparse_pixel_lists(const int* patches, const int* patch_count, int f, int B, int n, const int* H, int* const* rows,
+                                      const int64_t* capacity, int* const* counts, void* stream) {
+    CMU_CHECK_ARG(patches && patch_count && f > 0 && B > 0 && n > 0 && n <= SP_MAX_LISTS && H && rows && capacity && counts,
+                  "cmu_sparse_pixel_lists: bad args (at most %d levels per call)", SP_MAX_LISTS);
+    SpRowsBatch q = {};
+    q.f = f;
+    int64_t cmax = 0;
+    for (int i = 0; i < n; ++i) {
+        const int sb = sp_shift_bits(H[i], f);
+        CMU_CHECK_ARG(rows[i] && counts[i] && capacity[i] > 0 && sb >= 0 && (int64_t)B * H[i] * H[i] < (1ll << 31),
+                      "cmu_sparse_pixel_lists: null list, or H must be f << s (entry %d: H=%d, f=%d)", i, H[i], f);
+        q.s[i] = 1 << sb; q.H[i] = H[i]; q.rows[i] = rows[i]; q.count[i] = counts[i]; q.cap[i] = capacity[i];
+        if (capacity[i] > cmax) cmax = capacity[i];
+    }
+    const int grid = (int)(cmu_div_up64(cmax, 256) < 4096 ? cmu_div_up64(cmax, 256) : 4096);
+    hipLaunchKernelGGL(sparse_pixel_rows_multi_kernel, dim3(grid, n), dim3(256), 0, (hipStream_t)stream, patches, patch_count, q);
+    CMU_CHECK_LAUNCH("cmu_sparse_pixel_lists");
+    return CMU_OK;
 }
 extern "C" int cmu_sparse_tile_list(const uint8_t* active, int f, int B, int H, int W, int tile_h, int tile_w, int* list, int* count,
                                     void* stream) {

@@ -418,7 +418,11 @@ template <class TR>
 __global__ __launch_bounds__(256, CMU_C1F_WAVES) void conv3x3_c1_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask,
                                                             int mask_per_sample, const float* __restrict__ w,
                                                             typename TR::elem_t* __restrict__ y, int64_t ldy, float* stats, int B,
-                                                            int H, int W, int Cout, int tilesX, int tilesY) {
+                                                            int H, int W, int Cout, int tilesX, int tilesY,
+                                                            const int* __restrict__ tlist = nullptr, const int* __restrict__ tcount = nullptr) {
+    // tlist (SparK's sparse encoder, cmu_conv3x3_c1_fwd_tiles): only the listed 16 x 16 tiles are computed, round-robin over the
+    // workgroups; the slab then has one row per WORKGROUP (all written), and when every listed tile lies inside active patches its
+    // sums are the sparse BatchNorm statistics themselves
     constexpr int EPC = TR::EPC;
     __shared__ float halo[2][18 * 18];
     __shared__ float red[2][256];
@@ -456,15 +460,17 @@ __global__ __launch_bounds__(256, CMU_C1F_WAVES) void conv3x3_c1_fwd_kernel(cons
     float s1[EPC], s2[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
-    int tile = blockIdx.x;
-    if (tile < ntile) { halo_load(tile); halo_store(halo[0]); }
+    const int nwork = tlist != nullptr ? tcount[0] : ntile;
+    int wi = blockIdx.x;
+    if (wi < nwork) { halo_load(tlist != nullptr ? tlist[wi] : wi); halo_store(halo[0]); }
     __syncthreads();
-    for (int it = 0; tile < ntile; tile += gridDim.x, ++it) {
+    for (int it = 0; wi < nwork; wi += gridDim.x, ++it) {
+        const int tile = tlist != nullptr ? tlist[wi] : wi;
         const int tx = tile % tilesX, ty = (tile / tilesX) % tilesY, b = tile / tpi;
         const int ty0 = ty * 16, tx0 = tx * 16;
         const float* hb = halo[it & 1];
-        const bool more = tile + (int)gridDim.x < ntile;
-        if (more) halo_load(tile + gridDim.x);
+        const bool more = wi + (int)gridDim.x < nwork;
+        if (more) halo_load(tlist != nullptr ? tlist[wi + gridDim.x] : wi + (int)gridDim.x);
         if (active)
             for (int pix = prow; pix < 256; pix += ppi) {
                 const int py = pix >> 4, px = pix & 15;
@@ -486,13 +492,13 @@ __global__ __launch_bounds__(256, CMU_C1F_WAVES) void conv3x3_c1_fwd_kernel(cons
                 st_global16_nt(reinterpret_cast<unsigned char*>(y) + ((((int64_t)b * H + gy) * W + gx) * ldy + chunk * EPC) * sizeof(typename TR::elem_t),
                             TR::pack(o));
             }
-        if (stats != nullptr && it > 0)      // rows of the workgroup's later tiles: zero (its sums go to its first tile's row)
+        if (stats != nullptr && it > 0 && tlist == nullptr)      // rows of the workgroup's later tiles: zero (its sums go to its first tile's row)
             for (int c = tid; c < 2 * Cout; c += 256) stats[(int64_t)tile * 2 * Cout + c] = 0.f;
         if (more) halo_store(halo[(it + 1) & 1]);
         __syncthreads();
     }
-    if (stats == nullptr || (int)blockIdx.x >= ntile) return;
-    tile = blockIdx.x;
+    if (stats == nullptr || (tlist == nullptr && (int)blockIdx.x >= ntile)) return;
+    const int tile = blockIdx.x;                 // slab row: the workgroup's first tile (dense form) / the workgroup (list form)
     if ((nchunk & (nchunk - 1)) == 0 && nchunk <= 32 && nchunk * EPC <= 64) {
         // threads sharing a channel chunk sit nchunk lanes apart: fold inside the wave (fixed xor order), then the four
         // waves through LDS
@@ -541,16 +547,17 @@ __global__ __launch_bounds__(256, CMU_C1F_WAVES) void conv3x3_c1_fwd_kernel(cons
     }
 }
 
-template <class TR>
-static int conv3x3_c1_fwd_t(const float* x, const uint8_t* mask, int mps, const float* w, void* y, int64_t ldy, float* stats,
-                            int B, int H, int W, int Cout, hipStream_t st) {
-    const int tilesX = cmu_div_up(W, 16), tilesY = cmu_div_up(H, 16);
-    const int ntile = B * tilesX * tilesY;
 #ifndef CMU_C1F_CAP
 #define CMU_C1F_CAP 2048
 #endif
-    hipLaunchKernelGGL((conv3x3_c1_fwd_kernel<TR>), dim3(ntile < CMU_C1F_CAP ? ntile : CMU_C1F_CAP), dim3(256), 0, st, x, mask, mps, w,
-                       (typename TR::elem_t*)y, ldy, stats, B, H, W, Cout, tilesX, tilesY);
+template <class TR>
+static int conv3x3_c1_fwd_t(const float* x, const uint8_t* mask, int mps, const float* w, void* y, int64_t ldy, float* stats,
+                            int B, int H, int W, int Cout, hipStream_t st, const int* tlist = nullptr, const int* tcount = nullptr,
+                            int64_t max_tiles = 0) {
+    const int tilesX = cmu_div_up(W, 16), tilesY = cmu_div_up(H, 16);
+    const int64_t ntile = tlist != nullptr ? max_tiles : (int64_t)B * tilesX * tilesY;
+    hipLaunchKernelGGL((conv3x3_c1_fwd_kernel<TR>), dim3((unsigned)(ntile < CMU_C1F_CAP ? ntile : CMU_C1F_CAP)), dim3(256), 0, st, x, mask, mps, w,
+                       (typename TR::elem_t*)y, ldy, stats, B, H, W, Cout, tilesX, tilesY, tlist, tcount);
     CMU_CHECK_LAUNCH("cmu_conv3x3_c1_fwd");
     return CMU_OK;
 }
@@ -564,6 +571,24 @@ extern "C" int cmu_conv3x3_c1_fwd(const float* x, const uint8_t* mask, int mask_
     CMU_CHECK_ARG(Cout % epc == 0 && Cout / epc <= 256 && Cout > 0, "cmu_conv3x3_c1_fwd: Cout=%d must be a multiple of %d (<= %d)", Cout, epc, 256 * epc);
     CMU_CHECK_ARG(cmu_aligned16(y) && ldy % epc == 0 && ldy >= Cout, "cmu_conv3x3_c1_fwd: y alignment / stride");
     CMU_DISPATCH_DT(dt, conv3x3_c1_fwd_t, x, mask, mask_per_sample, w, y, ldy, stats, B, H, W, Cout, (hipStream_t)stream);
+}
+
+// The same over a list of 16 x 16 tiles (cmu_sparse_tile_list numbering; SparK's sparse encoder, Spark/encoder.py:20-23: the masked tiles
+// are never computed, y there is left untouched).  stats: [cmu_conv3x3_c1_fwd_tiles_rows(max_tiles)][2][Cout], fully written -- the sums
+// over the listed tiles' pixels.  max_tiles: host-side upper bound of tile_count[0] (sizes the grid).
+extern "C" int cmu_conv3x3_c1_fwd_tiles_rows(int64_t max_tiles) { return (int)(max_tiles < CMU_C1F_CAP ? (max_tiles < 1 ? 1 : max_tiles) : CMU_C1F_CAP); }
+extern "C" int cmu_conv3x3_c1_fwd_tiles(const float* x, const uint8_t* mask, int mask_per_sample, const float* w, void* y, int64_t ldy,
+                                        float* stats, const int* tile_list, const int* tile_count, int64_t max_tiles, int B, int H, int W,
+                                        int Cout, int dt, void* stream) {
+    const int es = cmu_dtype_size(dt);
+    CMU_CHECK_ARG(es > 0, "cmu_conv3x3_c1_fwd_tiles: bad dtype");
+    const int epc = 16 / es;
+    CMU_CHECK_ARG(x && w && y && tile_list && tile_count && B > 0 && H > 0 && W > 0, "cmu_conv3x3_c1_fwd_tiles: bad args");
+    CMU_CHECK_ARG(Cout % epc == 0 && Cout / epc <= 256 && Cout > 0, "cmu_conv3x3_c1_fwd_tiles: Cout=%d must be a multiple of %d (<= %d)", Cout, epc, 256 * epc);
+    CMU_CHECK_ARG(cmu_aligned16(y) && ldy % epc == 0 && ldy >= Cout, "cmu_conv3x3_c1_fwd_tiles: y alignment / stride");
+    if (max_tiles < 1) max_tiles = 1;
+    CMU_DISPATCH_DT(dt, conv3x3_c1_fwd_t, x, mask, mask_per_sample, w, y, ldy, stats, B, H, W, Cout, (hipStream_t)stream, tile_list, tile_count,
+                    max_tiles);
 }
 
 // ---------------------------------------------------------------------------------------------

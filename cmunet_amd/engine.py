@@ -32,6 +32,7 @@ BN_MOMENTUM = 0.1
 _FUSE_HEAD = os.environ.get("CMU_HEAD_FUSE", "1") != "0"   # A/B: "0" = the head's input gradient is stored and re-read by cmu_bn_bwd_apply
 _FUSE_DGRAD_BN = os.environ.get("CMU_DGRAD_BN", "1")    # A/B: "0" = BN-backward sums as a separate pass, "64"/"128" = fused up to C
 _FUSE_POOL = os.environ.get("CMU_POOL_FUSE", "1") != "0"   # A/B: "0" = the pool's input gradient is stored and re-read by cmu_bn_bwd_apply
+_POISON_NEW = os.environ.get("CMU_POISON_NEW", "0") == "1"    # tests: fresh activations are filled with NaN (reads of unwritten positions show)
 _C1W_RECOMP = os.environ.get("CMU_C1W_RECOMP", "1") != "0"  # A/B: "0" = the first layer's weight gradient reads the raw output instead of recomputing it
 
 
@@ -103,6 +104,8 @@ class UNetEngine:
     # helpers
     # ------------------------------------------------------------------------------------------
     def _new(self, B, H, W, C):
+        if _POISON_NEW:      # tests: every fresh activation starts as NaN, so a kernel that reads a position nobody wrote shows up
+            return Act(torch.full((B, H, W, C), float("nan"), dtype=self.tdt, device=self.device))
         return Act(torch.empty((B, H, W, C), dtype=self.tdt, device=self.device))
 
     def _f32(self, *shape):

@@ -7,6 +7,7 @@ GPU is missing (no CPU / eager fallback).
 its input tile) -- see the header for the convention.
 """
 import ctypes
+import os
 
 import torch
 
@@ -193,6 +194,31 @@ def conv3x3_c1_fwd(x_bhw, w, out, stats=None, mask=None, mask_per_sample=False):
         assert mask.dtype == torch.uint8 and mask.is_contiguous()
     call("cmu_conv3x3_c1_fwd", _p(_f32c(x_bhw)), _p(mask), int(mask_per_sample), _p(_f32c(w)), out.ptr(), out.ld,
          _p(stats), B, H, W, Cout, out.dt, _stream())
+
+
+def conv3x3_c1_fwd_tiles(x_bhw, w, out, tiles, max_tiles, mask=None, mask_per_sample=False, want_stats=True):
+    """``conv3x3_c1_fwd`` over a TileList of 16 x 16 tiles (``out`` elsewhere untouched) -> slab [rows][2][Cout] of the sums over the
+    listed tiles' pixels (None unless ``want_stats``).  ``max_tiles``: host-side upper bound of the list's count."""
+    B, H, W = x_bhw.shape
+    Cout = w.shape[0]
+    assert out.C == Cout and (out.B, out.H, out.W) == (B, H, W) and (tiles.tile_h, tiles.tile_w) == (16, 16)
+    stats = None
+    if want_stats:
+        stats = torch.empty((_lib.lib().cmu_conv3x3_c1_fwd_tiles_rows(int(max_tiles)), 2, Cout), dtype=torch.float32, device=out.buf.device)
+    call("cmu_conv3x3_c1_fwd_tiles", _p(_f32c(x_bhw)), _p(mask), int(mask_per_sample), _p(_f32c(w)), out.ptr(), out.ld, _p(stats),
+         _p(tiles.list), _p(tiles.count), int(max_tiles), B, H, W, Cout, out.dt, _stream())
+    return stats
+
+
+def conv3x3_c1_wgrad_bn_tiles(x_bhw, dA, yraw, scale, shift, save_mean, save_invstd, coef, dW, ws, tiles, max_tiles, mask=None,
+                              mask_per_sample=False, w=None):
+    """``conv3x3_c1_wgrad_bn`` with the contraction restricted to a TileList of 16 x 16 tiles (the gradient vanishes elsewhere)."""
+    B, H, W = x_bhw.shape
+    assert (tiles.tile_h, tiles.tile_w) == (16, 16)
+    call("cmu_conv3x3_c1_wgrad_bn_tiles", _p(_f32c(x_bhw)), _p(mask), int(mask_per_sample), dA.ptr(), dA.ld,
+         None if w is not None else yraw.ptr(), 0 if w is not None else yraw.ld, None if w is None else _p(_f32c(w)), _p(scale), _p(shift),
+         _p(save_mean), _p(save_invstd), _p(coef), _p(tiles.list), _p(tiles.count), int(max_tiles), _p(_f32c(dW)), B, H, W, dW.shape[0], dA.dt,
+         _p(ws), _stream())
 
 
 def conv3x3_fwd(x, wpacked, out, stats=None):
@@ -416,11 +442,37 @@ def bn_bwd_reduce_rows(dA, y, save_mean, save_invstd, dgamma, dbeta, coef, pixel
          _p(dbeta), _p(coef), _p(pixels.rows), _p(pixels.count), pixels.capacity, int(count), y.B, y.H, y.W, y.C, y.dt, _p(ws), _stream())
 
 
-def mask_select(x, active, out, relu=False, invert=False, fill=None, use_transform=True):
+_SPARK_CELLS = os.environ.get("CMU_SPARK_CELLS", "1") != "0"      # A/B: the pixel-organised masked kernels
+
+
+def cells_supported(x, active):
+    """Whether the patch-organised element-wise kernels (csrc/sparse_elem.hip) serve this level."""
+    if not _SPARK_CELLS:
+        return False
+    return bool(_lib.lib().cmu_cells_supported(x.B, x.H, x.W, active.shape[-1], x.C, x.dt))
+
+
+def mask_select(x, active, out, relu=False, invert=False, fill=None, use_transform=True, ring=False, cells=True):
+    """out = selected ? relu?(x * scale + shift) : fill.  With a zero fill and no inversion the patch-organised kernel is taken
+    (``cells``); ``ring``: only the one-pixel border frame of each masked patch is zeroed -- the caller guarantees that every consumer
+    of ``out`` is list-driven (reads active patches and a one-pixel halo only)."""
     sc = x.scale if use_transform else None
     sh = x.shift if use_transform else None
+    if cells and fill is None and not invert and cells_supported(x, active):
+        call("cmu_mask_select_cells", x.ptr(), x.ld, _p(sc), _p(sh), int(relu), _p(active), active.shape[-1], int(bool(ring)), out.ptr(),
+             out.ld, x.B, x.H, x.W, x.C, x.dt, _stream())
+        return
     call("cmu_mask_select", x.ptr(), x.ld, _p(sc), _p(sh), int(relu), _p(active), active.shape[-1], int(invert), _p(fill), out.ptr(),
          out.ld, x.B, x.H, x.W, x.C, x.dt, _stream())
+
+
+def cells_channel_sum(x, active, out, invert=False, ws=None):
+    """out[c] (fp32, C) = sum of x over the pixels of the active / masked (``invert``) patches: the mask-token gradient."""
+    assert out.dtype == torch.float32 and out.numel() == x.C and out.is_contiguous()
+    if ws is None:
+        ws = torch.empty(_lib.lib().cmu_cells_channel_sum_ws_bytes(x.C), dtype=torch.uint8, device=x.buf.device)
+    call("cmu_cells_channel_sum", x.ptr(), x.ld, _p(active), active.shape[-1], int(invert), _p(out), _p(ws), x.B, x.H, x.W, x.C, x.dt,
+         _stream())
 
 
 def bnrelu_maxpool_fwd_masked(y, active, out):
@@ -430,9 +482,10 @@ def bnrelu_maxpool_fwd_masked(y, active, out):
          y.B, y.H, y.W, y.C, y.dt, _stream())
 
 
-def maxpool_bwd_masked(dP, dSkip, y, dA, active):
+def maxpool_bwd_masked(dP, dSkip, y, dA, active, cells=True):
     """``maxpool_bwd`` on the raw ``y`` + transform at active windows only; dA of masked windows is left unwritten."""
-    call("cmu_maxpool_bwd_masked", dP.ptr(), dP.ld, None if dSkip is None else dSkip.ptr(), 0 if dSkip is None else dSkip.ld, y.ptr(), y.ld,
+    name = "cmu_maxpool_bwd_cells" if (cells and y.H // active.shape[-1] >= 2 and cells_supported(y, active)) else "cmu_maxpool_bwd_masked"
+    call(name, dP.ptr(), dP.ld, None if dSkip is None else dSkip.ptr(), 0 if dSkip is None else dSkip.ld, y.ptr(), y.ld,
          _p(y.scale), _p(y.shift), _p(active), active.shape[-1], dA.ptr(), dA.ld, y.B, y.H, y.W, y.C, y.dt, _stream())
 
 
@@ -441,38 +494,75 @@ def bn_bwd_reduce_masked(dA, y, save_mean, save_invstd, dgamma, dbeta, coef, act
          _p(dgamma), _p(dbeta), _p(coef), _p(active), active.shape[-1], int(count), y.B, y.H, y.W, y.C, y.dt, _p(ws), _stream())
 
 
-def bn_bwd_apply_masked(dA, y, save_mean, save_invstd, coef, dY, active):
+def bn_bwd_apply_masked(dA, y, save_mean, save_invstd, coef, dY, active, ring=False, cells=True):
+    """dY = BatchNorm+ReLU backward at active positions, zeros at masked ones (``ring``: see mask_select)."""
+    if cells and cells_supported(y, active):
+        call("cmu_bn_bwd_apply_cells", dA.ptr(), dA.ld, y.ptr(), y.ld, _p(y.scale), _p(y.shift), _p(save_mean), _p(save_invstd),
+             _p(coef), dY.ptr(), dY.ld, _p(active), active.shape[-1], int(bool(ring)), y.B, y.H, y.W, y.C, y.dt, _stream())
+        return
     call("cmu_bn_bwd_apply_masked", dA.ptr(), dA.ld, y.ptr(), y.ld, _p(y.scale), _p(y.shift), _p(save_mean), _p(save_invstd),
          _p(coef), dY.ptr(), dY.ld, _p(active), active.shape[-1], y.B, y.H, y.W, y.C, y.dt, _stream())
 
 
 class TileList:
     """Device-side list of the spatial tiles of one level that overlap an active patch (cmu_sparse_tile_list): ``list`` int32,
-    ``count`` int32 (1,) -- both stay on the device.  ``n_dense`` is the dense tile count (the list's capacity)."""
+    ``count`` int32 (1,) -- both stay on the device.  ``n_dense`` is the dense tile count (the list's capacity).  ``defer``: only
+    allocate; ``build_lists`` fills several lists in one launch."""
 
-    def __init__(self, active, H, W, tile_h, tile_w):
+    def __init__(self, active, H, W, tile_h, tile_w, defer=False):
         B, f = active.shape[0], active.shape[-1]
-        self.tile_h, self.tile_w = tile_h, tile_w
+        self.H, self.W, self.tile_h, self.tile_w = H, W, tile_h, tile_w
         self.n_dense = B * ((H + tile_h - 1) // tile_h) * ((W + tile_w - 1) // tile_w)
         self.list = torch.empty(self.n_dense, dtype=torch.int32, device=active.device)
         self.count = torch.empty(1, dtype=torch.int32, device=active.device)
-        call("cmu_sparse_tile_list", _p(active), f, B, H, W, tile_h, tile_w, _p(self.list), _p(self.count), _stream())
+        if not defer:
+            call("cmu_sparse_tile_list", _p(active), f, B, H, W, tile_h, tile_w, _p(self.list), _p(self.count), _stream())
 
 
 class PixelList:
     """Device-side list of the active pixels of one level (cmu_sparse_pixel_list): ``rows`` int32 dense pixel indices, patch-
     major, padded with -1 to ``capacity``; ``count`` int32 (1,).  ``max_rows``: host-side upper bound of the count (the number
-    of active patches x patch area when the caller knows it, else the dense pixel count)."""
+    of active patches x patch area when the caller knows it, else the dense pixel count).  ``defer``: see TileList."""
 
-    def __init__(self, active, H, W, max_rows=None):
+    def __init__(self, active, H, W, max_rows=None, defer=False):
         B, f = active.shape[0], active.shape[-1]
         dense = B * H * W
+        self.H, self.W = H, W
         self.max_rows = dense if max_rows is None else min(int(max_rows), dense)
         self.capacity = max(256, (self.max_rows + 255) // 256 * 256)
         self.rows = torch.empty(self.capacity, dtype=torch.int32, device=active.device)
         self.count = torch.empty(1, dtype=torch.int32, device=active.device)
-        ws = torch.empty(_lib.lib().cmu_sparse_pixel_list_ws_bytes(B, f), dtype=torch.uint8, device=active.device)
-        call("cmu_sparse_pixel_list", _p(active), f, B, H, W, _p(self.rows), self.capacity, _p(self.count), _p(ws), _stream())
+        if not defer:
+            ws = torch.empty(_lib.lib().cmu_sparse_pixel_list_ws_bytes(B, f), dtype=torch.uint8, device=active.device)
+            call("cmu_sparse_pixel_list", _p(active), f, B, H, W, _p(self.rows), self.capacity, _p(self.count), _p(ws), _stream())
+
+
+def build_lists(active, tile_lists=(), pixel_lists=()):
+    """Fill deferred TileLists / PixelLists of ONE patch map: every tile list (plus the patch list the pixel lists expand) in one launch
+    of one workgroup per list, every pixel list in a second launch -- instead of one or two single-workgroup launches per list."""
+    B, f = active.shape[0], active.shape[-1]
+    lib = _lib.lib()
+    tls = list(tile_lists)
+    cells = None
+    if pixel_lists:
+        assert all(pl.H == pl.W for pl in pixel_lists)
+        cells = TileList(active, f, f, 1, 1, defer=True)            # tiles of one patch: entries (b*f + fy)*f + fx
+        tls = tls + [cells]
+    mx = lib.cmu_sparse_tile_lists_max()
+    for i in range(0, len(tls), mx):
+        part = tls[i:i + mx]
+        n = len(part)
+        IA, PA = ctypes.c_int * n, ctypes.c_void_p * n
+        call("cmu_sparse_tile_lists", _p(active), f, B, n, IA(*[t.H for t in part]), IA(*[t.tile_h for t in part]),
+             IA(*[t.tile_w for t in part]), PA(*[t.list.data_ptr() for t in part]), PA(*[t.count.data_ptr() for t in part]), _stream())
+    pls = list(pixel_lists)
+    for i in range(0, len(pls), mx):
+        part = pls[i:i + mx]
+        n = len(part)
+        IA, PA, LA = ctypes.c_int * n, ctypes.c_void_p * n, ctypes.c_int64 * n
+        call("cmu_sparse_pixel_lists", _p(cells.list), _p(cells.count), f, B, n, IA(*[pl.H for pl in part]),
+             PA(*[pl.rows.data_ptr() for pl in part]), LA(*[pl.capacity for pl in part]), PA(*[pl.count.data_ptr() for pl in part]), _stream())
+    return cells
 
 
 def conv3x3_rows_supported(B, H, W, Cin, Cout, dt):

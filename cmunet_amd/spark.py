@@ -204,32 +204,61 @@ class SparK(_EngineOwner, nn.Module):
         import torch.distributed as dist
         return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
-    def _level_tiles(self, eng, active, B, H, W, n_cells):
-        """What one level can skip: {'conv': 16 x 32 tile list, 'wgrad': 16 x 16 tile list, 'cf' / 'wf': expected shares of
-        listed tiles (profiler only), 'pix': list of active pixels for the gather kernel} -- or None.  Patch side >= 8 px: tile
-        lists; smaller patches (every dense tile holds an active pixel): the pixel list."""
+    def _level_tiles(self, eng, active, B, H, W, n_cells, convs=(), need_grads=True, pending=None):
+        """What one level can skip: {'conv': 16 x 32 tile list, 'wgrad': tile lists by tile height, 'c1': 16 x 16 list of the one-channel
+        first layer, 'cf' / 'wf': expected shares of listed tiles (profiler only), 'pix': list of active pixels for the gather kernel and
+        the statistics passes} -- or None.  Patch side >= 8 px: tile lists; smaller patches (every dense tile holds an active pixel): the
+        pixel list.  ``convs``: (Cin, Cout) of the level's layers -- only the lists they use are built.  ``pending`` = (tile lists, pixel
+        lists): the lists are only allocated and collected there; ``ops.build_lists`` fills all of a step's lists in two launches
+        (round 4: one or two single-workgroup launches per list, 0.3 ms per step, sat on the critical path)."""
         if os.environ.get("CMU_SPARK_TILES", "1") == "0":
             return None
+        defer = pending is not None
         f = active.shape[-1]
         ps = H // f
         gather = os.environ.get("CMU_SPARK_GATHER", "1") != "0" and H == W
         # the list of active pixels drives the gather convolutions (small patches) and, at every level, the statistics passes
-        pix = ops.PixelList(active, H, W, n_cells * ps * ps) if gather else None
-        if ps < 8:
-            return {"conv": None, "wgrad": None, "cf": 1.0, "wf": 1.0, "pix": pix, "gather": True} if gather else None
-        if H % 16 != 0 or W % 32 != 0:
-            return {"conv": None, "wgrad": None, "cf": 1.0, "wf": 1.0, "pix": pix, "gather": True} if gather else None
+        pix = None
+        if gather:
+            pix = ops.PixelList(active, H, W, n_cells * ps * ps, defer=defer)
+            if defer:
+                pending[1].append(pix)
+        if ps < 8 or H % 16 != 0 or W % 32 != 0:
+            return {"conv": None, "wgrad": None, "c1": None, "cf": 1.0, "wf": 1.0, "pix": pix, "gather": True} if gather else None
         keep = 1.0 - self.mask_ratio
-        conv = ops.TileList(active, H, W, 16, 32)
+
+        def rows_ok(ci, co):
+            return pix is not None and ops.conv3x3_rows_supported(B, H, W, ci, co, eng.dt)
+
+        # the 16 x 32 list: only when a layer (or its data gradient) is served by the tile kernel and not by the gather kernel
+        multi = [(ci, co) for ci, co in convs if ci != 1]
+        want = [(a, b) for ci, co in multi for a, b in ((ci, co), (co, ci))] if convs else [(0, 0)]
+        need_conv = (not convs) or any((not rows_ok(a, b)) and ops.conv3x3_tiles_supported(B, H, W, a, b, eng.dt) for a, b in want)
+        conv = None
+        if need_conv:
+            conv = ops.TileList(active, H, W, 16, 32, defer=defer)
+            if defer:
+                pending[0].append(conv)
         cf = 1.0 - (1.0 - keep) ** max(1, (16 // ps) * (32 // ps))          # expected share of listed tiles (profiler only)
         # weight gradients: tile lists by tile height -- 16 x 16 tiles of the first kernel where a patch fills them (level 1), 8 x 16
-        # tiles (the wide kernel's K tile = two 8 x 8 patches at level 2: 44 % listed at mask ratio 0.75); built on first use
+        # tiles (the wide kernel's K tile = two 8 x 8 patches at level 2: 44 % listed at mask ratio 0.75); built on first use, or
+        # with the step's other lists when the layers are known
         wg = {"active": active, "H": H, "W": W, "lists": {}, "ps": ps, "keep": keep}
+        tiles = {"conv": conv, "wgrad": wg, "c1": None, "cf": cf, "wf": 1.0, "pix": pix, "gather": pix is not None}
+        if need_grads:
+            for ci, co in multi:
+                self._wgrad_list(tiles, ops.conv3x3_wgrad_tile_h(B, H, W, ci, co, eng.dt), pending)
+        # the one-channel first layer walks 16 x 16 tiles: with patches that are multiples of 16 pixels every listed tile lies inside
+        # an active patch -- masked tiles are neither computed nor read, the kernel's own sums are the sparse statistics
+        if any(ci == 1 for ci, _ in convs) and ps % 16 == 0 and os.environ.get("CMU_SPARK_C1_TILES", "1") != "0":
+            lst = self._wgrad_list(tiles, 16, pending)
+            if lst is not None:
+                tiles["c1"] = (lst[0], n_cells * (ps // 16) ** 2)
         # (where both apply -- level 2: 90 % of the tiles against 25 % of the rows -- the gather kernel is taken first)
-        return {"conv": conv, "wgrad": wg, "cf": cf, "wf": 1.0, "pix": pix, "gather": pix is not None}
+        return tiles
 
     @staticmethod
-    def _wgrad_list(tiles, tile_h):
+    def _wgrad_list(tiles, tile_h, pending=None):
         """(TileList, expected listed share) of a level for the weight-gradient kernel that walks ``tile_h`` x 16 tiles, or None when
         such tiles cannot skip anything worth a list (more than two patches per tile side)."""
         wg = tiles["wgrad"] if tiles is not None else None
@@ -240,16 +269,43 @@ class SparK(_EngineOwner, nn.Module):
             return None
         if tile_h not in wg["lists"]:
             share = 1.0 - (1.0 - wg["keep"]) ** max(1, (tile_h // ps) * (16 // ps))
-            wg["lists"][tile_h] = (ops.TileList(wg["active"], wg["H"], wg["W"], tile_h, 16), share)
+            tl = ops.TileList(wg["active"], wg["H"], wg["W"], tile_h, 16, defer=pending is not None)
+            if pending is not None:
+                pending[0].append(tl)
+            wg["lists"][tile_h] = (tl, share)
         return wg["lists"][tile_h]
 
-    def _sp_convbn_fwd(self, eng, sd, pconv, pbn, x, x_img, inv_pix, active, count, B, H, W, training, sync=False, tiles=None, need_a=True):
+    @classmethod
+    def _wgrad_inside(cls, tiles, tile_h):
+        """Whether the weight-gradient kernel of a layer walks a tile list whose every tile lies inside ONE patch (patch side a multiple
+        of 16 and of the tile height): it then never reads a masked patch beyond the one-pixel halo of an active one.  (An 8 x 16 tile
+        over two 8 x 8 patches may pair an active patch with a masked one, whose interior it reads.)"""
+        lst = cls._wgrad_list(tiles, tile_h)
+        return lst is not None and tiles["wgrad"]["ps"] % 16 == 0 and tiles["wgrad"]["ps"] % tile_h == 0
+
+    @staticmethod
+    def _fwd_listed(tiles, B, H, W, Cin, Cout, dt):
+        """Whether a 3x3 layer of this level runs on a list (gather rows or 16 x 32 tiles): it then reads active patches + a one-pixel
+        halo of its input and nothing else."""
+        if tiles is None:
+            return False
+        if tiles["gather"] and ops.conv3x3_rows_supported(B, H, W, Cin, Cout, dt):
+            return True
+        return tiles["conv"] is not None and ops.conv3x3_tiles_supported(B, H, W, Cin, Cout, dt)
+
+    def _sp_convbn_fwd(self, eng, sd, pconv, pbn, x, x_img, inv_pix, active, count, B, H, W, training, sync=False, tiles=None, need_a=True,
+                       ring=False):
         """``need_a`` False (a level's SECOND conv, round 3): the activated + masked copy of the output is not materialised -- its
-        consumers (the mask-aware pool, the densify select, the pool backward) work from the raw output + transform + mask."""
+        consumers (the mask-aware pool, the densify select, the pool backward) work from the raw output + transform + mask.
+        ``ring``: every consumer of the activated copy is list-driven, so only the border frame of masked patches is zeroed."""
         w = sd[pconv + "weight"]
         C = w.shape[0]
         y = eng._new(B, H, W, C)
-        if x_img is not None:
+        slab = None
+        c1 = tiles["c1"] if (tiles is not None and x_img is not None) else None
+        if c1 is not None:
+            slab = ops.conv3x3_c1_fwd_tiles(x_img, w.detach(), y, c1[0], c1[1], inv_pix, True, want_stats=training)     # masked tiles never computed
+        elif x_img is not None:
             ops.conv3x3_c1_fwd(x_img, w.detach(), y, None, inv_pix, True)
         elif tiles is not None and tiles["gather"] and ops.conv3x3_rows_supported(B, H, W, x.C, C, eng.dt):
             ops.conv3x3_fwd_rows(x, eng._wp(pconv, w, False), y, tiles["pix"])                   # GEMM rows = active pixels only
@@ -258,8 +314,8 @@ class SparK(_EngineOwner, nn.Module):
         else:
             ops.conv3x3_fwd(x, eng._wp(pconv, w, False), y, None)
         scale, shift, mean, invstd = eng._f32(C), eng._f32(C), eng._f32(C), eng._f32(C)
-        if not training:
-            slab = None
+        if not training or slab is not None:
+            pass
         elif tiles is not None and tiles["pix"] is not None:
             slab = ops.rows_channel_stats(y, tiles["pix"])                         # statistics over the list of active pixels
         else:
@@ -280,7 +336,7 @@ class SparK(_EngineOwner, nn.Module):
         a = None
         if need_a:
             a = eng._new(B, H, W, C)
-            ops.mask_select(yt, active, a, relu=True)                              # BN + ReLU, zeros at masked positions
+            ops.mask_select(yt, active, a, relu=True, ring=ring)                   # BN + ReLU, zeros at masked positions
         return {"pconv": pconv, "pbn": pbn, "x": x, "x_img": x_img, "mask": inv_pix, "mps": True, "y": yt, "a": a,
                 "mean": mean, "invstd": invstd, "sync": sync, "count_all": count, "tiles": tiles}
 
@@ -304,18 +360,31 @@ class SparK(_EngineOwner, nn.Module):
             tot = torch.stack([dbeta, dgamma]).double()
             dist.all_reduce(tot)
             coef.copy_((tot / float(s["count_all"])).float())
-        dY = Act(dA.buf, dA.coff, dA.C)
-        ops.bn_bwd_apply_masked(dA, y, s["mean"], s["invstd"], coef, dY, active)
         grads[s["pbn"] + "weight"], grads[s["pbn"] + "bias"] = dgamma, dbeta
         gb = eng._gbuf(s["pconv"] + "bias", sd[s["pconv"] + "bias"])     # identically zero in front of a training-mode BatchNorm
         eng._zero_pending.append(gb)
         grads[s["pconv"] + "bias"] = gb
         dW = eng._gbuf(s["pconv"] + "weight", w)
+        c1 = tiles["c1"] if (tiles is not None and s["x_img"] is not None) else None
+        if c1 is not None:
+            # the first layer over its tile list: the BatchNorm backward is applied on the fly inside the listed tiles -- no apply pass,
+            # no dY tensor (the layer has no data gradient)
+            ops.conv3x3_c1_wgrad_bn_tiles(s["x_img"], dA, y, y.scale, y.shift, s["mean"], s["invstd"], coef, dW,
+                                          eng.scratch.get("wg", eng.lib.cmu_conv3x3_c1_wgrad_ws_bytes(B, H, W, C)), c1[0], c1[1], s["mask"], True)
+            grads[s["pconv"] + "weight"] = dW
+            return None
+        Cin = w.shape[1]
+        lst = None if s["x_img"] is not None else self._wgrad_list(tiles, ops.conv3x3_wgrad_tile_h(B, H, W, Cin, C, eng.dt))
+        want_dx = need_dx and s["x_img"] is None
+        # zeros are only needed where a consumer of dY looks: list-driven consumers read active patches + a one-pixel halo
+        ring = (lst is not None and self._wgrad_inside(tiles, ops.conv3x3_wgrad_tile_h(B, H, W, Cin, C, eng.dt))
+                and (not want_dx or self._fwd_listed(tiles, B, H, W, C, Cin, eng.dt)))
+        dY = Act(dA.buf, dA.coff, dA.C)
+        ops.bn_bwd_apply_masked(dA, y, s["mean"], s["invstd"], coef, dY, active, ring=ring)
         if s["x_img"] is not None:
             ops.conv3x3_c1_wgrad(s["x_img"], dY, dW, eng.scratch.get("wg", eng.lib.cmu_conv3x3_c1_wgrad_ws_bytes(B, H, W, C)), s["mask"], True)
         else:
             wsb = eng.scratch.get("wg", eng.lib.cmu_conv3x3_wgrad_ws_bytes(B, H, W, w.shape[1], C, eng.dt))
-            lst = self._wgrad_list(tiles, ops.conv3x3_wgrad_tile_h(B, H, W, w.shape[1], C, eng.dt))
             if lst is not None:
                 ops.conv3x3_wgrad_tiles(s["x"], dY, dW, wsb, lst[0], lst[1])      # dY is zero outside the listed tiles
             else:
@@ -361,15 +430,34 @@ class SparK(_EngineOwner, nn.Module):
         ep, dp = "sparse_encoder.sp_cnn.", "dense_decoder."
         nd = eng.n_down(sd, ep)
 
+        # ---- the step's lists: every level's tile / pixel lists in two launches, before the first layer ----
+        pending = ([], [])
+        plans = []
+        for k in range(nd + 1):
+            p = f"{ep}down_conv{k + 1}.double_conv.double_conv." if k < nd else f"{ep}double_conv.double_conv."
+            w0, w3 = sd[p + "0.weight"], sd[p + "3.weight"]
+            convs = ((w0.shape[1], w0.shape[0]), (w3.shape[1], w3.shape[0]))
+            plans.append((self._level_tiles(eng, active, B, H >> k, W >> k, n_cells, convs, need_grads, pending) if (k < nd or nd > 0) else None,
+                          convs))
+        if pending[0] or pending[1]:
+            ops.build_lists(active, pending[0], pending[1])
+
+        def ring_ok(tl, hh, ww, conv2):
+            """The activated copy of a level's first conv output only needs its masked patches' border frames zeroed when the second
+            conv reads it through a list, forward and (if there is a backward) in its weight gradient."""
+            if tl is None or not self._fwd_listed(tl, B, hh, ww, conv2[0], conv2[1], eng.dt):
+                return False
+            return (not need_grads) or self._wgrad_inside(tl, ops.conv3x3_wgrad_tile_h(B, hh, ww, conv2[0], conv2[1], eng.dt))
+
         # ---- sparse encoder (custom.py:152-182) ----
         levels = []
         x, ximg, h, w_ = None, x_img, H, W
         for i in range(1, nd + 1):
             p = f"{ep}down_conv{i}.double_conv.double_conv."
             cnt = n_cells * (h // f) * (w_ // f)
-            tl = self._level_tiles(eng, active, B, h, w_, n_cells)
+            tl, convs = plans[i - 1]
             s1 = self._sp_convbn_fwd(eng, sd, p + "0.", p + "1.", x, ximg, inv_pix if ximg is not None else None, active, cnt, B, h, w_, training,
-                                     tiles=tl)
+                                     tiles=tl, ring=ring_ok(tl, h, w_, convs[1]))
             fuse_pool = _FUSE_POOL and (h // f) >= 2
             s2 = self._sp_convbn_fwd(eng, sd, p + "3.", p + "4.", s1["a"], None, None, active, cnt, B, h, w_, training, tiles=tl,
                                      need_a=not fuse_pool)
@@ -385,8 +473,9 @@ class SparK(_EngineOwner, nn.Module):
         p = f"{ep}double_conv.double_conv."
         cnt_b = n_cells * (h // f) * (w_ // f)
         sbn = bool(getattr(self.sparse_encoder, "sbn", False))     # (SparK's own ``sbn`` only concerns the densify norms)
-        tlb = self._level_tiles(eng, active, B, h, w_, n_cells) if nd > 0 else None
-        b1 = self._sp_convbn_fwd(eng, sd, p + "0.", p + "1.", x, ximg, None, active, cnt_b, B, h, w_, training, sync=sbn, tiles=tlb)
+        tlb, convs_b = plans[nd]
+        b1 = self._sp_convbn_fwd(eng, sd, p + "0.", p + "1.", x, ximg, None, active, cnt_b, B, h, w_, training, sync=sbn, tiles=tlb,
+                                 ring=ring_ok(tlb, h, w_, convs_b[1]))
         b2 = self._sp_convbn_fwd(eng, sd, p + "3.", p + "4.", b1["a"], None, None, active, cnt_b, B, h, w_, training, sync=sbn, tiles=tlb,
                                  need_a=not _FUSE_POOL)
 
@@ -442,8 +531,14 @@ class SparK(_EngineOwner, nn.Module):
             ready("dense_decoder.", grads)
         d_feats = [d_lat] + list(reversed(d_skips))              # same order as feats / mask_tokens
         for i, d in enumerate(d_feats):
-            slab = ops.masked_channel_stats(Act(d.buf, d.coff, d.C), active, invert=True)     # sum over NON-active pixels
-            grads[f"mask_tokens.{i}"] = slab[:, 0, :].sum(0).view_as(self.mask_tokens[i])
+            dv = Act(d.buf, d.coff, d.C)
+            if ops.cells_supported(dv, active):                                    # sum over the pixels of the MASKED patches
+                g = eng._gbuf(f"mask_tokens.{i}", self.mask_tokens[i])
+                ops.cells_channel_sum(dv, active, g.view(-1), invert=True, ws=eng.scratch.get("csum", eng.lib.cmu_cells_channel_sum_ws_bytes(d.C)))
+                grads[f"mask_tokens.{i}"] = g
+            else:
+                slab = ops.masked_channel_stats(dv, active, invert=True)
+                grads[f"mask_tokens.{i}"] = slab[:, 0, :].sum(0).view_as(self.mask_tokens[i])
         dA = self._sp_convbn_bwd(eng, sd, b2, d_feats[0], active, cnt_b, grads, True)
         dP = self._sp_convbn_bwd(eng, sd, b1, dA, active, cnt_b, grads, nd > 0)
         if ready is not None:

@@ -331,6 +331,53 @@ int cmu_bn_bwd_reduce_rows(const void* dA, int64_t ldd, const void* y, int64_t l
                            const int* n_rows, int64_t max_rows, int64_t count, int B, int H, int W, int C, int dt, void* ws, void* stream);
 int64_t cmu_sparse_pixel_list_ws_bytes(int B, int f);
 int cmu_sparse_pixel_list(const uint8_t* active, int f, int B, int H, int W, int* rows, int64_t capacity, int* count, void* ws, void* stream);
+/* Every list of a step in one launch each (the mask is known before the step starts): cmu_sparse_tile_lists builds n <=
+ * cmu_sparse_tile_lists_max() tile lists (entry i: level side H[i] = f << s, tiles tile_h[i] x tile_w[i], lists[i] / counts[i] as in
+ * cmu_sparse_tile_list -- element for element the same lists); cmu_sparse_pixel_lists expands ONE patch list (a tile list with tiles
+ * of one patch, e.g. H = f and 1 x 1 tiles) into the pixel lists of n levels, exactly as cmu_sparse_pixel_list writes them.
+ * H, tile_h, tile_w, lists, counts, rows, capacity are HOST arrays of length n.                                              */
+int cmu_sparse_tile_lists_max(void);
+int cmu_sparse_tile_lists(const uint8_t* active, int f, int B, int n, const int* H, const int* tile_h, const int* tile_w, int* const* lists,
+                          int* const* counts, void* stream);
+int cmu_sparse_pixel_lists(const int* patches, const int* patch_count, int f, int B, int n, const int* H, int* const* rows,
+                           const int64_t* capacity, int* const* counts, void* stream);
+/* Patch-organised forms of the sparse encoder's element-wise passes (csrc/sparse_elem.hip; Spark/encoder.py:12-56, spark.py:98-111):
+ * the unit of work is a group of patch rows, the branch on the patch's bit is uniform per workgroup, masked patches cost no loads.
+ * Outputs at active positions are bit-identical to the pixel-organised entries named beside them.
+ *   cmu_cells_supported        square level with H = f << s and a power-of-two number (<= 256) of 16-byte chunks per pixel
+ *   cmu_bn_bwd_apply_cells     = cmu_bn_bwd_apply_masked; ring = 1: zeros are written only to the one-pixel border frame of each masked
+ *                              patch (enough when every consumer of dY is list-driven: they read active patches + a one-pixel halo;
+ *                              the interior of masked patches stays unwritten)
+ *   cmu_mask_select_cells      = cmu_mask_select(invert 0, fill NULL): relu?(x * scale + shift) in active patches, zeros (ring as above)
+ *   cmu_maxpool_bwd_cells      = cmu_maxpool_bwd_masked: active patches only, dA elsewhere unwritten (H / f >= 2)
+ *   cmu_cells_channel_sum      out[c] = sum of x over the pixels of the active (invert 0) / masked (invert 1) patches -- the mask-token
+ *                              gradient of spark.py:104-108; fixed-order fp32 partial sums, double final; ws: cmu_cells_channel_sum_ws_bytes(C) */
+/* The first layer (Conv2d(1, Cout, 3, p=1), Finetuning/model.py:17) over a list of 16 x 16 tiles (cmu_sparse_tile_list numbering) for the
+ * sparse encoder: cmu_conv3x3_c1_fwd_tiles computes the listed tiles only (y elsewhere untouched); stats, if given, is
+ * [cmu_conv3x3_c1_fwd_tiles_rows(max_tiles)][2][Cout], fully written -- when the patches are multiples of 16 pixels these are the
+ * sparse BatchNorm statistics.  cmu_conv3x3_c1_wgrad_bn_tiles = cmu_conv3x3_c1_wgrad_bn (yraw) / cmu_conv3x3_c1_wgrad_bn_w (w) with the
+ * contraction restricted to the listed tiles: no masked BatchNorm-backward apply pass, no dY tensor.  max_tiles: host-side upper bound
+ * of tile_count[0].  ws: cmu_conv3x3_c1_wgrad_ws_bytes.                                                                       */
+int cmu_conv3x3_c1_fwd_tiles_rows(int64_t max_tiles);
+int cmu_conv3x3_c1_fwd_tiles(const float* x, const uint8_t* mask, int mask_per_sample, const float* w, void* y, int64_t ldy, float* stats,
+                             const int* tile_list, const int* tile_count, int64_t max_tiles, int B, int H, int W, int Cout, int dt,
+                             void* stream);
+int cmu_conv3x3_c1_wgrad_bn_tiles(const float* x, const uint8_t* mask, int mask_per_sample, const void* dA, int64_t ldd, const void* yraw,
+                                  int64_t ldy, const float* w, const float* scale, const float* shift, const float* save_mean,
+                                  const float* save_invstd, const float* coef, const int* tile_list, const int* tile_count,
+                                  int64_t max_tiles, float* dW, int B, int H, int W, int Cout, int dt, void* ws, void* stream);
+int cmu_cells_supported(int B, int H, int W, int f, int C, int dt);
+int cmu_bn_bwd_apply_cells(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift,
+                           const float* save_mean, const float* save_invstd, const float* coef, void* dY, int64_t ldo,
+                           const uint8_t* active, int f, int ring, int B, int H, int W, int C, int dt, void* stream);
+int cmu_mask_select_cells(const void* x, int64_t ldx, const float* scale, const float* shift, int relu, const uint8_t* active, int f,
+                          int ring, void* out, int64_t ldo, int B, int H, int W, int C, int dt, void* stream);
+int cmu_maxpool_bwd_cells(const void* dP, int64_t ldp, const void* dSkip, int64_t lds, const void* y, int64_t ldy, const float* scale,
+                          const float* shift, const uint8_t* active, int f, void* dA, int64_t lda, int B, int H, int W, int C, int dt,
+                          void* stream);
+int64_t cmu_cells_channel_sum_ws_bytes(int C);
+int cmu_cells_channel_sum(const void* x, int64_t ldx, const uint8_t* active, int f, int invert, float* out, void* ws, int B, int H, int W,
+                          int C, int dt, void* stream);
 int cmu_conv3x3_rows_supported(int B, int H, int W, int Cin, int Cout, int dt);
 int cmu_conv3x3_fwd_rows(const void* x, int64_t ldx, const void* wpacked, void* y, int64_t ldy, const int* rows, const int* n_rows,
                          int64_t max_rows, int B, int H, int W, int Cin, int Cout, int dt, void* stream);

@@ -295,16 +295,24 @@ def test_spark_step_with_and_without_tile_skipping(ops, dt, tmp_path):
     only (CMU_SPARK_GATHER=0) and fully dense (CMU_SPARK_TILES=0): tile lists give the identical loss and equal gradients up to
     the weight gradients' summation order; the gather levels agree to rounding."""
     outs = {}
-    for flag, gather in (("1", "1"), ("1", "0"), ("0", "0")):
-        o = str(tmp_path / f"r{flag}{gather}.pt")
-        env = dict(os.environ, CMU_SPARK_TILES=flag, CMU_SPARK_GATHER=gather)
+    # ("10": tile lists only, the one-channel first layer on its dense kernels -- the same arithmetic as the dense step at every active
+    # pixel, patch-organised element-wise passes and border-frame zeroing included; "10c": the first layer over its tile list as well --
+    # its statistics are then summed in another order, which sparse BatchNorm amplifies like the gather levels' differences)
+    for key, flag, gather, c1 in (("11", "1", "1", "1"), ("10", "1", "0", "0"), ("10c", "1", "0", "1"), ("00", "0", "0", "1")):
+        o = str(tmp_path / f"r{key}.pt")
+        # (CMU_POISON_NEW: every fresh activation starts as NaN -- the list-driven layers leave masked patches unwritten, or zero only
+        # their border frames; a kernel that read such a position would poison the loss and the gradients)
+        env = dict(os.environ, CMU_SPARK_TILES=flag, CMU_SPARK_GATHER=gather, CMU_SPARK_C1_TILES=c1, CMU_POISON_NEW="1")
         subprocess.run([sys.executable, "-c", _STEP % ROOT, dt, o], env=env, check=True, timeout=420)
-        outs[flag + gather] = torch.load(o)
+        outs[key] = torch.load(o)
     # round 3: the mask-aware pools (no activated copy of a level's second conv output) against the materialised form, everything else
     # at its default: the forward is the same arithmetic (identical loss at f32), the backward differs by arg-max ties only
     o = str(tmp_path / "nofuse.pt")
-    subprocess.run([sys.executable, "-c", _STEP % ROOT, dt, o], env=dict(os.environ, CMU_SPARK_POOL_FUSE="0"), check=True, timeout=420)
+    subprocess.run([sys.executable, "-c", _STEP % ROOT, dt, o], env=dict(os.environ, CMU_SPARK_POOL_FUSE="0", CMU_POISON_NEW="1"), check=True,
+                   timeout=420)
     nofuse = torch.load(o)
+    for o_ in list(outs.values()) + [nofuse]:
+        assert bool(torch.isfinite(o_["loss"]).all()) and all(bool(torch.isfinite(g_).all()) for g_ in o_["grads"].values()), "an unwritten position was read"
     if dt == "f32":
         assert float(nofuse["loss"]) == float(outs["11"]["loss"])
     num = sum((outs["11"]["grads"][k] - g0).double().pow(2).sum().item() for k, g0 in nofuse["grads"].items())
@@ -319,7 +327,8 @@ def test_spark_step_with_and_without_tile_skipping(ops, dt, tmp_path):
     # (per tensor: a loose bound -- a 64-element bias can move by a third in f16; over all gradients together: a tighter one)
     ltol, gtol, atol = (1e-4, 5e-2, 2e-2) if dt == "f32" else (1e-2, 0.5, 0.15)
     assert abs(float(outs["11"]["loss"]) - float(outs["00"]["loss"])) <= ltol * abs(float(outs["00"]["loss"]))
-    for key, tol, all_tol in (("10", 1e-3 if dt == "f32" else 5e-2, 1e-3 if dt == "f32" else 5e-2), ("11", gtol, atol)):
+    assert abs(float(outs["10c"]["loss"]) - float(outs["00"]["loss"])) <= ltol * abs(float(outs["00"]["loss"]))
+    for key, tol, all_tol in (("10", 1e-3 if dt == "f32" else 5e-2, 1e-3 if dt == "f32" else 5e-2), ("10c", gtol, atol), ("11", gtol, atol)):
         num = den = 0.0
         for k, g0 in outs["00"]["grads"].items():
             g1 = outs[key]["grads"][k]
@@ -329,3 +338,174 @@ def test_spark_step_with_and_without_tile_skipping(ops, dt, tmp_path):
             num, den = num + d2, den + n2
         print(f"{dt} {key}: all gradients rel L2 {(num / den) ** 0.5:.3e}")
         assert (num / den) ** 0.5 <= all_tol, (key, (num / den) ** 0.5)
+
+
+# ---- round 4: patch-organised element-wise passes (csrc/sparse_elem.hip) and the batched list builders ------------------------------
+_CELL_CASES = [(2, 4, 16, 32), (3, 8, 16, 64), (1, 8, 32, 16), (2, 4, 64, 64), (2, 8, 64, 128), (1, 16, 32, 1024), (2, 4, 4, 256), (3, 2, 64, 8)]
+
+
+def _frame(act, H):
+    """(B, H, H) bool maps: pixels of active patches, and the one-pixel border frame of masked patches."""
+    B, f = act.shape[0], act.shape[-1]
+    s = H // f
+    up = act.bool().repeat_interleave(s, 1).repeat_interleave(s, 2)
+    yy = torch.arange(H, device=act.device) % s
+    edge = (yy == 0) | (yy == s - 1)
+    border = edge.view(1, H, 1) | edge.view(1, 1, H)
+    return up, (~up) & border
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("case", _CELL_CASES)
+def test_cells_bn_bwd_apply_and_select_bit_identical_to_pixel_form(ops, dt, case):
+    """cmu_bn_bwd_apply_cells / cmu_mask_select_cells against the pixel-organised masked kernels: the same bits everywhere (full-zero
+    form); ring form: the same bits in active patches, zeros on the border frame of masked patches, their interior untouched.
+    Strided operands (a channel slice of a wider buffer) included."""
+    B, f, H, C = case
+    tdt = ops.TORCH_DT[ops.dt_code(dt)]
+    if C % (16 // torch.empty(0, dtype=tdt).element_size()) != 0:
+        pytest.skip("C below one 16-byte chunk")
+    g = torch.Generator().manual_seed(sum(case))
+    act = _active(B, f, max(1, f * f // 4), seed=sum(case)).cuda()
+    y = ops.Act(torch.randn(B, H, H, 2 * C, generator=g).to(tdt).cuda(), C, C, (torch.rand(C, generator=g) + 0.5).cuda(),
+                (torch.randn(C, generator=g) * 0.3).cuda(), 0)
+    assert ops.cells_supported(y, act)
+    dA = ops.Act(torch.randn(B, H, H, C, generator=g).to(tdt).cuda())
+    mean, invstd = (torch.randn(C, generator=g) * 0.1).cuda(), (torch.rand(C, generator=g) + 0.5).cuda()
+    coef = (torch.randn(2, C, generator=g) * 0.01).cuda()
+    up, frame = _frame(act, H)
+    ref = ops.Act(torch.full((B, H, H, C), 7.0, dtype=tdt, device="cuda"))
+    ops.bn_bwd_apply_masked(dA, y, mean, invstd, coef, ref, act, cells=False)
+    got = ops.Act(torch.full((B, H, H, C), 7.0, dtype=tdt, device="cuda"))
+    ops.bn_bwd_apply_masked(dA, y, mean, invstd, coef, got, act)
+    assert torch.equal(ref.buf.view(torch.uint8), got.buf.view(torch.uint8))
+    ring = ops.Act(torch.full((B, H, H, C), 7.0, dtype=tdt, device="cuda"))
+    ops.bn_bwd_apply_masked(dA, y, mean, invstd, coef, ring, act, ring=True)
+    assert torch.equal(ring.buf[up], ref.buf[up]) and bool((ring.buf[frame] == 0).all()) and bool((ring.buf[~up & ~frame] == 7.0).all())
+    # select: BN + ReLU in active patches, zeros elsewhere; written into the right half of a wider buffer
+    for relu, tr in ((True, True), (False, True), (False, False)):
+        ref = ops.Act(torch.full((B, H, H, 2 * C), 7.0, dtype=tdt, device="cuda"), C, C)
+        got = ops.Act(torch.full((B, H, H, 2 * C), 7.0, dtype=tdt, device="cuda"), C, C)
+        ring = ops.Act(torch.full((B, H, H, 2 * C), 7.0, dtype=tdt, device="cuda"), C, C)
+        ops.mask_select(y, act, ref, relu=relu, use_transform=tr, cells=False)
+        ops.mask_select(y, act, got, relu=relu, use_transform=tr)
+        ops.mask_select(y, act, ring, relu=relu, use_transform=tr, ring=True)
+        assert torch.equal(ref.buf.view(torch.uint8), got.buf.view(torch.uint8))
+        r = ring.buf[..., C:]
+        assert torch.equal(r[up], ref.buf[..., C:][up]) and bool((r[frame] == 0).all()) and bool((r[~up & ~frame] == 7.0).all())
+        assert bool((ring.buf[..., :C] == 7.0).all())
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("case", [c for c in _CELL_CASES if c[2] // c[1] >= 2])
+def test_cells_maxpool_bwd_bit_identical_to_pixel_form(ops, dt, case):
+    B, f, H, C = case
+    tdt = ops.TORCH_DT[ops.dt_code(dt)]
+    if C % (16 // torch.empty(0, dtype=tdt).element_size()) != 0:
+        pytest.skip("C below one 16-byte chunk")
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    act = _active(B, f, max(1, f * f // 4), seed=sum(case)).cuda()
+    y = ops.Act(torch.randn(B, H, H, C, generator=g).to(tdt).cuda(), 0, C, (torch.rand(C, generator=g) + 0.5).cuda(),
+                (torch.randn(C, generator=g) * 0.3).cuda(), 0)
+    dP = ops.Act(torch.randn(B, H // 2, H // 2, C, generator=g).to(tdt).cuda())
+    dS = ops.Act(torch.randn(B, H, H, 2 * C, generator=g).to(tdt).cuda(), C, C)
+    for skip in (dS, None):
+        ref = ops.Act(torch.full((B, H, H, C), 7.0, dtype=tdt, device="cuda"))
+        got = ops.Act(torch.full((B, H, H, C), 7.0, dtype=tdt, device="cuda"))
+        ops.maxpool_bwd_masked(dP, skip, y, ref, act, cells=False)
+        ops.maxpool_bwd_masked(dP, skip, y, got, act)
+        assert torch.equal(ref.buf.view(torch.uint8), got.buf.view(torch.uint8))
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16"])
+@pytest.mark.parametrize("case", _CELL_CASES)
+def test_cells_channel_sum_vs_float64(ops, dt, case):
+    """The mask-token gradient sum (masked patches) and its complement against float64; bitwise reproducible."""
+    B, f, H, C = case
+    tdt = ops.TORCH_DT[ops.dt_code(dt)]
+    if C % (16 // torch.empty(0, dtype=tdt).element_size()) != 0:
+        pytest.skip("C below one 16-byte chunk")
+    g = torch.Generator().manual_seed(sum(case) + 2)
+    act = _active(B, f, max(1, f * f // 4), seed=sum(case)).cuda()
+    x = ops.Act(torch.randn(B, H, H, 2 * C, generator=g).to(tdt).cuda(), C, C)
+    up, _ = _frame(act, H)
+    xs = x.buf[..., C:].double()
+    for invert in (False, True):
+        sel = ~up if invert else up
+        ref = (xs * sel.unsqueeze(-1)).sum((0, 1, 2))
+        out, out2 = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        ops.cells_channel_sum(x, act, out, invert=invert)
+        ops.cells_channel_sum(x, act, out2, invert=invert)
+        assert torch.equal(out, out2)
+        scale = float((xs.abs() * sel.unsqueeze(-1)).sum((0, 1, 2)).max()) + 1e-6
+        assert (out.double() - ref).abs().max().item() <= 2e-6 * scale
+
+
+def test_build_lists_equals_one_list_per_launch(ops):
+    """ops.build_lists: every tile list in one launch and every pixel list in a second one -- the same lists, element for element, as
+    cmu_sparse_tile_list / cmu_sparse_pixel_list built one by one; more lists than one call holds included."""
+    B, f = 3, 8
+    act = _active(B, f, 19, seed=3).cuda()
+    specs = [(256, 16, 32), (256, 16, 16), (128, 8, 16), (64, 16, 32), (32, 4, 4), (256, 8, 16), (128, 16, 32), (64, 8, 16), (16, 2, 2),
+             (8, 1, 1), (512, 16, 32), (512, 16, 16), (512, 8, 16), (1024, 16, 32)]
+    tls = [ops.TileList(act, H, H, th, tw, defer=True) for H, th, tw in specs]
+    pls = [ops.PixelList(act, H, H, max_rows=19 * B * (H // f) ** 2, defer=True) for H in (256, 128, 64, 32, 16)]
+    cells = ops.build_lists(act, tls, pls)
+    assert int(cells.count.item()) == 19 * B
+    for t, (H, th, tw) in zip(tls, specs):
+        one = ops.TileList(act, H, H, th, tw)
+        n = int(one.count.item())
+        assert int(t.count.item()) == n and torch.equal(t.list[:n], one.list[:n])
+    for p, H in zip(pls, (256, 128, 64, 32, 16)):
+        one = ops.PixelList(act, H, H, max_rows=19 * B * (H // f) ** 2)
+        assert int(p.count.item()) == int(one.count.item()) and torch.equal(p.rows, one.rows)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("case", [(2, 4, 64, 64), (3, 2, 64, 16), (1, 8, 128, 64), (2, 4, 128, 32)])       # (B, f, H, Cout): patches of 16 / 32 px
+def test_first_layer_over_a_tile_list(ops, dt, case):
+    """cmu_conv3x3_c1_fwd_tiles / cmu_conv3x3_c1_wgrad_bn_tiles (the sparse encoder's one-channel first layer over its 16 x 16 tile list):
+    listed tiles carry the dense launch's bits, the others stay untouched; the slab sums are the statistics over the active pixels
+    (against float64); the weight gradient equals the dense fused pass on a gradient that vanishes outside the active patches, in
+    the reading and the recomputing form."""
+    from cmunet_amd import _lib
+    B, f, H, C = case
+    tdt = ops.TORCH_DT[ops.dt_code(dt)]
+    g = torch.Generator().manual_seed(sum(case))
+    act = _active(B, f, max(1, f * f // 4), seed=sum(case)).cuda()
+    n_cells = int(act.sum())
+    ps = H // f
+    up, _ = _frame(act, H)
+    inv_pix = (~up).to(torch.uint8).contiguous()
+    x = torch.randn(B, H, H, generator=g).cuda()
+    w = (torch.randn(C, 1, 3, 3, generator=g) * 0.3).cuda()
+    dense = ops.new_act(B, H, H, C, dt, "cuda")
+    ops.conv3x3_c1_fwd(x, w, dense, None, inv_pix, True)
+    tl = ops.TileList(act, H, H, 16, 16)
+    mx = n_cells * (ps // 16) ** 2
+    assert int(tl.count.item()) == mx
+    out = ops.Act(torch.full((B, H, H, C), 7.0, dtype=tdt, device="cuda"))
+    slab = ops.conv3x3_c1_fwd_tiles(x, w, out, tl, mx, inv_pix, True)
+    assert torch.equal(out.buf[up], dense.buf[up]) and bool((out.buf[~up] == 7.0).all())
+    ref = torch.nn.functional.conv2d((x * up).double().cpu().unsqueeze(1), w.double().cpu(), padding=1).permute(0, 2, 3, 1)[up.cpu()]
+    s = slab.double().sum(0).cpu()
+    assert (s[0] - ref.sum(0)).abs().max().item() <= 1e-5 * ref.abs().sum(0).max().item()
+    assert (s[1] - (ref * ref).sum(0)).abs().max().item() <= 1e-5 * (ref * ref).sum(0).max().item()
+    # weight gradient with the BatchNorm backward applied on the fly
+    sc, sh = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.1).cuda()
+    mean, invstd = (torch.randn(C, generator=g) * 0.1).cuda(), (torch.rand(C, generator=g) + 0.5).cuda()
+    coef = (torch.randn(2, C, generator=g) * 0.01).cuda()
+    dA = ops.Act((torch.randn(B, H, H, C, generator=g).cuda() * up.unsqueeze(-1)).to(tdt))
+    ws = torch.empty(_lib.lib().cmu_conv3x3_c1_wgrad_ws_bytes(B, H, H, C), dtype=torch.uint8, device="cuda")
+    yt = out.with_transform(sc, sh, 0)
+    # reference: the masked apply pass (zeros outside the active patches) followed by the plain first-layer weight gradient
+    dY = ops.new_act(B, H, H, C, dt, "cuda")
+    ops.bn_bwd_apply_masked(dA, dense.with_transform(sc, sh, 0), mean, invstd, coef, dY, act)
+    dW0 = torch.empty(C, 1, 3, 3, device="cuda")
+    ops.conv3x3_c1_wgrad(x, dY, dW0, ws, inv_pix, True)
+    for wf in (None, w):
+        dW = torch.full((C, 1, 3, 3), 7.0, device="cuda")
+        ops.conv3x3_c1_wgrad_bn_tiles(x, dA, yt, sc, sh, mean, invstd, coef, dW, ws, tl, mx, inv_pix, True, w=wf)
+        # (the fused pass keeps dY in fp32 where the two-pass form rounded it to the storage type)
+        tol = {"f32": 1e-5, "f16": 2e-3, "bf16": 1.6e-2}[dt]
+        assert (dW - dW0).abs().max().item() <= tol * dW0.abs().max().item(), (wf is None, (dW - dW0).abs().max().item(), dW0.abs().max().item())
