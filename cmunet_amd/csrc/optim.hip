@@ -114,15 +114,24 @@ __global__ __launch_bounds__(256) void lamb_update_kernel(const float* __restric
         part2[2 * (int64_t)blockIdx.x + 1] = su;
     }
 }
-__global__ void lamb_ratio_kernel(const float* __restrict__ part2, const int* __restrict__ t_blk0, const float* __restrict__ t_wd,
-                                  int ntensors, int always_adapt, int trust_clip, float* __restrict__ ratio) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per tensor: the lanes stride over the tensor's blocks, fixed-order xor fold in double (one THREAD per tensor walked up to
+// 2,304 partials through dependent loads: 0.29 ms per step on the SparK workload's 2 x 64-thread grid)
+__global__ __launch_bounds__(64) void lamb_ratio_kernel(const float* __restrict__ part2, const int* __restrict__ t_blk0, const float* __restrict__ t_wd,
+                                                       int ntensors, int always_adapt, int trust_clip, float* __restrict__ ratio) {
+    const int t = blockIdx.x;
     if (t >= ntensors) return;
     double sp = 0.0, su = 0.0;
-    for (int b = t_blk0[t]; b < t_blk0[t + 1]; ++b) {
+    const int b1 = t_blk0[t + 1];
+    for (int b = t_blk0[t] + (int)threadIdx.x; b < b1; b += 64) {
         sp += (double)part2[2 * (int64_t)b + 0];
         su += (double)part2[2 * (int64_t)b + 1];
     }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        sp += __shfl_xor(sp, o, 64);
+        su += __shfl_xor(su, o, 64);
+    }
+    if (threadIdx.x != 0) return;
     float r = 1.f;
     if (t_wd[t] != 0.f || always_adapt) {
         const float wn = (float)sqrt(sp), gn = (float)sqrt(su);
@@ -165,7 +174,7 @@ extern "C" int cmu_lamb_step(float* p, const float* g, float* m, float* v, float
     hipLaunchKernelGGL(lamb_update_kernel, dim3(nblocks), dim3(256), 0, st, (const float*)p, g, m, v, u, blk_start, blk_count, blk_tensor, t_wd,
                        (const float*)scal, grad_scale, beta1, beta2, b3, eps, (float)bc1, (float)sqrt(bc2), part2);
     CMU_CHECK_LAUNCH("cmu_lamb_step(update)");
-    hipLaunchKernelGGL(lamb_ratio_kernel, dim3(cmu_div_up(ntensors, 64)), dim3(64), 0, st, (const float*)part2, t_blk0, t_wd, ntensors,
+    hipLaunchKernelGGL(lamb_ratio_kernel, dim3(ntensors), dim3(64), 0, st, (const float*)part2, t_blk0, t_wd, ntensors,
                        always_adapt, trust_clip, ratio);
     CMU_CHECK_LAUNCH("cmu_lamb_step(trust ratio)");
     hipLaunchKernelGGL(lamb_apply_kernel, dim3(nblocks), dim3(256), 0, st, p, (const float*)u, blk_start, blk_count, blk_tensor,

@@ -19,26 +19,37 @@
 // (tests/test_gpu_sparse_tiles.py).
 #include "common.h"
 
+#ifndef CMU_CELLS_XLOG
+#define CMU_CELLS_XLOG 10     // log2 of the chunks a group of small patches is filled up to (tools/cells_bench.py: 0 / 8 / 9 / 10 ->
+                              // apply 614 / 611 / 593 / 589 us over the five levels, select 627 / 593 / 552 / 527, mask-token sum 373 / 359 / 339 / 329)
+#endif
+
 struct CellGeo {
     int f, ff;      // patch map side, f * f
     int sbits;      // log2(patch side in pixels at this level)
     int cbits;      // log2(16-byte chunks per pixel)
     int rbits;      // log2(patch rows per work item)
-    int gbits;      // log2(work items per patch) = sbits - rbits
+    int gbits;      // log2(row groups per patch) = sbits - rbits
+    int xbits;      // log2(horizontally adjacent patches per work item): small patches are taken several at a time
+    int fg;         // f >> xbits
     int H, W;
-    int nitems;     // B * f * f << gbits
+    int nitems;     // B * f * fg << gbits
 };
 
-// (patch, row group) of work item wi: image b, first pixel row y0, first pixel column x0, first row inside the patch yy0
-__device__ static inline void cell_decode(const CellGeo& g, int wi, int& cell, int& b, int& y0, int& x0, int& yy0) {
-    cell = wi >> g.gbits;
+// work item wi = (image b, patch row fy, group of 2^xbits adjacent patches, row group): first patch cell0, first pixel row y0, first
+// pixel column x0, first row inside the patch yy0.  Chunk k of the item: channel chunk k & cmask, pixel column j = (k >> cbits) &
+// (2^(sbits + xbits) - 1) -- patch cell0 + (j >> sbits), column j & (ps - 1) inside it -- and row k >> (cbits + sbits + xbits).
+__device__ static inline void cell_decode(const CellGeo& g, int wi, int& cell0, int& b, int& y0, int& x0, int& yy0) {
+    const int cg = wi >> g.gbits;
     const int rg = wi & ((1 << g.gbits) - 1);
-    b = cell / g.ff;
-    const int rem = cell - b * g.ff;
-    const int fy = rem / g.f, fx = rem - fy * g.f;
+    const int per_img = g.f * g.fg;
+    b = cg / per_img;
+    const int rem = cg - b * per_img;
+    const int fy = rem / g.fg, fxg = rem - fy * g.fg;
+    cell0 = (b * g.f + fy) * g.f + (fxg << g.xbits);
     yy0 = rg << g.rbits;
     y0 = (fy << g.sbits) + yy0;
-    x0 = fx << g.sbits;
+    x0 = (fxg << g.xbits) << g.sbits;
 }
 
 static bool cells_geometry(int B, int H, int W, int C, int epc, int f, int max_chunks_log2, bool pooled, CellGeo* g) {
@@ -58,9 +69,16 @@ static bool cells_geometry(int B, int H, int W, int C, int epc, int f, int max_c
     if (rb > g->sbits) rb = g->sbits;
     g->rbits = rb;
     g->gbits = g->sbits - rb;
+    // whole patches smaller than a workgroup's four chunks per thread: several side by side (a thread whose chunks are all masked
+    // skips the BatchNorm constants -- loading them in every workgroup was what made grouped items slower than small ones)
+    int xb = CMU_CELLS_XLOG - g->sbits - cb - rb;
+    if (xb < 0) xb = 0;
+    while (xb > 0 && (f & ((1 << xb) - 1)) != 0) --xb;
+    g->xbits = xb;
+    g->fg = f >> xb;
     g->H = pooled ? H / 2 : H;
     g->W = pooled ? W / 2 : W;
-    g->nitems = (B * f * f) << g->gbits;
+    g->nitems = (B * f * g->fg) << g->gbits;
     return true;
 }
 
@@ -75,7 +93,7 @@ extern "C" int cmu_cells_supported(int B, int H, int W, int f, int C, int dt) {
 // BatchNorm+ReLU backward, apply pass, sparse form: dY = scale * (gate * dA - c1 - xhat * c2) in active patches, zeros in masked
 // ones (cmu_bn_bwd_apply_masked's contract; ring = 1: zeros in the border frame of masked patches only)
 // ---------------------------------------------------------------------------------------------------
-template <class TR>
+template <class TR, bool MULTI>
 __global__ __launch_bounds__(256) void bn_bwd_apply_cells_kernel(const unsigned char* __restrict__ dA, int64_t ldd,
                                                                 const unsigned char* __restrict__ y, int64_t ldy,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
@@ -85,14 +103,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cells_kernel(const unsigned 
     constexpr int EPC = TR::EPC;
     constexpr int ES = (int)sizeof(typename TR::elem_t);
     const int tid = threadIdx.x;
-    int cell, b, y0, x0, yy0;
-    cell_decode(g, blockIdx.x, cell, b, y0, x0, yy0);
-    const int ps = 1 << g.sbits, cmask = (1 << g.cbits) - 1;
-    const int total = (1 << g.rbits) << (g.sbits + g.cbits);
+    int cell0, b, y0, x0, yy0;
+    cell_decode(g, blockIdx.x, cell0, b, y0, x0, yy0);
+    const int ps = 1 << g.sbits, cmask = (1 << g.cbits) - 1, wbits = g.sbits + g.xbits, wmask = (1 << wbits) - 1;
+    const int total = (1 << g.rbits) << (wbits + g.cbits);
     const int64_t row0 = (int64_t)b * g.H + y0;
-    if (active[cell] == 0) {
+    if (!MULTI && active[cell0] == 0) {         // one patch per work item: a masked one costs stores only (uniform branch)
         for (int k = tid; k < total; k += 256) {
-            const int c = k & cmask, j = (k >> g.cbits) & (ps - 1), r = k >> (g.cbits + g.sbits);
+            const int c = k & cmask, j = (k >> g.cbits) & wmask, r = k >> (g.cbits + wbits);
             if (ring) {
                 const int yy = yy0 + r;
                 if (!(yy == 0 || yy == ps - 1 || j == 0 || j == ps - 1)) continue;
@@ -103,29 +121,52 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cells_kernel(const unsigned 
         return;
     }
     const int ch = tid & cmask;                 // 256 % chunks-per-pixel == 0: the same channel chunk on every trip
-    float sc[EPC], sh[EPC], mu[EPC], is[EPC], c1[EPC], c2[EPC];
+    // several patches per item (at most 1,024 chunks: one trip): their bits first -- a thread whose chunks are all masked loads no
+    // BatchNorm constants (twelve 16-byte loads against two per chunk)
+    uint8_t ab[4] = {1, 1, 1, 1};
+    bool any = !MULTI;
+    if (MULTI) {
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-        const int c = ch * EPC + e;
-        sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; is[e] = invstd[c];
-        c1[e] = coef[c]; c2[e] = coef[C + c];
+        for (int i = 0; i < 4; ++i) {
+            const int k = tid + 256 * i;
+            ab[i] = k < total ? active[cell0 + (((k >> g.cbits) & wmask) >> g.sbits)] : (uint8_t)0;
+            any |= ab[i] != 0;
+        }
+    }
+    float sc[EPC], sh[EPC], mu[EPC], is[EPC], c1[EPC], c2[EPC];
+    if (any) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const int c = ch * EPC + e;
+            sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; is[e] = invstd[c];
+            c1[e] = coef[c]; c2[e] = coef[C + c];
+        }
     }
     for (int k0 = tid; k0 < total; k0 += 1024) {
         u32x4 gq[4], vq[4];
         int64_t p[4];
+        int st[4];                                 // 0: nothing to do, 1: active, 2: zero store
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int k = k0 + 256 * i;
+            st[i] = 0;
             if (k < total) {
-                const int j = (k >> g.cbits) & (ps - 1), r = k >> (g.cbits + g.sbits);
+                const int j = (k >> g.cbits) & wmask, r = k >> (g.cbits + wbits);
                 p[i] = (row0 + r) * g.W + x0 + j;
-                gq[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(dA + (p[i] * ldd + ch * EPC) * ES));
-                vq[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(y + (p[i] * ldy + ch * EPC) * ES));
+                if (ab[i] != 0) {
+                    st[i] = 1;
+                    gq[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(dA + (p[i] * ldd + ch * EPC) * ES));
+                    vq[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(y + (p[i] * ldy + ch * EPC) * ES));
+                } else {
+                    const int yy = yy0 + r, jj = j & (ps - 1);
+                    st[i] = (!ring || yy == 0 || yy == ps - 1 || jj == 0 || jj == ps - 1) ? 2 : 0;
+                }
             }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (k0 + 256 * i < total) {
+            if (st[i] == 2) st_global16(dY + (p[i] * ldo + ch * EPC) * ES, u32x4{0u, 0u, 0u, 0u});
+            if (st[i] == 1) {
                 float gg[EPC], v[EPC], o[EPC];
                 TR::unpack(gq[i], gg);
                 TR::unpack(vq[i], v);
@@ -161,8 +202,12 @@ template <class TR>
 static int bn_bwd_apply_cells_t(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift, const float* mean,
                                 const float* invstd, const float* coef, void* dY, int64_t ldo, const uint8_t* active, CellGeo g, int C, int ring,
                                 hipStream_t st) {
-    hipLaunchKernelGGL((bn_bwd_apply_cells_kernel<TR>), dim3(g.nitems), dim3(256), 0, st, (const unsigned char*)dA, ldd, (const unsigned char*)y, ldy,
-                       scale, shift, mean, invstd, coef, (unsigned char*)dY, ldo, active, g, C, ring);
+    if (g.xbits > 0)
+        hipLaunchKernelGGL((bn_bwd_apply_cells_kernel<TR, true>), dim3(g.nitems), dim3(256), 0, st, (const unsigned char*)dA, ldd, (const unsigned char*)y,
+                           ldy, scale, shift, mean, invstd, coef, (unsigned char*)dY, ldo, active, g, C, ring);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_cells_kernel<TR, false>), dim3(g.nitems), dim3(256), 0, st, (const unsigned char*)dA, ldd, (const unsigned char*)y,
+                           ldy, scale, shift, mean, invstd, coef, (unsigned char*)dY, ldo, active, g, C, ring);
     CMU_CHECK_LAUNCH("cmu_bn_bwd_apply_cells");
     return CMU_OK;
 }
@@ -182,21 +227,21 @@ extern "C" int cmu_bn_bwd_apply_cells(const void* dA, int64_t ldd, const void* y
 // ---------------------------------------------------------------------------------------------------
 // out = active ? relu?(x * scale + shift) : 0   (cmu_mask_select with a zero fill; ring as above)
 // ---------------------------------------------------------------------------------------------------
-template <class TR>
+template <class TR, bool MULTI>
 __global__ __launch_bounds__(256) void mask_select_cells_kernel(const unsigned char* __restrict__ x, int64_t ldx, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, int relu, unsigned char* __restrict__ out,
                                                                int64_t ldo, const uint8_t* __restrict__ active, CellGeo g, int ring) {
     constexpr int EPC = TR::EPC;
     constexpr int ES = (int)sizeof(typename TR::elem_t);
     const int tid = threadIdx.x;
-    int cell, b, y0, x0, yy0;
-    cell_decode(g, blockIdx.x, cell, b, y0, x0, yy0);
-    const int ps = 1 << g.sbits, cmask = (1 << g.cbits) - 1;
-    const int total = (1 << g.rbits) << (g.sbits + g.cbits);
+    int cell0, b, y0, x0, yy0;
+    cell_decode(g, blockIdx.x, cell0, b, y0, x0, yy0);
+    const int ps = 1 << g.sbits, cmask = (1 << g.cbits) - 1, wbits = g.sbits + g.xbits, wmask = (1 << wbits) - 1;
+    const int total = (1 << g.rbits) << (wbits + g.cbits);
     const int64_t row0 = (int64_t)b * g.H + y0;
-    if (active[cell] == 0) {
+    if (!MULTI && active[cell0] == 0) {
         for (int k = tid; k < total; k += 256) {
-            const int c = k & cmask, j = (k >> g.cbits) & (ps - 1), r = k >> (g.cbits + g.sbits);
+            const int c = k & cmask, j = (k >> g.cbits) & wmask, r = k >> (g.cbits + wbits);
             if (ring) {
                 const int yy = yy0 + r;
                 if (!(yy == 0 || yy == ps - 1 || j == 0 || j == ps - 1)) continue;
@@ -207,27 +252,46 @@ __global__ __launch_bounds__(256) void mask_select_cells_kernel(const unsigned c
         return;
     }
     const int ch = tid & cmask;
+    uint8_t ab[4] = {1, 1, 1, 1};
+    bool any = !MULTI;
+    if (MULTI) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = tid + 256 * i;
+            ab[i] = k < total ? active[cell0 + (((k >> g.cbits) & wmask) >> g.sbits)] : (uint8_t)0;
+            any |= ab[i] != 0;
+        }
+    }
     float sc[EPC], sh[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
-        sc[e] = scale ? scale[ch * EPC + e] : 1.f;
-        sh[e] = scale ? shift[ch * EPC + e] : 0.f;
+        sc[e] = (scale && any) ? scale[ch * EPC + e] : 1.f;
+        sh[e] = (scale && any) ? shift[ch * EPC + e] : 0.f;
     }
     for (int k0 = tid; k0 < total; k0 += 1024) {
         u32x4 vq[4];
         int64_t p[4];
+        int st[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int k = k0 + 256 * i;
+            st[i] = 0;
             if (k < total) {
-                const int j = (k >> g.cbits) & (ps - 1), r = k >> (g.cbits + g.sbits);
+                const int j = (k >> g.cbits) & wmask, r = k >> (g.cbits + wbits);
                 p[i] = (row0 + r) * g.W + x0 + j;
-                vq[i] = ld_global16(x + (p[i] * ldx + ch * EPC) * ES);
+                if (ab[i] != 0) {
+                    st[i] = 1;
+                    vq[i] = ld_global16(x + (p[i] * ldx + ch * EPC) * ES);
+                } else {
+                    const int yy = yy0 + r, jj = j & (ps - 1);
+                    st[i] = (!ring || yy == 0 || yy == ps - 1 || jj == 0 || jj == ps - 1) ? 2 : 0;
+                }
             }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (k0 + 256 * i < total) {
+            if (st[i] == 2) st_global16(out + (p[i] * ldo + ch * EPC) * ES, u32x4{0u, 0u, 0u, 0u});
+            if (st[i] == 1) {
                 u32x4 o = vq[i];
                 if (scale || relu) {
                     float v[EPC];
@@ -247,8 +311,12 @@ __global__ __launch_bounds__(256) void mask_select_cells_kernel(const unsigned c
 template <class TR>
 static int mask_select_cells_t(const void* x, int64_t ldx, const float* scale, const float* shift, int relu, void* out, int64_t ldo,
                                const uint8_t* active, CellGeo g, int ring, hipStream_t st) {
-    hipLaunchKernelGGL((mask_select_cells_kernel<TR>), dim3(g.nitems), dim3(256), 0, st, (const unsigned char*)x, ldx, scale, shift, relu,
-                       (unsigned char*)out, ldo, active, g, ring);
+    if (g.xbits > 0)
+        hipLaunchKernelGGL((mask_select_cells_kernel<TR, true>), dim3(g.nitems), dim3(256), 0, st, (const unsigned char*)x, ldx, scale, shift, relu,
+                           (unsigned char*)out, ldo, active, g, ring);
+    else
+        hipLaunchKernelGGL((mask_select_cells_kernel<TR, false>), dim3(g.nitems), dim3(256), 0, st, (const unsigned char*)x, ldx, scale, shift, relu,
+                           (unsigned char*)out, ldo, active, g, ring);
     CMU_CHECK_LAUNCH("cmu_mask_select_cells");
     return CMU_OK;
 }
@@ -266,7 +334,7 @@ extern "C" int cmu_mask_select_cells(const void* x, int64_t ldx, const float* sc
 // MaxPool2d(2) backward + skip-gradient add over ACTIVE patches only (cmu_maxpool_bwd_masked's contract: dA at masked positions is
 // left unwritten).  Work item: rows of POOLED pixels of one patch; per pooled chunk 1 + 4 + 4 loads and 4 stores.
 // ---------------------------------------------------------------------------------------------------
-template <class TR>
+template <class TR, bool MULTI>
 __global__ __launch_bounds__(256) void maxpool_bwd_cells_kernel(const unsigned char* __restrict__ dP, int64_t ldp,
                                                                const unsigned char* __restrict__ dS, int64_t lds,
                                                                const unsigned char* __restrict__ y, int64_t ldy, const float* __restrict__ scale,
@@ -275,11 +343,11 @@ __global__ __launch_bounds__(256) void maxpool_bwd_cells_kernel(const unsigned c
     constexpr int EPC = TR::EPC;
     constexpr int ES = (int)sizeof(typename TR::elem_t);
     const int tid = threadIdx.x;
-    int cell, b, y0, x0, yy0;
-    cell_decode(g, blockIdx.x, cell, b, y0, x0, yy0);        // pooled coordinates
-    if (active[cell] == 0) return;
-    const int ps = 1 << g.sbits, cmask = (1 << g.cbits) - 1;
-    const int total = (1 << g.rbits) << (g.sbits + g.cbits);
+    int cell0, b, y0, x0, yy0;
+    cell_decode(g, blockIdx.x, cell0, b, y0, x0, yy0);        // pooled coordinates
+    if (!MULTI && active[cell0] == 0) return;
+    const int cmask = (1 << g.cbits) - 1, wbits = g.sbits + g.xbits, wmask = (1 << wbits) - 1;
+    const int total = (1 << g.rbits) << (wbits + g.cbits);
     const int H = 2 * g.H, W = 2 * g.W;
     const int ch = tid & cmask;
     float sc[EPC], sh[EPC];
@@ -288,25 +356,33 @@ __global__ __launch_bounds__(256) void maxpool_bwd_cells_kernel(const unsigned c
     for (int k0 = tid; k0 < total; k0 += 512) {
         u32x4 gq[2], fq[2][4], dq[2][4];
         int64_t src[2][4];
+        bool on[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int k = k0 + 256 * i;
-            if (k < total) {
-                const int j = (k >> g.cbits) & (ps - 1), r = k >> (g.cbits + g.sbits);
-                const int yo = y0 + r, xo = x0 + j;
-                const int64_t pp = ((int64_t)b * g.H + yo) * g.W + xo;
-                gq[i] = ld_global16_nt(dP + (pp * ldp + ch * EPC) * ES);
+            on[i] = k < total && (!MULTI || active[cell0 + (((k >> g.cbits) & wmask) >> g.sbits)] != 0);
+        }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    src[i][q] = ((int64_t)b * H + 2 * yo + (q >> 1)) * W + 2 * xo + (q & 1);
-                    fq[i][q] = ld_global16(y + (src[i][q] * ldy + ch * EPC) * ES);
-                    if (dS) dq[i][q] = ld_global16_nt(dS + (src[i][q] * lds + ch * EPC) * ES);
+        for (int i = 0; i < 2; ++i) {
+            const int k = k0 + 256 * i;
+            {
+                const int j = (k >> g.cbits) & wmask, r = k >> (g.cbits + wbits);
+                if (on[i]) {
+                    const int yo = y0 + r, xo = x0 + j;
+                    const int64_t pp = ((int64_t)b * g.H + yo) * g.W + xo;
+                    gq[i] = ld_global16_nt(dP + (pp * ldp + ch * EPC) * ES);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        src[i][q] = ((int64_t)b * H + 2 * yo + (q >> 1)) * W + 2 * xo + (q & 1);
+                        fq[i][q] = ld_global16(y + (src[i][q] * ldy + ch * EPC) * ES);
+                        if (dS) dq[i][q] = ld_global16_nt(dS + (src[i][q] * lds + ch * EPC) * ES);
+                    }
                 }
             }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            if (k0 + 256 * i < total) {
+            if (on[i]) {
                 float best[EPC], gg[EPC];
                 int arg[EPC];
                 TR::unpack(gq[i], gg);
@@ -339,8 +415,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_cells_kernel(const unsigned c
 template <class TR>
 static int maxpool_bwd_cells_t(const void* dP, int64_t ldp, const void* dS, int64_t lds, const void* y, int64_t ldy, const float* scale,
                                const float* shift, void* dA, int64_t lda, const uint8_t* active, CellGeo g, hipStream_t st) {
-    hipLaunchKernelGGL((maxpool_bwd_cells_kernel<TR>), dim3(g.nitems), dim3(256), 0, st, (const unsigned char*)dP, ldp, (const unsigned char*)dS, lds,
-                       (const unsigned char*)y, ldy, scale, shift, (unsigned char*)dA, lda, active, g);
+    if (g.xbits > 0)
+        hipLaunchKernelGGL((maxpool_bwd_cells_kernel<TR, true>), dim3(g.nitems), dim3(256), 0, st, (const unsigned char*)dP, ldp, (const unsigned char*)dS,
+                           lds, (const unsigned char*)y, ldy, scale, shift, (unsigned char*)dA, lda, active, g);
+    else
+        hipLaunchKernelGGL((maxpool_bwd_cells_kernel<TR, false>), dim3(g.nitems), dim3(256), 0, st, (const unsigned char*)dP, ldp, (const unsigned char*)dS,
+                           lds, (const unsigned char*)y, ldy, scale, shift, (unsigned char*)dA, lda, active, g);
     CMU_CHECK_LAUNCH("cmu_maxpool_bwd_cells");
     return CMU_OK;
 }
@@ -363,39 +443,47 @@ extern "C" int cmu_maxpool_bwd_cells(const void* dP, int64_t ldp, const void* dS
 // fixed-order fold inside the workgroup and over the slab (no atomics): bitwise reproducible.
 // ---------------------------------------------------------------------------------------------------
 constexpr int CSUM_ROWS = 1024;
-template <class TR>
+template <class TR, bool MULTI>
 __global__ __launch_bounds__(256) void cells_channel_sum_kernel(const unsigned char* __restrict__ x, int64_t ldx, const uint8_t* __restrict__ active,
                                                                int invert, CellGeo g, int per, int C, float* __restrict__ slab) {
     constexpr int EPC = TR::EPC;
     constexpr int ES = (int)sizeof(typename TR::elem_t);
     __shared__ float red[256 * EPC];
     const int tid = threadIdx.x;
-    const int ps = 1 << g.sbits, cmask = (1 << g.cbits) - 1, nchunk = 1 << g.cbits;
-    const int total = (1 << g.rbits) << (g.sbits + g.cbits);
+    const int cmask = (1 << g.cbits) - 1, nchunk = 1 << g.cbits, wbits = g.sbits + g.xbits, wmask = (1 << wbits) - 1;
+    const int total = (1 << g.rbits) << (wbits + g.cbits);
     const int ch = tid & cmask;
     float s[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) s[e] = 0.f;
     const int w1 = (blockIdx.x + 1) * per < g.nitems ? (blockIdx.x + 1) * per : g.nitems;
     for (int wi = blockIdx.x * per; wi < w1; ++wi) {
-        int cell, b, y0, x0, yy0;
-        cell_decode(g, wi, cell, b, y0, x0, yy0);
-        if ((active[cell] != 0) == (invert != 0)) continue;
+        int cell0, b, y0, x0, yy0;
+        cell_decode(g, wi, cell0, b, y0, x0, yy0);
+        if (!MULTI && (active[cell0] != 0) == (invert != 0)) continue;
         const int64_t row0 = (int64_t)b * g.H + y0;
         for (int k0 = tid; k0 < total; k0 += 1024) {
             u32x4 vq[4];
+            bool on[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int k = k0 + 256 * i;
-                if (k < total) {
-                    const int j = (k >> g.cbits) & (ps - 1), r = k >> (g.cbits + g.sbits);
-                    const int64_t p = (row0 + r) * g.W + x0 + j;
-                    vq[i] = ld_global16_nt(x + (p * ldx + ch * EPC) * ES);
+                on[i] = k < total && (!MULTI || (active[cell0 + (((k >> g.cbits) & wmask) >> g.sbits)] != 0) != (invert != 0));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = k0 + 256 * i;
+                {
+                    const int j = (k >> g.cbits) & wmask, r = k >> (g.cbits + wbits);
+                    if (on[i]) {
+                        const int64_t p = (row0 + r) * g.W + x0 + j;
+                        vq[i] = ld_global16_nt(x + (p * ldx + ch * EPC) * ES);
+                    }
                 }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (k0 + 256 * i < total) {
+                if (on[i]) {
                     float v[EPC];
                     TR::unpack(vq[i], v);
 #pragma unroll
@@ -448,7 +536,10 @@ static int cells_channel_sum_t(const void* x, int64_t ldx, const uint8_t* active
     const int rows = g.nitems < CSUM_ROWS ? g.nitems : CSUM_ROWS;
     const int per = (g.nitems + rows - 1) / rows;
     const int used = (g.nitems + per - 1) / per;
-    hipLaunchKernelGGL((cells_channel_sum_kernel<TR>), dim3(used), dim3(256), 0, st, (const unsigned char*)x, ldx, active, invert, g, per, C, ws);
+    if (g.xbits > 0)
+        hipLaunchKernelGGL((cells_channel_sum_kernel<TR, true>), dim3(used), dim3(256), 0, st, (const unsigned char*)x, ldx, active, invert, g, per, C, ws);
+    else
+        hipLaunchKernelGGL((cells_channel_sum_kernel<TR, false>), dim3(used), dim3(256), 0, st, (const unsigned char*)x, ldx, active, invert, g, per, C, ws);
     CMU_CHECK_LAUNCH("cmu_cells_channel_sum");
     hipLaunchKernelGGL(cells_channel_sum_final_kernel, dim3(cmu_div_up(C, 16)), dim3(256), 0, st, (const float*)ws, used, C, out);
     CMU_CHECK_LAUNCH("cmu_cells_channel_sum(final)");

@@ -331,7 +331,7 @@ class SparK(_EngineOwner, nn.Module):
         ops.bn_finalize(slab, count, sd[pconv + "bias"].detach(), sd[pbn + "weight"].detach(), sd[pbn + "bias"].detach(),
                         sd[pbn + "running_mean"], sd[pbn + "running_var"], BN_MOMENTUM, BN_EPS, training, scale, shift, mean, invstd, ws)
         if training:
-            sd[pbn + "num_batches_tracked"] += 1
+            eng._nbt.append(sd[pbn + "num_batches_tracked"])      # += 1 of all layers in one multi-tensor launch (engine.flush_counters)
         yt = y.with_transform(scale, shift, 0)
         a = None
         if need_a:
@@ -478,6 +478,8 @@ class SparK(_EngineOwner, nn.Module):
                                  ring=ring_ok(tlb, h, w_, convs_b[1]))
         b2 = self._sp_convbn_fwd(eng, sd, p + "3.", p + "4.", b1["a"], None, None, active, cnt_b, B, h, w_, training, sync=sbn, tiles=tlb,
                                  need_a=not _FUSE_POOL)
+
+        eng.flush_counters()
 
         # ---- densify (spark.py:98-111): feature maps from the smallest to the largest, mask_tokens[i] likewise ----
         # (a feature map is the activated + masked second-conv output of its level: taken from the stored copy, or -- when that copy was

@@ -341,7 +341,10 @@ def test_spark_step_with_and_without_tile_skipping(ops, dt, tmp_path):
 
 
 # ---- round 4: patch-organised element-wise passes (csrc/sparse_elem.hip) and the batched list builders ------------------------------
-_CELL_CASES = [(2, 4, 16, 32), (3, 8, 16, 64), (1, 8, 32, 16), (2, 4, 64, 64), (2, 8, 64, 128), (1, 16, 32, 1024), (2, 4, 4, 256), (3, 2, 64, 8)]
+# (B, f, H, C): patches of 4, 2, 4, 16, 8, 2, 1, 32, 4, 2, 1 pixels; patch maps whose side is not a power of two; several small
+# patches side by side per work item
+_CELL_CASES = [(2, 4, 16, 32), (3, 8, 16, 64), (1, 8, 32, 16), (2, 4, 64, 64), (2, 8, 64, 128), (1, 16, 32, 1024), (2, 4, 4, 256), (3, 2, 64, 8),
+               (2, 6, 24, 64), (1, 14, 28, 128), (2, 32, 32, 1024), (3, 12, 12, 512)]
 
 
 def _frame(act, H):

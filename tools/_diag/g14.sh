@@ -2,11 +2,10 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 for WL in spark; do
+  :
   rm -rf $R/gpurun_out/tl_$WL
   rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tl_$WL -- python3 $R/bench.py --workload $WL --steps 2 --warmup 2 --no-cpu-baseline --no-kernel-events > $R/gpurun_out/tl_$WL.log 2>&1 || exit 1
   python3 $R/tools/step_timeline.py $R/gpurun_out/tl_$WL > $R/gpurun_out/timeline_$WL.txt || exit 1
-  CMU_SPARK_TILES=0 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tl_${WL}_dense -- python3 $R/bench.py --workload $WL --steps 2 --warmup 2 --no-cpu-baseline --no-kernel-events > $R/gpurun_out/tl_${WL}_dense.log 2>&1 || exit 1
-  python3 $R/tools/step_timeline.py $R/gpurun_out/tl_${WL}_dense > $R/gpurun_out/timeline_${WL}_dense.txt || exit 1
-  rm -rf $R/gpurun_out/tl_$WL $R/gpurun_out/tl_${WL}_dense
+  rm -rf $R/gpurun_out/tl_$WL
 done
 echo done
