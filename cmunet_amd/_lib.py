@@ -119,6 +119,9 @@ _SIGS = {
     "cmu_bn_bwd_apply_cells": (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cmu_mask_select_cells": (_I, [_P, _L, _P, _P, _I, _P, _I, _I, _P, _L, _I, _I, _I, _I, _I, _P]),
     "cmu_maxpool_bwd_cells": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _I, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "cmu_cells_stats_rows": (_I, []),
+    "cmu_cells_channel_stats": (_I, [_P, _L, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "cmu_bn_bwd_reduce_cells": (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P, _P]),
     "cmu_cells_channel_sum_ws_bytes": (_L, [_I]),
     "cmu_cells_channel_sum": (_I, [_P, _L, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cmu_sparse_pixel_list_ws_bytes": (_L, [_I, _I]),

@@ -438,24 +438,45 @@ extern "C" int cmu_maxpool_bwd_cells(const void* dP, int64_t ldp, const void* dS
 }
 
 // ---------------------------------------------------------------------------------------------------
-// out[c] = sum of x[p][c] over the pixels of the selected patches (invert = 1: the MASKED patches -- the mask-token gradient of
-// spark.py:104-108).  CSUM_ROWS workgroups, each over one contiguous range of work items, per-thread fp32 sums of one channel chunk,
-// fixed-order fold inside the workgroup and over the slab (no atomics): bitwise reproducible.
+// Per-channel sums over the pixels of the selected patches, three forms of one walk (CSUM_ROWS workgroups, each over one contiguous
+// range of work items, per-thread fp32 sums of one channel chunk, fixed-order fold inside the workgroup and over the slab, no atomics:
+// bitwise reproducible):
+//   MODE 0  sum of x                       -> cmu_cells_channel_sum (invert = 1: the MASKED patches -- the mask-token gradient of
+//                                             spark.py:104-108)
+//   MODE 1  sum and sum of squares of x    -> cmu_cells_channel_stats: the sparse BatchNorm statistics (encoder.py:26-36),
+//                                             slab [CSUM_ROWS][2][C] for cmu_bn_finalize
+//   MODE 2  BatchNorm+ReLU backward sums   -> cmu_bn_bwd_reduce_cells (= cmu_bn_bwd_reduce_masked): sum of dz and of dz * xhat with
+//                                             dz = gate * dA, into the cmu_bn_bwd_finalize workspace layout
 // ---------------------------------------------------------------------------------------------------
 constexpr int CSUM_ROWS = 1024;
-template <class TR, bool MULTI>
-__global__ __launch_bounds__(256) void cells_channel_sum_kernel(const unsigned char* __restrict__ x, int64_t ldx, const uint8_t* __restrict__ active,
-                                                               int invert, CellGeo g, int per, int C, float* __restrict__ slab) {
+constexpr int CSUM_HDR = 16;      // bytes in front of the MODE 2 slab (cmu_bn_bwd_ws layout: the number of rows)
+template <class TR, bool MULTI, int MODE>
+__global__ __launch_bounds__(256) void cells_channel_sum_kernel(const unsigned char* __restrict__ x, int64_t ldx, const unsigned char* __restrict__ y,
+                                                               int64_t ldy, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               const uint8_t* __restrict__ active, int invert, CellGeo g, int per, int C,
+                                                               float* __restrict__ slab) {
     constexpr int EPC = TR::EPC;
     constexpr int ES = (int)sizeof(typename TR::elem_t);
+    constexpr int NS = MODE == 0 ? 1 : 2;
     __shared__ float red[256 * EPC];
     const int tid = threadIdx.x;
     const int cmask = (1 << g.cbits) - 1, nchunk = 1 << g.cbits, wbits = g.sbits + g.xbits, wmask = (1 << wbits) - 1;
     const int total = (1 << g.rbits) << (wbits + g.cbits);
     const int ch = tid & cmask;
-    float s[EPC];
+    float s[NS][EPC];
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) s[e] = 0.f;
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) s[q][e] = 0.f;
+    float sc[EPC], sh[EPC], mu[EPC], is[EPC];
+    if (MODE == 2) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const int c = ch * EPC + e;
+            sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; is[e] = invstd[c];
+        }
+    }
     const int w1 = (blockIdx.x + 1) * per < g.nitems ? (blockIdx.x + 1) * per : g.nitems;
     for (int wi = blockIdx.x * per; wi < w1; ++wi) {
         int cell0, b, y0, x0, yy0;
@@ -463,7 +484,7 @@ __global__ __launch_bounds__(256) void cells_channel_sum_kernel(const unsigned c
         if (!MULTI && (active[cell0] != 0) == (invert != 0)) continue;
         const int64_t row0 = (int64_t)b * g.H + y0;
         for (int k0 = tid; k0 < total; k0 += 1024) {
-            u32x4 vq[4];
+            u32x4 vq[4], gq[4];
             bool on[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -473,11 +494,14 @@ __global__ __launch_bounds__(256) void cells_channel_sum_kernel(const unsigned c
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int k = k0 + 256 * i;
-                {
-                    const int j = (k >> g.cbits) & wmask, r = k >> (g.cbits + wbits);
-                    if (on[i]) {
-                        const int64_t p = (row0 + r) * g.W + x0 + j;
-                        vq[i] = ld_global16_nt(x + (p * ldx + ch * EPC) * ES);
+                const int j = (k >> g.cbits) & wmask, r = k >> (g.cbits + wbits);
+                if (on[i]) {
+                    const int64_t p = (row0 + r) * g.W + x0 + j;
+                    if (MODE == 2) {
+                        vq[i] = ld_global16(x + (p * ldx + ch * EPC) * ES);
+                        gq[i] = ld_global16(y + (p * ldy + ch * EPC) * ES);
+                    } else {
+                        vq[i] = MODE == 0 ? ld_global16_nt(x + (p * ldx + ch * EPC) * ES) : ld_global16(x + (p * ldx + ch * EPC) * ES);
                     }
                 }
             }
@@ -486,21 +510,44 @@ __global__ __launch_bounds__(256) void cells_channel_sum_kernel(const unsigned c
                 if (on[i]) {
                     float v[EPC];
                     TR::unpack(vq[i], v);
+                    if (MODE == 0) {
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) s[e] += v[e];
+                        for (int e = 0; e < EPC; ++e) s[0][e] += v[e];
+                    } else if (MODE == 1) {
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) {
+                            s[0][e] += v[e];
+                            s[NS - 1][e] = fmaf(v[e], v[e], s[NS - 1][e]);
+                        }
+                    } else {                       // x = dA, y = the raw output
+                        float yv[EPC];
+                        TR::unpack(gq[i], yv);
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) {
+                            const float dz = fmaf(yv[e], sc[e], sh[e]) > 0.f ? v[e] : 0.f;
+                            s[0][e] += dz;
+                            s[NS - 1][e] = fmaf(dz, (yv[e] - mu[e]) * is[e], s[NS - 1][e]);
+                        }
+                    }
                 }
             }
         }
     }
+    if (MODE == 2 && blockIdx.x == 0 && tid == 0) *reinterpret_cast<int*>(slab) = (int)gridDim.x;
+    float* out = MODE == 2 ? slab + CSUM_HDR / 4 : slab;
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) red[tid * EPC + e] = s[e];
-    __syncthreads();
-    if (tid < nchunk) {
+    for (int q = 0; q < NS; ++q) {
+        __syncthreads();
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            float a = 0.f;
-            for (int k = tid; k < 256; k += nchunk) a += red[k * EPC + e];
-            slab[(int64_t)blockIdx.x * C + tid * EPC + e] = a;
+        for (int e = 0; e < EPC; ++e) red[tid * EPC + e] = s[q][e];
+        __syncthreads();
+        if (tid < nchunk) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                float a = 0.f;
+                for (int k = tid; k < 256; k += nchunk) a += red[k * EPC + e];
+                out[((int64_t)blockIdx.x * NS + q) * C + tid * EPC + e] = a;
+            }
         }
     }
 }
@@ -531,17 +578,26 @@ __global__ __launch_bounds__(256) void cells_channel_sum_final_kernel(const floa
         out[c] = (float)s;
     }
 }
+// launches the walk with exactly `rows` workgroups (every slab row is written; workgroups past the work write zeros)
+template <class TR, int MODE>
+static int cells_sums_launch(const void* x, int64_t ldx, const void* y, int64_t ldy, const float* scale, const float* shift, const float* mean,
+                             const float* invstd, const uint8_t* active, int invert, CellGeo g, int C, float* slab, int rows, hipStream_t st) {
+    const int per = (g.nitems + rows - 1) / rows;
+    if (g.xbits > 0)
+        hipLaunchKernelGGL((cells_channel_sum_kernel<TR, true, MODE>), dim3(rows), dim3(256), 0, st, (const unsigned char*)x, ldx, (const unsigned char*)y,
+                           ldy, scale, shift, mean, invstd, active, invert, g, per, C, slab);
+    else
+        hipLaunchKernelGGL((cells_channel_sum_kernel<TR, false, MODE>), dim3(rows), dim3(256), 0, st, (const unsigned char*)x, ldx, (const unsigned char*)y,
+                           ldy, scale, shift, mean, invstd, active, invert, g, per, C, slab);
+    return CMU_OK;
+}
+static int csum_rows(const CellGeo& g) { return g.nitems < CSUM_ROWS ? g.nitems : CSUM_ROWS; }
 template <class TR>
 static int cells_channel_sum_t(const void* x, int64_t ldx, const uint8_t* active, int invert, CellGeo g, int C, float* out, float* ws, hipStream_t st) {
-    const int rows = g.nitems < CSUM_ROWS ? g.nitems : CSUM_ROWS;
-    const int per = (g.nitems + rows - 1) / rows;
-    const int used = (g.nitems + per - 1) / per;
-    if (g.xbits > 0)
-        hipLaunchKernelGGL((cells_channel_sum_kernel<TR, true>), dim3(used), dim3(256), 0, st, (const unsigned char*)x, ldx, active, invert, g, per, C, ws);
-    else
-        hipLaunchKernelGGL((cells_channel_sum_kernel<TR, false>), dim3(used), dim3(256), 0, st, (const unsigned char*)x, ldx, active, invert, g, per, C, ws);
+    const int rows = csum_rows(g);
+    cells_sums_launch<TR, 0>(x, ldx, nullptr, 0, nullptr, nullptr, nullptr, nullptr, active, invert, g, C, ws, rows, st);
     CMU_CHECK_LAUNCH("cmu_cells_channel_sum");
-    hipLaunchKernelGGL(cells_channel_sum_final_kernel, dim3(cmu_div_up(C, 16)), dim3(256), 0, st, (const float*)ws, used, C, out);
+    hipLaunchKernelGGL(cells_channel_sum_final_kernel, dim3(cmu_div_up(C, 16)), dim3(256), 0, st, (const float*)ws, rows, C, out);
     CMU_CHECK_LAUNCH("cmu_cells_channel_sum(final)");
     return CMU_OK;
 }
@@ -553,4 +609,45 @@ extern "C" int cmu_cells_channel_sum(const void* x, int64_t ldx, const uint8_t* 
     CMU_CHECK_ARG(active && out && ws, "cmu_cells_channel_sum: null argument");
     CMU_CELLS_GEOMETRY("cmu_cells_channel_sum", false, 10)
     CMU_DISPATCH_DT(dt, cells_channel_sum_t, x, ldx, active, invert, g, C, out, (float*)ws, (hipStream_t)stream);
+}
+
+template <class TR>
+static int cells_channel_stats_t(const void* x, int64_t ldx, const uint8_t* active, CellGeo g, int C, float* slab, hipStream_t st) {
+    cells_sums_launch<TR, 1>(x, ldx, nullptr, 0, nullptr, nullptr, nullptr, nullptr, active, 0, g, C, slab, CSUM_ROWS, st);
+    CMU_CHECK_LAUNCH("cmu_cells_channel_stats");
+    return CMU_OK;
+}
+extern "C" int cmu_cells_stats_rows(void) { return CSUM_ROWS; }
+extern "C" int cmu_cells_channel_stats(const void* x, int64_t ldx, const uint8_t* active, int f, float* slab, int B, int H, int W, int C, int dt,
+                                       void* stream) {
+    int rc;
+    if ((rc = check_cells_act("cmu_cells_channel_stats(x)", x, ldx, C, dt))) return rc;
+    CMU_CHECK_ARG(active && slab, "cmu_cells_channel_stats: null argument");
+    CMU_CELLS_GEOMETRY("cmu_cells_channel_stats", false, 10)
+    CMU_DISPATCH_DT(dt, cells_channel_stats_t, x, ldx, active, g, C, slab, (hipStream_t)stream);
+}
+
+template <class TR>
+static int bn_bwd_reduce_cells_t(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift, const float* mean,
+                                 const float* invstd, const uint8_t* active, CellGeo g, int C, float* ws, hipStream_t st) {
+    cells_sums_launch<TR, 2>(dA, ldd, y, ldy, scale, shift, mean, invstd, active, 0, g, C, ws, csum_rows(g), st);
+    CMU_CHECK_LAUNCH("cmu_bn_bwd_reduce_cells");
+    return CMU_OK;
+}
+extern "C" int cmu_bn_bwd_reduce_cells(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift,
+                                       const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* coef,
+                                       const uint8_t* active, int f, int64_t count, int B, int H, int W, int C, int dt, void* ws, void* stream) {
+    int rc;
+    if ((rc = check_cells_act("cmu_bn_bwd_reduce_cells(dA)", dA, ldd, C, dt))) return rc;
+    if ((rc = check_cells_act("cmu_bn_bwd_reduce_cells(y)", y, ldy, C, dt))) return rc;
+    CMU_CHECK_ARG(scale && shift && save_mean && save_invstd && coef && ws && active && count > 0, "cmu_bn_bwd_reduce_cells: null argument");
+    CMU_CELLS_GEOMETRY("cmu_bn_bwd_reduce_cells", false, 10)
+    {
+        const int es = cmu_dtype_size(dt);
+        int r2 = es == 4 ? bn_bwd_reduce_cells_t<F32Traits>(dA, ldd, y, ldy, scale, shift, save_mean, save_invstd, active, g, C, (float*)ws, (hipStream_t)stream)
+                 : dt == CMU_F16 ? bn_bwd_reduce_cells_t<F16Traits>(dA, ldd, y, ldy, scale, shift, save_mean, save_invstd, active, g, C, (float*)ws, (hipStream_t)stream)
+                                 : bn_bwd_reduce_cells_t<BF16Traits>(dA, ldd, y, ldy, scale, shift, save_mean, save_invstd, active, g, C, (float*)ws, (hipStream_t)stream);
+        if (r2 != CMU_OK) return r2;
+    }
+    return cmu_bn_bwd_finalize(ws, count, dgamma, dbeta, coef, C, stream);      // ws: cmu_bn_bwd_ws_bytes(C)
 }

@@ -466,6 +466,19 @@ def mask_select(x, active, out, relu=False, invert=False, fill=None, use_transfo
          out.ld, x.B, x.H, x.W, x.C, x.dt, _stream())
 
 
+def cells_channel_stats(x, active):
+    """masked_channel_stats / rows_channel_stats over the active patches, patch-organised -> slab [rows][2][C] fp32."""
+    slab = torch.empty((_lib.lib().cmu_cells_stats_rows(), 2, x.C), dtype=torch.float32, device=x.buf.device)
+    call("cmu_cells_channel_stats", x.ptr(), x.ld, _p(active), active.shape[-1], _p(slab), x.B, x.H, x.W, x.C, x.dt, _stream())
+    return slab
+
+
+def bn_bwd_reduce_cells(dA, y, save_mean, save_invstd, dgamma, dbeta, coef, active, count, ws):
+    """bn_bwd_reduce_masked / bn_bwd_reduce_rows, patch-organised."""
+    call("cmu_bn_bwd_reduce_cells", dA.ptr(), dA.ld, y.ptr(), y.ld, _p(y.scale), _p(y.shift), _p(save_mean), _p(save_invstd), _p(dgamma),
+         _p(dbeta), _p(coef), _p(active), active.shape[-1], int(count), y.B, y.H, y.W, y.C, y.dt, _p(ws), _stream())
+
+
 def cells_channel_sum(x, active, out, invert=False, ws=None):
     """out[c] (fp32, C) = sum of x over the pixels of the active / masked (``invert``) patches: the mask-token gradient."""
     assert out.dtype == torch.float32 and out.numel() == x.C and out.is_contiguous()

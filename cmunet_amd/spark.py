@@ -35,6 +35,7 @@ import torch.nn as nn
 from . import _lib, ops
 from .engine import BN_EPS, BN_MOMENTUM
 
+_CELL_STATS = os.environ.get("CMU_SPARK_CELL_STATS", "1") != "0"    # A/B: "0" = the statistics passes walk the pixel list
 _FUSE_POOL = os.environ.get("CMU_SPARK_POOL_FUSE", "1") != "0"     # A/B: "0" = the activated + masked copy of every conv output is stored
 from .model import DoubleConv, DownBlock, UpBlock, _EngineOwner, _named_state, _param_args, _require_cuda
 from .ops import Act
@@ -316,6 +317,8 @@ class SparK(_EngineOwner, nn.Module):
         scale, shift, mean, invstd = eng._f32(C), eng._f32(C), eng._f32(C), eng._f32(C)
         if not training or slab is not None:
             pass
+        elif _CELL_STATS and ops.cells_supported(y, active):
+            slab = ops.cells_channel_stats(y, active)                              # statistics over the active patches, row groups per workgroup
         elif tiles is not None and tiles["pix"] is not None:
             slab = ops.rows_channel_stats(y, tiles["pix"])                         # statistics over the list of active pixels
         else:
@@ -349,7 +352,9 @@ class SparK(_EngineOwner, nn.Module):
         dgamma, dbeta = eng._gbuf(s["pbn"] + "weight", sd[s["pbn"] + "weight"]), eng._gbuf(s["pbn"] + "bias", sd[s["pbn"] + "bias"])
         coef = eng._f32(2, C)
         tiles = s.get("tiles")
-        if tiles is not None and tiles["pix"] is not None:
+        if _CELL_STATS and ops.cells_supported(y, active):
+            ops.bn_bwd_reduce_cells(dA, y, s["mean"], s["invstd"], dgamma, dbeta, coef, active, count, eng._bn_ws(C))
+        elif tiles is not None and tiles["pix"] is not None:
             ops.bn_bwd_reduce_rows(dA, y, s["mean"], s["invstd"], dgamma, dbeta, coef, tiles["pix"], count, eng._bn_ws(C))
         else:
             ops.bn_bwd_reduce_masked(dA, y, s["mean"], s["invstd"], dgamma, dbeta, coef, active, count, eng._bn_ws(C))

@@ -375,6 +375,14 @@ int cmu_mask_select_cells(const void* x, int64_t ldx, const float* scale, const 
 int cmu_maxpool_bwd_cells(const void* dP, int64_t ldp, const void* dSkip, int64_t lds, const void* y, int64_t ldy, const float* scale,
                           const float* shift, const uint8_t* active, int f, void* dA, int64_t lda, int B, int H, int W, int C, int dt,
                           void* stream);
+/*   cmu_cells_channel_stats    = cmu_masked_channel_stats(invert 0) / cmu_rows_channel_stats: slab [cmu_cells_stats_rows()][2][C], fully written
+ *   cmu_bn_bwd_reduce_cells    = cmu_bn_bwd_reduce_masked / cmu_bn_bwd_reduce_rows (same sums in another fixed order); ws: cmu_bn_bwd_ws_bytes(C) */
+int cmu_cells_stats_rows(void);
+int cmu_cells_channel_stats(const void* x, int64_t ldx, const uint8_t* active, int f, float* slab, int B, int H, int W, int C, int dt,
+                            void* stream);
+int cmu_bn_bwd_reduce_cells(const void* dA, int64_t ldd, const void* y, int64_t ldy, const float* scale, const float* shift,
+                            const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* coef,
+                            const uint8_t* active, int f, int64_t count, int B, int H, int W, int C, int dt, void* ws, void* stream);
 int64_t cmu_cells_channel_sum_ws_bytes(int C);
 int cmu_cells_channel_sum(const void* x, int64_t ldx, const uint8_t* active, int f, int invert, float* out, void* ws, int B, int H, int W,
                           int C, int dt, void* stream);

@@ -512,3 +512,50 @@ def test_first_layer_over_a_tile_list(ops, dt, case):
         # (the fused pass keeps dY in fp32 where the two-pass form rounded it to the storage type)
         tol = {"f32": 1e-5, "f16": 2e-3, "bf16": 1.6e-2}[dt]
         assert (dW - dW0).abs().max().item() <= tol * dW0.abs().max().item(), (wf is None, (dW - dW0).abs().max().item(), dW0.abs().max().item())
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("case", _CELL_CASES)
+def test_cells_statistics_vs_float64_and_pixel_form(ops, dt, case):
+    """cmu_cells_channel_stats / cmu_bn_bwd_reduce_cells (sparse BatchNorm statistics and backward sums over the active patches, walked
+    as groups of patch rows) against float64 on the stored values and against the pixel-organised passes; bitwise reproducible."""
+    from cmunet_amd import _lib
+    B, f, H, C = case
+    tdt = ops.TORCH_DT[ops.dt_code(dt)]
+    if C % (16 // torch.empty(0, dtype=tdt).element_size()) != 0:
+        pytest.skip("C below one 16-byte chunk")
+    g = torch.Generator().manual_seed(sum(case) + 5)
+    act = _active(B, f, max(1, f * f // 4), seed=sum(case)).cuda()
+    up, _ = _frame(act, H)
+    y = ops.Act(torch.randn(B, H, H, 2 * C, generator=g).to(tdt).cuda(), C, C)
+    ys = y.buf[..., C:].double()[up]
+    slab = ops.cells_channel_stats(y, act)
+    assert torch.equal(slab, ops.cells_channel_stats(y, act))
+    s = slab.double().sum(0)
+    n = max(1, ys.shape[0])
+    assert (s[0] - ys.sum(0)).abs().max().item() <= 2e-6 * n ** 0.5 * max(1.0, float(ys.abs().max()))
+    assert (s[1] - (ys * ys).sum(0)).abs().max().item() <= 1e-5 * float((ys * ys).sum(0).max())
+    old = ops.masked_channel_stats(y, act).double().sum(0)
+    assert (s - old).abs().max().item() <= 1e-5 * old.abs().max().item()
+    sc, sh = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.1).cuda()
+    mean, invstd = (torch.randn(C, generator=g) * 0.1).cuda(), (torch.rand(C, generator=g) + 0.5).cuda()
+    yt = y.with_transform(sc, sh, 0)
+    dA = ops.Act(torch.randn(B, H, H, C, generator=g).to(tdt).cuda())
+    count = int(act.sum()) * (H // f) ** 2
+    outs = []
+    for cells in (True, True, False):
+        dg, db, coef = torch.empty(C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(2, C, device="cuda")
+        ws = torch.empty(_lib.lib().cmu_bn_bwd_ws_bytes(C), dtype=torch.uint8, device="cuda")
+        if cells:
+            ops.bn_bwd_reduce_cells(dA, yt, mean, invstd, dg, db, coef, act, count, ws)
+        else:
+            ops.bn_bwd_reduce_masked(dA, yt, mean, invstd, dg, db, coef, act, count, ws)
+        outs.append((dg.clone(), db.clone(), coef.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    for u, v in zip(outs[0], outs[2]):
+        assert (u - v).abs().max().item() <= 2e-5 * max(v.abs().max().item(), 1e-6)
+    # float64 on the stored values
+    dz = torch.where(ys * sc.double().cpu().cuda() + sh.double().cuda() > 0, dA.buf.double()[up], torch.zeros((), dtype=torch.float64, device="cuda"))
+    xh = (ys - mean.double()) * invstd.double()
+    assert (outs[0][1].double() - dz.sum(0)).abs().max().item() <= 1e-5 * max(1.0, float(dz.abs().sum(0).max()))
+    assert (outs[0][0].double() - (dz * xh).sum(0)).abs().max().item() <= 1e-5 * max(1.0, float((dz * xh).abs().sum(0).max()))
