@@ -33,6 +33,7 @@ _FUSE_HEAD = os.environ.get("CMU_HEAD_FUSE", "1") != "0"   # A/B: "0" = the head
 _FUSE_DGRAD_BN = os.environ.get("CMU_DGRAD_BN", "1")    # A/B: "0" = BN-backward sums as a separate pass, "64"/"128" = fused up to C
 _FUSE_POOL = os.environ.get("CMU_POOL_FUSE", "1") != "0"   # A/B: "0" = the pool's input gradient is stored and re-read by cmu_bn_bwd_apply
 _POISON_NEW = os.environ.get("CMU_POISON_NEW", "0") == "1"    # tests: fresh activations are filled with NaN (reads of unwritten positions show)
+_FUSE_POOL2 = os.environ.get("CMU_POOL_FUSE2", "1") != "0"   # A/B: "0" = with two skip gradients (joint model) the pool's input gradient is stored
 _C1W_RECOMP = os.environ.get("CMU_C1W_RECOMP", "1") != "0"  # A/B: "0" = the first layer's weight gradient reads the raw output instead of recomputing it
 
 
@@ -331,11 +332,12 @@ class UNetEngine:
             y2 = lv["s2"]["y"]
             ds = d_skips[i - 1] if d_skips is not None else None
             ds, ds2 = ds if isinstance(ds, (tuple, list)) else (ds, None)     # two decoders on this encoder: both gradients of the skip
-            if _FUSE_POOL and ds2 is None:
+            if _FUSE_POOL and (ds2 is None or _FUSE_POOL2):
                 # the pool's input gradient is never stored: sums first, dY recomputed from (dP, skip gradient) after their finalisation
-                # -- one tensor pass less (with two skip gradients the recomputation reads more than the stored form: not fused)
-                ops.maxpool_bwd(dP, ds, y2, None, lv["s2"]["mean"], lv["s2"]["invstd"], self._bn_ws(y2.C))
-                dA1 = self._convbn_bwd(sd, lv["s2"], None, grads, True, fused_stats=True, next_bn=lv["s1"], pool=(dP, ds, None))
+                # -- one tensor pass less; with two skip gradients (the joint model's two decoders) 6.5 reads + 1 write instead of
+                # 6.25 + 2: 74.91 -> 74.67 ms per joint step over three same-box pairs (round 4; CMU_POOL_FUSE2=0: the stored form)
+                ops.maxpool_bwd(dP, ds, y2, None, lv["s2"]["mean"], lv["s2"]["invstd"], self._bn_ws(y2.C), dSkip2=ds2)
+                dA1 = self._convbn_bwd(sd, lv["s2"], None, grads, True, fused_stats=True, next_bn=lv["s1"], pool=(dP, ds, ds2))
             else:
                 dA2 = self._new(y2.B, y2.H, y2.W, y2.C)
                 ops.maxpool_bwd(dP, ds, y2, dA2, lv["s2"]["mean"], lv["s2"]["invstd"], self._bn_ws(y2.C), dSkip2=ds2)
