@@ -360,6 +360,15 @@ static int bn_bwd_apply_t(const void* dA, int64_t ldd, const void* y, int64_t ld
     // four pixel chunks per thread, no grid cap: 3.4 ms per bench step against 4.1 with 4,096 workgroups looping 64 times (A/B: 1 chunk
     // per thread 4.6 ms, 2: 3.5, 8: 3.6)
     int gx = (int)(cmu_div_up64(npix, ppb * CMU_APPLY_PPT) < (1 << 20) ? cmu_div_up64(npix, ppb * CMU_APPLY_PPT) : (1 << 20));
+#ifndef CMU_HEADA_CAP
+#define CMU_HEADA_CAP 2048
+#endif
+    // head mode writes as much as it reads (dA is recomputed from dlogits): like the select pass of sparse.hip it runs best on a capped
+    // grid looping -- 0.650 ms uncapped, 0.483 / 0.460 / 0.466 with 2,048 / 1,024 / 3,072 workgroups (0.75 with 512), tools/elem_bench.py
+    if (hd_dlogits != nullptr && gx > CMU_HEADA_CAP) gx = CMU_HEADA_CAP;
+#ifdef CMU_APPLY_CAP
+    if (hd_dlogits == nullptr && gx > CMU_APPLY_CAP) gx = CMU_APPLY_CAP;
+#endif
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL((bn_bwd_apply_kernel<TR>), dim3(gx, gy), dim3(256), 0, st, (const unsigned char*)dA, ldd,
                        (const unsigned char*)y, ldy, scale, shift, mean, invstd, coef, (unsigned char*)dY, ldo, npix, C, cpb, ppb, active, f,
