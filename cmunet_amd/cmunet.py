@@ -19,6 +19,7 @@ call (A-2, weights injectable for tests); per-row target normalisation (A-3).  H
 ``"cuda:0"`` strings of the reference become the module's device.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -401,6 +402,9 @@ def _build(cfg):
     return _TYPES[cfg.pop("type")](**cfg)
 
 
+_SHARED_SKIPS = os.environ.get("CMU_SHARED_SKIPS", "1") != "0"     # A/B: "0" = the feature decoder copies the skips into its own concat buffers
+
+
 class _CMUNetFn(torch.autograd.Function):
     """Fused conv part of CM_UNet.forward_train (cmunet.py:121-124): online encoder (masked), target encoder,
     pixel + feature decoders sharing the skips; boundary tensors are the two 2-channel logit maps and the
@@ -410,21 +414,32 @@ class _CMUNetFn(torch.autograd.Function):
     def forward(ctx, module, img, img_t, mask, reduce_w, reduce_b, names, *params):
         eng = module._engine(img.device)
         sd = _named_state(module)
-        eng.prepack(sd)                # every conv / conv-transpose weight pack of the four networks in one launch
         tr = module.training
         x = img.detach().float().contiguous()
         # the online encoder writes its skips straight into the pixel decoder's concat buffers (as the fused UNet does); the feature
-        # decoder takes its copies of them
-        pcats = eng.decoder_alloc(sd, x.shape[0], x.shape[1], x.shape[2], "pixel_decoder.")
+        # decoder reads them from the same buffers through a (skip, up) view of channels [up_pixel | skip | up_feature] with its first
+        # convs' input channels rotated to match (engine.decoder_alloc_shared; CMU_SHARED_SKIPS=0: its own buffers and four copies)
+        shared = eng.decoder_alloc_shared(sd, x.shape[0], x.shape[1], x.shape[2], "pixel_decoder.", "feature_decoder.") if _SHARED_SKIPS else None
+        fcats = None
+        if shared is not None:
+            pcats, fcats = shared
+        else:
+            pcats = eng.decoder_alloc(sd, x.shape[0], x.shape[1], x.shape[2], "pixel_decoder.")
         nd = eng.n_down(sd, "backbone.")
         fits = len(pcats) == nd and all(c["Cskip"] == sd[f"backbone.down_conv{i + 1}.double_conv.double_conv.0.weight"].shape[0]
                                         for i, c in enumerate(pcats))
+        if not fits:
+            fcats = None
+        sdf = eng.rotated_weights(sd, "feature_decoder.", fcats) if fcats is not None else sd
+        eng.prepack(sdf)               # every conv / conv-transpose weight pack of the four networks in one launch (the feature
+                                       # decoder's first convs from their rotated copies)
         skip_out = [Act(c["buf"], c["Cup"], c["Cskip"]) for c in pcats] if fits else None
         skip_affine = [(c["scale"][c["Cup"]:], c["shift"][c["Cup"]:]) for c in pcats] if fits else None
         ectx = eng.encoder_forward(sd, x, tr, "backbone.", mask, not module.ref_compat, skip_out, skip_affine)
         tctx = eng.encoder_forward(sd, img_t.detach().float().contiguous(), tr, "target_backbone.", None)
         pctx = eng.decoder_forward(sd, ectx["latent"], ectx["skips"], tr, "pixel_decoder.", pcats if fits else None, True)
-        fctx = eng.decoder_forward(sd, ectx["latent"], ectx["skips"], tr, "feature_decoder.", None, True)
+        fctx = eng.decoder_forward(sdf, ectx["latent"], ectx["skips"], tr, "feature_decoder.", fcats, True)
+        fctx["shared_cats"] = fcats
         # cmunet.py:128-129: the per-call Conv2d(C, C/4, 1) on the target latent, straight from the raw NHWC latent and its
         # pending BatchNorm+ReLU into the NCHW fp32 tensor the reference re-views as an image (no gradient: target branch)
         latent_t = ops.conv1x1_nchw_fwd(tctx["latent"], reduce_w.detach().float(), None if reduce_b is None else reduce_b.detach().float())
@@ -446,7 +461,12 @@ class _CMUNetFn(torch.autograd.Function):
         dl_p, ds_p = eng.decoder_backward(sd, pctx, d_pix.contiguous().float(), grads, True)
         if ready is not None:
             ready("pixel_decoder.", grads)
-        dl_f, ds_f = eng.decoder_backward(sd, fctx, d_feat.contiguous().float(), grads, True)
+        fcats = fctx.get("shared_cats")
+        if fcats is not None:
+            dl_f, ds_f = eng.decoder_backward(eng.rotated_weights(sd, "feature_decoder.", fcats), fctx, d_feat.contiguous().float(), grads, True)
+            eng.unrotate_grads(sd, "feature_decoder.", fcats, grads)
+        else:
+            dl_f, ds_f = eng.decoder_backward(sd, fctx, d_feat.contiguous().float(), grads, True)
         if ready is not None:
             ready("feature_decoder.", grads)
         d_latent = Act(dl_p.buf + dl_f.buf)

@@ -237,6 +237,10 @@ __device__ static inline bool sp_active(const uint8_t* __restrict__ active, int 
     const bool a = active[((int64_t)b * f + (y >> sbits)) * f + (x >> sbits)] != 0;
     return invert ? !a : a;
 }
+// `relu_from` of a pending transform: channels c >= relu_from of the view are activated (a concat input whose LEFT part -- a
+// ConvTranspose output -- carries no activation); a NEGATIVE value -n activates the channels c < n instead (round 4: the concat view
+// (skip, up) of a decoder that shares its skip with another one -- see engine.decoder_forward, `skip_first`).
+__host__ __device__ static inline bool cmu_relu_on(int c0, int relu_from) { return relu_from >= 0 ? c0 >= relu_from : c0 < -relu_from; }
 static inline int sp_shift_bits(int H, int f) {
     int s = 0;
     while ((f << s) < H) ++s;

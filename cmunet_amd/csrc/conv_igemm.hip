@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IGParams p) {
                     sc[e] = p.in_scale[cc + e];
                     sh[e] = p.in_shift[cc + e];
                 }
-                lo_relu = (c0 >= p.relu_from) ? 0.f : -__builtin_inff();
+                lo_relu = cmu_relu_on(c0, p.relu_from) ? 0.f : -__builtin_inff();
             }
             const bool w_ok = (2 * s + (cg >> 1)) < p.nslices32;
             const unsigned wso = (unsigned)(2 * s * 9) * (unsigned)p.npad * 32u;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IGParams p) {
                 sc[e] = p.in_scale[c0 + e];
                 sh[e] = p.in_shift[c0 + e];
             }
-            relu = (c0 >= p.relu_from);
+            relu = cmu_relu_on(c0, p.relu_from);
         }
 #pragma unroll
         for (int it = 0; it < C::W_ITERS; ++it) {
@@ -628,7 +628,7 @@ extern "C" int cmu_conv3x3_fwd(const void* x, int64_t ldx, const float* in_scale
     if ((rc = check_act("cmu_conv3x3_fwd(y)", y, ldy, Cout, dt))) return rc;
     CMU_CHECK_ARG(wpacked && cmu_aligned16(wpacked), "cmu_conv3x3_fwd: packed weights null/unaligned");
     CMU_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "cmu_conv3x3_fwd: scale/shift must both be set");
-    CMU_CHECK_ARG(relu_from >= 0 && relu_from % (16 / cmu_dtype_size(dt)) == 0, "cmu_conv3x3_fwd: relu_from=%d must be a multiple of the 16-byte chunk", relu_from);
+    CMU_CHECK_ARG(relu_from % (16 / cmu_dtype_size(dt)) == 0, "cmu_conv3x3_fwd: relu_from=%d must be a multiple of the 16-byte chunk", relu_from);
     CMU_CHECK_ARG((int64_t)B * cmu_div_up(H, CMU_TH) * cmu_div_up(W, CMU_TW) * cmu_div_up(Cout, 64) < (1ll << 31),
                   "cmu_conv3x3_fwd: grid too large");
     IGParams p = {};
@@ -649,7 +649,7 @@ extern "C" int cmu_convT2x2_fwd(const void* x, int64_t ldx, const float* in_scal
     if ((rc = check_act("cmu_convT2x2_fwd(out)", out, ldo, Cout, dt))) return rc;
     CMU_CHECK_ARG(wpacked && cmu_aligned16(wpacked) && bias, "cmu_convT2x2_fwd: weights/bias null or unaligned");
     CMU_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "cmu_convT2x2_fwd: scale/shift must both be set");
-    CMU_CHECK_ARG(relu_from >= 0 && relu_from % (16 / cmu_dtype_size(dt)) == 0, "cmu_convT2x2_fwd: relu_from=%d must be a multiple of the 16-byte chunk", relu_from);
+    CMU_CHECK_ARG(relu_from % (16 / cmu_dtype_size(dt)) == 0, "cmu_convT2x2_fwd: relu_from=%d must be a multiple of the 16-byte chunk", relu_from);
     IGParams p = {};
     p.x = x; p.ldx = ldx; p.in_scale = in_scale; p.in_shift = in_shift; p.relu_from = relu_from;
     p.w = wpacked; p.y = out; p.ldy = ldo; p.stats = nullptr; p.bias = bias;
@@ -697,7 +697,7 @@ extern "C" int cmu_conv3x3_fwd_tiles(const void* x, int64_t ldx, const float* in
     if ((rc = check_act("cmu_conv3x3_fwd_tiles(y)", y, ldy, Cout, dt))) return rc;
     CMU_CHECK_ARG(wpacked && cmu_aligned16(wpacked), "cmu_conv3x3_fwd_tiles: packed weights null/unaligned");
     CMU_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "cmu_conv3x3_fwd_tiles: scale/shift must both be set");
-    CMU_CHECK_ARG(relu_from >= 0 && relu_from % (16 / cmu_dtype_size(dt)) == 0, "cmu_conv3x3_fwd_tiles: relu_from=%d must be a multiple of the 16-byte chunk", relu_from);
+    CMU_CHECK_ARG(relu_from % (16 / cmu_dtype_size(dt)) == 0, "cmu_conv3x3_fwd_tiles: relu_from=%d must be a multiple of the 16-byte chunk", relu_from);
     IGParams p = {};
     p.x = x; p.ldx = ldx; p.in_scale = in_scale; p.in_shift = in_shift; p.relu_from = relu_from;
     p.w = wpacked; p.y = y; p.ldy = ldy; p.stats = nullptr; p.bias = nullptr;

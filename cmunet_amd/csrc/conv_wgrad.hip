@@ -144,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WGParams p) {
         sc[e] = (has_tf && b_cok) ? p.b_scale[b_c0 + e] : 1.f;
         sh[e] = (has_tf && b_cok) ? p.b_shift[b_c0 + e] : 0.f;
     }
-    const bool relu = has_tf && (b_c0 >= p.relu_from);
+    const bool relu = has_tf && cmu_relu_on(b_c0, p.relu_from);
 
     f32x16 acc[C::TAPS];
 #pragma unroll
@@ -847,7 +847,7 @@ extern "C" int cmu_conv3x3_wgrad(const void* x, int64_t ldx, const float* in_sca
     if ((rc = wg_check("cmu_conv3x3_wgrad(dY)", dY, ldd, Cout, dt))) return rc;
     CMU_CHECK_ARG(dW && ws && B > 0 && H > 0 && W > 0, "cmu_conv3x3_wgrad: null argument / bad dims");
     CMU_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "cmu_conv3x3_wgrad: scale/shift must both be set");
-    CMU_CHECK_ARG(relu_from >= 0 && relu_from % (16 / cmu_dtype_size(dt)) == 0, "cmu_conv3x3_wgrad: relu_from=%d must be a multiple of the 16-byte chunk", relu_from);
+    CMU_CHECK_ARG(relu_from % (16 / cmu_dtype_size(dt)) == 0, "cmu_conv3x3_wgrad: relu_from=%d must be a multiple of the 16-byte chunk", relu_from);
     WGParams p = {};
     p.a = dY; p.lda = ldd; p.b = x; p.ldb = ldx; p.b_scale = in_scale; p.b_shift = in_shift; p.relu_from = relu_from;
     p.ws = (float*)ws; p.B = B; p.H = H; p.W = W; p.CA = Cout; p.CB = Cin;
@@ -903,7 +903,7 @@ extern "C" int cmu_conv3x3_wgrad_tiles(const void* x, int64_t ldx, const float* 
     if ((rc = wg_check("cmu_conv3x3_wgrad_tiles(dY)", dY, ldd, Cout, dt))) return rc;
     CMU_CHECK_ARG(dW && ws && tile_list && tile_count && B > 0 && H > 0 && W > 0, "cmu_conv3x3_wgrad_tiles: null argument / bad dims");
     CMU_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "cmu_conv3x3_wgrad_tiles: scale/shift must both be set");
-    CMU_CHECK_ARG(relu_from >= 0 && relu_from % (16 / cmu_dtype_size(dt)) == 0, "cmu_conv3x3_wgrad_tiles: relu_from=%d must be a multiple of the 16-byte chunk", relu_from);
+    CMU_CHECK_ARG(relu_from % (16 / cmu_dtype_size(dt)) == 0, "cmu_conv3x3_wgrad_tiles: relu_from=%d must be a multiple of the 16-byte chunk", relu_from);
     CMU_CHECK_ARG(tile_h == 16 || tile_h == 8, "cmu_conv3x3_wgrad_tiles: tile_h=%d (16: 16 x 16 tiles, 8: 8 x 16 tiles)", tile_h);
     WGParams p = {};
     p.a = dY; p.lda = ldd; p.b = x; p.ldb = ldx; p.b_scale = in_scale; p.b_shift = in_shift; p.relu_from = relu_from;
@@ -955,7 +955,7 @@ extern "C" int cmu_convT2x2_wgrad(const void* x, int64_t ldx, const float* in_sc
     if ((rc = wg_check("cmu_convT2x2_wgrad(dOut)", dOut, ldd, Cout, dt))) return rc;
     CMU_CHECK_ARG(dW && dbias && ws && B > 0 && H > 0 && W > 0, "cmu_convT2x2_wgrad: null argument / bad dims");
     CMU_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "cmu_convT2x2_wgrad: scale/shift must both be set");
-    CMU_CHECK_ARG(relu_from >= 0 && relu_from % (16 / cmu_dtype_size(dt)) == 0, "cmu_convT2x2_wgrad: relu_from=%d must be a multiple of the 16-byte chunk", relu_from);
+    CMU_CHECK_ARG(relu_from % (16 / cmu_dtype_size(dt)) == 0, "cmu_convT2x2_wgrad: relu_from=%d must be a multiple of the 16-byte chunk", relu_from);
     WGParams p = {};
     p.a = dOut; p.lda = ldd; p.b = x; p.ldb = ldx; p.b_scale = in_scale; p.b_shift = in_shift; p.relu_from = relu_from;
     p.ws = (float*)ws; p.B = B; p.H = H; p.W = W; p.CA = Cout; p.CB = Cin;

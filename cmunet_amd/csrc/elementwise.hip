@@ -790,7 +790,7 @@ __global__ void apply_to_nchw_kernel(const typename TR::elem_t* __restrict__ y, 
         float v = TR::to_float(y[(((int64_t)b * H + yy) * W + x) * ldy + c]);
         if (scale) {
             v = fmaf(v, scale[c], shift[c]);
-            if (c >= relu_from) v = fmaxf(v, 0.f);
+            if (cmu_relu_on(c, relu_from)) v = fmaxf(v, 0.f);
         }
         out[o] = v;
     }

@@ -366,6 +366,77 @@ class UNetEngine:
             h, w_ = h // 2, w_ // 2
         return cats
 
+    def decoder_alloc_shared(self, sd, B, H, W, prefix_a, prefix_b):
+        """Concat buffers of TWO decoders that read the same skips (the joint model's pixel and feature decoders): per level ONE
+        buffer of channels [up_a | skip | up_b] and one pair of pending-transform arrays of the same layout.  Decoder a sees the
+        usual view (up, skip) at channel 0; decoder b sees (skip, up) at channel Cup_a -- ``skip_first``: its first conv runs on
+        weights whose input channels are rotated accordingly (``rotated_weights``), ReLU applies to the view's FIRST Cskip channels
+        (a negative ``relu_from``).  The skip is written once, by the encoder; no copy (round 4: four strided copies, 0.66 ms per step).
+        Returns (cats_a, cats_b), or None when the two decoders' levels do not match."""
+        ca, cb = [], []
+        i = 1
+        h, w_ = H, W
+        while f"{prefix_a}up_conv{i}.double_conv.double_conv.0.weight" in sd:
+            wa = sd[f"{prefix_a}up_conv{i}.double_conv.double_conv.0.weight"]
+            wb = sd.get(f"{prefix_b}up_conv{i}.double_conv.double_conv.0.weight")
+            ka, kb = f"{prefix_a}up_conv{i}.up_sample.weight", f"{prefix_b}up_conv{i}.up_sample.weight"
+            if wb is None or ka not in sd or kb not in sd:
+                return None
+            Cup_a, Cup_b = sd[ka].shape[1], sd[kb].shape[1]
+            Cs = wa.shape[1] - Cup_a
+            epc = 16 // torch.empty(0, dtype=self.tdt).element_size()
+            if Cs <= 0 or wb.shape[1] - Cup_b != Cs or any(c % epc for c in (Cup_a, Cup_b, Cs)):
+                return None
+            C3 = Cup_a + Cs + Cup_b
+            buf = torch.empty((B, h, w_, C3), dtype=self.tdt, device=self.device)
+            scale = torch.ones(C3, dtype=torch.float32, device=self.device)
+            shift = torch.zeros(C3, dtype=torch.float32, device=self.device)
+            ca.append({"buf": buf, "scale": scale[:Cup_a + Cs], "shift": shift[:Cup_a + Cs], "Cup": Cup_a, "Cskip": Cs})
+            cb.append({"buf": buf, "scale": scale[Cup_a:], "shift": shift[Cup_a:], "Cup": Cup_b, "Cskip": Cs, "base": Cup_a, "skip_first": True})
+            i += 1
+            h, w_ = h // 2, w_ // 2
+        return ca, cb
+
+    def rotated_weights(self, sd, prefix, cats):
+        """Overlay of ``sd`` for a ``skip_first`` decoder: the first conv of every level with its input channels rotated from the
+        reference's (up, skip) order to the view's (skip, up) -- persistent buffers, refreshed when the parameter changes (one
+        concatenating copy of the weight per level and step: 25 MB in all for the reference UNet)."""
+        store = self.__dict__.setdefault("_rot_w", {})
+        over = dict(sd)
+        for i, cat in enumerate(cats, start=1):
+            if not cat.get("skip_first"):
+                continue
+            k = f"{prefix}up_conv{i}.double_conv.double_conv.0.weight"
+            w = sd[k]
+            Cup = cat["Cup"]
+            ent = store.get(k)
+            if ent is None or ent[0].shape != w.shape or ent[0].device != w.device:
+                ent = [torch.empty_like(w, dtype=torch.float32), None]
+                store[k] = ent
+            ver = (w._version, w.data_ptr(), ops.PARAM_GENERATION)
+            if ent[1] != ver:
+                torch.cat((w.detach()[:, Cup:], w.detach()[:, :Cup]), 1, out=ent[0])
+                ent[1] = ver
+            over[k] = ent[0]
+        return over
+
+    def unrotate_grads(self, sd, prefix, cats, grads):
+        """The weight gradients a ``skip_first`` decoder's first convs produced (in the view's channel order) back into the
+        reference's order, written where the parameter's gradient belongs (``_gbuf``)."""
+        for i, cat in enumerate(cats, start=1):
+            if not cat.get("skip_first"):
+                continue
+            k = f"{prefix}up_conv{i}.double_conv.double_conv.0.weight"
+            g_rot = grads.get(k)
+            if g_rot is None:
+                continue
+            Cs = cat["Cskip"]
+            g = self._gbuf(k, sd[k])
+            if g.data_ptr() == g_rot.data_ptr():          # (an explicit grad_target maps the name to the parameter's own slot)
+                g_rot = g_rot.clone()
+            torch.cat((g_rot[:, Cs:], g_rot[:, :Cs]), 1, out=g)
+            grads[k] = g
+
     def decoder_forward(self, sd, latent, skips, training, prefix="", cats=None, head=True):
         """latent: Act with pending transform; skips[i-1]: Act with pending transform (level i).
         If ``cats`` is given and a skip already lives in cats[i-1]['buf'] (fused UNet), no copy is made."""
@@ -382,25 +453,29 @@ class UNetEngine:
             Cup, Cs = cat["Cup"], cat["Cskip"]
             sk = skips[i - 1]
             assert sk.C == Cs
-            right = Act(cat["buf"], Cup, Cs)
-            if not (sk.buf is cat["buf"] and sk.coff == Cup):
-                right.buf[..., Cup:].copy_(sk.buf[..., sk.coff:sk.coff + sk.C])   # split encoder/decoder: one strided copy
+            # the view of this decoder inside the buffer: channels [base, base + Cup + Cs), (up, skip) -- or (skip, up) for the second
+            # of two decoders sharing their skips (decoder_alloc_shared)
+            base, sf = cat.get("base", 0), bool(cat.get("skip_first", False))
+            up_off, sk_off = base + (Cs if sf else 0), base + (0 if sf else Cup)
+            s_lo = 0 if sf else Cup                                   # the skip's place in the view's pending-transform arrays
+            if not (sk.buf is cat["buf"] and sk.coff == sk_off):
+                cat["buf"][..., sk_off:sk_off + Cs].copy_(sk.buf[..., sk.coff:sk.coff + sk.C])   # split encoder/decoder: one strided copy
             if sk.scale is not None:
-                if sk.scale.data_ptr() != cat["scale"][Cup:].data_ptr():
-                    cat["scale"][Cup:].copy_(sk.scale)
-                    cat["shift"][Cup:].copy_(sk.shift)
+                if sk.scale.data_ptr() != cat["scale"][s_lo:].data_ptr():
+                    cat["scale"][s_lo:s_lo + Cs].copy_(sk.scale)
+                    cat["shift"][s_lo:s_lo + Cs].copy_(sk.shift)
                     cat["ident"] = False
-                relu_from = Cup
+                relu_from = -Cs if sf else Cup
             else:                      # already-activated skip handed over at a module boundary: identity, no ReLU
                 if not cat.get("ident", False):      # (buffers reused from step to step keep the identity: two fills per level saved)
-                    cat["scale"][Cup:].fill_(1.0)
-                    cat["shift"][Cup:].zero_()
+                    cat["scale"][s_lo:s_lo + Cs].fill_(1.0)
+                    cat["shift"][s_lo:s_lo + Cs].zero_()
                     cat["ident"] = True
                 relu_from = Cup + Cs
             wt = sd[p + "up_sample.weight"]
-            left = Act(cat["buf"], 0, Cup)
+            left = Act(cat["buf"], up_off, Cup)
             ops.convT2x2_fwd(x, self._wpT(p + "up_sample.", wt, 0), sd[p + "up_sample.bias"].detach(), left)
-            cat_act = Act(cat["buf"], 0, Cup + Cs, cat["scale"], cat["shift"], relu_from)
+            cat_act = Act(cat["buf"], base, Cup + Cs, cat["scale"], cat["shift"], relu_from)
             Cout = sd[p + "double_conv.double_conv.0.weight"].shape[0]
             s1, s2 = self._double_conv_fwd(sd, p + "double_conv.double_conv.", cat_act, self._new(B, sk.H, sk.W, Cout), training)
             ctx["levels"][i - 1] = {"s1": s1, "s2": s2, "x_up": x, "cat": cat}
@@ -447,8 +522,9 @@ class UNetEngine:
             dA1 = self._convbn_bwd(sd, lv["s2"], dA, grads, True, fused_stats=(fused and i == 1), next_bn=lv["s1"],
                                    head=head if i == 1 else None)
             dcat = self._convbn_bwd(sd, lv["s1"], dA1, grads, True)
-            d_skips[i - 1] = Act(dcat.buf, Cup, Cs)
-            dleft = Act(dcat.buf, 0, Cup)
+            sf = bool(cat.get("skip_first", False))                  # the gradient has the view's channel order
+            d_skips[i - 1] = Act(dcat.buf, 0 if sf else Cup, Cs)
+            dleft = Act(dcat.buf, Cs if sf else 0, Cup)
             wt = sd[p + "up_sample.weight"]
             xu = lv["x_up"]
             dWt, dbt = self._gbuf(p + "up_sample.weight", wt), self._gbuf(p + "up_sample.bias", sd[p + "up_sample.bias"])

@@ -17,6 +17,8 @@
  *     gradients of parameters and logits are fp32.
  *   - a "pending transform" (in_scale, in_shift, relu_from) is a training-mode BatchNorm+ReLU that the
  *     producer left un-applied: the consumer applies  v = x*scale[c]+shift[c]; if (c>=relu_from) v=max(v,0)
+ *     (relu_from = -n < 0, the 3x3 conv / weight-gradient entries: the channels c < n are the activated ones instead --
+ *     a concat view whose activated skip comes FIRST, cmu_conv1x1_nchw_fwd excepted)
  *     while staging its input tile (BatchNorm2d + ReLU of Finetuning/model.py:18-19,21-22 fused into the
  *     next conv / pool / convT load).  in_scale == NULL means identity.
  */

@@ -120,9 +120,13 @@ def test_conv3x3_wgrad_random_shapes_of_the_wide_kernels(ops, dt, seed):
     if tf:
         sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
         rf = 8 * int(rs.randint(0, Cin // 8 + 1))
-        xa = xa.with_transform(sc.cuda(), sh.cuda(), rf)
+        neg = bool(seed % 2) and rf > 0      # a negative relu_from: the FIRST rf channels are the activated ones (round 4)
+        xa = xa.with_transform(sc.cuda(), sh.cuda(), -rf if neg else rf)
         t = x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
-        t[:, rf:] = t[:, rf:].clamp_min(0)
+        if neg:
+            t[:, :rf] = t[:, :rf].clamp_min(0)
+        else:
+            t[:, rf:] = t[:, rf:].clamp_min(0)
         ref_in = q(t.float(), dt, ops).double()
     dW = torch.full((Cout, Cin, 3, 3), 9.0, device="cuda")
     ws = ws_bytes(_lib.lib().cmu_conv3x3_wgrad_ws_bytes(B, H, W, Cin, Cout, ops.dt_code(dt)))
