@@ -872,7 +872,7 @@ def _collect_hip_layers(last_ctx):
     return out
 
 
-@pytest.mark.parametrize("case", [("f32", 224, 4, 32), ("f16", 224, 4, 32), ("f16", 512, 2, 64)])
+@pytest.mark.parametrize("case", [("f32", 224, 4, 32), ("f16", 224, 4, 32), ("f16", 512, 2, 64), ("bf16", 224, 4, 32)])
 def test_masked_recon_step_gate_forced_backward(cuda, case):
     """The HEADLINE step (BASELINE config 2: masked reconstruction through ``MaskedReconPretrainer``'s engine path -- mask fused into the
     first conv, skips written into the concat buffers, head / pool fusions, first-layer weight gradient with the recomputed raw
@@ -959,8 +959,10 @@ def test_masked_recon_step_gate_forced_backward(cuda, case):
     finally:
         OU.TAP = None
     assert taps.seen == set(layers)
-    assert abs(float(loss) - float(ref_loss.detach())) <= (2e-5 if dt == "f32" else 2e-3) * max(1.0, abs(float(ref_loss.detach())))
-    bar = 1e-4 if dt == "f32" else 1e-2
+    assert abs(float(loss) - float(ref_loss.detach())) <= {"f32": 2e-5, "f16": 2e-3, "bf16": 2e-2}[dt] * max(1.0, abs(float(ref_loss.detach())))
+    # (bf16, the opt-in storage type: eight times f16's rounding step -- with the gates forced this is a bar on the kernels' arithmetic
+    # alone, where the unforced whole-step comparison has to allow 15-35 % for gate flips)
+    bar = {"f32": 1e-4, "f16": 1e-2, "bf16": 1e-1}[dt]          # measured worst: 1.2e-5 / 2.8e-3 / 5.9e-2 (a ConvTranspose bias each time)
     worst, n = ("", 0.0), 0
     for k, v in osd.items():
         if not (torch.is_tensor(v) and v.requires_grad) or k.endswith(("0.bias", "3.bias")):     # (conv biases in front of BN: identically zero)
