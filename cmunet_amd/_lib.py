@@ -117,7 +117,7 @@ _SIGS = {
     "cmu_conv3x3_c1_wgrad_bn_tiles": (_I, [_P, _P, _I, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),
     "cmu_cells_supported": (_I, [_I, _I, _I, _I, _I, _I]),
     "cmu_bn_bwd_apply_cells": (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "cmu_mask_select_cells": (_I, [_P, _L, _P, _P, _I, _P, _I, _I, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "cmu_mask_select_cells": (_I, [_P, _L, _P, _P, _I, _P, _I, _I, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "cmu_maxpool_bwd_cells": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _I, _P, _L, _I, _I, _I, _I, _I, _P]),
     "cmu_cells_stats_rows": (_I, []),
     "cmu_cells_channel_stats": (_I, [_P, _L, _P, _I, _P, _I, _I, _I, _I, _I, _P]),

@@ -230,7 +230,8 @@ extern "C" int cmu_bn_bwd_apply_cells(const void* dA, int64_t ldd, const void* y
 template <class TR, bool MULTI>
 __global__ __launch_bounds__(256) void mask_select_cells_kernel(const unsigned char* __restrict__ x, int64_t ldx, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, int relu, unsigned char* __restrict__ out,
-                                                               int64_t ldo, const uint8_t* __restrict__ active, CellGeo g, int ring) {
+                                                               int64_t ldo, const uint8_t* __restrict__ active, CellGeo g, int ring,
+                                                               const float* __restrict__ fill) {
     constexpr int EPC = TR::EPC;
     constexpr int ES = (int)sizeof(typename TR::elem_t);
     const int tid = threadIdx.x;
@@ -239,6 +240,15 @@ __global__ __launch_bounds__(256) void mask_select_cells_kernel(const unsigned c
     const int ps = 1 << g.sbits, cmask = (1 << g.cbits) - 1, wbits = g.sbits + g.xbits, wmask = (1 << wbits) - 1;
     const int total = (1 << g.rbits) << (wbits + g.cbits);
     const int64_t row0 = (int64_t)b * g.H + y0;
+    // what masked positions receive: zeros, or the per-channel fill vector (the densify step's mask tokens, spark.py:103-107) -- the
+    // thread's channel chunk is the same on every trip (256 % chunks-per-pixel == 0)
+    u32x4 fillv = u32x4{0u, 0u, 0u, 0u};
+    if (fill != nullptr) {
+        float fl[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) fl[e] = fill[(tid & cmask) * EPC + e];
+        fillv = TR::pack(fl);
+    }
     if (!MULTI && active[cell0] == 0) {
         for (int k = tid; k < total; k += 256) {
             const int c = k & cmask, j = (k >> g.cbits) & wmask, r = k >> (g.cbits + wbits);
@@ -247,7 +257,7 @@ __global__ __launch_bounds__(256) void mask_select_cells_kernel(const unsigned c
                 if (!(yy == 0 || yy == ps - 1 || j == 0 || j == ps - 1)) continue;
             }
             const int64_t p = (row0 + r) * g.W + x0 + j;
-            st_global16(out + (p * ldo + c * EPC) * ES, u32x4{0u, 0u, 0u, 0u});
+            st_global16(out + (p * ldo + c * EPC) * ES, fillv);
         }
         return;
     }
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(256) void mask_select_cells_kernel(const unsigned c
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (st[i] == 2) st_global16(out + (p[i] * ldo + ch * EPC) * ES, u32x4{0u, 0u, 0u, 0u});
+            if (st[i] == 2) st_global16(out + (p[i] * ldo + ch * EPC) * ES, fillv);
             if (st[i] == 1) {
                 u32x4 o = vq[i];
                 if (scale || relu) {
@@ -310,24 +320,25 @@ __global__ __launch_bounds__(256) void mask_select_cells_kernel(const unsigned c
 }
 template <class TR>
 static int mask_select_cells_t(const void* x, int64_t ldx, const float* scale, const float* shift, int relu, void* out, int64_t ldo,
-                               const uint8_t* active, CellGeo g, int ring, hipStream_t st) {
+                               const uint8_t* active, CellGeo g, int ring, const float* fill, hipStream_t st) {
     if (g.xbits > 0)
         hipLaunchKernelGGL((mask_select_cells_kernel<TR, true>), dim3(g.nitems), dim3(256), 0, st, (const unsigned char*)x, ldx, scale, shift, relu,
-                           (unsigned char*)out, ldo, active, g, ring);
+                           (unsigned char*)out, ldo, active, g, ring, fill);
     else
         hipLaunchKernelGGL((mask_select_cells_kernel<TR, false>), dim3(g.nitems), dim3(256), 0, st, (const unsigned char*)x, ldx, scale, shift, relu,
-                           (unsigned char*)out, ldo, active, g, ring);
+                           (unsigned char*)out, ldo, active, g, ring, fill);
     CMU_CHECK_LAUNCH("cmu_mask_select_cells");
     return CMU_OK;
 }
 extern "C" int cmu_mask_select_cells(const void* x, int64_t ldx, const float* scale, const float* shift, int relu, const uint8_t* active, int f,
-                                     int ring, void* out, int64_t ldo, int B, int H, int W, int C, int dt, void* stream) {
+                                     int ring, const float* fill, void* out, int64_t ldo, int B, int H, int W, int C, int dt, void* stream) {
     int rc;
     if ((rc = check_cells_act("cmu_mask_select_cells(x)", x, ldx, C, dt))) return rc;
     if ((rc = check_cells_act("cmu_mask_select_cells(out)", out, ldo, C, dt))) return rc;
     CMU_CHECK_ARG(active && (scale == nullptr) == (shift == nullptr), "cmu_mask_select_cells: null patch map, or only one of scale / shift");
     CMU_CELLS_GEOMETRY("cmu_mask_select_cells", false, 10)
-    CMU_DISPATCH_DT(dt, mask_select_cells_t, x, ldx, scale, shift, relu, out, ldo, active, g, ring, (hipStream_t)stream);
+    CMU_CHECK_ARG(!(ring && fill), "cmu_mask_select_cells: border-frame zeroing and a fill vector exclude each other");
+    CMU_DISPATCH_DT(dt, mask_select_cells_t, x, ldx, scale, shift, relu, out, ldo, active, g, ring, fill, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -453,14 +453,14 @@ def cells_supported(x, active):
 
 
 def mask_select(x, active, out, relu=False, invert=False, fill=None, use_transform=True, ring=False, cells=True):
-    """out = selected ? relu?(x * scale + shift) : fill.  With a zero fill and no inversion the patch-organised kernel is taken
+    """out = selected ? relu?(x * scale + shift) : fill.  Without inversion the patch-organised kernel is taken
     (``cells``); ``ring``: only the one-pixel border frame of each masked patch is zeroed -- the caller guarantees that every consumer
     of ``out`` is list-driven (reads active patches and a one-pixel halo only)."""
     sc = x.scale if use_transform else None
     sh = x.shift if use_transform else None
-    if cells and fill is None and not invert and cells_supported(x, active):
-        call("cmu_mask_select_cells", x.ptr(), x.ld, _p(sc), _p(sh), int(relu), _p(active), active.shape[-1], int(bool(ring)), out.ptr(),
-             out.ld, x.B, x.H, x.W, x.C, x.dt, _stream())
+    if cells and not invert and cells_supported(x, active):
+        call("cmu_mask_select_cells", x.ptr(), x.ld, _p(sc), _p(sh), int(relu), _p(active), active.shape[-1], int(bool(ring) and fill is None),
+             _p(fill), out.ptr(), out.ld, x.B, x.H, x.W, x.C, x.dt, _stream())
         return
     call("cmu_mask_select", x.ptr(), x.ld, _p(sc), _p(sh), int(relu), _p(active), active.shape[-1], int(invert), _p(fill), out.ptr(),
          out.ld, x.B, x.H, x.W, x.C, x.dt, _stream())

@@ -350,7 +350,8 @@ int cmu_sparse_pixel_lists(const int* patches, const int* patch_count, int f, in
  *   cmu_bn_bwd_apply_cells     = cmu_bn_bwd_apply_masked; ring = 1: zeros are written only to the one-pixel border frame of each masked
  *                              patch (enough when every consumer of dY is list-driven: they read active patches + a one-pixel halo;
  *                              the interior of masked patches stays unwritten)
- *   cmu_mask_select_cells      = cmu_mask_select(invert 0, fill NULL): relu?(x * scale + shift) in active patches, zeros (ring as above)
+ *   cmu_mask_select_cells      = cmu_mask_select(invert 0): relu?(x * scale + shift) in active patches, elsewhere zeros (ring as above) or fill[c]
+ *                              (nullable; the densify step's mask tokens, spark.py:103-107)
  *   cmu_maxpool_bwd_cells      = cmu_maxpool_bwd_masked: active patches only, dA elsewhere unwritten (H / f >= 2)
  *   cmu_cells_channel_sum      out[c] = sum of x over the pixels of the active (invert 0) / masked (invert 1) patches -- the mask-token
  *                              gradient of spark.py:104-108; fixed-order fp32 partial sums, double final; ws: cmu_cells_channel_sum_ws_bytes(C) */
@@ -373,7 +374,7 @@ int cmu_bn_bwd_apply_cells(const void* dA, int64_t ldd, const void* y, int64_t l
                            const float* save_mean, const float* save_invstd, const float* coef, void* dY, int64_t ldo,
                            const uint8_t* active, int f, int ring, int B, int H, int W, int C, int dt, void* stream);
 int cmu_mask_select_cells(const void* x, int64_t ldx, const float* scale, const float* shift, int relu, const uint8_t* active, int f,
-                          int ring, void* out, int64_t ldo, int B, int H, int W, int C, int dt, void* stream);
+                          int ring, const float* fill, void* out, int64_t ldo, int B, int H, int W, int C, int dt, void* stream);
 int cmu_maxpool_bwd_cells(const void* dP, int64_t ldp, const void* dSkip, int64_t lds, const void* y, int64_t ldy, const float* scale,
                           const float* shift, const uint8_t* active, int f, void* dA, int64_t lda, int B, int H, int W, int C, int dt,
                           void* stream);

@@ -397,6 +397,13 @@ def test_cells_bn_bwd_apply_and_select_bit_identical_to_pixel_form(ops, dt, case
         r = ring.buf[..., C:]
         assert torch.equal(r[up], ref.buf[..., C:][up]) and bool((r[frame] == 0).all()) and bool((r[~up & ~frame] == 7.0).all())
         assert bool((ring.buf[..., :C] == 7.0).all())
+    # densify: the per-channel fill vector (mask tokens) at masked positions
+    tok = torch.randn(C, generator=g).cuda()
+    ref = ops.Act(torch.full((B, H, H, 2 * C), 7.0, dtype=tdt, device="cuda"), C, C)
+    got = ops.Act(torch.full((B, H, H, 2 * C), 7.0, dtype=tdt, device="cuda"), C, C)
+    ops.mask_select(y, act, ref, relu=True, fill=tok, cells=False)
+    ops.mask_select(y, act, got, relu=True, fill=tok)
+    assert torch.equal(ref.buf.view(torch.uint8), got.buf.view(torch.uint8))
 
 
 @pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
