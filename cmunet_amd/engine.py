@@ -358,7 +358,7 @@ class UNetEngine:
             wt = sd[f"{prefix}up_conv{i}.double_conv.double_conv.0.weight"]
             Cout, C2 = wt.shape[0], wt.shape[1]
             Cs = C2 - Cout if f"{prefix}up_conv{i}.up_sample.weight" not in sd else sd[f"{prefix}up_conv{i}.up_sample.weight"].shape[1]
-            buf = torch.empty((B, h, w_, C2), dtype=self.tdt, device=self.device)
+            buf = self._new(B, h, w_, C2).buf
             scale = torch.ones(C2, dtype=torch.float32, device=self.device)
             shift = torch.zeros(C2, dtype=torch.float32, device=self.device)
             cats.append({"buf": buf, "scale": scale, "shift": shift, "Cup": Cs, "Cskip": C2 - Cs})
@@ -388,7 +388,7 @@ class UNetEngine:
             if Cs <= 0 or wb.shape[1] - Cup_b != Cs or any(c % epc for c in (Cup_a, Cup_b, Cs)):
                 return None
             C3 = Cup_a + Cs + Cup_b
-            buf = torch.empty((B, h, w_, C3), dtype=self.tdt, device=self.device)
+            buf = self._new(B, h, w_, C3).buf
             scale = torch.ones(C3, dtype=torch.float32, device=self.device)
             shift = torch.zeros(C3, dtype=torch.float32, device=self.device)
             ca.append({"buf": buf, "scale": scale[:Cup_a + Cs], "shift": shift[:Cup_a + Cs], "Cup": Cup_a, "Cskip": Cs})
