@@ -560,22 +560,27 @@ static bool wgT2_shape_ok(int CA, int CB, int dt) {
     static const bool on = []() { const char* e = getenv("CMU_WGRAD_WIDE"); return !(e && e[0] == '0'); }();
     return on && cmu_dtype_size(dt) == 2 && CA % 64 == 0 && CB % 128 == 0;
 }
+// 256 X channels per workgroup (conv_wgrad2.inc, NXI = 4) where Cin allows: the deeper decoder levels (CMU_WGT2_NX256=0: A/B)
+static bool wgT2_wide_x(int CB) {
+    static const bool on = []() { const char* e = getenv("CMU_WGT2_NX256"); return !(e && e[0] == '0'); }();
+    return on && CB % 256 == 0;
+}
 static void wgT2_geometry(int B, int H, int W, int CA, int CB, WGParams& p) {
     p.tilesX = cmu_div_up(W, 16);
     p.tilesY = cmu_div_up(H, 4);
     p.ntiles = B * p.tilesX * p.tilesY;
     p.nAB = CA / 64;
-    p.nBB = CB / 128;
+    p.nBB = CB / (wgT2_wide_x(CB) ? 256 : 128);
     p.CApad = CA;
     p.CBpad = CB;
     p.splitk = wg_splitk(p.nAB * p.nBB, p.ntiles, 1, cmu_wg_wide_target());
 }
-template <class TR>
-static int wgradT_wide_t(WGParams p, float* dW, float* dbias, hipStream_t st) {
-    typedef WGT2Cfg<TR> C;
+template <class TR, int NXI>
+static int wgradT_wide_launch(const WG2Params& pp, hipStream_t st) {
+    typedef WGT2Cfg<TR, NXI> C;
     static CmuPerDevice attr_set;   // hipFuncSetAttribute is per device
     if (!attr_set.done()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgradT2_kernel<TR>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgradT2_kernel<TR, NXI>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            C::LDS_BYTES);
         if (e != hipSuccess) {
             cmu_set_error("cmu_convT2x2_wgrad(wide): hipFuncSetAttribute(%d B LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
@@ -583,12 +588,18 @@ static int wgradT_wide_t(WGParams p, float* dW, float* dbias, hipStream_t st) {
         }
         attr_set.mark();
     }
+    hipLaunchKernelGGL((conv_wgradT2_kernel<TR, NXI>), dim3(pp.g.nAB * pp.g.nBB * pp.g.splitk), dim3(512), C::LDS_BYTES, st, pp);
+    return CMU_OK;
+}
+template <class TR>
+static int wgradT_wide_t(WGParams p, float* dW, float* dbias, hipStream_t st) {
     WG2Params pp;
     pp.g = p;
     pp.dtx = p.splitk % p.tilesX;
     pp.dty = (p.splitk / p.tilesX) % p.tilesY;
     pp.dtb = p.splitk / (p.tilesX * p.tilesY);
-    hipLaunchKernelGGL((conv_wgradT2_kernel<TR>), dim3(p.nAB * p.nBB * p.splitk), dim3(512), C::LDS_BYTES, st, pp);
+    const int rc = wgT2_wide_x(p.CB) ? wgradT_wide_launch<TR, 4>(pp, st) : wgradT_wide_launch<TR, 2>(pp, st);
+    if (rc != CMU_OK) return rc;
     cmu_set_kernel_tag("conv_wgradT2_kernel");
     CMU_CHECK_LAUNCH("cmu_convT2x2_wgrad(wide)");
     launch_wgrad_reduce((const float*)p.ws, p.splitk, 4, p.CApad, p.CBpad, p.CA, p.CB, dW, 2, st);
