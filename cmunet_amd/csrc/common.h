@@ -34,7 +34,7 @@ static inline bool cmu_aligned16(const void* p) { return (reinterpret_cast<uintp
 // Dispatch switches that tests A/B inside ONE process (elementwise.hip): the environment variable of the same name is read ONCE
 // (no getenv on the launch path: an environment scan per conv launch, racing with setenv from loader threads -- advisor, round 3);
 // cmu_set_dispatch_override (test entry of the C-ABI) forces a value afterwards.  Default of every switch: on.
-enum CmuSwitch { CMU_SW_CONV_NARROW = 0, CMU_SW_CONV_SLIM, CMU_SW_CONV_PERSIST_PART, CMU_SW_WGRAD_SQUARE, CMU_SW_WGRAD_WIDE_F32, CMU_SW_COUNT };
+enum CmuSwitch { CMU_SW_CONV_NARROW = 0, CMU_SW_CONV_SLIM, CMU_SW_CONV_PERSIST_PART, CMU_SW_WGRAD_SQUARE, CMU_SW_WGRAD_WIDE_F32, CMU_SW_CONV_V5, CMU_SW_COUNT };
 bool cmu_switch_on(int id);
 
 // the calling thread's current HIP device (the one its launches go to)
@@ -130,6 +130,10 @@ struct F16Traits {
     __device__ static inline void mma16(const u32x4& a, const u32x4& b, f32x16& acc) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
     }
+    // acc(16x16 f32) += A(16 x 32) * B(32 x 16): lane l holds A[l & 15][8 (l >> 4) ..+8), B[8 (l >> 4) ..+8)[l & 15]; D[4 (l >> 4) + e][l & 15]
+    __device__ static inline void mma32(const u32x4& a, const u32x4& b, f32x4& acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+    }
     __device__ static inline float to_float(_Float16 v) { return (float)v; }
     __device__ static inline _Float16 from_float(float v) { return (_Float16)v; }
     __device__ static inline uint32_t pack2(float a, float b) {   // a in the low half, b in the high half
@@ -164,6 +168,9 @@ struct BF16Traits {
     }
     __device__ static inline void mma16(const u32x4& a, const u32x4& b, f32x16& acc) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+    __device__ static inline void mma32(const u32x4& a, const u32x4& b, f32x4& acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
     }
     __device__ static inline float to_float(__bf16 v) { return (float)v; }
     __device__ static inline __bf16 from_float(float v) { return (__bf16)v; }
