@@ -112,6 +112,8 @@ def case(H, Cin, Cout, mode):
 shapes = [(256, 128, 128), (128, 256, 256), (64, 512, 512), (32, 1024, 1024), (256, 64, 128), (256, 256, 128), (128, 512, 256), (64, 1024, 512), (32, 512, 1024)]
 if QUICK:
     shapes = [(64, 128, 128), (32, 64, 128)]
+if os.environ.get("V5_SHAPES"):
+    shapes = [tuple(int(v) for v in t.split(",")) for t in os.environ["V5_SHAPES"].split(";")]
 for (H, ci, co) in shapes:
     for mode in ("fwd_tf", "fwd", "dgrad_bn"):
         if mode == "dgrad_bn" and ci % 128 != 0:
