@@ -442,6 +442,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if use_dist and tr is not None:
+        tr.time_exchange = True          # the trainers then bracket their exchange waits with a host clock and two stream events
     for i in range(args.warmup):
         step(i)
     if args.graph:
@@ -486,7 +488,9 @@ def main():
         ones = torch.ones(1, dtype=torch.float32, device=dev)
         dist.all_reduce(ones)
         rccl = {"world": dist.get_world_size(), "ranks_seen": int(round(float(ones.item()))), "backend": str(dist.get_backend()),
-                "exchange": getattr(tr, "last_exchange", None)}
+                # (exchange_report(): + wait_ms = host clock around the waits of the LAST timed step, exposed_ms = how long the compute
+                # stream stood still for the collectives -- events on that stream around the waits; time, not launch-order bookkeeping)
+                "exchange": tr.exchange_report() if hasattr(tr, "exchange_report") else getattr(tr, "last_exchange", None)}
         if rccl["world"] != world or rccl["ranks_seen"] != world:
             raise SystemExit(f"process group saw {rccl['ranks_seen']} of {rccl['world']} ranks, WORLD_SIZE={world}")
     loss_val = float(loss.reshape(-1)[0].item())

@@ -920,7 +920,8 @@ __global__ void sparse_pixel_rows_multi_kernel(const int* __restrict__ plist, co
         }
         rows[r] = v;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) q.count[i][0] = (int)n;
+    // (never more rows than the list holds: a host-side count that overstates the capacity must not send the list-driven kernels past it)
+    if (blockIdx.x == 0 && threadIdx.x == 0) q.count[i][0] = (int)(n < cap ? n : cap);
 }
 extern "C" int cmu_sparse_pixel_lists(const int* patches, const int* patch_count, int f, int B, int n, const int* H, int* const* rows,
                                       const int64_t* capacity, int* const* counts, void* stream) {

@@ -41,8 +41,11 @@ bool cmu_switch_on(int id) {
     }
     return v != 0;
 }
+#include <mutex>
+static std::mutex g_switch_mutex;   // (test hook: concurrent setters are serialised; readers on the launch path take relaxed atomic loads)
 extern "C" int cmu_set_dispatch_override(const char* name, int value) {
     CMU_CHECK_ARG(name != nullptr && value >= -1 && value <= 1, "cmu_set_dispatch_override: value must be -1 (environment), 0 or 1");
+    std::lock_guard<std::mutex> lock(g_switch_mutex);
     for (int i = 0; i < CMU_SW_COUNT; ++i)
         if (strcmp(name, g_switch_names[i]) == 0) {
             __atomic_store_n(&g_switch_override[i], value, __ATOMIC_RELAXED);

@@ -185,7 +185,8 @@ class UNetEngine:
             self._nbt.append(sd[pbn + "num_batches_tracked"])
         return {"pconv": pconv, "pbn": pbn, "x": x, "x_img": x_img, "mask": mask, "mps": mask_per_sample,
                 "y": out.with_transform(scale, shift, 0), "mean": mean, "invstd": invstd,
-                "w_ver": (w._version, w.data_ptr()) if x_img is not None else None}
+                # (ops.PARAM_GENERATION: the fused optimisers / EMA / broadcast rewrite the arena through raw pointers, no version bump)
+                "w_ver": (w._version, w.data_ptr(), ops.PARAM_GENERATION) if x_img is not None else None}
 
     def _double_conv_fwd(self, sd, prefix, x, out2, training, x_img=None, mask=None, mask_per_sample=False, affine_out2=None):
         """DoubleConv (model.py:16-26).  ``out2``: where the second conv writes its raw output."""
@@ -256,7 +257,7 @@ class UNetEngine:
             wsb = self.scratch.get("wg", self.lib.cmu_conv3x3_c1_wgrad_ws_bytes(B, H, W, C))
             # the raw output is recomputed from the image when the weights are still the ones the forward used (same bits, half
             # the traffic of the pass); a parameter rewritten between forward and backward falls back to the stored tensor
-            same_w = (_C1W_RECOMP and s.get("w_ver") == (w._version, w.data_ptr())
+            same_w = (_C1W_RECOMP and s.get("w_ver") == (w._version, w.data_ptr(), ops.PARAM_GENERATION)
                       and getattr(self.lib, "cmu_conv3x3_c1_wgrad_bn_w", None) is not None)    # (older builds under CMU_LIB_PATH: A/B runs)
             ops.conv3x3_c1_wgrad_bn(s["x_img"], dA, y, y.scale, y.shift, s["mean"], s["invstd"], coef, dW, wsb, s["mask"], s["mps"],
                                     w=w.detach() if same_w else None)
@@ -464,7 +465,7 @@ class UNetEngine:
                 if sk.scale.data_ptr() != cat["scale"][s_lo:].data_ptr():
                     cat["scale"][s_lo:s_lo + Cs].copy_(sk.scale)
                     cat["shift"][s_lo:s_lo + Cs].copy_(sk.shift)
-                    cat["ident"] = False
+                cat["ident"] = False        # (also when the producer wrote scale / shift in place: the arrays no longer hold the identity)
                 relu_from = -Cs if sf else Cup
             else:                      # already-activated skip handed over at a module boundary: identity, no ReLU
                 if not cat.get("ident", False):      # (buffers reused from step to step keep the identity: two fills per level saved)

@@ -9,12 +9,13 @@ AmpOptimWrapper.update_params -> AdamW.step, cmunet_config.py:76-91) is ONE kern
     masked MSE on logits[:,1]             cmu_masked_mse_fwd_bwd (per-row normalised target, A-3)
     backward                              engine.unet_backward  (gradients written into the flat arena)
     gradient exchange                     one RCCL all-reduce over the arena (data parallel, C1)
-    AdamW                                 cmu_adam_step over the arena (bias / norm parameters: no decay)
+    AdamW                                 cmu_adam_step over the arena (biases exempt from decay; BatchNorm weights decay: cmunet_config.py:84-91)
 
 ``ct_weight = 0`` drops the contrastive branch (target encoder, feature decoder, projector, predictor),
 exactly the "masked-recon only" configuration SURVEY 8(d)-(2) names; the joint step lives in cmunet.py.
 """
 import math
+import time
 import os
 
 import numpy as np
@@ -22,7 +23,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib, ops
-from .optim import FlatParams, FusedAdam, FusedLAMB, FusedSGD, dp_exchanges, dp_world, no_decay_bias_norm
+from .optim import FlatParams, FusedAdam, FusedLAMB, FusedSGD, cmunet_paramwise_decay, dp_exchanges, dp_world
 
 
 def create_random_patch_mask(batch_size, img_size, patch_size=16, mask_ratio=0.65, rng=None):
@@ -80,7 +81,7 @@ class MaskedReconPretrainer:
         self.device = next(model.parameters()).device
         self.flat = FlatParams(model)
         self.opt = FusedAdam(self.flat, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decoupled=True,
-                             decay_filter=no_decay_bias_norm)
+                             decay_filter=cmunet_paramwise_decay)
         self.engine = model._engine(self.device)
         self.sd = dict(model.named_parameters())
         self.sd.update(dict(model.named_buffers()))
@@ -170,13 +171,33 @@ class MaskedReconPretrainer:
             rest_hi = self._bott[0] if self._bott is not None else self._dec_off
             works = [w for w in self._pending if w is not None]
             works.append(self.flat.all_reduce_range_async(0, rest_hi, self.group))
+            # timed like ArenaTrainer._wait_works when ``time_exchange`` is set: host clock around the waits + the compute stream's
+            # standstill (events), resolved by ``exchange_report()``
+            timed = getattr(self, "time_exchange", False) and self.device.type == "cuda"
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                t0 = time.perf_counter()
             for w in works:
                 if w is not None:
                     w.wait()
+            if timed:
+                self.last_exchange["wait_ms"] = (time.perf_counter() - t0) * 1e3
+                e1.record()
+                self._exposed_events = (e0, e1)
             self._pending = []
         else:
             self.flat.all_reduce_mean(self.group)
         return 1.0 / world
+
+    def exchange_report(self):
+        """``last_exchange`` with the timed fields resolved (synchronises: call it outside the timed region)."""
+        rep = dict(getattr(self, "last_exchange", {}) or {})
+        ev = getattr(self, "_exposed_events", None)
+        if ev is not None:
+            ev[1].synchronize()
+            rep["exposed_ms"] = float(ev[0].elapsed_time(ev[1]))
+        return rep
 
     def step(self, img, mask):
         loss = self.forward_backward(img, mask)
@@ -305,9 +326,48 @@ class ArenaTrainer:
                 self._launch(b)
         from .optim import _SINKS_CLAIMED
         _SINKS_CLAIMED.difference_update(id(p) for p in self.flat.params.values())
+        self._wait_works()
+
+    def _wait_works(self):
+        """Wait for every exchange in flight.  TIMED when ``self.time_exchange`` is set (bench.py, tests): ``wait_ms`` is the host clock
+        around the waits (what a blocking backend -- gloo -- costs the step), ``exposed_ms`` the time the COMPUTE stream stood still for
+        them (events on the current stream around the waits: on RCCL ``work.wait()`` only makes the stream wait, the host runs on) --
+        resolved lazily by ``exchange_report()``, never by a synchronisation inside the step."""
+        timed = getattr(self, "time_exchange", False) and self._works and torch.cuda.is_available() and self.device.type == "cuda"
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            t0 = time.perf_counter()
         for w in self._works:
             w.wait()
+        if timed:
+            self.last_exchange["wait_ms"] = (time.perf_counter() - t0) * 1e3
+            e1.record()
+            self._exposed_events = (e0, e1)
         self._works = []
+
+    def _abort_overlap(self):
+        """A forward / backward raised while exchanges were in flight: wait for them (the next step's arena writes would race the
+        un-waited collectives), give the claimed gradient sinks back, forget the bucket state (advisor, round 4)."""
+        from .optim import _SINKS_CLAIMED
+        self._ov_active = False
+        try:
+            for w in self._works:
+                w.wait()
+        finally:
+            self._works = []
+            _SINKS_CLAIMED.difference_update(id(p) for p in self.flat.params.values())
+            for b in self._buckets:
+                b["pending"], b["launched"] = len(b["names"]), False
+
+    def exchange_report(self):
+        """``last_exchange`` with the timed fields resolved (synchronises: call it outside the timed region)."""
+        rep = dict(getattr(self, "last_exchange", {}) or {})
+        ev = getattr(self, "_exposed_events", None)
+        if ev is not None:
+            ev[1].synchronize()
+            rep["exposed_ms"] = float(ev[0].elapsed_time(ev[1]))
+        return rep
 
     @staticmethod
     def trainable(model):
@@ -374,7 +434,8 @@ class ArenaTrainer:
 
 class JointPretrainer(ArenaTrainer):
     """Joint contrastive + masked-reconstruction step of CM-UNet (BASELINE config 4; cmunet.py:108-135 under
-    cmunet_config.py:76-114): AdamW(lr, betas (0.9, 0.95), wd 0.05, no decay on bias / norm parameters), then the EMA of the
+    cmunet_config.py:76-114): AdamW(lr, betas (0.9, 0.95), wd 0.05; exempt from decay: names containing 'ln' / 'bias' / ... --
+    the BatchNorm weights decay, ``optim.cmunet_paramwise_decay``), then the EMA of the
     target backbone + projector (MomentumUpdateHook.after_train_iter) as two launches between two arenas."""
 
     def __init__(self, model, lr=1.5e-4, betas=(0.9, 0.95), weight_decay=0.05, eps=1e-8, process_group=None, amp=None):
@@ -383,7 +444,7 @@ class JointPretrainer(ArenaTrainer):
         model -- what ``cmunet_config()`` / ``CM_UNet`` default to --, off otherwise (``default_amp``); False: off."""
         model.train()
         flat = self.trainable(model)
-        opt = FusedAdam(flat, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decoupled=True, decay_filter=no_decay_bias_norm)
+        opt = FusedAdam(flat, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decoupled=True, decay_filter=cmunet_paramwise_decay)
         super().__init__(model, opt, process_group)
         amp = default_amp(model, amp)
         self.amp = ops.AmpScaler(self.device) if amp is True else (amp or None)
@@ -508,6 +569,10 @@ class SparKPretrainer(ArenaTrainer):
                 #                                            rescale of gradients whose all-reduce may be in flight
             loss = self.model(inp_bchw, active_b1ff=active_b1ff)
             self.backward_and_step(loss, loss_scale, overlap_begun=begun)
+        except BaseException:
+            if begun:
+                self._abort_overlap()
+            raise
         finally:
             self.model.grad_scale = 1.0
             self.model._unit_backward = False

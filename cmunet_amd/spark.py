@@ -153,7 +153,10 @@ class SparK(_EngineOwner, nn.Module):
         h, w = self.fmap_h, self.fmap_w
         idx = torch.rand(B, h * w, generator=generator).argsort(dim=1)[:, :self.len_keep].to(device)
         active = torch.zeros(B, h * w, dtype=torch.bool, device=device).scatter_(dim=1, index=idx, value=True).view(B, 1, h, w)
-        active._cmu_n_active = B * self.len_keep      # known by construction: the step needs it on the host and would read it back otherwise
+        # known by construction (the step needs the count on the host and would read it back otherwise); stored with the tensor's version:
+        # an in-place edit of the mask (forcing a patch active, ...) invalidates it (advisor, round 4: a stale count fed the sparse
+        # BatchNorm counts and the list capacities -- list-driven kernels walking past their rows)
+        active._cmu_n_active = (active._version, B * self.len_keep)
         return active
 
     def forward(self, inp_bchw, active_b1ff=None, vis=False):
@@ -419,6 +422,8 @@ class SparK(_EngineOwner, nn.Module):
         # number of active patches, needed on the host (statistics counts, list capacities): carried by masks from ``mask()``,
         # remembered per mask tensor otherwise -- a read-back per step stalls the launch queue behind the previous step
         n_cells = getattr(active_b1ff, "_cmu_n_active", None)
+        if n_cells is not None:
+            n_cells = n_cells[1] if n_cells[0] == active_b1ff._version else None     # edited in place since mask(): count it again
         if n_cells is None:
             import weakref
             cache = self.__dict__.setdefault("_n_active_cache", {})

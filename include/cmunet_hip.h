@@ -43,9 +43,14 @@ const char* cmu_last_error(void);
 /* name of the compute kernel the calling thread's last GEMM-shaped entry launched ("" if none): for profilers */
 const char* cmu_last_kernel(void);
 int cmu_version(void);
-/* Test entry: force one of the dispatch switches that A/B two kernel forms with bit-identical results -- "CMU_CONV_NARROW",
- * "CMU_CONV_SLIM", "CMU_CONV_PERSIST_PART", "CMU_WGRAD_SQUARE", "CMU_WGRAD_WIDE_F32" -- to 0 / 1, or back to the environment
- * variable of the same name (value -1; the environment is read once, never on the launch path).  Unknown name: CMU_ERR_ARG. */
+/* TEST HOOK -- the one piece of process-global mutable state in this library (every other entry is re-entrant and keeps no state
+ * between calls: SURVEY section 8b).  Forces one of the dispatch switches that A/B two kernel forms -- "CMU_CONV_NARROW", "CMU_CONV_SLIM",
+ * "CMU_CONV_PERSIST_PART", "CMU_WGRAD_SQUARE", "CMU_WGRAD_WIDE_F32" (bit-identical results either way), "CMU_CONV_V5" (the 16x16x32 conv
+ * kernel of round 5 against the 32x32x16 family: equal to rounding) -- to 0 / 1, or back to the environment variable of the same name
+ * (value -1; the environment is read once, never on the launch path).  The override applies to EVERY thread of the process from the
+ * moment it is set: set it while no other thread is launching (the tests are single-threaded); stores and loads of the switch are atomic,
+ * calls are serialised by a mutex, a launch in flight on another thread may see either value.  Product code never calls it.
+ * Unknown name: CMU_ERR_ARG. */
 int cmu_set_dispatch_override(const char* name, int value);
 /* element size in bytes of a cmu_dtype */
 int cmu_dtype_size(int dt);

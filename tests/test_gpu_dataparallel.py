@@ -131,7 +131,7 @@ def test_masked_recon_two_ranks_different_batches_vs_oracle(cuda):
         n = p0.numel()
         got = two[0]["arena"][off:off + n].view_as(p0)
         off += ((n + 3) // 4) * 4
-        wd = 0.0 if (k.endswith(".bias") or p0.dim() <= 1) else 0.05
+        wd = 0.0 if any(key in k for key in ("ln", "bias", "pos_embed", "mask_token", "cls_token")) else 0.05   # cmunet_config.py:84-91 (BatchNorm weights decay)
         exp = p0 * (1 - 1e-3 * wd) - 1e-3 * g / (g.abs() + 1e-8)
         sure = g.abs() > 2e-3 * g.abs().max()
         if ".0.bias" in k or ".3.bias" in k or not bool(sure.any()):
@@ -164,7 +164,7 @@ def _check_joint(r, ref, osd, lr=1e-3, momentum=0.9):
         g = v.grad
         if g.abs().max() < 1e-6:
             continue
-        wd = 0.0 if (k.endswith(".bias") or v.dim() <= 1) else 0.05
+        wd = 0.0 if any(key in k for key in ("ln", "bias", "pos_embed", "mask_token", "cls_token")) else 0.05   # cmunet_config.py:84-91 (BatchNorm weights decay)
         exp = init[k] * (1 - lr * wd) - lr * g / (g.abs() + 1e-8)
         sure = g.abs() > 2e-2 * g.abs().max()            # (gradient parity is 5e-3 of the max norm: test_gpu_pretrain)
         assert (final[k] - exp)[sure].abs().max().item() <= 5e-6, k

@@ -604,8 +604,9 @@ def test_masked_recon_trainer_matches_autograd_path(cuda):
     a.load_state_dict(sd); b.load_state_dict(sd)
     a, b = a.to(cuda).train(), b.to(cuda).train()
     tr = MaskedReconPretrainer(a, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05)
-    decay = [p for n, p in b.named_parameters() if not (n.endswith(".bias") or p.dim() <= 1)]
-    nodecay = [p for n, p in b.named_parameters() if n.endswith(".bias") or p.dim() <= 1]
+    keys = ("ln", "bias", "pos_embed", "mask_token", "cls_token")       # cmunet_config.py:84-91 as mmengine applies it: substring match, BatchNorm weights decay
+    decay = [p for n, p in b.named_parameters() if not any(k in n for k in keys)]
+    nodecay = [p for n, p in b.named_parameters() if any(k in n for k in keys)]
     opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.05}, {"params": nodecay, "weight_decay": 0.0}], lr=1e-3, betas=(0.9, 0.95))
     g = torch.Generator(device=cuda).manual_seed(0)
     for it in range(3):
@@ -1057,3 +1058,42 @@ def test_cmunet_joint_step_reference_geometry(cuda, mode):
         assert e <= max(floor, 2.0 * sens[k]), f"d{k}: relative L2 error {e:.2e} against a spread of {sens[k]:.2e} (max over {nseeds} seeds)"
 
 
+
+
+def test_adamw_decay_groups_one_step_batchnorm_weight_moves_by_lr_wd_gamma(cuda):
+    """the CM-UNet trainers' AdamW follows cmunet_config.py:84-91 as mmengine applies it -- only names containing
+    'bias' (/'ln'/...) are exempt, so a BatchNorm WEIGHT with a zero gradient moves by exactly lr * wd * gamma in one step (decoupled
+    decay; Adam's own update of a zero gradient is 0), a bias does not move at all."""
+    from cmunet_amd import model as M
+    from cmunet_amd.pretrain import JointPretrainer, MaskedReconPretrainer
+    from cmunet_amd import cmunet as C
+    lr, wd = 1e-2, 0.05
+
+    def check(tr, tag):
+        g = torch.Generator().manual_seed(5)
+        with torch.no_grad():
+            tr.flat.arena.copy_((torch.rand(tr.flat.arena.shape, generator=g) + 0.5).to(cuda))   # gammas away from 1, nothing zero
+        w0 = tr.flat.arena.clone()
+        tr.flat.grad.zero_()
+        tr.opt.step()
+        torch.cuda.synchronize()
+        n_bn = n_bias = 0
+        for n in tr.flat.names:
+            off, cnt = tr.flat.offsets[n]
+            a, b = w0[off:off + cnt], tr.flat.arena[off:off + cnt]
+            if "bias" in n:
+                assert torch.equal(a, b), (tag, n)
+                n_bias += 1
+            else:
+                want = a * (1.0 - lr * wd)
+                assert float((b - want).abs().max()) <= 1e-7, (tag, n, float((b - want).abs().max()))
+                assert float((a - b).abs().min()) > 0.4 * lr * wd, (tag, n)     # it did move (gamma >= 0.5)
+                n_bn += tr.flat.params[n].dim() == 1
+        return n_bn, n_bias
+    net = M.UNet(out_classes=2, dtype="f32", base_ch=16, depth=3).to(cuda)
+    n_bn, n_bias = check(MaskedReconPretrainer(net, lr=lr, weight_decay=wd, amp=False), "recon")
+    assert n_bn == 2 * (2 * 3 - 1) and n_bias > n_bn          # five DoubleConvs of a depth-3 UNet: ten BatchNorm weights, all decayed
+    torch.manual_seed(0)
+    model = C.build_model(C.cmunet_config(img_size=32, base_ch=16, depth=3, dtype="f32")).to(cuda).train()
+    n_bn, _ = check(JointPretrainer(model, lr=lr, weight_decay=wd, amp=False), "joint")
+    assert n_bn > 10

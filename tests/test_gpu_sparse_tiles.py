@@ -566,3 +566,34 @@ def test_cells_statistics_vs_float64_and_pixel_form(ops, dt, case):
     xh = (ys - mean.double()) * invstd.double()
     assert (outs[0][1].double() - dz.sum(0)).abs().max().item() <= 1e-5 * max(1.0, float(dz.abs().sum(0).max()))
     assert (outs[0][0].double() - (dz * xh).sum(0)).abs().max().item() <= 1e-5 * max(1.0, float((dz * xh).abs().sum(0).max()))
+
+
+def test_spark_mask_edited_in_place_is_recounted(ops):
+    """Advisor (round 4): ``SparK.mask()`` hands the active-patch count to the step on the mask tensor; an in-place edit of that mask used
+    to leave the count stale (sparse BatchNorm counts, list capacities).  The count now carries the tensor's version: a mask from
+    ``mask()`` with one more patch forced active gives bit for bit the loss and gradients of a fresh tensor with the same content."""
+    from cmunet_amd import spark as S
+
+    def run(edit_in_place):
+        torch.manual_seed(5)
+        enc = S.build_sparse_encoder("unet_sparse", input_size=64, base_ch=16, depth=5, dtype="f32")
+        model = S.SparK(enc, S.UnetDecoder(base_ch=16, depth=5, dtype="f32"), mask_ratio=0.75, densify_norm="", dtype="f32").cuda().train()
+        g = torch.Generator().manual_seed(11)
+        x = torch.randn(4, 1, 64, 64, generator=g).cuda()
+        active = model.mask(4, "cuda", g)
+        first_off = (~active[0, 0]).nonzero()[0]
+        if edit_in_place:
+            active[0, 0, first_off[0], first_off[1]] = True                  # same tensor object: the attribute survives, its version does not
+            assert hasattr(active, "_cmu_n_active") and active._cmu_n_active[0] != active._version
+        else:
+            fresh = active.clone()
+            fresh[0, 0, first_off[0], first_off[1]] = True
+            active = fresh                                                   # no attribute: counted from the tensor
+            assert not hasattr(active, "_cmu_n_active")
+        loss = model(x, active_b1ff=active)
+        loss.backward()
+        return loss.detach().cpu(), {k: p.grad.cpu() for k, p in model.named_parameters() if p.grad is not None}
+    l0, g0 = run(False)
+    l1, g1 = run(True)
+    assert bool(torch.isfinite(l1).all()) and float(l0) == float(l1)
+    assert g0.keys() == g1.keys() and all(torch.equal(g0[k], g1[k]) for k in g0)
