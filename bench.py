@@ -422,6 +422,13 @@ def main():
     if args.dry_run_env:
         sys.exit(dry_run_env(plan, dist, torch))
     from cmunet_amd import _lib
+    # An older library under a newer host package (CMU_LIB_PATH in an A/B script) lacks entry points: say so in ONE line instead of a
+    # traceback from the middle of a step -- round 4's g21 A/B printed nothing for exactly that variant (the round-3 library under the
+    # round-4 package, `2>&1 | tail -1` in front of a JSON parser; profiles/HISTORY.md section E)
+    missing = _lib.missing_symbols()
+    if missing and os.environ.get("CMU_LIB_PATH"):
+        sys.exit(f"bench.py: {_lib.LIB_PATH} does not export {len(missing)} entry point(s) this package calls (first: {missing[0]}): "
+                 "an older build under CMU_LIB_PATH? -- no line printed")
     # CMU_DP_REHEARSE=1 under a launcher with one rank: the RCCL group is built and every collective of the step runs on it
     use_dist = world > 1 or (os.environ.get("CMU_DP_REHEARSE", "0") == "1" and "WORLD_SIZE" in os.environ)
     if use_dist:
@@ -527,8 +534,20 @@ def main():
         tot_ms = sum(v["ms"] for v in summ.values())
         # the MFMA entries grouped by the kernel that served them (rocprofv3 lists kernels, not entry points)
         mf = prof.by_kernel()
-        name = max(mf, key=lambda k: mf[k]["ms"])
-        d = mf[name]
+        # The dominant kernel is the persistent 3x3 implicit-GEMM conv kernel in its two instruction shapes: conv_igemm5_kernel (16x16x32
+        # MFMA, round 5: the whole-tile 128-channel layers) and conv_igemm3p_kernel (32x32x16: everything else).  They serve the SAME 34
+        # launches per step as before round 5 (forward + data gradient of the 17 multi-channel 3x3 convs); taken together, so that
+        # `frac` stays comparable across rounds -- the faster shape alone would flatter it (0.55 against 0.50 over all 34).
+        FAMILY = ("conv_igemm5_kernel", "conv_igemm3p_kernel")
+        fam = [k for k in FAMILY if k in mf]
+        if len(fam) == 2:
+            name = "+".join(fam)
+            mf_all = dict(mf)
+            d = {"ms": sum(mf[k]["ms"] for k in fam), "calls": sum(mf[k]["calls"] for k in fam), "work": sum(mf[k]["work"] for k in fam),
+                 "entries": set().union(*(mf[k]["entries"] for k in fam))}
+        else:
+            name = max(mf, key=lambda k: mf[k]["ms"])
+            d = mf[name]
         ach = d["work"] / (d["ms"] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
         # HBM bytes per launch of that kernel come from a separate rocprofv3 --pmc run of this same command
@@ -538,6 +557,10 @@ def main():
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 tj = json.load(f)
             ent = tj.get(name)
+            if ent is None and "+" in name:      # two kernels: launch-weighted mean of their per-launch traffic
+                parts = [(tj.get(k), mf[k]["calls"]) for k in name.split("+")]
+                if all(e for e, _ in parts):
+                    ent = {"hbm_bytes_per_launch": sum(e["hbm_bytes_per_launch"] * c for e, c in parts) / sum(c for _, c in parts)}
             if ent and tj.get("_command", {}).get("dtype", "bf16") == args.dtype and args.workload == "recon" and B == 32 and H == 512:
                 traffic = int(round(ent["hbm_bytes_per_launch"]))
         except (OSError, ValueError, KeyError, AttributeError):

@@ -100,6 +100,13 @@ _SIGS = {
     "cmu_moco_ws_bytes": (_L, [_I, _I, _I]),
     "cmu_moco_infonce_enqueue": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P]),
     "cmu_l2_normalize_rows": (_I, [_P, _P, _I, _I, _P]),
+    "cmu_l2_normalize_rows_bwd": (_I, [_P, _P, _P, _I, _I, _P]),
+    "cmu_moco_logits_assemble": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "cmu_moco_logits_split": (_I, [_P, _P, _I, _I, _F, _P]),
+    "cmu_moco_logits_addpos": (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
+    "cmu_row_cross_entropy": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "cmu_scale_by_device_scalar": (_I, [_P, _P, _L, _P]),
+    "cmu_patchify": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "cmu_masked_stats_rows": (_I, []),
     "cmu_masked_channel_stats": (_I, [_P, _L, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P]),
     "cmu_mask_select": (_I, [_P, _L, _P, _P, _I, _P, _I, _I, _P, _P, _L, _I, _I, _I, _I, _I, _P]),

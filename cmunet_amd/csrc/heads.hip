@@ -877,3 +877,138 @@ extern "C" int cmu_softmax2_threshold(const float* logits, float threshold, floa
     CMU_CHECK_LAUNCH("cmu_softmax2_threshold");
     return CMU_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Round 5: the pieces of the NON-fused MoCo API (moco2_module.py:224-285, 311-329: ``forward`` / ``_compute_l_s`` / ``validation_step``) that
+// ran on ATen ops until round 4 (F.normalize, torch.cat, F.cross_entropy, topk): row normalisation backward, the logits row
+// [q.k | q @ queue] / T assembled in place, its backward split, the row-wise cross entropy (+ the rank of the target for precision@k).
+// Not the training hot path (the fused step is cmu_moco_infonce_enqueue): simple one-block-per-row kernels, fixed-order sums.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2norm_rows_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int D) {
+    __shared__ float red[4];
+    const float* r = x + (int64_t)blockIdx.x * D;
+    const float* g = dy + (int64_t)blockIdx.x * D;
+    float s = 0.f, t = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) { s = fmaf(r[d], r[d], s); t = fmaf(r[d], g[d], t); }
+    const float n2 = block_sum(s, red);
+    __syncthreads();
+    const float xg = block_sum(t, red);
+    const float n = sqrtf(n2);
+    // y = x / max(n, eps): dx = dy / n - x (x . dy) / n^3 above the clamp, dy / eps below it (F.normalize's own backward)
+    if (n > 1e-12f) {
+        const float inv = 1.f / n, c = xg * inv * inv * inv;
+        for (int d = threadIdx.x; d < D; d += 256) dx[(int64_t)blockIdx.x * D + d] = fmaf(g[d], inv, -r[d] * c);
+    } else {
+        for (int d = threadIdx.x; d < D; d += 256) dx[(int64_t)blockIdx.x * D + d] = g[d] * 1e12f;
+    }
+}
+extern "C" int cmu_l2_normalize_rows_bwd(const float* x, const float* dy, float* dx, int B, int D, void* stream) {
+    CMU_CHECK_ARG(x && dy && dx && B > 0 && D > 0, "cmu_l2_normalize_rows_bwd: bad args");
+    hipLaunchKernelGGL(l2norm_rows_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, dy, dx, D);
+    CMU_CHECK_LAUNCH("cmu_l2_normalize_rows_bwd");
+    return CMU_OK;
+}
+
+// logits[b] = [ q[b].k[b] | lneg[b][0..K) ] * inv_t   (torch.cat([l_pos, l_neg], 1) / T of moco2_module.py:264-267)
+__global__ __launch_bounds__(256) void moco_logits_assemble_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ lneg,
+                                                                  float* __restrict__ logits, int D, int K, float inv_t) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    float s = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) s = fmaf(q[(int64_t)b * D + d], k[(int64_t)b * D + d], s);
+    const float pos = block_sum(s, red);
+    float* out = logits + (int64_t)b * (K + 1);
+    if (threadIdx.x == 0) out[0] = pos * inv_t;
+    for (int j = threadIdx.x; j < K; j += 256) out[1 + j] = lneg[(int64_t)b * K + j] * inv_t;
+}
+extern "C" int cmu_moco_logits_assemble(const float* q, const float* k, const float* lneg, float* logits, int B, int D, int K, float inv_t, void* stream) {
+    CMU_CHECK_ARG(q && k && lneg && logits && B > 0 && D > 0 && K > 0, "cmu_moco_logits_assemble: bad args");
+    hipLaunchKernelGGL(moco_logits_assemble_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, q, k, lneg, logits, D, K, inv_t);
+    CMU_CHECK_LAUNCH("cmu_moco_logits_assemble");
+    return CMU_OK;
+}
+// backward, first half: dlneg[b][j] = dlogits[b][1 + j] * inv_t (the operand of dq_neg = dlneg @ queue^T on the skinny kernel)
+__global__ __launch_bounds__(256) void moco_logits_split_kernel(const float* __restrict__ dlogits, float* __restrict__ dlneg, int K, float inv_t) {
+    const int b = blockIdx.x;
+    for (int j = threadIdx.x; j < K; j += 256) dlneg[(int64_t)b * K + j] = dlogits[(int64_t)b * (K + 1) + 1 + j] * inv_t;
+}
+// second half: dq[b] += dlogits[b][0] * inv_t * k[b]
+__global__ __launch_bounds__(256) void moco_logits_addpos_kernel(const float* __restrict__ dlogits, const float* __restrict__ k, float* __restrict__ dq, int D, int K,
+                                                                float inv_t) {
+    const int b = blockIdx.x;
+    const float c = dlogits[(int64_t)b * (K + 1)] * inv_t;
+    for (int d = threadIdx.x; d < D; d += 256) dq[(int64_t)b * D + d] = fmaf(c, k[(int64_t)b * D + d], dq[(int64_t)b * D + d]);
+}
+extern "C" int cmu_moco_logits_split(const float* dlogits, float* dlneg, int B, int K, float inv_t, void* stream) {
+    CMU_CHECK_ARG(dlogits && dlneg && B > 0 && K > 0, "cmu_moco_logits_split: bad args");
+    hipLaunchKernelGGL(moco_logits_split_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dlogits, dlneg, K, inv_t);
+    CMU_CHECK_LAUNCH("cmu_moco_logits_split");
+    return CMU_OK;
+}
+extern "C" int cmu_moco_logits_addpos(const float* dlogits, const float* k, float* dq, int B, int D, int K, float inv_t, void* stream) {
+    CMU_CHECK_ARG(dlogits && k && dq && B > 0 && D > 0 && K > 0, "cmu_moco_logits_addpos: bad args");
+    hipLaunchKernelGGL(moco_logits_addpos_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dlogits, k, dq, D, K, inv_t);
+    CMU_CHECK_LAUNCH("cmu_moco_logits_addpos");
+    return CMU_OK;
+}
+
+// F.cross_entropy(logits, target) with mean reduction over the rows (moco2_module.py:283, 324): per row logsumexp - x[target]; dlogits = (softmax -
+// onehot) / B (the gradient of the MEAN; the caller multiplies by the incoming scalar with cmu_scale_by_device_scalar); rank[b] = number of
+// logits strictly above the target's (precision@k: hit iff rank < k).  One block per row, two passes over the row; the mean in a
+// second one-block launch (fixed order).
+__global__ __launch_bounds__(256) void row_ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, float* __restrict__ row_loss,
+                                                    float* __restrict__ dlogits, int* __restrict__ rank, int N, float inv_b) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* x = logits + (int64_t)b * N;
+    const int t = (int)target[b];
+    float m = -__builtin_inff();
+    for (int j = tid; j < N; j += 256) m = fmaxf(m, x[j]);
+    m = block_max(m, red);
+    __syncthreads();
+    const float xt = x[t];
+    float s = 0.f, above = 0.f;
+    for (int j = tid; j < N; j += 256) {
+        s += __expf(x[j] - m);
+        above += x[j] > xt ? 1.f : 0.f;
+    }
+    s = block_sum(s, red);
+    __syncthreads();
+    above = block_sum(above, red);
+    const float lse = m + __logf(s);
+    if (tid == 0) {
+        row_loss[b] = lse - xt;
+        if (rank != nullptr) rank[b] = (int)above;
+    }
+    if (dlogits != nullptr) {
+        float* d = dlogits + (int64_t)b * N;
+        for (int j = tid; j < N; j += 256) d[j] = (__expf(x[j] - lse) - (j == t ? 1.f : 0.f)) * inv_b;
+    }
+}
+__global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict__ v, float* __restrict__ out, int B) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < B; i += 256) s += v[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = s / (float)B;
+}
+extern "C" int cmu_row_cross_entropy(const float* logits, const int64_t* target, float* loss, float* row_loss, float* dlogits, int* rank, int B, int N,
+                                     void* stream) {
+    CMU_CHECK_ARG(logits && target && loss && row_loss && B > 0 && N > 0, "cmu_row_cross_entropy: bad args");
+    hipLaunchKernelGGL(row_ce_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, target, row_loss, dlogits, rank, N, 1.f / (float)B);
+    hipLaunchKernelGGL(mean_rows_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, row_loss, loss, B);
+    CMU_CHECK_LAUNCH("cmu_row_cross_entropy");
+    return CMU_OK;
+}
+// v[i] *= s[0] (s on the device: the incoming gradient of a scalar loss, never read back)
+__global__ void scale_by_device_scalar_kernel(float* __restrict__ v, const float* __restrict__ s, int64_t n) {
+    const float c = s[0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) v[i] *= c;
+}
+extern "C" int cmu_scale_by_device_scalar(float* v, const float* s, int64_t n, void* stream) {
+    CMU_CHECK_ARG(v && s && n > 0, "cmu_scale_by_device_scalar: bad args");
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(scale_by_device_scalar_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, v, s, n);
+    CMU_CHECK_LAUNCH("cmu_scale_by_device_scalar");
+    return CMU_OK;
+}

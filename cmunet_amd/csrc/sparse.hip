@@ -284,3 +284,27 @@ extern "C" int cmu_spark_loss_fwd_bwd(const float* rec, const float* img, const 
     }
     return CMU_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// SparK.patchify / unpatchify (Spark/spark.py:133-148): (B, C, h*p, w*p) <-> (B, h*w, p*p*C), element (b, c, hy*p + py, wx*p + px) <->
+// (b, hy*w + wx, (py*p + px)*C + c) -- the reference's einsum('bchpwq->bhwpqc') + reshape and its inverse as one gather pass (fp32).
+// ---------------------------------------------------------------------------------------------
+__global__ void patchify_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int h, int w, int p, int64_t total, int inverse) {
+    const int H = h * p, W = w * p;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        // i indexes the (B, C, H, W) tensor (coalesced on that side; the patch side is strided by C)
+        const int x = (int)(i % W), y = (int)((i / W) % H), c = (int)((i / ((int64_t)W * H)) % C);
+        const int64_t b = i / ((int64_t)W * H * C);
+        const int64_t j = ((b * h + y / p) * w + x / p) * (int64_t)(p * p * C) + ((y % p) * p + (x % p)) * C + c;
+        if (inverse) dst[i] = src[j];
+        else dst[j] = src[i];
+    }
+}
+extern "C" int cmu_patchify(const float* src, float* dst, int B, int C, int h, int w, int p, int inverse, void* stream) {
+    CMU_CHECK_ARG(src && dst && B > 0 && C > 0 && h > 0 && w > 0 && p > 0, "cmu_patchify: bad args");
+    const int64_t total = (int64_t)B * C * h * p * w * p;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, C, h, w, p, total, inverse);
+    CMU_CHECK_LAUNCH("cmu_patchify");
+    return CMU_OK;
+}

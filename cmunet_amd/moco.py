@@ -84,6 +84,72 @@ class _QueueLogitsFn(torch.autograd.Function):
         return ops.skinny_gemm_fwd(dl.contiguous(), queue.detach()), None
 
 
+class _L2NormRowsFn(torch.autograd.Function):
+    """F.normalize(x, dim=1) (moco2_module.py:256, 259) on cmu_l2_normalize_rows / _bwd."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.detach().float().contiguous()
+        out = torch.empty_like(x)
+        ops.l2_normalize_rows(x, out)
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        ops.l2_normalize_rows_bwd(x, dy.float().contiguous(), dx)
+        return dx
+
+
+class _MocoLogitsFn2(torch.autograd.Function):
+    """logits = cat([einsum("nc,nc->n", q, k)[:, None], einsum("nc,ck->nk", q, queue)], 1) / T (moco2_module.py:258-267): the negatives on the
+    skinny kernels (``_QueueLogitsFn``'s arithmetic), positives + concatenation + temperature in one assemble kernel; backward: one split
+    kernel, the skinny kernel for dq = dl_neg @ queue^T, one kernel adding the positive term -- a single gradient for q (no accumulation
+    of two autograd branches)."""
+
+    @staticmethod
+    def forward(ctx, q, k, queue, temperature):
+        q, k, queue = q.detach().contiguous(), k.detach().contiguous(), queue.detach()
+        lneg = ops.skinny_gemm_dgrad(q, queue)
+        logits = torch.empty((q.shape[0], queue.shape[1] + 1), dtype=torch.float32, device=q.device)
+        ops.moco_logits_assemble(q, k, lneg, logits, 1.0 / temperature)
+        ctx.save_for_backward(k, queue)
+        ctx.inv_t = 1.0 / temperature
+        return logits
+
+    @staticmethod
+    def backward(ctx, dl):
+        k, queue = ctx.saved_tensors
+        dl = dl.float().contiguous()
+        dlneg = torch.empty((dl.shape[0], dl.shape[1] - 1), dtype=torch.float32, device=dl.device)
+        ops.moco_logits_split(dl, dlneg, ctx.inv_t)
+        dq = ops.skinny_gemm_fwd(dlneg, queue)
+        ops.moco_logits_addpos(dl, k, dq, ctx.inv_t)
+        return dq, None, None, None
+
+
+class _RowCrossEntropyFn(torch.autograd.Function):
+    """F.cross_entropy(logits, target) with mean reduction (moco2_module.py:283, 324) on cmu_row_cross_entropy."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        loss, dl, _ = ops.row_cross_entropy(logits.detach().float().contiguous(), target, want_grad=logits.requires_grad)
+        ctx.dl = dl
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, go):
+        dl, ctx.dl = ctx.dl, None
+        ops.scale_by_device_scalar(dl, go.float().contiguous())
+        return dl, None
+
+
+def row_cross_entropy(logits, target):
+    return _RowCrossEntropyFn.apply(logits, target)
+
+
 def queue_logits(q, queue):
     """``einsum("nc,ck->nk", [q, queue])`` of the non-fused ``Moco_v2.forward`` on the skinny kernels: up to
     ``ops.SKINNY_MAX_ROWS`` = 256 query rows per GPU (the reference's batch size, moco2_module.py:91); no library GEMM behind it."""
@@ -199,18 +265,21 @@ class Moco_v2(nn.Module):
             return self.encoder_k(img_k)
 
     def forward(self, img_q, img_k, queue):
-        q = F.normalize(self.encoder_q(img_q), dim=1)
+        """moco2_module.py:224-270 on the library's kernels only (round 5: F.normalize / torch.cat / the elementwise positives are gone
+        from this path): row normalisation, [q.k | q @ queue] / T."""
+        q = _L2NormRowsFn.apply(self.encoder_q(img_q))
         with torch.no_grad():
-            k = F.normalize(self._encode_keys(img_k), dim=1)
-        l_pos = (q * k).sum(dim=1, keepdim=True)                     # einsum("nc,nc->n")
+            k = _L2NormRowsFn.apply(self._encode_keys(img_k))
         # moco2_module.py:262 multiplies by queue.clone().detach(): the reference's order is forward -> _dequeue_and_enqueue ->
         # loss.backward(), and the backward needs the PRE-enqueue queue.  The copy is only made where a backward can follow (grad
         # mode on and q in the graph); validation (no_grad) reads the live buffer.  The fused training_step needs neither.
         qd = queue.detach()
         if torch.is_grad_enabled() and q.requires_grad:
             qd = qd.clone()
-        l_neg = queue_logits(q, qd)
-        logits = torch.cat([l_pos, l_neg], dim=1) / self.hparams["softmax_temperature"]
+        if not (q.is_cuda and 1 <= q.shape[0] <= ops.SKINNY_MAX_ROWS and qd.is_contiguous() and qd.shape[1] % 8 == 0 and qd.dtype == torch.float32):
+            raise RuntimeError(f"Moco_v2.forward: needs CUDA fp32 features (rows <= {ops.SKINNY_MAX_ROWS}) and a contiguous (D, K) queue with K % 8 == 0, "
+                               f"got q {tuple(q.shape)} on {q.device}, queue {tuple(qd.shape)} {qd.dtype} (no library / CPU fallback)")
+        logits = _MocoLogitsFn2.apply(q, k, qd, float(self.hparams["softmax_temperature"]))
         labels = torch.zeros(logits.shape[0], dtype=torch.long, device=logits.device)
         return logits, labels, k, q
 
@@ -231,7 +300,7 @@ class Moco_v2(nn.Module):
         InfoNCE cross entropy of ``output`` (the logits of ``forward``) against ``target``."""
         self._dequeue_and_enqueue(keys, queue=self.queue, queue_ptr=self.queue_ptr)
         self.__dict__.pop("_ptr_shadow", None)       # the pointer moved outside the fused step: its host-side shadow is re-read
-        return F.cross_entropy(output.float(), target.long())
+        return row_cross_entropy(output, target)
 
     def configure_optimizers(self, max_epochs=None):
         """moco2_module.py:338-349: SGD(lr, momentum, weight_decay) over the trainable parameters + cosine annealing over
@@ -271,14 +340,21 @@ class Moco_v2(nn.Module):
         x = batch[0] if isinstance(batch[0], (tuple, list)) else batch
         output, target, keys, _ = self(img_q=x[0], img_k=x[1], queue=self.val_queue)
         self._dequeue_and_enqueue(keys, queue_ptr=self.val_queue_ptr, queue=self.val_queue)
-        loss = F.cross_entropy(output.float(), target)
-        acc1, acc5 = precision_at_k(output, target, top_k=(1, 5))
-        return {"val_loss": loss, "val_acc1": acc1, "val_acc5": acc5}
+        # cross entropy + the target's rank in one kernel (precision@k: hit iff fewer than k logits lie strictly above the target's)
+        loss, _, rank = ops.row_cross_entropy(output.detach().float().contiguous(), target, want_grad=False, want_rank=True)
+        acc1, acc5 = precision_from_rank(rank, (1, 5))
+        return {"val_loss": loss.reshape(()), "val_acc1": acc1, "val_acc5": acc5}
 
     @staticmethod
     def validation_epoch_end(outputs):
         """moco2_module.py:331-337: the means of the per-batch results (returned instead of logged)."""
         return {k: torch.stack([o[k].reshape(()) for o in outputs]).mean() for k in ("val_loss", "val_acc1", "val_acc5")}
+
+
+def precision_from_rank(rank, top_k=(1,)):
+    """precision_at_k from the per-row rank of the target (cmu_row_cross_entropy): percentage of rows with rank < k, as (1,) tensors."""
+    rows = rank.shape[0]
+    return [(rank < k).sum(dtype=torch.float32).reshape(1) * (100.0 / rows) for k in top_k]
 
 
 def precision_at_k(output, target, top_k=(1,)):

@@ -417,6 +417,54 @@ def l2_normalize_rows(x, out):
     call("cmu_l2_normalize_rows", _p(_f32c(x)), _p(out), x.shape[0], x.shape[1], _stream())
 
 
+def l2_normalize_rows_bwd(x, dy, dx):
+    call("cmu_l2_normalize_rows_bwd", _p(_f32c(x)), _p(_f32c(dy)), _p(dx), x.shape[0], x.shape[1], _stream())
+
+
+def moco_logits_assemble(q, k, lneg, logits, inv_t):
+    B, D = q.shape
+    call("cmu_moco_logits_assemble", _p(_f32c(q)), _p(_f32c(k)), _p(_f32c(lneg)), _p(logits), B, D, lneg.shape[1], float(inv_t), _stream())
+
+
+def moco_logits_split(dlogits, dlneg, inv_t):
+    call("cmu_moco_logits_split", _p(_f32c(dlogits)), _p(dlneg), dlneg.shape[0], dlneg.shape[1], float(inv_t), _stream())
+
+
+def moco_logits_addpos(dlogits, k, dq, inv_t):
+    B, D = dq.shape
+    call("cmu_moco_logits_addpos", _p(_f32c(dlogits)), _p(_f32c(k)), _p(dq), B, D, dlogits.shape[1] - 1, float(inv_t), _stream())
+
+
+def row_cross_entropy(logits, target, want_grad=True, want_rank=False):
+    """F.cross_entropy(logits, target) (mean) on one kernel: -> (loss (1,), dlogits or None = d mean / d logits, rank (B,) int32 or None)."""
+    B, N = logits.shape
+    dev = logits.device
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    rows = torch.empty(B, dtype=torch.float32, device=dev)
+    dl = torch.empty((B, N), dtype=torch.float32, device=dev) if want_grad else None
+    rank = torch.empty(B, dtype=torch.int32, device=dev) if want_rank else None
+    tgt = target if (target.dtype == torch.int64 and target.is_contiguous()) else target.to(torch.int64).contiguous()
+    call("cmu_row_cross_entropy", _p(_f32c(logits)), _p(tgt), _p(loss), _p(rows), _p(dl), _p(rank), B, N, _stream())
+    return loss, dl, rank
+
+
+def patchify(x, h, w, p, inverse=False):
+    """SparK.patchify (inverse False: (B, C, h*p, w*p) -> (B, h*w, p*p*C)) / unpatchify (inverse True) on cmu_patchify, fp32."""
+    x = x.float().contiguous()
+    if not inverse:
+        B, C = x.shape[:2]
+        out = torch.empty((B, h * w, p * p * C), dtype=torch.float32, device=x.device)
+    else:
+        B, C = x.shape[0], x.shape[-1] // (p * p)
+        out = torch.empty((B, C, h * p, w * p), dtype=torch.float32, device=x.device)
+    call("cmu_patchify", _p(x), _p(out), B, C, h, w, p, int(inverse), _stream())
+    return out
+
+
+def scale_by_device_scalar(v, s):
+    call("cmu_scale_by_device_scalar", _p(v), _p(_f32c(s.reshape(-1))), v.numel(), _stream())
+
+
 # ------------------------------------------------------------------------------------------------
 # SparK sparse ops
 # ------------------------------------------------------------------------------------------------

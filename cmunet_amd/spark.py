@@ -187,14 +187,14 @@ class SparK(_EngineOwner, nn.Module):
     def patchify(self, bchw):
         """spark.py:133-139: (B, C, H, W) -> (B, f*f, C*p*p)."""
         p, h, w = self.downsample_raito, self.fmap_h, self.fmap_w
-        B, C = bchw.shape[:2]
-        return torch.einsum('bchpwq->bhwpqc', bchw.reshape(B, C, h, p, w, p)).reshape(B, h * w, C * p * p)
+        _require_cuda(bchw, "SparK.patchify")
+        return ops.patchify(bchw, h, w, p).to(bchw.dtype)          # one gather pass (cmu_patchify), no einsum
 
     def unpatchify(self, bln):
         """spark.py:141-148: the inverse of ``patchify``."""
         p, h, w = self.downsample_raito, self.fmap_h, self.fmap_w
-        B, C = bln.shape[0], bln.shape[-1] // p ** 2
-        return torch.einsum('bhwpqc->bchpwq', bln.reshape(B, h, w, p, p, C)).reshape(B, C, h * p, w * p)
+        _require_cuda(bln, "SparK.unpatchify")
+        return ops.patchify(bln, h, w, p, inverse=True).to(bln.dtype)
 
     # ---------------------------------------------------------------------------------------------
     def _ident(self, eng, C):

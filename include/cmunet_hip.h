@@ -284,6 +284,26 @@ int cmu_moco_infonce_enqueue(const float* q_raw, const float* k_raw, const float
                              int B, int D, int K, float temperature, void* ws, void* stream);
 /* L2-normalise rows (F.normalize(dim=1), eps 1e-12) -- used before the key all-gather. */
 int cmu_l2_normalize_rows(const float* x, float* out, int B, int D, void* stream);
+/* The NON-fused MoCo API (moco2_module.py:224-285 ``forward`` / ``_compute_l_s``, :311-329 ``validation_step``; round 5: no ATen op left in
+ * those paths).  All fp32, one workgroup per row, fixed-order sums.
+ *   cmu_l2_normalize_rows_bwd: backward of F.normalize(x, dim=1) (:256, :259): dx = dy / n - x (x . dy) / n^3, n = |x| (dy / eps below the clamp)
+ *   cmu_moco_logits_assemble:  logits (B, 1 + K) = [ q[b] . k[b] | lneg[b][:] ] * inv_t   (torch.cat([l_pos, l_neg], 1) / T, :258-267)
+ *   cmu_moco_logits_split / _addpos: its backward -- dlneg (B, K) = dlogits[:, 1:] * inv_t (operand of dq = dlneg @ queue^T), then
+ *                              dq[b] += dlogits[b][0] * inv_t * k[b]
+ *   cmu_row_cross_entropy:     F.cross_entropy(logits (B, N), target int64 (B)) with mean reduction (:283, :324): loss[0], row_loss[B],
+ *                              dlogits (optional) = (softmax - onehot) / B, rank (optional) [b] = number of logits strictly above the
+ *                              target's (pl_bolts precision_at_k, metrics/aggregation.py:19-32: hit iff rank < k)
+ *   cmu_scale_by_device_scalar: v[i] *= s[0], s on the device (the incoming gradient of a scalar loss) */
+int cmu_l2_normalize_rows_bwd(const float* x, const float* dy, float* dx, int B, int D, void* stream);
+int cmu_moco_logits_assemble(const float* q, const float* k, const float* lneg, float* logits, int B, int D, int K, float inv_t, void* stream);
+int cmu_moco_logits_split(const float* dlogits, float* dlneg, int B, int K, float inv_t, void* stream);
+int cmu_moco_logits_addpos(const float* dlogits, const float* k, float* dq, int B, int D, int K, float inv_t, void* stream);
+int cmu_row_cross_entropy(const float* logits, const int64_t* target, float* loss, float* row_loss, float* dlogits, int* rank, int B, int N,
+                          void* stream);
+int cmu_scale_by_device_scalar(float* v, const float* s, int64_t n, void* stream);
+/* SparK.patchify / unpatchify (Pretraining/Spark/spark.py:133-148), fp32: inverse 0: src (B, C, h*p, w*p) -> dst (B, h*w, p*p*C) with
+ * dst[b][hy*w + wx][(py*p + px)*C + c] = src[b][c][hy*p + py][wx*p + px]; inverse 1: the other way round (src is the patch tensor). */
+int cmu_patchify(const float* src, float* dst, int B, int C, int h, int w, int p, int inverse, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * SparK sparse (masked) convolution support (Pretraining/Spark/encoder.py:12-56, spark.py:88-131).

@@ -188,20 +188,89 @@ def test_unet_full_fixture(M, golden_dir, dt):
     tol = TOLS[dt]
     e = rel_err(logits, fx["logits"])
     assert e <= tol * 2, f"logits {e:.3e}"
-    # the bottleneck of a 32x32 input is 2x2x2 = 8 values per channel: BatchNorm there is ill-conditioned, so
-    # gradients are compared by norm for all parameters and element-wise for a few named ones
-    gn = {str(k): float(v) for k, v in zip(fx["grad_norm_keys"], fx["grad_norms"])}
-    worst = 0.0
-    for k, p in m.named_parameters():
-        if ".0.bias" in k or ".3.bias" in k:
+    # Gradients: the bottleneck of a 32x32 input is 2x2x2 = 8 values per channel -- BatchNorm there is ill-conditioned and a ReLU network's
+    # gradient is a discontinuous function of its forward, so rounds 1-4 held the fixture's gradient NORMS to tol * 20.
+    # Since round 5 every parameter gradient is held to the kernels' own arithmetic instead: the oracle's float64 backward pass on the
+    # HIP path's OWN forward (every raw conv output, ReLU gate and activated value taken from the engine's saved state), flat bars
+    # 1e-4 (f32) / 1e-2 (f16) / 1e-1 (bf16) on the relative L2 error of each tensor -- the technique of
+    # tests/test_gpu_pretrain.py::test_masked_recon_step_gate_forced_backward on the reference network and the fixture's input.
+    from cmunet_amd import ops
+    from cmunet_amd.optim import FlatParams
+    sd0 = OU.make_state_dict(base_ch=64, depth=5, seed=int(fx["seed"]))
+    net = M.UNet(dtype=dt)
+    net.load_state_dict(sd0)
+    net = net.cuda().train()
+    flat = FlatParams(net)
+    sdd = dict(net.named_parameters())
+    sdd.update(dict(net.named_buffers()))
+    eng = net._engine(torch.device("cuda"))
+    eng.prepack(sdd)
+    x = fx["x"]
+    x3 = x if x.dim() == 3 else x[:, 0]
+    lg, ctx = eng.unet_forward(sdd, x3.contiguous().float().cuda(), True, None)
+    go = fx["go"]
+    dlogits = go.contiguous().float().cuda()            # the engine's logits are (B, K, H, W) fp32
+    assert dlogits.shape == lg.shape
+    layers = {}
+
+    def add(st):
+        y = st["y"]
+        raw = y.buf[..., y.coff:y.coff + y.C].float()
+        z = (raw.double() * y.scale.double() + y.shift.double()).float()
+        layers[st["pconv"]] = (raw.permute(0, 3, 1, 2).contiguous().cpu(), torch.clamp_min(z, 0).permute(0, 3, 1, 2).contiguous().cpu(),
+                               (z > 0).permute(0, 3, 1, 2).contiguous().cpu())
+    for lv in ctx["enc"]["levels"]:
+        add(lv["s1"]); add(lv["s2"])
+    add(ctx["enc"]["bott"]["s1"]); add(ctx["enc"]["bott"]["s2"])
+    for lv in ctx["dec"]["levels"]:
+        add(lv["s1"]); add(lv["s2"])
+    assert len(layers) == 18
+    eng.grad_target, eng.grad_prefix = flat.grad_views, ""
+    try:
+        eng.unet_backward(sdd, ctx, dlogits)
+    finally:
+        eng.grad_target = None
+
+    class Taps:
+        seen = set()
+
+        def conv(self, key, y):
+            self.seen.add(key)
+            return y + (layers[key][0].to(y.dtype) - y).detach()
+
+        def act(self, key, z):
+            a = z * layers[key][2].to(z.dtype)
+            return a + (layers[key][1].to(z.dtype) - a).detach()
+    taps = Taps()
+    tdt = ops.TORCH_DT[ops.dt_code(dt)]
+
+    def wq(k, v):        # float64 on the weights the kernels multiply with (16-bit storage: the packed copies hold the rounded weights)
+        if not v.is_floating_point():
+            return v.clone()
+        v = v.to(tdt).double() if (v.dim() == 4 and dt != "f32" and "conv_last" not in k) else v.double()
+        return v.requires_grad_(True) if "running" not in k else v
+    osd = {k: wq(k, v) for k, v in sd0.items()}
+    OU.TAP = taps
+    try:
+        out = OU.unet_forward(x3.double(), osd, training=True)
+        (out * go.double()).sum().backward()
+    finally:
+        OU.TAP = None
+    assert taps.seen == set(layers)
+    bar = {"f32": 1e-4, "f16": 1e-2, "bf16": 1e-1}[dt]
+    worst = ("", 0.0)
+    for k, v in osd.items():
+        if not (torch.is_tensor(v) and v.requires_grad) or k.endswith(("0.bias", "3.bias")):     # conv biases in front of BN: identically zero
             continue
-        r = abs(p.grad.norm().item() - gn[k]) / max(gn[k], 1e-6)
-        worst = max(worst, r)
-        assert r <= tol * 20, f"|d{k}|: {p.grad.norm().item():.4e} vs {gn[k]:.4e}"
-    for k in ("conv_last.weight", "conv_last.bias", "down_conv1.double_conv.double_conv.0.weight", "up_conv1.up_sample.bias"):
-        e2 = rel_err(m.get_parameter(k).grad, fx["grad." + k])
-        assert e2 <= tol * 20, f"d{k}: {e2:.3e}"
-    print(f"[unet_full {dt}] logits err {e:.2e}, worst grad-norm err {worst:.2e}")
+        got = flat.grad_views[k].detach().double().cpu()
+        e2 = float((got - v.grad).norm() / v.grad.norm().clamp_min(1e-30))
+        if k.endswith("up_sample.bias"):       # the border remainder of sums that cancel: held to the bar on its layer's scale
+            wg = osd[k[:-len("bias")] + "weight"].grad
+            e2 = (got - v.grad).norm().item() / max(v.grad.norm().item(), 1e-2 * wg.norm().item())
+        if e2 > worst[1]:
+            worst = (k, e2)
+        assert e2 <= bar, f"d{k}: relative L2 error {e2:.2e} with the gates forced (bar {bar:.0e}, {dt})"
+    print(f"[unet_full {dt}] logits err {e:.2e}; gate-forced float64 backward on the 32 x 32 fixture input: worst {worst[0]} {worst[1]:.2e} (bar {bar:.0e})")
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])

@@ -1097,3 +1097,65 @@ def test_adamw_decay_groups_one_step_batchnorm_weight_moves_by_lr_wd_gamma(cuda)
     model = C.build_model(C.cmunet_config(img_size=32, base_ch=16, depth=3, dtype="f32")).to(cuda).train()
     n_bn, _ = check(JointPretrainer(model, lr=lr, weight_decay=wd, amp=False), "joint")
     assert n_bn > 10
+
+
+def test_moco_nonfused_api_pieces_vs_torch(cuda):
+    """Round 5: ``Moco_v2.forward`` / ``_compute_l_s`` / ``validation_step`` no longer call ATen compute ops -- the
+    row normalisation, the [q.k | q @ queue] / T logits and the mean cross entropy (+ precision@k from the target's rank) run on the library's
+    kernels.  Each piece, forward and backward, against the torch expression of moco2_module.py:256-285 in float64."""
+    import torch.nn.functional as F
+    from cmunet_amd import moco as MO, ops
+    g = torch.Generator().manual_seed(3)
+    B, D, K, T = 48, 128, 512, 0.2
+    x = torch.randn(B, D, generator=g)
+    x[5] = 0.0                                                     # a zero row: F.normalize's eps clamp
+    xq = x.clone().to(cuda).requires_grad_(True)
+    y = MO._L2NormRowsFn.apply(xq)
+    go = torch.randn(B, D, generator=g)
+    y.backward(go.to(cuda))
+    xr = x.double().requires_grad_(True)
+    yr = F.normalize(xr, dim=1)
+    yr.backward(go.double())
+    assert rel(y, yr.float()) <= 1e-6 and rel(xq.grad[torch.arange(B) != 5], xr.grad[torch.arange(B) != 5].float()) <= 1e-5
+    # logits
+    q = F.normalize(torch.randn(B, D, generator=g), dim=1)
+    k = F.normalize(torch.randn(B, D, generator=g), dim=1)
+    queue = F.normalize(torch.randn(D, K, generator=g), dim=0)
+    qc = q.clone().to(cuda).requires_grad_(True)
+    logits = MO._MocoLogitsFn2.apply(qc, k.to(cuda), queue.to(cuda), T)
+    gl = torch.randn(B, K + 1, generator=g)
+    logits.backward(gl.to(cuda))
+    qd = q.double().requires_grad_(True)
+    lr_ = torch.cat([(qd * k.double()).sum(1, keepdim=True), qd @ queue.double()], 1) / T
+    lr_.backward(gl.double())
+    assert logits.shape == (B, K + 1) and rel(logits, lr_.float()) <= 1e-6 and rel(qc.grad, qd.grad.float()) <= 1e-5
+    # cross entropy (mean) with an incoming gradient that is not 1, and the target's rank
+    lo = (torch.randn(B, K + 1, generator=g) * 3).to(cuda).requires_grad_(True)
+    tgt = torch.randint(0, K + 1, (B,), generator=g).to(cuda)
+    loss = MO.row_cross_entropy(lo, tgt)
+    (loss * 2.5).backward()
+    lod = lo.detach().double().cpu().requires_grad_(True)
+    lref = F.cross_entropy(lod, tgt.cpu())
+    (lref * 2.5).backward()
+    assert loss.shape == () and abs(float(loss) - float(lref)) <= 1e-5 * abs(float(lref)) and rel(lo.grad, lod.grad.float()) <= 1e-5
+    _, _, rank = ops.row_cross_entropy(lo.detach(), tgt, want_grad=False, want_rank=True)
+    a1, a5 = MO.precision_from_rank(rank, (1, 5))
+    r1, r5 = MO.precision_at_k(lo.detach(), tgt, (1, 5))
+    assert float(a1) == float(r1) and float(a5) == float(r5)
+    assert torch.equal(rank.cpu().long(), (lo.detach().cpu() > lo.detach().cpu().gather(1, tgt.cpu().view(-1, 1))).sum(1))
+
+
+def test_spark_patchify_unpatchify_are_the_reference_einsums(cuda):
+    """Spark/spark.py:133-148 on cmu_patchify: bit for bit the reference's einsum + reshape, and inverse of each other."""
+    from cmunet_amd import spark as S
+    enc = S.build_sparse_encoder("unet_sparse", input_size=64, base_ch=16, depth=5, dtype="f32")
+    model = S.SparK(enc, S.UnetDecoder(base_ch=16, depth=5, dtype="f32"), mask_ratio=0.75, densify_norm="", dtype="f32").to(cuda)
+    p, h, w = model.downsample_raito, model.fmap_h, model.fmap_w
+    g = torch.Generator().manual_seed(2)
+    for C in (1, 3):
+        x = torch.randn(3, C, h * p, w * p, generator=g).to(cuda)
+        ref = torch.einsum('bchpwq->bhwpqc', x.reshape(3, C, h, p, w, p)).reshape(3, h * w, C * p * p)
+        got = model.patchify(x)
+        assert got.shape == ref.shape and torch.equal(got, ref)
+        assert torch.equal(model.unpatchify(got), x)
+        assert torch.equal(model.unpatchify(ref), torch.einsum('bhwpqc->bchpwq', ref.reshape(3, h, w, p, p, C)).reshape(3, C, h * p, w * p))

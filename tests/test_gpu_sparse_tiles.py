@@ -80,7 +80,8 @@ def test_conv_tiles_bit_identical_on_listed_tiles_and_untouched_elsewhere(ops, d
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
-@pytest.mark.parametrize("shape", [(2, 128, 64, 64, 8), (2, 64, 32, 64, 4), (1, 128, 128, 64, 8)])
+@pytest.mark.parametrize("shape", [(2, 128, 64, 64, 8), (2, 64, 32, 64, 4), (1, 128, 128, 64, 8),
+                                   (2, 512, 64, 64, 32)])      # level 1 of a 512 x 512 input, two images (config 5's geometry)
 def test_wgrad_tiles_equals_dense_when_dy_is_masked(ops, dt, shape):
     """Weight gradient over the listed 16 x 16 tiles == the dense weight gradient when dY vanishes outside the active patches
     (the sparse BatchNorm backward writes zeros there); only the split-K summation order differs."""
@@ -102,14 +103,18 @@ def test_wgrad_tiles_equals_dense_when_dy_is_masked(ops, dt, shape):
     e = (dW - dWt).abs().max().item() / dW.abs().max().item()
     assert e <= (1e-5 if dt != "f32" else 2e-5), e
     # against float64 as well
-    ref = torch.nn.grad.conv2d_weight(x.double().cpu().permute(0, 3, 1, 2), (Cout, Cin, 3, 3), dy.double().cpu().permute(0, 3, 1, 2), padding=1)
+    rdev = "cuda" if S >= 256 else "cpu"           # (the full-size geometry: float64 on the GPU, 39 GFLOP)
+    ref = torch.nn.grad.conv2d_weight(x.double().to(rdev).permute(0, 3, 1, 2), (Cout, Cin, 3, 3), dy.double().to(rdev).permute(0, 3, 1, 2), padding=1).cpu()
     assert (dWt.double().cpu() - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 64, 64, 128, 8), (3, 96, 128, 128, 12), (2, 128, 64, 256, 16), (1, 32, 128, 128, 2),
                                    # 64 -> 64 (SparK level 1): the 64 n x 64 c form (conv_wgrad2s.inc) walks the same 8 x 16 lists
-                                   (2, 128, 64, 64, 8), (3, 64, 64, 64, 4)])
+                                   (2, 128, 64, 64, 8), (3, 64, 64, 64, 4),
+                                   # config 5's geometry, two-image sub-batch of a 512 x 512 input: level 1 (64 -> 64 @ 512) and level 2
+                                   # (64 -> 128 and 128 -> 128 @ 256), 32 x 32 patch map
+                                   (2, 512, 64, 64, 32), (2, 256, 64, 128, 32), (2, 256, 128, 128, 32)])
 def test_wgrad_tiles_wide_kernel_8x16_list(ops, dt, shape):
     """The wide weight-gradient kernel over a list of 8 x 16 pixel tiles (its K tile; SparK level 2: one tile = two 8 x 8 patches):
     equal to the dense launch when dY vanishes outside the active patches, and to float64.  Lists longer and shorter than the
@@ -136,8 +141,9 @@ def test_wgrad_tiles_wide_kernel_8x16_list(ops, dt, shape):
     ops.conv3x3_wgrad_tiles(xa, ops.Act(dy), dWt, ws, tl)
     e = (dW - dWt).abs().max().item() / dW.abs().max().item()
     assert e <= 1e-5, e
-    xt = torch.relu(x.double().cpu() * sc.double().cpu() + sh.double().cpu())
-    ref = torch.nn.grad.conv2d_weight(xt.permute(0, 3, 1, 2), (Cout, Cin, 3, 3), dy.double().cpu().permute(0, 3, 1, 2), padding=1)
+    rdev = "cuda" if S >= 256 else "cpu"           # (the full-size geometry: float64 on the GPU)
+    xt = torch.relu(x.double().to(rdev) * sc.double().to(rdev) + sh.double().to(rdev))
+    ref = torch.nn.grad.conv2d_weight(xt.permute(0, 3, 1, 2), (Cout, Cin, 3, 3), dy.double().to(rdev).permute(0, 3, 1, 2), padding=1).cpu()
     assert (dWt.double().cpu() - ref).abs().max().item() <= (2e-3 if dt == "f16" else 1.6e-2) * ref.abs().max().item()
     # a 16 x 16 list is refused for nothing: it runs the first kernel; an 8 x 16 list on a shape of the first kernel is refused
     with pytest.raises(Exception, match="8 x 16 tile list needs"):
@@ -344,7 +350,10 @@ def test_spark_step_with_and_without_tile_skipping(ops, dt, tmp_path):
 # (B, f, H, C): patches of 4, 2, 4, 16, 8, 2, 1, 32, 4, 2, 1 pixels; patch maps whose side is not a power of two; several small
 # patches side by side per work item
 _CELL_CASES = [(2, 4, 16, 32), (3, 8, 16, 64), (1, 8, 32, 16), (2, 4, 64, 64), (2, 8, 64, 128), (1, 16, 32, 1024), (2, 4, 4, 256), (3, 2, 64, 8),
-               (2, 6, 24, 64), (1, 14, 28, 128), (2, 32, 32, 1024), (3, 12, 12, 512)]
+               (2, 6, 24, 64), (1, 14, 28, 128), (2, 32, 32, 1024), (3, 12, 12, 512),
+               # round 5: the geometry BASELINE config 5 is quoted on -- a two-image sub-batch of a 512 x 512
+               # input (32 x 32 patch map, mask 0.75) at levels 1 and 2 of the sparse encoder
+               (2, 32, 512, 64), (2, 32, 256, 128)]
 
 
 def _frame(act, H):
@@ -472,7 +481,8 @@ def test_build_lists_equals_one_list_per_launch(ops):
 
 
 @pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
-@pytest.mark.parametrize("case", [(2, 4, 64, 64), (3, 2, 64, 16), (1, 8, 128, 64), (2, 4, 128, 32)])       # (B, f, H, Cout): patches of 16 / 32 px
+@pytest.mark.parametrize("case", [(2, 4, 64, 64), (3, 2, 64, 16), (1, 8, 128, 64), (2, 4, 128, 32),       # (B, f, H, Cout): patches of 16 / 32 px
+                                  (2, 32, 512, 64)])      # the first layer of config 5: 512 x 512, 32 x 32 patch map, two images
 def test_first_layer_over_a_tile_list(ops, dt, case):
     """cmu_conv3x3_c1_fwd_tiles / cmu_conv3x3_c1_wgrad_bn_tiles (the sparse encoder's one-channel first layer over its 16 x 16 tile list):
     listed tiles carry the dense launch's bits, the others stay untouched; the slab sums are the statistics over the active pixels
