@@ -88,3 +88,42 @@ def test_bench_self_launch_propagates_rank_failure():
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert '"metric"' not in r.stdout
+
+
+def test_conv_igemm5_kernels_use_no_scratch(tmp_path):
+    """csrc/conv_igemm5.inc issues its weight / halo loads through inline asm with hand-placed s_waitcnt: hipcc does not know those registers
+    are in flight, so a register SPILL right behind such a load would store (and later reload) bytes that have not arrived yet -- it happened
+    once in round 5 (21 spilled registers in the data-gradient form: the halo chunks across its epilogue).  The kernels must therefore
+    allocate no scratch at all: checked on the code object inside the built library (kernel descriptors' private_segment_fixed_size)."""
+    import re
+    import shutil
+    import subprocess
+    lib = os.path.join(ROOT, "cmunet_amd", "csrc", "libcmunet_hip.so")
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
+    if not os.path.exists(lib) or not all(os.path.exists(t) for t in tools):
+        pytest.skip("library or LLVM tools not present")
+    fat = str(tmp_path / "fat.bin")
+    subprocess.run([tools[0], f"--dump-section=.hip_fatbin={fat}", lib], check=True)
+    blob = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+    assert starts, "no offload bundle in .hip_fatbin"
+    found = {}
+    for i, a in enumerate(starts):
+        part = str(tmp_path / f"b{i}.bin")
+        open(part, "wb").write(blob[a:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+        co = str(tmp_path / f"co{i}.o")
+        r = subprocess.run([tools[1], "--unbundle", "--type=o", f"--input={part}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"],
+                           capture_output=True, text=True)
+        if r.returncode != 0 or not os.path.exists(co) or os.path.getsize(co) == 0:
+            continue
+        notes = subprocess.run([tools[2], "--notes", co], capture_output=True, text=True).stdout
+        # AMDGPU metadata (YAML): per kernel a block with .name and .private_segment_fixed_size
+        for blk in notes.split("- .agpr_count")[1:]:
+            nm = re.search(r"\.name:\s+(\S+)", blk)
+            ps = re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk)
+            if nm and ps and "conv_igemm5_kernel" in nm.group(1):
+                found[nm.group(1)] = int(ps.group(1))
+    assert len(found) == 6, f"expected the six conv_igemm5_kernel instantiations (f16 / bf16 x transform / plain / data-gradient), found {sorted(found)}"
+    assert all(v == 0 for v in found.values()), f"conv_igemm5_kernel allocates scratch (a spill behind an asm load is a wrong result): {found}"

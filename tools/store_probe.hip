@@ -26,8 +26,13 @@ __global__ __launch_bounds__(512) void probe(unsigned char* out, int ld, int nst
             unsigned off;
             if (SHAPE == 0) off = (unsigned)(((i >> 1) * 16 + (lane & 15)) * ld + (i & 1) * 64 + (lane >> 4) * 16);
             else if (SHAPE == 1) off = (unsigned)((i * 8 + (lane >> 3)) * ld + (lane & 7) * 16);
-            else off = (unsigned)(i * 1024 + lane * 16);
-            u32x4* p = reinterpret_cast<u32x4*>(base + off);
+            else if (SHAPE == 3) {
+                // what conv_igemm5's epilogue writes: row i of the wave's 8 x 16-pixel block of a 256-pixel-wide, 128-channel image (pixel 256 B,
+                // image row 64 KB), two full-line instructions per row (8 pixels x 128 B each); wave w: rows 8 (w >> 1).., columns 16 (w & 1)..
+                const int row = 8 * (wave >> 1) + (i >> 1), col = 16 * (wave & 1) + 8 * (i & 1) + (lane >> 3);
+                off = (unsigned)(row * 65536 + col * 256 + (lane & 7) * 16);      // relative to the workgroup's region (< 32 * 65536 = 2 MiB)
+            } else off = (unsigned)(i * 1024 + lane * 16);
+            u32x4* p = reinterpret_cast<u32x4*>((SHAPE == 3 ? base - (long long)wave * 16 * 16 * ld : base) + off);
             if (NT) __builtin_nontemporal_store(v, p);
             else *p = v;
             v[0] += 1;
@@ -50,17 +55,17 @@ template <int SHAPE, bool NT>
 static void run(const char* name, int threads, int ld, int nst, int grid, unsigned char* buf, long long wg_stride, unsigned long long* dstamps) {
     const int rounds = 16;
     hipLaunchKernelGGL((probe<SHAPE, NT>), dim3(grid), dim3(threads), 0, 0, buf, ld, nst, wg_stride, dstamps, rounds);
-    hipDeviceSynchronize();
+    (void)hipDeviceSynchronize();
     hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    hipEventRecord(e0);
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0);
     hipLaunchKernelGGL((probe<SHAPE, NT>), dim3(grid), dim3(threads), 0, 0, buf, ld, nst, wg_stride, dstamps, rounds);
-    hipEventRecord(e1);
-    hipEventSynchronize(e1);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
     float ms = 0;
-    hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
     std::vector<unsigned long long> h(grid * 16);
-    hipMemcpy(h.data(), dstamps, h.size() * 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(h.data(), dstamps, h.size() * 8, hipMemcpyDeviceToHost);
     std::vector<unsigned long long> is, dr;
     const int waves = threads / 64;
     for (int b = 0; b < grid; ++b)
@@ -75,15 +80,17 @@ int main() {
     const long long wg_stride = 8ll << 20;
     unsigned char* buf;
     unsigned long long* dstamps;
-    hipMalloc(&buf, 256 * wg_stride);
-    hipMalloc(&dstamps, 256 * 16 * 8);
-    hipMemset(buf, 0, 256 * wg_stride);
+    (void)hipMalloc(&buf, 256 * wg_stride);
+    (void)hipMalloc(&dstamps, 256 * 16 * 8);
+    (void)hipMemset(buf, 0, 256 * wg_stride);
     for (int grid : {1, 32, 256}) {
         for (int thr : {256, 512}) {
             run<0, true>("64-byte pieces, nt", thr, 256, 16, grid, buf, wg_stride, dstamps);
             run<0, false>("64-byte pieces", thr, 256, 16, grid, buf, wg_stride, dstamps);
             run<1, true>("full lines, nt", thr, 256, 16, grid, buf, wg_stride, dstamps);
             run<1, false>("full lines", thr, 256, 16, grid, buf, wg_stride, dstamps);
+            run<3, true>("conv_igemm5 rows (64 KB apart), nt", thr, 256, 16, grid, buf, wg_stride, dstamps);
+            run<3, false>("conv_igemm5 rows (64 KB apart)", thr, 256, 16, grid, buf, wg_stride, dstamps);
             run<2, true>("1 KiB contiguous, nt", thr, 256, 16, grid, buf, wg_stride, dstamps);
             run<2, false>("1 KiB contiguous", thr, 256, 16, grid, buf, wg_stride, dstamps);
         }

@@ -87,5 +87,10 @@ for slot in range(2):
                 continue
             rel = (2 * nsl - 3 + it) % nsl - (nsl - 1)
             nxt = s[it + 1][0] if it + 1 < NIT and s[it + 1][0] else t[7]
+            if os.environ.get("V5_STAMPS_EPI"):      # build with -DCMU_IG_STAMPS -DCMU_IG_STAMPS_EPI: slots 1, 2 are taken INSIDE the epilogue
+                if rel == 0:
+                    print(f"  pos {rel:+3d} (last): mfma {t[3] - t[0]:6d}  barrier {t[4] - t[3]:6d}  stage {t[5] - t[4]:6d}  epilogue: part A (statistics / constants) {t[1] - t[5]:6d}"
+                          f"  part B (conversion + stores / rows) {t[2] - t[1]:6d}  part C (rest: folds, clearing) {t[6] - t[2]:6d}  tail {t[7] - t[6]:6d}")
+                continue
             print(f"  pos {rel:+3d}{' (last)' if rel == 0 else '       '}: tap0 {t[1] - t[0]:6d}  tap1 {t[2] - t[1]:6d}  taps2-8 {t[3] - t[2]:6d}  barrier {t[4] - t[3]:6d}  stage {t[5] - t[4]:6d}"
                   f"  epilogue {t[6] - t[5]:6d}  tail {t[7] - t[6]:6d}  | position total {nxt - t[0]:6d}")
