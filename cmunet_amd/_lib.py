@@ -54,6 +54,7 @@ _SIGS = {
     "cmu_version": (_I, []),
     "cmu_set_dispatch_override": (_I, [ctypes.c_char_p, _I]),
     "cmu_mfma_sustained_rate": (_I, [_I, _I, _I, _I, _P, _P, _P, _P]),
+    "cmu_probe_stream_reduce": (_I, [_P, _P, _P, _L, _I, _I, _P]),
     "cmu_dtype_size": (_I, [_I]),
     "cmu_pack_conv3x3_elems": (_L, [_I, _I, _I, _I]),
     "cmu_pack_conv3x3": (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -196,3 +196,34 @@ extern "C" int cmu_mfma_sustained_rate(int dt, int pattern, int lds_fed, int ite
     *clock_mhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
     return CMU_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// cmu_probe_stream_reduce -- a stand-in for a collective's reduction kernel on ONE GPU (round 5, tools/exchange_probe.py): `grid`
+// workgroups of 256 threads sweep out[i] = a[i] + b[i] over n floats `passes` times (RCCL's ring all-reduce of a gradient bucket runs a
+// few dozen such workgroups for bytes / link-rate seconds).  What the probe answers: launched on a side stream where a bucket is announced
+// inside the backward pass, does it make progress beside the persistent conv kernels (one 512-thread workgroup with ~160 KB of LDS and
+// 2 x 248 registers per SIMD on every CU), and what does the backward pass lose?  The kernel keeps 64 floats per lane in registers on purpose
+// (a collective kernel's register footprint: it cannot slip into the 16 registers per SIMD lane the conv workgroups leave free).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stream_reduce_probe_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t n4,
+                                                                 int passes) {
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(b);
+    f32x4* o4 = reinterpret_cast<f32x4*>(out);
+    for (int pass = 0; pass < passes; ++pass) {
+        for (int64_t i0 = (int64_t)blockIdx.x * 256 * 16 + threadIdx.x; i0 < n4; i0 += (int64_t)gridDim.x * 256 * 16) {
+            f32x4 va[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) va[u] = i0 + u * 256 < n4 ? a4[i0 + u * 256] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (i0 + u * 256 < n4) o4[i0 + u * 256] = va[u] + b4[i0 + u * 256];
+        }
+    }
+}
+extern "C" int cmu_probe_stream_reduce(const float* a, const float* b, float* out, int64_t n, int grid, int passes, void* stream) {
+    CMU_CHECK_ARG(a && b && out && n > 0 && n % 4 == 0 && grid > 0 && grid <= 1024 && passes > 0, "cmu_probe_stream_reduce: bad args (n % 4 == 0, grid <= 1024)");
+    hipLaunchKernelGGL(stream_reduce_probe_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4, passes);
+    CMU_CHECK_LAUNCH("cmu_probe_stream_reduce");
+    return CMU_OK;
+}

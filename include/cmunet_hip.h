@@ -605,6 +605,11 @@ int cmu_conv1x1_nchw_fwd(const void* x, int64_t ldx, const float* in_scale, cons
  * after a synchronisation of the stream.  scratch64: 64 bytes of device memory.  Host-blocking; not for the hot path. */
 int cmu_mfma_sustained_rate(int dt, int pattern, int lds_fed, int iters, void* scratch64, double* tflops, double* clock_mhz,
                             void* stream);
+/* Diagnostic (tools/exchange_probe.py): a stand-in for a collective's reduction kernel -- `grid` workgroups of 256
+ * threads compute out = a + b over n floats (n % 4 == 0) `passes` times on `stream`.  Launched on a side stream where a trainer announces a
+ * gradient bucket (reference: DDP's bucketed all-reduce, Pretraining/Spark/main.py:102), it shows on ONE GPU whether such a kernel runs beside
+ * the persistent conv kernels and what the backward pass loses.  Not used by the product path. */
+int cmu_probe_stream_reduce(const float* a, const float* b, float* out, int64_t n, int grid, int passes, void* stream);
 
 #ifdef __cplusplus
 }
