@@ -45,7 +45,7 @@ with open(os.path.join(root, "profiles", f"{tag}_hbm_traffic_per_step.csv"), "w"
 tj = {}
 for k in rows:
     base = k.split("<")[0]
-    if base in ("conv_igemm3p_kernel", "conv_igemm3_kernel", "conv_igemm_kernel", "conv_wgrad2_kernel", "conv_wgrad2s_kernel", "conv_wgrad_kernel", "conv_wgradT2_kernel", "conv_gemm_kernel", "conv_gemm_s_kernel") and trait in k:
+    if base in ("conv_igemm5_kernel", "conv_igemm3p_kernel", "conv_igemm3_kernel", "conv_igemm_kernel", "conv_wgrad2_kernel", "conv_wgrad2s_kernel", "conv_wgrad_kernel", "conv_wgradT2_kernel", "conv_gemm_kernel", "conv_gemm_s_kernel") and trait in k:
         d = tj.setdefault(base, {"launches_per_step": 0, "fetch": 0.0, "write": 0.0, "instances": []})
         d["launches_per_step"] += launches[k]
         d["fetch"] += fetch[k]
