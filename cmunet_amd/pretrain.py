@@ -67,6 +67,40 @@ def default_amp(model, amp):
     return amp
 
 
+_TEST_AFTER_LAUNCH = None      # test hook: callable(flat, lo, hi) run right after a bucket's exchange was started (tests/dp_child.py)
+
+
+def _start_bucket_exchange(flat, lo, hi, group, snapshots):
+    """Start the SUM all-reduce of arena gradient elements [lo, hi).  ``snapshots`` is None in normal operation.  In the debug mode
+    CMU_DP_CHECK_LATE_WRITES=1 (one-rank groups: the SUM is an identity) it is a list: the collective then runs on a COPY of the range
+    taken now, the arena keeps the producer's values, and ``_check_bucket_snapshots`` compares the two after the waits -- any write
+    into the range behind the launch shows, whichever side of the collective's own read / write-back it would have landed on."""
+    if snapshots is not None and dp_exchanges(group) and hi > lo:
+        snap = flat.grad[lo:hi].clone()
+        snapshots.append((lo, hi, snap))
+        w = dist.all_reduce(snap, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    else:
+        w = flat.all_reduce_range_async(lo, hi, group)
+    if _TEST_AFTER_LAUNCH is not None and w is not None:
+        _TEST_AFTER_LAUNCH(flat, lo, hi)
+    return w
+
+
+def _check_bucket_snapshots(flat, snaps, group):
+    if not snaps:
+        return
+    if dp_world(group) != 1:
+        raise RuntimeError("CMU_DP_CHECK_LATE_WRITES=1 compares a bucket with a copy taken at the launch of an IDENTITY all-reduce: use it on a one-rank group")
+    for lo, hi, snap in snaps:
+        now = flat.grad[lo:hi]
+        if not torch.equal(snap.view(torch.int32), now.view(torch.int32)):         # bit for bit (NaNs included)
+            bad = (snap.view(torch.int32) != now.view(torch.int32)).nonzero()
+            first = int(bad[0]) + int(lo)
+            owner = next((n for n, (off, cnt) in flat.offsets.items() if off <= first < off + cnt), "?")
+            raise RuntimeError(f"gradient exchange: {int(bad.numel())} element(s) of the bucket [{lo}, {hi}) were written after its all-reduce had "
+                               f"started (first: arena index {first}, parameter {owner})")
+
+
 class MaskedReconPretrainer:
     """One object = model + flat arenas + fused AdamW + (optional) data-parallel group."""
 
@@ -136,6 +170,8 @@ class MaskedReconPretrainer:
                                self.rc_weight * self.loss_scale, self._ws, self.amp)
         eng.grad_target, eng.grad_prefix = self.flat.grad_views, ""
         self._pending = []
+        self._snaps = []
+        late_check = os.environ.get("CMU_DP_CHECK_LATE_WRITES", "0") == "1"      # debug: see ArenaTrainer.__init__
         exch = dp_exchanges(self.group)
         # what the exchange of this step looked like (bench.py prints it next to the RCCL world size): buckets, how many of them
         # were started from inside the backward pass, bytes left for after it
@@ -144,14 +180,14 @@ class MaskedReconPretrainer:
 
         def decoder_done():
             if self._dec_off is not None:
-                self._pending.append(self.flat.all_reduce_range_async(self._dec_off, self.flat.grad.numel(), self.group))
+                self._pending.append(_start_bucket_exchange(self.flat, self._dec_off, self.flat.grad.numel(), self.group, self._snaps if late_check else None))
                 if exch:
                     self.last_exchange["early"] += 1
                     self.last_exchange["exposed_bytes"] -= 4 * int(self.flat.grad.numel() - self._dec_off)
 
         def bottleneck_done():
             if self._bott is not None:
-                self._pending.append(self.flat.all_reduce_range_async(self._bott[0], self._bott[1], self.group))
+                self._pending.append(_start_bucket_exchange(self.flat, self._bott[0], self._bott[1], self.group, self._snaps if late_check else None))
                 if exch:
                     self.last_exchange["early"] += 1
                     self.last_exchange["exposed_bytes"] -= 4 * int(self._bott[1] - self._bott[0])
@@ -186,6 +222,8 @@ class MaskedReconPretrainer:
                 e1.record()
                 self._exposed_events = (e0, e1)
             self._pending = []
+            snaps, self._snaps = getattr(self, "_snaps", []), []
+            _check_bucket_snapshots(self.flat, snaps, self.group)
         else:
             self.flat.all_reduce_mean(self.group)
         return 1.0 / world
@@ -244,6 +282,12 @@ class ArenaTrainer:
         self._bucket_of = {n: b for b in self._buckets for n in b["names"]}
         self._ov_active = False
         self._works = []
+        # Debug mode (CMU_DP_CHECK_LATE_WRITES=1, meant for one-rank groups -- CMU_DP_REHEARSE=1 -- where the SUM all-reduce is an
+        # identity): every bucket's range is copied when its exchange STARTS and compared after all exchanges were waited for; a
+        # gradient written into a bucket after its all-reduce was launched (what the in-forward announcements of SparK's fused node
+        # and the fused nodes' ``notify_ready`` must never allow) raises instead of silently exchanging a stale value (advisor, round 4).
+        self._late_check = os.environ.get("CMU_DP_CHECK_LATE_WRITES", "0") == "1"
+        self._snapshots = []
         # (hooks hold the trainer weakly: a model that outlives its trainer keeps no arena alive, and a dead trainer's hooks are no-ops)
         import weakref
         me = weakref.ref(self)
@@ -269,6 +313,7 @@ class ArenaTrainer:
         for b in self._buckets:
             b["pending"], b["launched"] = len(b["names"]), False
         self._works = []
+        self._snapshots = []
         self._ov_active = True
         # per step: how many buckets started from inside a fused node ("early"), from autograd's hooks ("in_backward") or only after
         # the backward pass ("flushed"), with their bytes; "exposed_bytes" = the flushed ones (nothing left to hide them under)
@@ -279,7 +324,7 @@ class ArenaTrainer:
         """Gradients of bucket ``b`` are final: bring stragglers into the arena, start its all-reduce (async, on the group's stream)."""
         b["launched"] = True
         self.flat.gather_names(b["names"])
-        w = self.flat.all_reduce_range_async(b["lo"], b["hi"], self.group)
+        w = self._start_exchange(b["lo"], b["hi"])
         if w is not None:
             self._works.append(w)
 
@@ -311,7 +356,7 @@ class ArenaTrainer:
                 b["launched"] = True          # (their hooks fire when the node returns: nothing left to do then)
                 self.last_exchange["early"] += 1
                 self.last_exchange["bytes_early"] += 4 * int(b["hi"] - b["lo"])
-                w = self.flat.all_reduce_range_async(b["lo"], b["hi"], self.group)
+                w = self._start_exchange(b["lo"], b["hi"])
                 if w is not None:
                     self._works.append(w)
 
@@ -327,6 +372,14 @@ class ArenaTrainer:
         from .optim import _SINKS_CLAIMED
         _SINKS_CLAIMED.difference_update(id(p) for p in self.flat.params.values())
         self._wait_works()
+        self._check_snapshots()
+
+    def _start_exchange(self, lo, hi):
+        return _start_bucket_exchange(self.flat, lo, hi, self.group, self._snapshots if self._late_check else None)
+
+    def _check_snapshots(self):
+        snaps, self._snapshots = self._snapshots, []
+        _check_bucket_snapshots(self.flat, snaps, self.group)
 
     def _wait_works(self):
         """Wait for every exchange in flight.  TIMED when ``self.time_exchange`` is set (bench.py, tests): ``wait_ms`` is the host clock
@@ -356,6 +409,7 @@ class ArenaTrainer:
                 w.wait()
         finally:
             self._works = []
+            self._snapshots = []
             _SINKS_CLAIMED.difference_update(id(p) for p in self.flat.params.values())
             for b in self._buckets:
                 b["pending"], b["launched"] = len(b["names"]), False

@@ -26,9 +26,35 @@ def main():
     backend = os.environ.get("CMU_DIST_BACKEND", "gloo")
     dev = torch.device("cuda", rank if (backend == "nccl" and torch.cuda.device_count() > rank) else 0)
     torch.cuda.set_device(dev)
-    if world > 1:
+    rehearse = world == 1 and os.environ.get("CMU_DP_REHEARSE") == "1"       # a one-rank group that runs every collective
+    if world > 1 or rehearse:
+        if rehearse:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", opts.get("port", "29531"))
         dist.init_process_group(backend, rank=rank, world_size=world)
     from cmunet_amd import pretrain as P
+    if opts.get("late") == "1":
+        # a gradient written into a bucket BEHIND its all-reduce (what CMU_DP_CHECK_LATE_WRITES=1 must catch): the first early exchange
+        # of the run is followed by a write into its range
+        fired = []
+
+        def late(flat, lo, hi):
+            if not fired:
+                fired.append((lo, hi))
+                flat.grad[lo:lo + 1] += 1.0
+        P._TEST_AFTER_LAUNCH = late
+    try:
+        _run(mode, out, opts, world, rank, dev, P)
+    except RuntimeError as e:
+        if opts.get("late") != "1":
+            raise
+        torch.save({"raised": str(e)}, f"{out}.{rank}")
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _run(mode, out, opts, world, rank, dev, P):
     from oracle import unet as OU
     steps = int(opts.get("steps", "2"))
     dseed = 100 + (rank if opts.get("data") == "rank" else 0)
@@ -183,9 +209,6 @@ def main():
     else:
         raise SystemExit(f"unknown mode {mode}")
     torch.save(res, f"{out}.{rank}")
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

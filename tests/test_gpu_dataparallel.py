@@ -350,12 +350,34 @@ def test_arena_trainers_overlapped_exchange_is_bit_identical(cuda, mode):
     assert plain[0]["exchange"] is None or plain[0]["exchange"].get("early", 0) == 0
 
 
+@pytest.mark.parametrize("mode", ["recon", "joint", "moco", "spark"])
+def test_no_gradient_is_written_behind_its_bucket_exchange(cuda, mode):
+    """The in-forward / in-backward bucket announcements are the only guarantee that no gradient of a bucket is written after that
+    bucket's all-reduce started (advisor, round 4): on a one-rank group (CMU_DP_REHEARSE=1: the SUM is an identity, a late write would
+    pass every equal-loss test) CMU_DP_CHECK_LATE_WRITES=1 copies each bucket when its exchange starts and compares it bit for bit
+    after the waits.  The trainers' own steps pass; a deliberate write behind the first exchange (late=1) is caught."""
+    env = {"CMU_DP_REHEARSE": "1", "CMU_DP_CHECK_LATE_WRITES": "1"}
+    keys = {"recon": ("losses",), "spark": ("losses",), "joint": ("loss_ct", "loss_rc"), "moco": ("loss",)}[mode]
+    ok = run_ranks(mode, 1, extra_env=env, port=_free_port())[0]
+    assert "raised" not in ok
+    plain = run_ranks(mode, 1)[0]
+    for k in keys:
+        assert np.all(np.isfinite(ok[k])) and ok[k] == plain[k], (k, ok[k], plain[k])
+    if mode != "recon":
+        ex = ok["exchange"]
+        assert ex is not None and ex["early"] + ex["in_backward"] >= 1, ex       # exchanges really started inside the step
+    bad = run_ranks(mode, 1, extra_env=env, port=_free_port(), late=1)[0]
+    assert "raised" in bad and "after its all-reduce had started" in bad["raised"], bad
+
+
 @pytest.mark.parametrize("workload", ["recon", "joint", "moco", "spark"])
 def test_bench_step_on_a_one_rank_rccl_group(cuda, workload):
     """The collectives of every trainer on RCCL itself (backend "nccl"): bench.py as ONE rank of an initialised group with
     CMU_DP_REHEARSE=1 -- the overlapped bucket all-reduces behind the backward, the arena all-reduce, the embedding all-gathers,
     the barrier and the MAX over ranks all run on the process group's stream -- must give the loss of the same steps without a group
-    (a SUM over one rank is the identity).  Two RCCL ranks cannot share the one card of this box; the two-rank tests above use gloo."""
+    (a SUM over one rank is the identity).  Two RCCL ranks cannot share the one card of this box; the two-rank tests above use gloo.
+    CMU_DP_CHECK_LATE_WRITES=1: every bucket is copied when its exchange starts and compared after the waits -- a gradient written into
+    a bucket behind its (identity) all-reduce, which equal losses would not show, raises."""
     import json
     root = os.path.dirname(HERE)
     argv = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "4", "--size", "128",
@@ -365,7 +387,7 @@ def test_bench_step_on_a_one_rank_rccl_group(cuda, workload):
         base.pop(k, None)
     lines = []
     for env in (base, dict(base, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
-                           CMU_DP_REHEARSE="1")):
+                           CMU_DP_REHEARSE="1", CMU_DP_CHECK_LATE_WRITES="1")):
         r = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=420)
         assert r.returncode == 0, r.stderr[-2000:]
         lines.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]))
