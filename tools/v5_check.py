@@ -68,37 +68,43 @@ def case(H, Cin, Cout, mode):
     shift = torch.randn(Cin, device=dev) * 0.1
     mean = torch.randn(Cin, device=dev) * 0.1
     invstd = torch.rand(Cin, device=dev) + 0.5
+    # Fair protocol (round 5, after the first form of this tool was found to favour whichever kernel ran SECOND by up to 4 %: fresh output
+    # buffers per variant): ONE set of output buffers, the two kernels alternate (old, v5, old, v5, old, v5), the reported time of each is the
+    # median of its three measurements.
+    tf = mode == "fwd_tf"
+    if mode in ("fwd_tf", "fwd"):
+        wp = pack(w, 0)
+        y = torch.full((B, H, W, Cout), float("nan"), dtype=TDT, device=dev)
+        stats = torch.full((ntiles * 2 * Cout,), float("nan"), device=dev)
+
+        def run():
+            rc = lib.cmu_conv3x3_fwd(vp(x.data_ptr()), i64(Cin), vp(sc.data_ptr() if tf else 0), vp(sh.data_ptr() if tf else 0), 0, vp(wp.data_ptr()),
+                                     vp(y.data_ptr()), i64(Cout), vp(stats.data_ptr()), B, H, W, Cin, Cout, DT, vp(0))
+            assert rc == 0, lib.cmu_last_error()
+        outs = (y, stats)
+    else:   # dgrad_bn: dY (B,H,W,K=Cout of the layer) -> dX (N = Cin of the layer) + BN-backward sums of the producer
+        K, N = Cout, Cin
+        wp = pack(w, 1)   # w: (Cout, Cin, 3, 3) -> flipped pack contracts over Cout
+        dx = torch.full((B, H, W, N), float("nan"), dtype=TDT, device=dev)
+        bst = torch.full((ntiles * 2 * N,), float("nan"), device=dev)
+
+        def run():
+            rc = lib.cmu_conv3x3_dgrad_bn(vp(dy.data_ptr()), i64(K), vp(wp.data_ptr()), vp(dx.data_ptr()), i64(N), vp(yraw.data_ptr()), i64(N),
+                                          vp(scale.data_ptr()), vp(shift.data_ptr()), vp(mean.data_ptr()), vp(invstd.data_ptr()), vp(bst.data_ptr()),
+                                          B, H, W, K, N, DT, vp(0))
+            assert rc == 0, lib.cmu_last_error()
+        outs = (dx, bst)
+    times = {0: [], 1: []}
+    for rnd in range(3):
+        for v in (0, 1):
+            override(v)
+            run()
+            kern = lib.cmu_last_kernel().decode()
+            times[v].append(timeit(run))
+            if rnd == 0:
+                res[v] = [outs[0].clone(), outs[1].clone(), 0.0, kern]
     for v in (0, 1):
-        override(v)
-        if mode == "fwd_tf" or mode == "fwd":
-            wp = pack(w, 0)
-            y = torch.full((B, H, W, Cout), float("nan"), dtype=TDT, device=dev)
-            stats = torch.full((ntiles * 2 * Cout,), float("nan"), device=dev)
-            tf = mode == "fwd_tf"
-
-            def run():
-                rc = lib.cmu_conv3x3_fwd(vp(x.data_ptr()), i64(Cin), vp(sc.data_ptr() if tf else 0), vp(sh.data_ptr() if tf else 0), 0, vp(wp.data_ptr()),
-                                         vp(y.data_ptr()), i64(Cout), vp(stats.data_ptr()), B, H, W, Cin, Cout, DT, vp(0))
-                assert rc == 0, lib.cmu_last_error()
-            run()
-            kern = lib.cmu_last_kernel().decode()
-            ms = timeit(run)
-            res[v] = (y.clone(), stats.clone(), ms, kern)
-        else:   # dgrad_bn: dY (B,H,W,K=Cout of the layer) -> dX (N = Cin of the layer) + BN-backward sums of the producer
-            K, N = Cout, Cin
-            wp = pack(w, 1)   # w: (Cout, Cin, 3, 3) -> flipped pack contracts over Cout
-            dx = torch.full((B, H, W, N), float("nan"), dtype=TDT, device=dev)
-            bst = torch.full((ntiles * 2 * N,), float("nan"), device=dev)
-
-            def run():
-                rc = lib.cmu_conv3x3_dgrad_bn(vp(dy.data_ptr()), i64(K), vp(wp.data_ptr()), vp(dx.data_ptr()), i64(N), vp(yraw.data_ptr()), i64(N),
-                                              vp(scale.data_ptr()), vp(shift.data_ptr()), vp(mean.data_ptr()), vp(invstd.data_ptr()), vp(bst.data_ptr()),
-                                              B, H, W, K, N, DT, vp(0))
-                assert rc == 0, lib.cmu_last_error()
-            run()
-            kern = lib.cmu_last_kernel().decode()
-            ms = timeit(run)
-            res[v] = (dx.clone(), bst.clone(), ms, kern)
+        res[v][2] = sorted(times[v])[1]
     override(-1)
     y0, s0, ms0, k0 = res[0]
     y1, s1, ms1, k1 = res[1]
