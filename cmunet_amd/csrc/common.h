@@ -34,8 +34,9 @@ static inline bool cmu_aligned16(const void* p) { return (reinterpret_cast<uintp
 // Dispatch switches that tests A/B inside ONE process (elementwise.hip): the environment variable of the same name is read ONCE
 // (no getenv on the launch path: an environment scan per conv launch, racing with setenv from loader threads -- advisor, round 3);
 // cmu_set_dispatch_override (test entry of the C-ABI) forces a value afterwards.  Default of every switch: on.
-enum CmuSwitch { CMU_SW_CONV_NARROW = 0, CMU_SW_CONV_SLIM, CMU_SW_CONV_PERSIST_PART, CMU_SW_WGRAD_SQUARE, CMU_SW_WGRAD_WIDE_F32, CMU_SW_CONV_V5, CMU_SW_COUNT };
+enum CmuSwitch { CMU_SW_CONV_NARROW = 0, CMU_SW_CONV_SLIM, CMU_SW_CONV_PERSIST_PART, CMU_SW_WGRAD_SQUARE, CMU_SW_WGRAD_WIDE_F32, CMU_SW_CONV_V5, CMU_SW_CONV_V6, CMU_SW_COUNT };
 bool cmu_switch_on(int id);
+bool cmu_switch_forced(int id);
 
 // the calling thread's current HIP device (the one its launches go to)
 static inline int cmu_current_device() {

@@ -539,6 +539,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IGParams p) {
 #include "conv_igemm3.inc"
 #include "conv_igemm3p.inc"
 #include "conv_igemm5.inc"
+#include "conv_igemm6.inc"
 #include "conv_gemm.inc"
 #include "conv_gather.inc"
 

@@ -27,9 +27,9 @@ extern "C" int cmu_version(void) { return 100; }
 
 // ---- dispatch switches (common.h: CmuSwitch) -----------------------------------------------------------------------------------
 static const char* const g_switch_names[CMU_SW_COUNT] = {"CMU_CONV_NARROW", "CMU_CONV_SLIM", "CMU_CONV_PERSIST_PART", "CMU_WGRAD_SQUARE",
-                                                         "CMU_WGRAD_WIDE_F32", "CMU_CONV_V5"};
-static int g_switch_env[CMU_SW_COUNT] = {-1, -1, -1, -1, -1, -1};        // -1: environment not read yet; 0 / 1 afterwards
-static int g_switch_override[CMU_SW_COUNT] = {-1, -1, -1, -1, -1, -1};   // -1: no override
+                                                         "CMU_WGRAD_WIDE_F32", "CMU_CONV_V5", "CMU_CONV_V6"};
+static int g_switch_env[CMU_SW_COUNT] = {-1, -1, -1, -1, -1, -1, -1};        // -1: environment not read yet; 0 / 1 afterwards
+static int g_switch_override[CMU_SW_COUNT] = {-1, -1, -1, -1, -1, -1, -1};   // -1: no override
 bool cmu_switch_on(int id) {
     const int ov = __atomic_load_n(&g_switch_override[id], __ATOMIC_RELAXED);
     if (ov >= 0) return ov != 0;
@@ -41,6 +41,8 @@ bool cmu_switch_on(int id) {
     }
     return v != 0;
 }
+// 1 while a test forces the switch ON through cmu_set_dispatch_override (conv_igemm6: a forced switch also lifts the launch-size gates)
+bool cmu_switch_forced(int id) { return __atomic_load_n(&g_switch_override[id], __ATOMIC_RELAXED) == 1; }
 #include <mutex>
 static std::mutex g_switch_mutex;   // (test hook: concurrent setters are serialised; readers on the launch path take relaxed atomic loads)
 extern "C" int cmu_set_dispatch_override(const char* name, int value) {

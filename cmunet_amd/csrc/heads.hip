@@ -961,12 +961,15 @@ __global__ __launch_bounds__(256) void row_ce_kernel(const float* __restrict__ l
     __shared__ float red[4];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* x = logits + (int64_t)b * N;
-    const int t = (int)target[b];
+    // a target outside [0, N) (F.cross_entropy asserts on it): no read outside the row -- the row's loss, and with it the mean, becomes NaN
+    const int64_t t64 = target[b];
+    const bool t_ok = t64 >= 0 && t64 < (int64_t)N;
+    const int t = t_ok ? (int)t64 : 0;
     float m = -__builtin_inff();
     for (int j = tid; j < N; j += 256) m = fmaxf(m, x[j]);
     m = block_max(m, red);
     __syncthreads();
-    const float xt = x[t];
+    const float xt = t_ok ? x[t] : __builtin_nanf("");
     float s = 0.f, above = 0.f;
     for (int j = tid; j < N; j += 256) {
         s += __expf(x[j] - m);

@@ -141,7 +141,8 @@ class _RowCrossEntropyFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, go):
-        dl, ctx.dl = ctx.dl, None
+        # (scaled into a fresh tensor: ctx.dl survives a backward with retain_graph=True, as F.cross_entropy's saved tensors do)
+        dl = ctx.dl.clone()
         ops.scale_by_device_scalar(dl, go.float().contiguous())
         return dl, None
 

@@ -449,7 +449,17 @@ def row_cross_entropy(logits, target, want_grad=True, want_rank=False):
 
 
 def patchify(x, h, w, p, inverse=False):
-    """SparK.patchify (inverse False: (B, C, h*p, w*p) -> (B, h*w, p*p*C)) / unpatchify (inverse True) on cmu_patchify, fp32."""
+    """SparK.patchify (inverse False: (B, C, h*p, w*p) -> (B, h*w, p*p*C)) / unpatchify (inverse True) on cmu_patchify, fp32.
+    Contract: CUDA tensors, no autograd (the reference's einsum form is differentiable; here it serves the `vis` path only).
+    A shape that does not match (h, w, p) raises, as the reference's reshape does (spark.py:133-149)."""
+    if not x.is_cuda:
+        raise RuntimeError("ops.patchify: CUDA tensor required (no CPU fallback)")
+    if not inverse:
+        if x.dim() != 4 or x.shape[2] != h * p or x.shape[3] != w * p:
+            raise ValueError(f"patchify: input {tuple(x.shape)} is not (B, C, {h * p}, {w * p}) for h={h}, w={w}, p={p}")
+    else:
+        if x.dim() != 3 or x.shape[1] != h * w or x.shape[2] % (p * p) != 0 or x.shape[2] == 0:
+            raise ValueError(f"unpatchify: input {tuple(x.shape)} is not (B, {h * w}, {p * p}*C) for h={h}, w={w}, p={p}")
     x = x.float().contiguous()
     if not inverse:
         B, C = x.shape[:2]

@@ -461,11 +461,15 @@ class ArenaTrainer:
         if self._overlap and dp_exchanges(self.group):
             if not overlap_begun:
                 self._begin_overlap()
+            # (a raise in the backward pass or in the waits: every arena trainer gets the cleanup SparKPretrainer.step has -- in-flight
+            # all-reduces waited for, gradient sinks released, buckets reset -- before the exception travels on)
             try:
                 loss.backward()
-            finally:
                 self._ov_active = False
-            self._finish_overlap()
+                self._finish_overlap()
+            except BaseException:
+                self._abort_overlap()
+                raise
             scale = 1.0 / self.world()
         else:
             loss.backward()

@@ -19,10 +19,13 @@ vp, i64 = ctypes.c_void_p, ctypes.c_int64
 DT = int(os.environ.get("CMU_SWEEP_DT", "1"))
 TDT = {1: torch.float16, 2: torch.bfloat16}[DT]
 B = int(os.environ.get("CMU_SWEEP_B", 32))
+# round 6: V_SWITCH=CMU_CONV_V6 compares conv_igemm6 (64-channel items) with what the shape ran on before; V5_MODES="fwd_tf,fwd" picks the forms
+SWITCH = os.environ.get("V_SWITCH", "CMU_CONV_V5").encode()
+MODES = tuple(os.environ.get("V5_MODES", "fwd_tf,fwd,dgrad_bn").split(","))
 
 
 def override(v):
-    rc = lib.cmu_set_dispatch_override(b"CMU_CONV_V5", v)
+    rc = lib.cmu_set_dispatch_override(SWITCH, v)
     assert rc == 0, lib.cmu_last_error()
 
 
@@ -111,7 +114,7 @@ def case(H, Cin, Cout, mode):
     ry, rs = rel(y1, y0), rel(s1, s0)
     Kc, Nc = (Cin, Cout) if mode != "dgrad_bn" else (Cout, Cin)
     fl = 2.0 * B * H * W * Kc * Nc * 9
-    print(f"{mode:8s} {Cin:4d}->{Cout:4d} @{H:3d} B={B}: old {ms0:.3f} ms {fl / ms0 / 1e9:5.0f} TF [{k0}] | v5 {ms1:.3f} ms {fl / ms1 / 1e9:5.0f} TF [{k1}]"
+    print(f"{mode:8s} {Cin:4d}->{Cout:4d} @{H:3d} B={B}: old {ms0:.3f} ms {fl / ms0 / 1e9:5.0f} TF [{k0}] | new {ms1:.3f} ms {fl / ms1 / 1e9:5.0f} TF [{k1}]"
           f" | y relL2 {ry[0]:.2e} max {ry[1]:.2e} nan {int(torch.isnan(y1).sum())} | stats relL2 {rs[0]:.2e} nan {int(torch.isnan(s1).sum())}", flush=True)
 
 
@@ -121,7 +124,7 @@ if QUICK:
 if os.environ.get("V5_SHAPES"):
     shapes = [tuple(int(v) for v in t.split(",")) for t in os.environ["V5_SHAPES"].split(";")]
 for (H, ci, co) in shapes:
-    for mode in ("fwd_tf", "fwd", "dgrad_bn"):
+    for mode in MODES:
         if mode == "dgrad_bn" and ci % 128 != 0:
             continue
         case(H, ci, co, mode)
