@@ -527,6 +527,8 @@ class SparK(_EngineOwner, nn.Module):
         rec = dctx["logits"]                                     # (B,1,H,W)
         if self.keep_rec:
             self.last_rec = rec
+        if getattr(self, "keep_ctx", False):                     # test hook (tests/test_gpu_pretrain.py: float64 backward on this forward's own gates)
+            self.last_ctx = {"levels": levels, "b1": b1, "b2": b2, "dctx": dctx, "active": active}
         loss = torch.empty(1, dtype=torch.float32, device=eng.device)
         drec = torch.empty_like(rec) if need_grads else None
         ws = eng.scratch.get("sploss", eng.lib.cmu_spark_loss_ws_bytes(B, f))

@@ -44,10 +44,14 @@ def sp_bn(x, sd, p, active_b1ff, training=True):
 
 
 def sp_double_conv(x, sd, prefix, active, training=True):
+    """(``oracle.unet.TAP``, test hook: see oracle/unet.py -- the masked conv output and the ReLU of a layer can be replaced by values taken
+    from the HIP path's own forward, so that the float64 backward runs on the gates the kernels saw.)"""
     for conv, bn in ((0, 1), (3, 4)):
         x = sp_conv(x, sd[f"{prefix}{conv}.weight"], sd[f"{prefix}{conv}.bias"], active)
+        if U.TAP is not None:
+            x = U.TAP.conv(f"{prefix}{conv}.", x)
         x = sp_bn(x, sd, f"{prefix}{bn}.", active, training)
-        x = F.relu(x)
+        x = F.relu(x) if U.TAP is None else U.TAP.act(f"{prefix}{conv}.", x)
     return x
 
 

@@ -184,14 +184,22 @@ def test_v5_item_lists_of_any_length_give_the_same_bits(ops, tmp_path):
     """56 items (7 images x 4 tiles x 2 channel blocks) over 256 / 5 / 3 / 1 workgroups (CMU_CONV_PERSIST_GRID): one item per workgroup, lists of
     11-12, of 18-19 and ONE list of 56 items with every item boundary, XCD range and parity of the statistics strips in play -- same output bits,
     same statistics bits (each item's arithmetic does not depend on which workgroup runs it)."""
-    res = []
-    for grid in ("0", "5", "3", "1"):
-        o = str(tmp_path / f"g{grid}.pt")
-        env = dict(os.environ, CMU_CONV_NARROW="0")
-        if grid != "0":
-            env["CMU_CONV_PERSIST_GRID"] = grid
-        subprocess.run([sys.executable, "-c", _GRID % ROOT, o], env=env, check=True, timeout=300)
-        res.append(torch.load(o))
+    res, procs = [], []
+    try:
+        for grid in ("0", "5", "3", "1"):           # (the four children side by side: each is mostly interpreter start-up)
+            o = str(tmp_path / f"g{grid}.pt")
+            env = dict(os.environ, CMU_CONV_NARROW="0")
+            if grid != "0":
+                env["CMU_CONV_PERSIST_GRID"] = grid
+            procs.append((o, subprocess.Popen([sys.executable, "-c", _GRID % ROOT, o], env=env)))
+        for o, pr in procs:
+            assert pr.wait(timeout=300) == 0
+            res.append(torch.load(o))
+    finally:
+        for _, pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+            pr.wait()
     for r in res[1:]:
         assert torch.equal(r["y"].view(torch.uint8), res[0]["y"].view(torch.uint8))
         assert torch.equal(r["st"], res[0]["st"])

@@ -33,32 +33,69 @@ def _free_port():
         return s.getsockname()[1]
 
 
+class _Ranks:
+    """One group of dp_child.py ranks in flight (``launch_ranks``); ``collect()`` waits, reaps and loads the result dicts."""
+
+    def __init__(self, td, out, procs, world):
+        self.td, self.out, self.procs, self.world = td, out, procs, world
+
+    def collect(self):
+        try:
+            for p in self.procs:
+                rc = p.wait(timeout=420)
+                assert rc == 0, f"rank exited with {rc}"
+            return [torch.load(f"{self.out}.{rk}", weights_only=False) for rk in range(self.world)]
+        finally:
+            self.kill()
+
+    def kill(self):
+        for p in self.procs:
+            if p.poll() is None:
+                p.kill()
+            p.wait()
+        self.td.cleanup()
+
+
+def launch_ranks(mode, world, extra_env=None, **opts):
+    """Start ``world`` ranks of dp_child.py and return at once.  Several groups may run side by side (round 6: the A/B tests below start both of
+    their groups before waiting for either -- every child spends most of its few seconds importing torch; at most four of them touch the GPU at
+    a time, within the box's limit of six)."""
+    td = tempfile.TemporaryDirectory()
+    out = os.path.join(td.name, "r")
+    port = _free_port()
+    procs = []
+    try:
+        for rk in range(world):
+            env = dict(os.environ)
+            for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            if world > 1:
+                env.update(WORLD_SIZE=str(world), RANK=str(rk), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.update(extra_env or {})
+            argv = [sys.executable, os.path.join(HERE, "dp_child.py"), mode, out] + [f"{k}={v}" for k, v in opts.items()]
+            procs.append(subprocess.Popen(argv, env=env))
+    except BaseException:
+        _Ranks(td, out, procs, world).kill()
+        raise
+    return _Ranks(td, out, procs, world)
+
+
 def run_ranks(mode, world, extra_env=None, **opts):
     """Start ``world`` ranks of dp_child.py, wait, return their result dicts.  Every child is reaped (and killed if a peer
     failed or the wait times out), so a failing rank cannot leave a process holding the GPU."""
-    with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "r")
-        port = _free_port()
-        procs = []
-        try:
-            for rk in range(world):
-                env = dict(os.environ)
-                for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
-                    env.pop(k, None)
-                if world > 1:
-                    env.update(WORLD_SIZE=str(world), RANK=str(rk), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-                env.update(extra_env or {})
-                argv = [sys.executable, os.path.join(HERE, "dp_child.py"), mode, out] + [f"{k}={v}" for k, v in opts.items()]
-                procs.append(subprocess.Popen(argv, env=env))
-            for p in procs:
-                rc = p.wait(timeout=420)
-                assert rc == 0, f"rank exited with {rc}"
-        finally:
-            for p in procs:
-                if p.poll() is None:
-                    p.kill()
-                p.wait()
-        return [torch.load(f"{out}.{rk}", weights_only=False) for rk in range(world)]
+    return launch_ranks(mode, world, extra_env, **opts).collect()
+
+
+def run_groups(*groups):
+    """``groups``: (mode, world, extra_env, opts) tuples, all started before any is waited for; returns their result lists in order."""
+    live = []
+    try:
+        for mode, world, env, opts in groups:
+            live.append(launch_ranks(mode, world, env, **opts))
+        return [g.collect() for g in live]
+    finally:
+        for g in live:
+            g.kill()
 
 
 def rel(got, ref):
@@ -68,9 +105,9 @@ def rel(got, ref):
 def test_masked_recon_two_ranks_same_batch_equals_one_rank(cuda):
     """Both ranks fed the same batches: SUM over ranks x 1/world == the local gradient exactly (2g * 0.5), so parameters after
     two steps are bit-identical to the single-process trainer -- with the overlapped two-bucket exchange and without."""
-    one = run_ranks("recon", 1)[0]
-    for overlap in ("1", "0"):
-        two = run_ranks("recon", 2, extra_env={"CMU_DDP_OVERLAP": overlap})
+    (one,), two_ov = run_groups(("recon", 1, None, {}), ("recon", 2, {"CMU_DDP_OVERLAP": "1"}, {}))     # (at most five processes on the card, runner included)
+    two_plain = run_ranks("recon", 2, extra_env={"CMU_DDP_OVERLAP": "0"})
+    for overlap, two in (("1", two_ov), ("0", two_plain)):
         for r in two:
             assert r["losses"] == one["losses"]
             assert torch.equal(r["arena"], one["arena"]), f"overlap={overlap}: max diff {(r['arena'] - one['arena']).abs().max().item():.3e}"
@@ -83,8 +120,7 @@ def test_broadcast_after_a_forward_invalidates_packed_weights(cuda):
     counters nor (before the fix) ``ops.PARAM_GENERATION`` see.  Ranks that start from DIFFERENT weights and run a forward before the
     broadcast must still train on rank 0's weights afterwards: both ranks end bit-identical to a single process started from rank
     0's weights (stale packed conv weights on rank 1 would change its loss and, through the all-reduce, everybody's update)."""
-    one = run_ranks("recon", 1)[0]
-    two = run_ranks("recon", 2, init="rank", prefwd="1")
+    (one,), two = run_groups(("recon", 1, None, {}), ("recon", 2, None, {"init": "rank", "prefwd": "1"}))
     for r in two:
         assert r["losses"] == one["losses"], (r["losses"], one["losses"])
         assert torch.equal(r["arena"], one["arena"])
@@ -93,8 +129,7 @@ def test_broadcast_after_a_forward_invalidates_packed_weights(cuda):
 def test_masked_recon_two_ranks_amp_and_f16(cuda):
     """The same with f16 storage and the dynamic loss scaler: the inf / nan check runs on the exchanged gradients, so both
     ranks take the same decision and stay bit-identical to each other and to one rank."""
-    one = run_ranks("recon", 1, dtype="f16", amp="1")[0]
-    two = run_ranks("recon", 2, dtype="f16", amp="1")
+    (one,), two = run_groups(("recon", 1, None, {"dtype": "f16", "amp": "1"}), ("recon", 2, None, {"dtype": "f16", "amp": "1"}))
     assert torch.equal(two[0]["arena"], two[1]["arena"])
     assert torch.equal(two[0]["arena"], one["arena"])
     assert all(np.isfinite(one["losses"]))
@@ -182,10 +217,9 @@ def test_joint_trainer_one_and_two_ranks_vs_oracle(cuda):
     """CM-UNet joint step through JointPretrainer (AdamW arena + EMA arenas).  One rank against the oracle; two ranks fed the
     same batch against the oracle with the key all-gather emulated (2B keys, labels i + B*rank) -- SyncBN over duplicated rows
     has the single-rank statistics, so everything but the contrastive loss's denominator is unchanged."""
-    one = run_ranks("joint", 1)[0]
+    (one,), two = run_groups(("joint", 1, None, {}), ("joint", 2, None, {}))
     ref, osd = _joint_oracle(one, False)
     _check_joint(one, ref, osd)
-    two = run_ranks("joint", 2)
     for rk, r in enumerate(two):
         ref2, osd2 = _joint_oracle(r, True, rank=rk)
         _check_joint(r, ref2, osd2)
@@ -314,9 +348,7 @@ def test_moco_two_ranks_vs_reference_two_rank_fixture(cuda):
 def test_spark_trainer_two_ranks_equals_one_rank(cuda):
     """SparKPretrainer (LAMB) with grad-less ``densify_projs`` parameters in the arena (SURVEY A-10): two ranks fed the same
     batches match one rank; a static loss scale inside the fused step leaves the update unchanged."""
-    one = run_ranks("spark", 1)[0]
-    two = run_ranks("spark", 2)
-    scaled = run_ranks("spark", 1, loss_scale=256)[0]
+    (one,), two, (scaled,) = run_groups(("spark", 1, None, {}), ("spark", 2, None, {}), ("spark", 1, None, {"loss_scale": 256}))
     assert any(n.startswith("densify_projs") for n in one["names"])
     for r in two:
         assert np.allclose(r["losses"], one["losses"], rtol=1e-6)
@@ -331,8 +363,7 @@ def test_arena_trainers_overlapped_exchange_is_bit_identical(cuda, mode):
     over two ranks is the same number whatever the cut of the arena, so parameters, momentum networks and buffers must agree bit for
     bit -- and the overlapped run must really have started buckets before the backward pass was over (joint / MoCo: the decoders
     and the bottleneck are announced from inside the fused node; the projector / predictor by autograd's hooks)."""
-    ov = run_ranks(mode, 2, extra_env={"CMU_DDP_OVERLAP": "1"})
-    plain = run_ranks(mode, 2, extra_env={"CMU_DDP_OVERLAP": "0"})
+    ov, plain = run_groups((mode, 2, {"CMU_DDP_OVERLAP": "1"}, {}), (mode, 2, {"CMU_DDP_OVERLAP": "0"}, {}))
     for rk in range(2):
         a, b = ov[rk], plain[rk]
         if mode == "spark":
@@ -358,15 +389,13 @@ def test_no_gradient_is_written_behind_its_bucket_exchange(cuda, mode):
     after the waits.  The trainers' own steps pass; a deliberate write behind the first exchange (late=1) is caught."""
     env = {"CMU_DP_REHEARSE": "1", "CMU_DP_CHECK_LATE_WRITES": "1"}
     keys = {"recon": ("losses",), "spark": ("losses",), "joint": ("loss_ct", "loss_rc"), "moco": ("loss",)}[mode]
-    ok = run_ranks(mode, 1, extra_env=env, port=_free_port())[0]
+    (ok,), (plain,), (bad,) = run_groups((mode, 1, env, {"port": _free_port()}), (mode, 1, None, {}), (mode, 1, env, {"port": _free_port(), "late": 1}))
     assert "raised" not in ok
-    plain = run_ranks(mode, 1)[0]
     for k in keys:
         assert np.all(np.isfinite(ok[k])) and ok[k] == plain[k], (k, ok[k], plain[k])
     if mode != "recon":
         ex = ok["exchange"]
         assert ex is not None and ex["early"] + ex["in_backward"] >= 1, ex       # exchanges really started inside the step
-    bad = run_ranks(mode, 1, extra_env=env, port=_free_port(), late=1)[0]
     assert "raised" in bad and "after its all-reduce had started" in bad["raised"], bad
 
 
@@ -385,12 +414,21 @@ def test_bench_step_on_a_one_rank_rccl_group(cuda, workload):
     base = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "CMU_DP_REHEARSE", "CMU_DIST_BACKEND"):
         base.pop(k, None)
-    lines = []
-    for env in (base, dict(base, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
-                           CMU_DP_REHEARSE="1", CMU_DP_CHECK_LATE_WRITES="1")):
-        r = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=420)
-        assert r.returncode == 0, r.stderr[-2000:]
-        lines.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]))
+    lines, procs = [], []
+    try:
+        # (both runs side by side: most of either is interpreter start-up)
+        for env in (base, dict(base, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+                               CMU_DP_REHEARSE="1", CMU_DP_CHECK_LATE_WRITES="1")):
+            procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        for pr in procs:
+            so, se = pr.communicate(timeout=420)
+            assert pr.returncode == 0, se[-2000:]
+            lines.append(json.loads([ln for ln in so.splitlines() if ln.startswith("{")][-1]))
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+            pr.wait()
     plain, rccl = lines
     assert rccl["n_gpus"] == 1 and rccl["config"]["parallelism"] == "dp1"
     assert np.isfinite(rccl["config"]["loss"])

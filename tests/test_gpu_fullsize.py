@@ -591,11 +591,20 @@ g = torch.Generator().manual_seed(3)
 x = torch.randn(B, 1, 512, 512, generator=g).cuda()
 active = model.mask(B, "cuda", torch.Generator().manual_seed(5))
 model.grad_scale = 4096.0          # the bench's static loss scale (the activations' gradients are stored in f16)
+model.keep_ctx = True
 loss = model(x, active_b1ff=active)
 loss.backward()
 torch.cuda.synchronize()
-torch.save({"loss": loss.detach().float().cpu(), "grads": {k: (p.grad.float() / 4096.0).cpu() for k, p in model.named_parameters() if p.grad is not None}},
-           sys.argv[1])
+# the ReLU gates of the bottleneck's two convs at the active positions (what the two kernel families may decide differently)
+c = model.last_ctx
+m = c["active"].bool().unsqueeze(-1)
+gates = {}
+for name, st in (("b1", c["b1"]), ("b2", c["b2"])):
+    y = st["y"]
+    z = y.buf[..., y.coff:y.coff + y.C].float() * y.scale + y.shift
+    gates[name] = ((z > 0) & m).cpu()
+torch.save({"loss": loss.detach().float().cpu(), "grads": {k: (p.grad.float() / 4096.0).cpu() for k, p in model.named_parameters() if p.grad is not None},
+            "gates": gates, "n_active": int(m.sum()) * c["b1"]["y"].C}, sys.argv[1])
 '''
 
 
@@ -605,7 +614,14 @@ def test_spark_full_size_list_driven_gradients_vs_dense_kernels(tmp_path):
     against the step on the dense kernels (``CMU_SPARK_TILES=0``: the kernels whose arithmetic the fp64-window tests of this file check at
     this size), per tensor and over all gradients, with the bars of the 128-pixel test (tests/test_gpu_sparse_tiles.py::
     test_spark_step_with_and_without_tile_skipping): the forward is the same arithmetic at every active pixel up to summation order, the
-    sparse BatchNorm over a few hundred positions amplifies the difference.  Every fresh activation starts as NaN (CMU_POISON_NEW)."""
+    sparse BatchNorm over a few hundred positions amplifies the difference.  Every fresh activation starts as NaN (CMU_POISON_NEW).
+    Round 6: the bars are 3 x what was measured (worst tensor 0.105 -> 0.32, all gradients together 2.4e-3 -> 7.5e-3) instead of the small test's
+    0.5 / 0.15, and the worst tensor is explained: it is the bottleneck's FIRST conv weight (``sparse_encoder.sp_cnn.double_conv.double_conv.0.weight``),
+    behind two sparse BatchNorms over 32 x 256 = 8,192 active positions per channel, and the two kernel families -- which round their fp32 sums in
+    another order -- decide 3,656 / 4,194 of the 8,388,608 active ReLU gates of the bottleneck's two convs differently (0.04-0.05 %; counted below,
+    printed and recorded); with the gates FORCED the list-driven backward agrees with the oracle to 1.3e-3 on every tensor at f16
+    (tests/test_gpu_pretrain.py::test_spark_step_gate_forced_backward), so the 10 % is flipped gates
+    through a sparse BatchNorm, not a kernel."""
     import os
     import subprocess
     import sys
@@ -630,8 +646,18 @@ def test_spark_full_size_list_driven_gradients_vs_dense_kernels(tmp_path):
         e = (d2 / max(n2, 1e-30)) ** 0.5
         if e > worst[1]:
             worst = (k, e)
-        assert d2 ** 0.5 <= 0.5 * max(n2 ** 0.5, 1e-12), (k, e)          # per tensor (f16: the small test's bar)
+        assert d2 ** 0.5 <= 0.32 * max(n2 ** 0.5, 1e-12), (k, e)         # per tensor: 3 x the measured worst (0.105)
         num, den = num + d2, den + n2
     tot = (num / den) ** 0.5
-    print(f"[fullsize spark bs 32 f16, list-driven vs dense kernels] {len(b['grads'])} gradients: all together rel L2 {tot:.3e}, worst tensor {worst[0]} {worst[1]:.3e}")
-    assert tot <= 0.15, tot
+    flips = {n: int((a["gates"][n] != b["gates"][n]).sum()) for n in ("b1", "b2")}
+    print(f"[fullsize spark bs 32 f16, list-driven vs dense kernels] {len(b['grads'])} gradients: all together rel L2 {tot:.3e}, worst tensor {worst[0]} {worst[1]:.3e}; "
+          f"ReLU gates decided differently by the two kernel families in the bottleneck: conv 1 {flips['b1']}, conv 2 {flips['b2']} of {a['n_active']} active values each")
+    try:
+        import os as _os
+        with open(_os.path.join(root, "gpurun_out", "parity_record.txt"), "a") as f:
+            f.write(f"SparK full size (bs 32, 512x512, mask 0.75, f16), list-driven vs dense kernels: {len(b['grads'])} gradients, all together rel L2 {tot:.3e}, "
+                    f"worst tensor {worst[0]} {worst[1]:.3e}; bottleneck ReLU gates that differ between the two kernel families: conv 1 {flips['b1']}, "
+                    f"conv 2 {flips['b2']} of {a['n_active']}\n")
+    except OSError:
+        pass
+    assert tot <= 7.5e-3, tot                                             # 3 x the measured 2.4e-3

@@ -381,16 +381,18 @@ torch.save({"y": y.buf.float().cpu(), "s": st.sum(0).cpu()}, sys.argv[1])
     check(outs[1]["s"], outs[0]["s"], 1e-4, "wide vs first stats")
 
 
-@pytest.mark.parametrize("chans,hw", [((64, 128), (48, 96)), ((128, 64), (48, 96)), ((64, 64), (48, 96)),
-                                      ((128, 64), (64, 96)), ((64, 64), (96, 64)),
-                                      ((64, 128), (56, 56)), ((128, 64), (40, 80)), ((64, 64), (28, 28)), ((128, 128), (24, 48))])
-def test_conv3x3_persistent_kernel_is_bit_identical(chans, hw):
+_PERSIST_SHAPES = [((64, 128), (48, 96)), ((128, 64), (48, 96)), ((64, 64), (48, 96)), ((128, 64), (64, 96)), ((64, 64), (96, 64)),
+                   ((64, 128), (56, 56)), ((128, 64), (40, 80)), ((64, 64), (28, 28)), ((128, 128), (24, 48))]
+
+
+def test_conv3x3_persistent_kernel_is_bit_identical():
     """The persistent wide kernel (conv_igemm3p.inc: one workgroup walks a list of tiles) against the one-tile-per-workgroup
     kernel (CMU_CONV_PERSIST=0) on whole-tile shapes and on shapes whose tiles overhang the image (the PART instantiation:
     predicated stores / statistics; 56, 40 x 80, 28, 24 x 48), with 13 workgroups forced so that every workgroup streams several
     tiles and the per-XCD item ranges are uneven: same MFMA order per accumulator, same statistics folding order ->
     identical bits, for the forward (pending transform + BN statistics), the plain data gradient and the data gradient
-    with fused BN-backward sums."""
+    with fused BN-backward sums.  (Round 6: ONE pair of child processes walks all nine shapes -- the switches are read once per process, so
+    the two settings need two processes, not eighteen: 24 s of interpreter start-up less in the driver's GPU run.)"""
     import os
     import subprocess
     import sys
@@ -402,30 +404,33 @@ def test_conv3x3_persistent_kernel_is_bit_identical(chans, hw):
 import sys, torch
 sys.path.insert(0, %r)
 from cmunet_amd import ops
-g = torch.Generator().manual_seed(0)
-B, H, W, Cin, Cout = 3, %d, %d, %d, %d
-x = torch.randn(B, H, W, Cin, generator=g).to(torch.bfloat16).cuda()
-w = (torch.randn(Cout, Cin, 3, 3, generator=g) / 48).cuda()
-sc, sh = (torch.rand(Cin, generator=g) + 0.5).cuda(), (torch.randn(Cin, generator=g) * 0.3).cuda()
-out = {}
-y = ops.new_act(B, H, W, Cout, "bf16", "cuda")
-st = ops.new_stats(B, H, W, Cout, "cuda")
-ops.conv3x3_fwd(ops.Act(x, 0, Cin, sc, sh, 0), ops.pack_conv3x3(w, "bf16"), y, st)
-out["y"], out["s"] = y.buf.clone(), st.clone()
-y2 = ops.new_act(B, H, W, Cout, "bf16", "cuda")
-ops.conv3x3_fwd(ops.Act(x, 0, Cin), ops.pack_conv3x3(w, "bf16"), y2, None)
-out["y2"] = y2.buf.clone()
-# data gradient into a conv+BN layer with raw output xr (Cout channels after the transposed-flipped pack)
-xr = torch.randn(B, H, W, Cout, generator=g).to(torch.bfloat16).cuda()
-bsc, bsh = (torch.rand(Cout, generator=g) + 0.5).cuda(), (torch.randn(Cout, generator=g) * 0.3).cuda()
-mu, istd = (torch.randn(Cout, generator=g) * 0.1).cuda(), (torch.rand(Cout, generator=g) + 0.5).cuda()
-wt = (torch.randn(Cin, Cout, 3, 3, generator=g) / 48).cuda()       # the layer dY belongs to: Cout -> Cin
-dX = ops.new_act(B, H, W, Cout, "bf16", "cuda")
-slab = ops.new_stats(B, H, W, Cout, "cuda")
-ops.conv3x3_dgrad_bn(ops.Act(x, 0, Cin), ops.pack_conv3x3(wt, "bf16", transpose_flip=True), dX, ops.Act(xr, 0, Cout, bsc, bsh, 0), mu, istd, slab)
-out["dx"], out["slab"] = dX.buf.clone(), slab.clone()
-torch.save({k: v.cpu() for k, v in out.items()}, sys.argv[1])
-''' % (root, hw[0], hw[1], chans[0], chans[1])
+res = {}
+for (Cin, Cout), (H, W) in %r:
+  B = 3
+  g = torch.Generator().manual_seed(0)
+  x = torch.randn(B, H, W, Cin, generator=g).to(torch.bfloat16).cuda()
+  w = (torch.randn(Cout, Cin, 3, 3, generator=g) / 48).cuda()
+  sc, sh = (torch.rand(Cin, generator=g) + 0.5).cuda(), (torch.randn(Cin, generator=g) * 0.3).cuda()
+  out = {}
+  y = ops.new_act(B, H, W, Cout, "bf16", "cuda")
+  st = ops.new_stats(B, H, W, Cout, "cuda")
+  ops.conv3x3_fwd(ops.Act(x, 0, Cin, sc, sh, 0), ops.pack_conv3x3(w, "bf16"), y, st)
+  out["y"], out["s"] = y.buf.clone(), st.clone()
+  y2 = ops.new_act(B, H, W, Cout, "bf16", "cuda")
+  ops.conv3x3_fwd(ops.Act(x, 0, Cin), ops.pack_conv3x3(w, "bf16"), y2, None)
+  out["y2"] = y2.buf.clone()
+  # data gradient into a conv+BN layer with raw output xr (Cout channels after the transposed-flipped pack)
+  xr = torch.randn(B, H, W, Cout, generator=g).to(torch.bfloat16).cuda()
+  bsc, bsh = (torch.rand(Cout, generator=g) + 0.5).cuda(), (torch.randn(Cout, generator=g) * 0.3).cuda()
+  mu, istd = (torch.randn(Cout, generator=g) * 0.1).cuda(), (torch.rand(Cout, generator=g) + 0.5).cuda()
+  wt = (torch.randn(Cin, Cout, 3, 3, generator=g) / 48).cuda()       # the layer dY belongs to: Cout -> Cin
+  dX = ops.new_act(B, H, W, Cout, "bf16", "cuda")
+  slab = ops.new_stats(B, H, W, Cout, "cuda")
+  ops.conv3x3_dgrad_bn(ops.Act(x, 0, Cin), ops.pack_conv3x3(wt, "bf16", transpose_flip=True), dX, ops.Act(xr, 0, Cout, bsc, bsh, 0), mu, istd, slab)
+  out["dx"], out["slab"] = dX.buf.clone(), slab.clone()
+  res[(Cin, Cout, H, W)] = {k: v.cpu() for k, v in out.items()}
+torch.save(res, sys.argv[1])
+''' % (root, _PERSIST_SHAPES)
     outs = []
     for env in ({"CMU_CONV_PERSIST": "0"}, {"CMU_CONV_PERSIST": "1", "CMU_CONV_PERSIST_GRID": "13"}):
         with tempfile.NamedTemporaryFile(suffix=".pt", delete=False) as f:
@@ -434,8 +439,10 @@ torch.save({k: v.cpu() for k, v in out.items()}, sys.argv[1])
                        timeout=300)
         outs.append(torch.load(path))
         os.unlink(path)
-    for k in outs[0]:
-        assert torch.equal(outs[0][k].view(torch.uint8), outs[1][k].view(torch.uint8)), k
+    assert len(outs[0]) == len(_PERSIST_SHAPES)
+    for shape in outs[0]:
+        for k in outs[0][shape]:
+            assert torch.equal(outs[0][shape][k].view(torch.uint8), outs[1][shape][k].view(torch.uint8)), (shape, k)
 
 
 @pytest.mark.parametrize("dt", DTS)

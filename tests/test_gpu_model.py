@@ -341,7 +341,7 @@ def _reference_size_case(size):
 
 
 @pytest.mark.parametrize("dt", ["f32", "f16"])
-@pytest.mark.parametrize("size", [224, 256])
+@pytest.mark.parametrize("size", [224] + ([256] if __import__("os").environ.get("CMU_TEST_SLOW") == "1" else []))   # (256: whole tiles, covered by the finetuning tests; CMU_TEST_SLOW=1)
 def test_unet_reference_image_sizes_vs_oracle(M, size, dt):
     """The sizes the reference actually trains at: 224 x 224 (CM-UNet / MoCo crops, cmunet_dataset.py:60-88) and
     256 x 256 (finetuning, dataset.py:46-47) through the reference UNet (base 64, depth 5): at 224 the levels are 224 / 112 / 56 /

@@ -8,6 +8,10 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+# Round 6 (the driver's GPU run took 702 s of its 900 s limit): representatives run by default, their twins -- the second input mask of the joint
+# step's geometry / gate-forced tests (float64 oracle on the CPU: 12-13 s each), the 256-pixel SparK gate-forced case -- with CMU_TEST_SLOW=1
+# (run once per round by the builder; numbers in profiles/r06_parity.txt).
+SLOW = __import__("os").environ.get("CMU_TEST_SLOW") == "1"
 
 
 def _parity_record(line):
@@ -946,16 +950,21 @@ def test_masked_recon_step_gate_forced_backward(cuda, case):
             return a + (layers[key][1].to(z.dtype) - a).detach()
     taps = Taps()
     # the oracle in float64 on the weights the kernels multiply with (16-bit storage: the packed copies hold the rounded weights)
+    # (round 6: float64 where the bar needs it -- f32 storage, 1e-4 -- and float32 for the 16-bit cases, whose bars are 1e-2 / 1e-1: the fp32
+    # oracle sits ~1e-5 from the fp64 one with the gates forced, DESIGN section 2, and runs the CPU convs several times faster: 47 s -> 12 s of the
+    # driver's GPU test run)
+    odt = torch.float64 if dt == "f32" else torch.float32
+
     def wq(k, v):
         if not v.is_floating_point():
             return v.clone()
-        v = v.to(tdt).double() if (v.dim() == 4 and dt != "f32" and "conv_last" not in k) else v.double()
+        v = v.to(tdt).to(odt) if (v.dim() == 4 and dt != "f32" and "conv_last" not in k) else v.to(odt)
         return v.requires_grad_(True) if "running" not in k else v
     osd = {k: wq(k, v) for k, v in sd.items()}
     OU.TAP = taps
     try:
-        out = OU.unet_forward(img.double() * (1 - mask[0]).double(), osd, training=True)
-        ref_loss = OC.masked_mse(out[:, 1], img.double(), mask)
+        out = OU.unet_forward(img.to(odt) * (1 - mask[0]).to(odt), osd, training=True)
+        ref_loss = OC.masked_mse(out[:, 1], img.to(odt), mask)
         ref_loss.backward()
     finally:
         OU.TAP = None
@@ -980,11 +989,11 @@ def test_masked_recon_step_gate_forced_backward(cuda, case):
             worst = (k, e)
         assert e <= bar, f"d{k}: relative L2 error {e:.2e} with the gates forced (bar {bar:.0e}, {dt})"
     print(f"[masked-recon step @ {S} {dt} bs {B} base {base}, oracle backward on the HIP forward] {n} parameter gradients, worst {worst[0]}: {worst[1]:.2e} (bar {bar:.0e})")
-    _parity_record(f"masked-reconstruction step (engine path of MaskedReconPretrainer) {dt} at {S}x{S}, bs {B}, base {base}, depth 5, float64 oracle backward on the HIP "
+    _parity_record(f"masked-reconstruction step (engine path of MaskedReconPretrainer) {dt} at {S}x{S}, bs {B}, base {base}, depth 5, {'float64' if dt == 'f32' else 'float32'} oracle backward on the HIP "
                    f"path's own forward values and ReLU gates: {n} parameter gradients, worst relative L2 error {worst[1]:.2e} ({worst[0]}), bar {bar:.0e}")
 
 
-@pytest.mark.parametrize("mode", ["random65", "tie_free"])
+@pytest.mark.parametrize("mode", ["random65"] + (["tie_free"] if SLOW else []))
 def test_cmunet_joint_step_gate_forced_backward(cuda, mode):
     """The twin of test_cmunet_joint_step_reference_geometry that CAN fail on the conv chain.  Two fp32 implementations of this step
     cannot agree to better than ~3e-3 on the encoder's gradients because a rounding-sized change of the forward flips ReLU gates
@@ -1026,7 +1035,7 @@ def test_cmunet_joint_step_gate_forced_backward(cuda, mode):
         assert e <= 1e-4, f"d{k}: relative L2 error {e:.2e} with the gates forced (bar 1e-4)"
 
 
-@pytest.mark.parametrize("mode", ["random65", "tie_free"])
+@pytest.mark.parametrize("mode", ["random65"] + (["tie_free"] if SLOW else []))
 def test_cmunet_joint_step_reference_geometry(cuda, mode):
     """The joint step at the reference's own geometry (224 x 224 crops, depth 5, projector in_channels = 224*224 =
     50,176 -> 1,536 -> 256, cmunet_config.py:18-26; mask ratio 0.65 -> 127 of 196 patches) with base 32 channels, f32 storage,
@@ -1159,3 +1168,111 @@ def test_spark_patchify_unpatchify_are_the_reference_einsums(cuda):
         assert got.shape == ref.shape and torch.equal(got, ref)
         assert torch.equal(model.unpatchify(got), x)
         assert torch.equal(model.unpatchify(ref), torch.einsum('bhwpqc->bchpwq', ref.reshape(3, h, w, p, p, C)).reshape(3, C, h * p, w * p))
+
+
+@pytest.mark.parametrize("case", [("f32", 128, 8), ("f16", 128, 8)] + ([("f16", 256, 2)] if SLOW else []))
+def test_spark_step_gate_forced_backward(cuda, case):
+    """SparK's list-driven backward pinned the way the dense paths are (round-5 review, item 2): BASELINE config 5's model (base 64, depth 5,
+    ``unet_sparse`` + ``UnetDecoder``, mask ratio 0.75) at 128 x 128, bs 8 (and 256 x 256, bs 2: 16-pixel patches span whole 16 x 32 tiles at level 1,
+    so the tile-list kernels, the gather levels and the patch-organised passes all run), every list-driven switch at its default (on), with the
+    oracle's FLOAT64 backward (``oracle/spark.py``: Spark/encoder.py:20-52, spark.py:88-131) run on the HIP path's OWN forward: the masked raw
+    output, the ReLU gates and the activated values of all ten sparse-encoder convs and eight decoder convs come from the step's saved state
+    (``SparK.keep_ctx``) through ``oracle.unet.TAP``.  A gradient of a ReLU network is discontinuous in its weights, and a sparse
+    BatchNorm over a few hundred active positions amplifies every flip -- so the unforced comparisons of this path need 10 % bars at f16 and cannot
+    tell a kernel that is off by a few per cent from a flipped gate; this one can.  One flat bar on EVERY parameter gradient (87 tensors incl. the
+    mask tokens): 1e-4 (f32) / 1e-2 (f16) relative L2.  Measured (profiles/r06_parity.txt): f32 worst 5.0e-6, f16 1.3e-3; the 256-pixel case
+    (CMU_TEST_SLOW=1; 14 s of float64 on the CPU) 1.25e-3."""
+    dt, S, B = case
+    from cmunet_amd import spark as SP, ops
+    from oracle import spark as OS, unet as OU
+    torch.manual_seed(0)
+    enc = SP.build_sparse_encoder("unet_sparse", input_size=S, dtype=dt)
+    model = SP.SparK(enc, SP.UnetDecoder(dtype=dt), mask_ratio=0.75, densify_norm="", dtype=dt).train()
+    gw = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() == 1 and (".1." in n or ".4." in n):
+                p.add_(0.2 * torch.randn(p.shape, generator=gw))          # BatchNorm weights / biases off their init values
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items() if k != "config"}
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, 1, S, S, generator=g)
+    active = model.mask(B, "cpu", torch.Generator().manual_seed(5))
+    model = model.to(cuda)
+    scale = 1.0 if dt == "f32" else 1024.0
+    model.grad_scale, model.keep_ctx = scale, True
+    loss = model(x.to(cuda), active_b1ff=active.to(cuda))
+    loss.backward()
+    torch.cuda.synchronize()
+    ctx = model.last_ctx
+    tdt = ops.TORCH_DT[ops.dt_code(dt)]
+    layers = {}
+
+    def add(st, act_mask):
+        y = st["y"]
+        raw = y.buf[..., y.coff:y.coff + y.C].float()
+        z = (raw.double() * y.scale.double() + y.shift.double()).float()            # = fmaf(y, scale, shift) as the consumers compute it
+        if act_mask is not None:                                                   # sparse layers: nothing lives at a masked position
+            m = act_mask.repeat_interleave(y.H // act_mask.shape[1], 1).repeat_interleave(y.W // act_mask.shape[2], 2).unsqueeze(-1).bool()
+            raw, z = torch.where(m, raw, torch.zeros_like(raw)), torch.where(m, z, torch.full_like(z, -1.0))
+        layers[st["pconv"]] = (raw.permute(0, 3, 1, 2).contiguous().cpu(), torch.clamp_min(z, 0).permute(0, 3, 1, 2).contiguous().cpu(),
+                               (z > 0).permute(0, 3, 1, 2).contiguous().cpu())
+    for lv in ctx["levels"]:
+        add(lv["s1"], ctx["active"]); add(lv["s2"], ctx["active"])
+    add(ctx["b1"], ctx["active"]); add(ctx["b2"], ctx["active"])
+    for lv in ctx["dctx"]["levels"]:
+        add(lv["s1"], None); add(lv["s2"], None)
+    assert len(layers) == 18
+
+    class Taps:
+        seen = set()
+
+        def conv(self, key, y):
+            self.seen.add(key)
+            return y + (layers[key][0].to(y.dtype) - y).detach()
+
+        def act(self, key, z):
+            a = z * layers[key][2].to(z.dtype)
+            return a + (layers[key][1].to(z.dtype) - a).detach()
+    taps = Taps()
+
+    odt = torch.float64 if dt == "f32" else torch.float32     # (the f16 bar is 1e-2: a float32 oracle is exact enough and several times faster)
+
+    def wq(k, v):                     # the oracle on the weights the kernels multiply with (16-bit storage: the packs hold the rounded weights)
+        if not v.is_floating_point():
+            return v.clone()
+        v = v.to(tdt).to(odt) if (v.dim() == 4 and dt != "f32" and "conv_last" not in k and "mask_tokens" not in k) else v.to(odt)
+        return v.requires_grad_(True) if "running" not in k else v
+    osd = {k: wq(k, v) for k, v in sd.items()}
+    toks = [osd[f"mask_tokens.{i}"] for i in range(len(model.mask_tokens))]
+    OU.TAP = taps
+    try:
+        ref_loss, _ = OS.forward(x.to(odt), active, osd, toks)
+        ref_loss.backward()
+    finally:
+        OU.TAP = None
+    assert taps.seen == set(layers)
+    lbar = {"f32": 2e-5, "f16": 2e-3}[dt]
+    assert abs(float(loss) - float(ref_loss.detach())) <= lbar * max(1.0, abs(float(ref_loss.detach()))), (float(loss), float(ref_loss))
+    bar = {"f32": 1e-4, "f16": 1e-2}[dt]
+    errs = []
+    for k, p in model.named_parameters():
+        if k.startswith("densify_projs") or not osd[k].requires_grad:
+            continue
+        gref = osd[k].grad
+        assert gref is not None and p.grad is not None, k
+        got = p.grad.detach().double().cpu() / scale
+        if k.endswith(".0.bias") or k.endswith(".3.bias"):
+            # a conv bias in front of a training-mode BatchNorm: the true gradient is zero, both sides hold rounding noise -- measured on the
+            # scale of the same layer's weight gradient
+            den = osd[k[:-len("bias")] + "weight"].grad.norm().item()
+        elif k.endswith("up_sample.bias"):
+            den = osd[k[:-len("bias")] + "weight"].grad.norm().item()      # cancellation remainder (see test_spark_step_vs_reference_fixture)
+        else:
+            den = gref.norm().item()
+        errs.append(((got - gref).norm().item() / max(den, 1e-30), k))
+    errs.sort(reverse=True)
+    top = "; ".join(f"{k}: {e:.2e}" for e, k in errs[:4])
+    print(f"[spark gate-forced {dt} {S}x{S} bs {B}] {len(errs)} gradients, worst {top}")
+    _parity_record(f"SparK step {dt} at {S}x{S}, bs {B}, base 64, mask 0.75, list-driven kernels, {'float64' if dt == 'f32' else 'float32'} oracle backward on the HIP path's own forward values and "
+                   f"gates: {len(errs)} parameter gradients, worst relative L2 {top} (bar {bar:.0e})")
+    assert len(errs) >= 85 and errs[0][0] <= bar, top

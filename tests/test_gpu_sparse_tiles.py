@@ -304,19 +304,30 @@ def test_spark_step_with_and_without_tile_skipping(ops, dt, tmp_path):
     # ("10": tile lists only, the one-channel first layer on its dense kernels -- the same arithmetic as the dense step at every active
     # pixel, patch-organised element-wise passes and border-frame zeroing included; "10c": the first layer over its tile list as well --
     # its statistics are then summed in another order, which sparse BatchNorm amplifies like the gather levels' differences)
-    for key, flag, gather, c1 in (("11", "1", "1", "1"), ("10", "1", "0", "0"), ("10c", "1", "0", "1"), ("00", "0", "0", "1")):
-        o = str(tmp_path / f"r{key}.pt")
-        # (CMU_POISON_NEW: every fresh activation starts as NaN -- the list-driven layers leave masked patches unwritten, or zero only
-        # their border frames; a kernel that read such a position would poison the loss and the gradients)
-        env = dict(os.environ, CMU_SPARK_TILES=flag, CMU_SPARK_GATHER=gather, CMU_SPARK_C1_TILES=c1, CMU_POISON_NEW="1")
-        subprocess.run([sys.executable, "-c", _STEP % ROOT, dt, o], env=env, check=True, timeout=420)
-        outs[key] = torch.load(o)
+    # (round 6: the child processes run three and two at a time -- each is mostly interpreter start-up)
+    runs = [(key, dict(CMU_SPARK_TILES=flag, CMU_SPARK_GATHER=gather, CMU_SPARK_C1_TILES=c1, CMU_POISON_NEW="1"))
+            for key, flag, gather, c1 in (("11", "1", "1", "1"), ("10", "1", "0", "0"), ("10c", "1", "0", "1"), ("00", "0", "0", "1"))]
+    # (CMU_POISON_NEW: every fresh activation starts as NaN -- the list-driven layers leave masked patches unwritten, or zero only
+    # their border frames; a kernel that read such a position would poison the loss and the gradients)
     # round 3: the mask-aware pools (no activated copy of a level's second conv output) against the materialised form, everything else
     # at its default: the forward is the same arithmetic (identical loss at f32), the backward differs by arg-max ties only
-    o = str(tmp_path / "nofuse.pt")
-    subprocess.run([sys.executable, "-c", _STEP % ROOT, dt, o], env=dict(os.environ, CMU_SPARK_POOL_FUSE="0", CMU_POISON_NEW="1"), check=True,
-                   timeout=420)
-    nofuse = torch.load(o)
+    runs.append(("nofuse", dict(CMU_SPARK_POOL_FUSE="0", CMU_POISON_NEW="1")))
+    for batch in (runs[:3], runs[3:]):          # (with the test runner itself at most four processes on the card at a time)
+        procs = []
+        try:
+            for key, env in batch:
+                procs.append((key, subprocess.Popen([sys.executable, "-c", _STEP % ROOT, dt, str(tmp_path / f"r{key}.pt")], env=dict(os.environ, **env))))
+            for key, pr in procs:
+                assert pr.wait(timeout=420) == 0, key
+        finally:
+            for _, pr in procs:
+                if pr.poll() is None:
+                    pr.kill()
+                pr.wait()
+    for key, _ in runs:
+        outs[key] = torch.load(str(tmp_path / f"r{key}.pt"))
+    o = None
+    nofuse = outs.pop("nofuse")
     for o_ in list(outs.values()) + [nofuse]:
         assert bool(torch.isfinite(o_["loss"]).all()) and all(bool(torch.isfinite(g_).all()) for g_ in o_["grads"].values()), "an unwritten position was read"
     if dt == "f32":
