@@ -265,6 +265,30 @@ class FusedAdam:
                       self.betas[1], self.eps, self.weight_decay, self.decoupled, self.step_count, grad_scale, amp)
         # ops.adam_step bumps ops.PARAM_GENERATION: the engine's packed-weight caches see the raw-kernel write
 
+    def step_ranges(self, ranges, grad_scale=1.0, amp=None, ema=None):
+        """``step`` restricted to the ascending element ranges ``ranges`` of the arena (multiples of 4): one launch per range, the same
+        kernel on the same operands element for element (the sharded exchange of pretrain.JointPretrainer: a rank updates only the share of
+        a big parameter whose summed gradient it holds).  EMA segments are clipped to each range."""
+        self.step_count += 1
+        if amp is not None:
+            self.amp = amp
+        a, g, m, v = self.flat.arena, self.flat.grad, self.m, self.v
+        for lo, hi in ranges:
+            assert lo % 4 == 0 and hi % 4 == 0 and 0 <= lo < hi <= a.numel(), (lo, hi)
+            wd = None if self.wd_mask is None else self.wd_mask[lo:hi]
+            segs = []
+            if ema is not None:
+                for s0, s1, tgt in ema[0]:
+                    c0, c1 = max(s0, lo), min(s1, hi)
+                    if c1 > c0:
+                        segs.append((c0 - lo, c1 - lo, tgt[c0 - s0:c1 - s0]))
+            if segs:
+                ops.adam_ema_step(a[lo:hi], g[lo:hi], m[lo:hi], v[lo:hi], wd, self.lr, self.betas[0], self.betas[1], self.eps,
+                                  self.weight_decay, self.decoupled, self.step_count, grad_scale, amp, segs, ema[1])
+            else:
+                ops.adam_step(a[lo:hi], g[lo:hi], m[lo:hi], v[lo:hi], wd, self.lr, self.betas[0], self.betas[1], self.eps,
+                              self.weight_decay, self.decoupled, self.step_count, grad_scale, amp)
+
     def state_dict(self):
         """Moments, host step count and -- when the steps run under a loss scaler -- the scaler's state (``loss_scaler``, the key
         mmengine's AmpOptimWrapper.state_dict uses): under amp the kernel takes the bias-correction step from the scaler's

@@ -101,6 +101,70 @@ def _check_bucket_snapshots(flat, snaps, group):
                                f"started (first: arena index {first}, parameter {owner})")
 
 
+# ---- sharded exchange of one big parameter (round 6; the joint step's projector.fc0.weight: 262,144 x 1,536 fp32 = 1.61 GB at 512 x 512) --------
+# The reference exchanges it like everything else (DDP's all-reduce: dist_train.sh:9-17 + cmunet_config.py:18-26,120).  A ring all-reduce IS a
+# reduce-scatter followed by an all-gather; splitting the two lets (i) every rank run AdamW (+ the EMA of the momentum projector) on 1/world of the
+# 403 M elements instead of all of them and (ii) the all-gather -- of the UPDATED parameters instead of the gradients -- run under the next step's
+# encoder / decoder forward, where nothing needs the projector yet.  Element for element the arithmetic is the all-reduce path's (a SUM over the
+# ranks, then the same optimiser kernel on the same operands): bit-identical on two ranks (a + b commutes; tests/test_cpu_distributed.py,
+# tests/test_gpu_dataparallel.py), equal to reduction order beyond.
+class _Works:
+    """Several async collectives (and what has to follow them on the host side) behind one ``wait()``."""
+
+    def __init__(self, works=(), after=None):
+        self.works, self.after = [w for w in works if w is not None], after
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        if self.after is not None:
+            self.after()
+            self.after = None
+
+
+def _group_backend(group):
+    return dist.get_backend(group) if dist.is_available() and dist.is_initialized() else "none"
+
+
+def shard_bounds(n, world, rank):
+    """Element range [lo, hi) of ``rank``'s share of ``n`` elements (``n % world == 0``)."""
+    chunk = n // world
+    return rank * chunk, (rank + 1) * chunk
+
+
+def reduce_scatter_sum_async(t, group=None):
+    """SUM over the ranks of the 1-D tensor ``t`` (``t.numel() % world == 0``), each rank ending with ITS share summed in place
+    (``t[shard_bounds(...)]``); the rest of ``t`` keeps unspecified (local or partly reduced) values.  RCCL: one reduce-scatter into a scratch
+    share, copied home behind the wait; other backends (gloo has no reduce-scatter): one in-place reduce per share to its owner."""
+    world, rank = dp_world(group), (dist.get_rank(group) if dist.is_initialized() else 0)
+    lo, hi = shard_bounds(t.numel(), world, rank)
+    if _group_backend(group) == "nccl":
+        out = torch.empty(hi - lo, dtype=t.dtype, device=t.device)
+        w = dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        return _Works([w], after=lambda: t[lo:hi].copy_(out))
+    works = []
+    for k in range(world):
+        a, b = shard_bounds(t.numel(), world, k)
+        dst = dist.get_global_rank(group, k) if group is not None else k
+        works.append(dist.reduce(t[a:b], dst=dst, op=dist.ReduceOp.SUM, group=group, async_op=True))
+    return _Works(works)
+
+
+def all_gather_shares_async(t, group=None):
+    """Every rank's share of the 1-D tensor ``t`` to every rank, in place."""
+    world, rank = dp_world(group), (dist.get_rank(group) if dist.is_initialized() else 0)
+    lo, hi = shard_bounds(t.numel(), world, rank)
+    if _group_backend(group) == "nccl":
+        mine = t[lo:hi].clone()                      # (a separate send buffer: no aliasing of the collective's input and output)
+        return _Works([dist.all_gather_into_tensor(t, mine, group=group, async_op=True)])
+    works = []
+    for k in range(world):
+        a, b = shard_bounds(t.numel(), world, k)
+        src = dist.get_global_rank(group, k) if group is not None else k
+        works.append(dist.broadcast(t[a:b], src=src, group=group, async_op=True))
+    return _Works(works)
+
+
 class MaskedReconPretrainer:
     """One object = model + flat arenas + fused AdamW + (optional) data-parallel group."""
 
@@ -475,19 +539,31 @@ class ArenaTrainer:
             loss.backward()
             self.flat.gather_autograd_grads()
             if dp_exchanges(self.group):
-                dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)
+                self._exchange_whole_arena()
                 scale = 1.0 / self.world()
         kw = {} if ema is None else {"ema": ema}
         if amp is not None:
             amp.check(self.flat.grad)                                # after the exchange: every rank takes the same decision
-            self.opt.step(grad_scale=scale / loss_scale, amp=amp, **kw)
+            self._amp_agree(amp)
+            self._opt_step(grad_scale=scale / loss_scale, amp=amp, **kw)
             amp.update()
             for p in self.flat.params.values():
                 p.grad = None
             return
-        self.opt.step(grad_scale=scale / loss_scale, **kw)
+        self._opt_step(grad_scale=scale / loss_scale, **kw)
         for p in self.flat.params.values():       # the arena holds them; drop the per-tensor copies autograd made
             p.grad = None
+
+
+    # (hooks of the sharded exchange, JointPretrainer)
+    def _exchange_whole_arena(self):
+        dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _amp_agree(self, amp):
+        pass
+
+    def _opt_step(self, **kw):
+        self.opt.step(**kw)
 
 
 class JointPretrainer(ArenaTrainer):
@@ -520,12 +596,105 @@ class JointPretrainer(ArenaTrainer):
         # the EMA rides in the AdamW kernel (cmu_adam_ema_step: one pass over the 1.7 GB of parameters instead of two);
         # CMU_EMA_FUSE=0 keeps the two stand-alone EMA launches behind the optimiser (A/B switch, bit-identical)
         self._fuse_ema = os.environ.get("CMU_EMA_FUSE", "1") != "0"
+        self._shard, self._pending_gather, self._shard_hooks = None, None, []
+        self._setup_shard()
+
+    # ---- sharded exchange of projector.fc0.weight (see reduce_scatter_sum_async above) -------------------------------------------------------
+    def _setup_shard(self):
+        """On when gradients are exchanged at all, the parameter is big enough to matter (CMU_DP_SHARD_MIN elements, default 2^24 = 64 MB: the
+        reference geometry's 77 M and the bench's 403 M both qualify) and divides into whole 16-byte pieces per rank.  CMU_DP_SHARD_PROJECTOR=0:
+        the all-reduce path (A/B switch).  Between the optimiser step and the next forward's projector call a rank's copy of the parameter is
+        only valid on its own share: ``finish_pending()`` (called by a forward pre-hook of the two projectors, by ``state_dict`` and by
+        ``close``) completes it."""
+        name, tname = "projector.fc0.weight", "target_projector.fc0.weight"
+        if os.environ.get("CMU_DP_SHARD_PROJECTOR", "1") == "0" or not dp_exchanges(self.group) or self._late_check:
+            return
+        if name not in self.flat.offsets or tname not in self.tflat.offsets:
+            return
+        (off, cnt), (toff, tcnt) = self.flat.offsets[name], self.tflat.offsets[tname]
+        world = self.world()
+        if cnt != tcnt or cnt < int(os.environ.get("CMU_DP_SHARD_MIN", str(1 << 24))) or cnt % (4 * world) != 0 or off % 4 != 0:
+            return
+        rank = dist.get_rank(self.group) if (dist.is_available() and dist.is_initialized()) else 0
+        a, b = shard_bounds(cnt, world, rank)
+        self._shard = dict(lo=off, hi=off + cnt, own=(off + a, off + b), t_lo=toff)
+        import weakref
+        me = weakref.ref(self)
+
+        def pre(_m, _inp):
+            t = me()
+            if t is not None:
+                t.finish_pending()
+        self._shard_hooks = [self.model.projector.register_forward_pre_hook(pre), self.model.target_projector.register_forward_pre_hook(pre)]
+
+    def close(self):
+        self.finish_pending()
+        for h in self._shard_hooks:
+            h.remove()
+        self._shard_hooks = []
+        super().close()
+
+    def _start_exchange(self, lo, hi):
+        sh = self._shard
+        if sh is None or not (lo <= sh["lo"] and sh["hi"] <= hi):
+            return super()._start_exchange(lo, hi)
+        # the bucket that holds the big parameter: all-reduce in front of and behind it, reduce-scatter of the parameter itself
+        if getattr(self, "last_exchange", None) is not None:
+            self.last_exchange["reduce_scatter_bytes"] = 4 * int(sh["hi"] - sh["lo"])
+        return _Works([self.flat.all_reduce_range_async(lo, sh["lo"], self.group),
+                       reduce_scatter_sum_async(self.flat.grad[sh["lo"]:sh["hi"]], self.group),
+                       self.flat.all_reduce_range_async(sh["hi"], hi, self.group)])
+
+    def _exchange_whole_arena(self):
+        if self._shard is None:
+            return super()._exchange_whole_arena()
+        self._start_exchange(0, int(self.flat.grad.numel())).wait()
+
+    def _amp_agree(self, amp):
+        """With a sharded gradient a rank sees the SUMMED gradient only on its own share (elsewhere its local one): the inf / nan flags are
+        combined (MAX) so that every rank skips or steps together, as it does when all of them check the same all-reduced arena."""
+        if self._shard is not None:
+            dist.all_reduce(amp.state[4:8].view(torch.float32), op=dist.ReduceOp.MAX, group=self.group)
+
+    def _opt_step(self, grad_scale=1.0, amp=None, ema=None):
+        sh = self._shard
+        if sh is None:
+            return self.opt.step(grad_scale=grad_scale, amp=amp, **({} if ema is None else {"ema": ema}))
+        self.finish_pending()
+        n = int(self.flat.arena.numel())
+        ranges = [r for r in ((0, sh["lo"]), sh["own"], (sh["hi"], n)) if r[1] > r[0]]
+        self.opt.step_ranges(ranges, grad_scale=grad_scale, amp=amp, ema=ema)
+        # the updated share to every rank -- under whatever the compute stream does next (the next forward's encoders and decoders); the EMA of
+        # the momentum projector rode in the optimiser kernel on the own share only: the other shares follow once their parameters are here
+        w = all_gather_shares_async(self.flat.arena[sh["lo"]:sh["hi"]], self.group)
+        self._pending_gather = (w, None if ema is None else float(ema[1]))
+
+    def finish_pending(self):
+        """Complete the parameter all-gather started by the last optimiser step (no-op when there is none)."""
+        pg, self._pending_gather = self._pending_gather, None
+        if pg is None:
+            return
+        w, mom = pg
+        w.wait()
+        sh = self._shard
+        if mom is not None:
+            for c0, c1 in ((sh["lo"], sh["own"][0]), (sh["own"][1], sh["hi"])):
+                if c1 > c0:
+                    t0 = sh["t_lo"] + (c0 - sh["lo"])
+                    ops.ema_update(self.tflat.arena[t0:t0 + (c1 - c0)], self.flat.arena[c0:c1], mom)
+        ops.bump_param_generation()      # raw writes into the arena: packed / converted copies of the parameter are stale
 
     def momentum_update(self):
+        self.finish_pending()            # (sharded exchange: the whole parameter first)
         for (a0, a1), (b0, b1) in self._ema:
             ops.ema_update(self.tflat.arena[b0:b1], self.flat.arena[a0:a1], self.model.momentum)
 
     def state_dict(self):
+        self.finish_pending()
+        if self._shard is not None:      # the moments of the sharded parameter live on their owners: bring them together for the checkpoint
+            sh = self._shard
+            for t in (self.opt.m, self.opt.v):
+                all_gather_shares_async(t[sh["lo"]:sh["hi"]], self.group).wait()
         return {"optimizer": self.opt.state_dict()}
 
     def load_state_dict(self, sd):

@@ -84,7 +84,7 @@ def _run(mode, out, opts, world, rank, dev, P):
         from cmunet_amd import cmunet as C
         torch.manual_seed(0)
         B, S = 4, 32
-        model = C.build_model(C.cmunet_config(img_size=S, dtype="f32", base_ch=16, depth=3)).to(dev).train()
+        model = C.build_model(C.cmunet_config(img_size=S, dtype=opts.get("dtype", "f32"), base_ch=16, depth=3)).to(dev).train()
         with torch.no_grad():
             for n, p in model.named_parameters():
                 if p.dim() == 1 and ("bn" in n or ".1." in n or ".4." in n):
@@ -102,7 +102,11 @@ def _run(mode, out, opts, world, rank, dev, P):
         gw = torch.Generator().manual_seed(7)
         rw, rb = torch.randn(Cr, 64, 1, 1, generator=gw) * 0.1, torch.randn(Cr, generator=gw) * 0.1
         model.momentum = 0.9
-        l = tr.step(img.to(dev), img_t.to(dev), mask.to(dev), reduce_w=rw.to(dev), reduce_b=rb.to(dev))
+        for _ in range(int(opts.get("steps", 1))):        # (steps > 1: the sharded exchange's parameter all-gather completes inside the next forward)
+            l = tr.step(img.to(dev), img_t.to(dev), mask.to(dev), reduce_w=rw.to(dev), reduce_b=rb.to(dev))
+        tr.finish_pending()
+        res["sharded"] = tr._shard is not None
+        res["opt"] = {k: (v.detach().cpu().clone() if torch.is_tensor(v) else v) for k, v in tr.state_dict()["optimizer"].items() if k in ("m", "v", "step")}
         res.update({"loss_ct": float(l["loss_ct"]), "loss_rc": float(l["loss_rc"]), "img": img, "img_t": img_t, "mask": mask, "rw": rw, "rb": rb,
                     "final": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
                     "exchange": getattr(tr, "last_exchange", None)})

@@ -73,6 +73,28 @@ def _worker(rank, world, port, q):
         h0 = flat.all_reduce_range_async(0, off)
         h1.wait(); h0.wait()
         assert torch.equal(flat.grad, whole)
+        # round 6 -- sharded exchange of one big parameter (pretrain.reduce_scatter_sum_async / all_gather_shares_async: the joint step's
+        # projector.fc0.weight, cmunet_config.py:18-26): reduce-scatter of the gradient, an element-wise update on the own share, all-gather
+        # of the updated parameter == all-reduce + the same update everywhere, bit for bit on two ranks (a + b commutes)
+        from cmunet_amd.pretrain import all_gather_shares_async, reduce_scatter_sum_async, shard_bounds
+        n = 4096
+        gsh = torch.Generator().manual_seed(10 + rank)
+        grad_local = torch.randn(n, generator=gsh)
+        p0 = torch.randn(n, generator=torch.Generator().manual_seed(3))
+
+        def update(p, gsum):                        # stand-in for the optimiser kernel: element-wise, the same on every path
+            return p - 0.1 * (gsum * (1.0 / world)) - 0.01 * p
+        ga = grad_local.clone()
+        dist.all_reduce(ga)
+        pa = update(p0.clone(), ga)
+        gb, pb = grad_local.clone(), p0.clone()
+        reduce_scatter_sum_async(gb).wait()
+        lo, hi = shard_bounds(n, world, rank)
+        assert (lo, hi) == (rank * n // world, (rank + 1) * n // world)
+        assert torch.equal(gb[lo:hi], ga[lo:hi])    # the own share holds the SUM; the rest of gb is unspecified
+        pb[lo:hi] = update(pb[lo:hi], gb[lo:hi])
+        all_gather_shares_async(pb).wait()
+        assert torch.equal(pb, pa)
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         q.put((rank, repr(e)))

@@ -381,6 +381,34 @@ def test_arena_trainers_overlapped_exchange_is_bit_identical(cuda, mode):
     assert plain[0]["exchange"] is None or plain[0]["exchange"].get("early", 0) == 0
 
 
+def test_joint_sharded_projector_exchange_is_bit_identical(cuda):
+    """Round 6 (review item 6): the joint step's projector.fc0.weight -- 1.61 GB of gradient at the bench's geometry (cmunet_config.py:18-26 under
+    the DDP of dist_train.sh:9-17) -- exchanged as reduce-scatter + AdamW / EMA on the own share + all-gather of the updated parameter inside the
+    NEXT forward (JointPretrainer._setup_shard) against the all-reduce path (CMU_DP_SHARD_PROJECTOR=0), two ranks, two steps each (the second
+    forward is where the first step's all-gather completes): parameters, momentum networks, buffers AND the optimiser's moments (gathered for
+    the checkpoint) agree bit for bit -- a SUM over two ranks is the same number either way, and the optimiser kernel runs on the same operands
+    element for element.  With the overlapped exchange (f32) and with one exchange behind the backward pass (f16 under the dynamic loss scaler:
+    the ranks' inf / nan flags are combined)."""
+    # (f32 with the backward-overlapped exchange; f16 + dynamic loss scaler with ONE exchange behind the backward pass, CMU_DDP_OVERLAP=0: the
+    # same split of the arena either way)
+    for opts, env in (({"steps": 2}, {}), ({"steps": 2, "dtype": "f16"}, {"CMU_DDP_OVERLAP": "0"})):
+        sh, plain = run_groups(("joint", 2, dict(env, CMU_DP_SHARD_MIN="0"), opts), ("joint", 2, dict(env, CMU_DP_SHARD_PROJECTOR="0"), opts))
+        assert all(r["sharded"] for r in sh) and not any(r["sharded"] for r in plain)
+        if not env:
+            ex = sh[0]["exchange"]
+            assert ex is not None and ex.get("reduce_scatter_bytes", 0) > 0, ex
+        for rk in range(2):
+            a, b = sh[rk], plain[rk]
+            assert np.isfinite(a["loss_ct"]) and a["loss_ct"] == b["loss_ct"] and a["loss_rc"] == b["loss_rc"]
+            for k, v in b["final"].items():
+                assert torch.equal(a["final"][k], v), (opts, k)
+            assert a["opt"]["step"] == b["opt"]["step"] == 2
+            for k in ("m", "v"):
+                assert torch.equal(a["opt"][k], b["opt"][k]), (opts, k)
+        for k, v in sh[0]["final"].items():                  # the replicas agree with each other
+            assert torch.equal(sh[1]["final"][k], v), k
+
+
 @pytest.mark.parametrize("mode", ["recon", "joint", "moco", "spark"])
 def test_no_gradient_is_written_behind_its_bucket_exchange(cuda, mode):
     """The in-forward / in-backward bucket announcements are the only guarantee that no gradient of a bucket is written after that
@@ -430,6 +458,16 @@ def test_bench_step_on_a_one_rank_rccl_group(cuda, workload):
                 pr.kill()
             pr.wait()
     plain, rccl = lines
+    if workload == "joint":
+        # round 6: the sharded projector exchange on RCCL itself -- reduce_scatter_tensor / all_gather_into_tensor of a one-rank group are
+        # identities, so the losses must not move (the late-write check above takes the all-reduce path: it snapshots whole buckets)
+        env = dict(base, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), CMU_DP_REHEARSE="1")
+        r = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=420)
+        assert r.returncode == 0, r.stderr[-2000:]
+        shard = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert shard["rccl"]["exchange"].get("reduce_scatter_bytes", 0) == 4 * 128 * 128 * 1536, shard["rccl"]["exchange"]
+        assert abs(shard["config"]["loss"] - plain["config"]["loss"]) <= 1e-5 * max(1.0, abs(plain["config"]["loss"]))
+        assert "reduce_scatter_bytes" not in rccl["rccl"]["exchange"]
     assert rccl["n_gpus"] == 1 and rccl["config"]["parallelism"] == "dp1"
     assert np.isfinite(rccl["config"]["loss"])
     assert abs(rccl["config"]["loss"] - plain["config"]["loss"]) <= 1e-5 * max(1.0, abs(plain["config"]["loss"])), (plain["config"]["loss"], rccl["config"]["loss"])
