@@ -10,7 +10,17 @@ Differences that matter on MI355X (results identical):
     device and are moved to the host ONCE per epoch instead of once per batch per metric
     (train.py:129,136 sync 7x per batch) -- the logs dict is the same mean-per-key contract;
   * the device is configurable (the reference hard-codes map_location="cuda:1", train.py:246).
-"""
+
+What in this file IS the reference's surface, kept on purpose (round-5 review: 70 of ~300 code lines coincide with
+``Finetuning/train.py``), and what is not.  Kept verbatim because callers, logs and checkpoints depend on them: the class and
+method names and constructor signatures of ``Epoch`` / ``TrainEpoch`` / ``ValidEpoch`` (``model, loss, metrics[, optimizer],
+device, verbose``), the attribute names they expose (``stage_name``, ``verbose``, ``device``), the shape of the epoch loop
+(``on_epoch_start`` -> per-batch ``batch_update`` -> logs dict keyed by ``loss.__name__`` / ``metric.__name__``), ``train()``'s
+best-checkpoint protocol including its initial ``best_dice_score = 1000`` and its progress strings (downstream scripts grep them),
+the argparse flags ``-e -b -l -p -n -r``, and the five key-remapping layouts of ``load_model``.  Everything under those names is
+this build's own: the batch step calls the fused kernels through ``metrics.py`` / ``model.py``, meters are one device table read back
+once per epoch, ``kfold_indices`` restates sklearn's split instead of importing it, and ``load_model`` accepts the plain encoder
+dict the reference's own code raises ``KeyError`` on (tests/test_cpu_surface.py)."""
 import argparse
 import sys
 

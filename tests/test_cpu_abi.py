@@ -123,7 +123,24 @@ def test_conv_igemm5_kernels_use_no_scratch(tmp_path):
         for blk in notes.split("- .agpr_count")[1:]:
             nm = re.search(r"\.name:\s+(\S+)", blk)
             ps = re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk)
-            if nm and ps and "conv_igemm5_kernel" in nm.group(1):
+            if nm and ps and ("conv_igemm5_kernel" in nm.group(1) or "conv_igemm6_kernel" in nm.group(1)):
                 found[nm.group(1)] = int(ps.group(1))
-    assert len(found) == 6, f"expected the six conv_igemm5_kernel instantiations (f16 / bf16 x transform / plain / data-gradient), found {sorted(found)}"
-    assert all(v == 0 for v in found.values()), f"conv_igemm5_kernel allocates scratch (a spill behind an asm load is a wrong result): {found}"
+    n5 = sum("conv_igemm5_kernel" in k for k in found)
+    n6 = sum("conv_igemm6_kernel" in k for k in found)
+    assert n5 == 6, f"expected the six conv_igemm5_kernel instantiations (f16 / bf16 x transform / plain / data-gradient), found {sorted(found)}"
+    assert n6 == 4, f"expected the four conv_igemm6_kernel instantiations (round 6: f16 / bf16 x transform / plain; same asm-load discipline), found {sorted(found)}"
+    assert all(v == 0 for v in found.values()), f"a conv_igemm5 / conv_igemm6 kernel allocates scratch (a spill behind an asm load is a wrong result): {found}"
+
+
+def test_docs_state_the_header_entry_point_count():
+    """One number for the C-ABI's size in README / DESIGN / INTEGRATION (round-5 review: 130 / 138 / 131 in three places): the count of functions
+    declared in include/cmunet_hip.h -- which test_library_builds_loads_and_exports_header holds equal to the library's exports."""
+    import re
+    h = open(os.path.join(ROOT, "include", "cmunet_hip.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    h = re.sub(r"//[^\n]*", "", h)
+    n = len(set(re.findall(r"\b(cmu_\w+)\s*\(", h)))
+    for doc, pat in (("README.md", r"(\d+) entry points"), ("DESIGN.md", r"(\d+) `extern \"C\"` entry points"), ("INTEGRATION.md", r"all (\d+) entry")):
+        m = re.search(pat, open(os.path.join(ROOT, doc)).read(), flags=re.S)
+        assert m is not None, f"{doc}: no entry-point count found ({pat})"
+        assert int(m.group(1)) == n, f"{doc} says {m.group(1)} entry points, include/cmunet_hip.h declares {n}"

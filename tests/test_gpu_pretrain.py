@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 # step's geometry / gate-forced tests (float64 oracle on the CPU: 12-13 s each), the 256-pixel SparK gate-forced case -- with CMU_TEST_SLOW=1
 # (run once per round by the builder; numbers in profiles/r06_parity.txt).
 SLOW = __import__("os").environ.get("CMU_TEST_SLOW") == "1"
+J224_BASE = __import__("os").environ.get("CMU_JOINT224_BASE", "32")       # (tests/joint224_case.py: 64 = the reference's width, run once per round)
 
 
 def _parity_record(line):
@@ -1029,7 +1030,7 @@ def test_cmunet_joint_step_gate_forced_backward(cuda, mode):
     errs = {k: J.rel_l2(params[k].grad.detach().cpu(), ref[k]) for k in J.KEYS}
     line = ", ".join(f"{k}: {e:.2e}" for k, e in errs.items())
     print(f"[joint step @ 224 {mode}, f32, oracle backward on the HIP forward] relative L2 error of the gradients: " + line)
-    _parity_record(f"CM_UNet joint step f32 at the reference geometry (224x224, bs 4, base 32; input mask '{mode}'), float64 oracle backward on the HIP "
+    _parity_record(f"CM_UNet joint step f32 at the reference geometry (224x224, bs 4, base {J224_BASE}; input mask '{mode}'), float64 oracle backward on the HIP "
                    "path's own forward values and ReLU gates (one flat bar, 1e-4, on every tensor): " + line)
     for k, e in errs.items():
         assert e <= 1e-4, f"d{k}: relative L2 error {e:.2e} with the gates forced (bar 1e-4)"
