@@ -132,6 +132,74 @@ def test_conv_igemm5_kernels_use_no_scratch(tmp_path):
     assert all(v == 0 for v in found.values()), f"a conv_igemm5 / conv_igemm6 kernel allocates scratch (a spill behind an asm load is a wrong result): {found}"
 
 
+def test_asm_load_kernels_keep_their_mfma_phase_clean(tmp_path):
+    """Advisor, round 5: conv_igemm5 / conv_igemm6 issue weight and halo loads through inline asm and wait for them with hand-placed
+    ``s_waitcnt vmcnt(N)`` -- hipcc believes the destination registers are complete when the asm statement ends, so a ``v_mov`` / ``v_accvgpr``
+    copy of one of them (or a spill) scheduled in front of the wait would read bytes that have not arrived, and the N of the first wait of a
+    position counts the epilogue's 16 stores.  Nothing in the source can assert that; the DISASSEMBLY of the built library can: between
+    ``s_setprio 2`` and ``s_setprio 0`` (the MFMA phase) every instantiation holds exactly its MFMAs (288 per position; conv_igemm6 runs a pair:
+    576), its weight loads (4 per tap) and LDS fragment reads -- no register copies, no scratch --, and the whole kernel stores its tile with
+    exactly 16 ``global_store_dwordx4`` (fewer would make the counted waits too loose)."""
+    import re
+    import subprocess
+    from collections import Counter
+    lib = os.path.join(ROOT, "cmunet_amd", "csrc", "libcmunet_hip.so")
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf", "llvm-objdump")]
+    if not os.path.exists(lib) or not all(os.path.exists(t) for t in tools):
+        pytest.skip("library or LLVM tools not present")
+    fat = str(tmp_path / "fat.bin")
+    subprocess.run([tools[0], f"--dump-section=.hip_fatbin={fat}", lib], check=True)
+    blob = open(fat, "rb").read()
+    starts = [m.start() for m in re.finditer(re.escape(b"__CLANG_OFFLOAD_BUNDLE__"), blob)]
+    seen = {}
+    for i, a in enumerate(starts):
+        part = str(tmp_path / f"b{i}.bin")
+        open(part, "wb").write(blob[a:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+        co = str(tmp_path / f"co{i}.o")
+        r = subprocess.run([tools[1], "--unbundle", "--type=o", f"--input={part}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"],
+                           capture_output=True, text=True)
+        if r.returncode != 0 or not os.path.exists(co) or os.path.getsize(co) == 0:
+            continue
+        syms = subprocess.run([tools[2], "-s", "-W", co], capture_output=True, text=True).stdout
+        names = sorted({w for ln in syms.splitlines() for w in ln.split()[-1:] if re.match(r"_Z18conv_igemm[56]_kernel", w) and not w.endswith(".kd")})
+        if not names:
+            continue
+        dis = subprocess.run([tools[3], "-d", "--mcpu=gfx950", "--disassemble-symbols=" + ",".join(names), co], capture_output=True, text=True).stdout
+        cur = None
+        for ln in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", ln)
+            if m:
+                cur = m.group(1)
+                seen[cur] = []
+            elif cur is not None:
+                t = re.sub(r"//.*", "", ln).strip()
+                if t and not t.endswith(":"):
+                    seen[cur].append(t)
+    assert len(seen) == 10, sorted(seen)
+    for name, ins in seen.items():
+        v6 = "conv_igemm6" in name
+        phase, phases = None, []
+        for t in ins:
+            if t.startswith("s_setprio 2"):
+                phase = []
+            elif t.startswith("s_setprio 0"):
+                if phase is not None:
+                    phases.append(phase)
+                phase = None
+            elif phase is not None:
+                phase.append(t.split()[0])
+        assert len(phases) == 1, (name, len(phases))
+        c = Counter(phases[0])
+        assert sum(v for k, v in c.items() if k.startswith("v_mfma")) == (576 if v6 else 288), (name, c)
+        assert c.get("buffer_load_dwordx4", 0) == (72 if v6 else 36), (name, c)
+        bad = [k for k in c if k.startswith(("v_mov", "v_accvgpr", "v_pk_mov", "scratch_", "v_swap", "v_perm"))]
+        assert not bad, f"{name}: register copies / scratch inside the MFMA phase (a copy of an asm-load destination in front of its wait reads stale bytes): {bad}"
+        allc = Counter(t.split()[0] for t in ins)
+        assert allc.get("global_store_dwordx4", 0) == 16, (name, allc.get("global_store_dwordx4", 0))
+        assert not any(k.startswith("scratch_") for k in allc), name
+
+
 def test_docs_state_the_header_entry_point_count():
     """One number for the C-ABI's size in README / DESIGN / INTEGRATION (round-5 review: 130 / 138 / 131 in three places): the count of functions
     declared in include/cmunet_hip.h -- which test_library_builds_loads_and_exports_header holds equal to the library's exports."""
