@@ -698,8 +698,13 @@ class JointPretrainer(ArenaTrainer):
         return {"optimizer": self.opt.state_dict()}
 
     def load_state_dict(self, sd):
+        self.finish_pending()            # (a parameter all-gather still in flight would land on top of what the caller loads next)
         self.opt.load_state_dict(sd["optimizer"], amp=self.amp)
         ops.bump_param_generation()
+
+    def broadcast_parameters(self, src=0):
+        self.finish_pending()
+        super().broadcast_parameters(src)
 
     def step(self, img, img_t, mask=None, cur_iter=None, max_iter=None, **kw):
         if cur_iter is not None and max_iter:
